@@ -1,0 +1,176 @@
+/*
+ * wfsparse.h -- C ABI of libwfsparse.so: the MI355X (gfx950) sparse-convolution hot path of
+ * WaveformML's LitPSD training step.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one operator of the third-party
+ * package the reference calls for this path, spconv~=1.2.1 (reference requirements.txt:15), i.e.
+ * the torch custom ops behind its Python surface:
+ *
+ *   torch.ops.spconv.get_indice_pairs      <- spconv.ops.get_indice_pairs, called from
+ *       SparseConvolution.forward for every layer the reference constructs at
+ *       src/models/SPConvBlocks.py:75,134,191,249,298,335,370,498,502,803,809 and by config
+ *       strings "spconv.SubMConv3d" etc. (src/utils/ModelValidation.py:24-31)
+ *   torch.ops.spconv.indice_conv           <- spconv.functional.indice_conv / indice_subm_conv /
+ *   torch.ops.spconv.indice_conv_backward     indice_inverse_conv (same call sites; inverse conv
+ *                                             at src/models/SPConvBlocks.py:804,810)
+ *   SparseConvTensor.dense()               <- spconv.ToDense (src/models/SPConvBlocks.py:81,515),
+ *                                             src/engineering/LitBase.py:138-146
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers (HBM), sizes, and an opaque hipStream_t passed as
+ *     void*.  No torch types.  The library owns no memory and keeps no global state besides a
+ *     thread-local error string and an opt-in event-timing table; all outputs and workspaces
+ *     are caller-allocated (two-phase "plan" -> "run" where a size is data dependent).
+ *   - every call is asynchronous on `stream` unless documented otherwise.
+ *   - return value: 0 = WFS_OK, otherwise one of WFS_E*; wfs_last_error() gives the text.
+ *     The Python shim maps WFS_EINVAL -> AssertionError / RuntimeError as spconv raises them
+ *     (SURVEY.md 8b "Error conventions").
+ *   - index tensors are int32, batch-first [N, ndim+1] exactly as spconv's (the reference
+ *     permutes its (x,y[,t],evt) columns to batch-first at src/models/SPConvNet.py:47-52,64).
+ *   - feature dtype codes: WFS_F32 (fp32 storage, fp32 accumulate) and WFS_BF16 (bf16 storage,
+ *     fp32 accumulate).  Filters [K, Cin, Cout] are fp32 in both cases (master weights).
+ */
+#ifndef WFSPARSE_H
+#define WFSPARSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFS_OK 0
+#define WFS_EINVAL 1      /* bad argument / unsupported configuration                    */
+#define WFS_EOVERFLOW 2   /* batch * prod(out_shape) >= 2^31 (spconv asserts the same)    */
+#define WFS_EHIP 3        /* a HIP runtime call failed                                    */
+#define WFS_EWORKSPACE 4  /* workspace too small                                          */
+
+#define WFS_F32 0
+#define WFS_BF16 1
+
+#define WFS_MAX_DIM 4
+
+/* library / device ------------------------------------------------------------------------ */
+int wfs_abi_version(void);
+const char *wfs_last_error(void);
+
+/* Geometry of one sparse convolution, host side (all arrays have ndim entries).
+ * For SubM the front door forces stride = 1, padding = ksize/2, out_shape = spatial
+ * (SURVEY.md A.2); call wfs_geometry_init to apply those rules and validate.              */
+typedef struct wfs_geometry {
+    int32_t ndim;
+    int32_t batch_size;
+    int32_t subm;
+    int32_t K;                          /* prod(ksize), filled by wfs_geometry_init          */
+    int32_t spatial[WFS_MAX_DIM];       /* input spatial shape                               */
+    int32_t out_shape[WFS_MAX_DIM];     /* filled by wfs_geometry_init                       */
+    int32_t ksize[WFS_MAX_DIM];
+    int32_t stride[WFS_MAX_DIM];
+    int32_t padding[WFS_MAX_DIM];
+    int32_t dilation[WFS_MAX_DIM];
+} wfs_geometry;
+
+/* Validates and completes a geometry (replaces the Python front door of
+ * spconv.ops.get_indice_pairs, A.2).  WFS_EINVAL if a dim has stride>1 and dilation>1,
+ * WFS_EOVERFLOW if batch*prod(out_shape) >= 2^31.                                            */
+int wfs_geometry_init(wfs_geometry *g);
+
+/* rulebook ---------------------------------------------------------------------------------
+ * Replaces torch.ops.spconv.get_indice_pairs.  Besides spconv's own encoding
+ * (indice_pairs int32 [2,K,N] padded with -1, indice_pair_num int32 [K], both bit-identical
+ * to the CPU algorithm of A.3, including first-seen output numbering) the build produces the
+ * gather tables the compute kernels consume:
+ *     nbr_out int32 [K, N] : for input row j and kernel offset k, the output row, or -1
+ *     nbr_in  int32 [K, M] : for output row i and kernel offset k, the input row, or -1
+ * (SubM with odd kernels and dilation 1: nbr_in[k] == nbr_out[K-1-k], so nbr_in may be NULL.)
+ *
+ * Phase 1  wfs_rulebook_plan : site table build (hash or direct grid), candidate lookup,
+ *          first-seen numbering.  SubM: nbr_out is final.  Regular conv: nbr_out holds table
+ *          slots until phase 2.  Synchronises `stream` ONCE to return, on the host,
+ *          host_info = {M, input_has_duplicate_coordinates (SubM only)}.
+ * Phase 2  wfs_rulebook_emit : regular conv: writes out_indices [M, ndim+1], finalises nbr_out,
+ *          fills nbr_in [K, M] if given.  SubM: fills nbr_in if given (needed only for even
+ *          kernels / dilation).  Both: spconv's indice_pairs / indice_pair_num if given
+ *          (indice_pair_num alone is allowed; pass NULL for both to skip the compaction).
+ *
+ * `workspace` must hold wfs_rulebook_workspace_bytes(g, N) bytes and stay untouched between
+ * the two phases.  WFS_EINVAL if an index row lies outside batch_size / spatial.             */
+size_t wfs_rulebook_workspace_bytes(const wfs_geometry *g, int64_t N);
+
+int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, int64_t N,
+                      int32_t *nbr_out, void *workspace, size_t workspace_bytes,
+                      int64_t host_info[2], void *stream);
+
+int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, int64_t N, int64_t M,
+                      int32_t *nbr_out, int32_t *out_indices, int32_t *nbr_in,
+                      int32_t *indice_pairs, int32_t *indice_pair_num,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Duplicate-coordinate / range check of an index set whose uniqueness is unknown before a
+ * REGULAR conv (SubM learns it for free in its plan; a regular conv's output is unique by
+ * construction).  g_subm: a SubM geometry over the set's own spatial shape; workspace as for
+ * that geometry.  Synchronises.  host_info = {N, has_duplicates}.                           */
+int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indices, int64_t N,
+                      void *workspace, size_t workspace_bytes, int64_t host_info[2], void *stream);
+
+/* gather - GEMM - (no) scatter --------------------------------------------------------------
+ * Replaces torch.ops.spconv.indice_conv (forward) and the dX half of indice_conv_backward.
+ * Output-stationary: every output row r gathers its <= K source rows through
+ * table [K, R] (entry -1 = no neighbour) and contracts them with the per-offset filter:
+ *     Y[r, :] = bias + sum_k  X[table[kmap[k], r], :] . W[k]            (transpose_w == 0)
+ *     Y[r, :] =        sum_k  X[table[kmap[k], r], :] . W[k]^T          (transpose_w == 1)
+ * W is fp32 [K, Cw_in, Cw_out]; with transpose_w the contraction runs over Cw_out.
+ * kmap (host array of K ints, may be NULL = identity) lets SubM reuse nbr_out as nbr_in.
+ * identity_k >= 0 names the offset whose source row is r itself (SubM centre: spconv computes
+ * it as a plain X.W[k*] with k* = argmax indice_pair_num, A.4); -1 = none.  table may be NULL
+ * only for K == 1 && identity_k == 0.
+ * No atomics: each output row is written exactly once, results are run-to-run reproducible. */
+int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                    int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
+                    int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
+                    int32_t dtype, void *stream);
+
+/* Replaces the dW half of torch.ops.spconv.indice_conv_backward:
+ *     dW[k, a, b] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 0)
+ *     dW[k, b, a] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 1)
+ * S = the stationary rows [R, Cs], G = the gathered rows [*, Cg].  Deterministic two-stage
+ * reduction through `workspace` (wfs_gather_dw_workspace_bytes).                             */
+size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg);
+
+int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *S,
+                  int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
+                  int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Scatter form with fp32 atomics, used ONLY when the input holds duplicate coordinates (then
+ * the inverse of a gather table is not a function):
+ *     Y_accum[table[k, r], :] += X[r, :] . W[k]  (or W[k]^T)      Y_accum fp32, caller-initialised */
+int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X,
+                     int32_t Cx, const float *W, int32_t Cw_in, int32_t Cw_out, int32_t transpose_w,
+                     float *Y_accum, int32_t dtype, void *stream);
+
+/* SparseConvTensor.dense() -------------------------------------------------------------------
+ * Y is [B, C, *spatial] (channels first, contiguous) and must be zero-filled by the caller;
+ * rows are assigned, not accumulated.  winner_ws: NULL when coordinates are unique, else int32
+ * [B * volume] scratch that makes "the highest row wins" deterministic, as the reference's CPU
+ * assignment order does (A.1).  wfs_to_dense_bwd gathers dX[m,c] = dY[b,c,pos] for every row. */
+int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, int32_t ndim,
+                 const int32_t *spatial_host, int32_t batch_size, int32_t C, void *Y,
+                 int32_t *winner_ws, int32_t dtype, void *stream);
+
+int wfs_to_dense_bwd(const void *dY, const int32_t *indices, int64_t M, int32_t ndim,
+                     const int32_t *spatial_host, int32_t batch_size, int32_t C, void *dX,
+                     int32_t dtype, void *stream);
+
+/* opt-in per-kernel timing (HIP events on the launch stream), used by bench.py's roofline ---- */
+#define WFS_TIMER_GATHER_CONV 0
+#define WFS_TIMER_GATHER_DW 1
+#define WFS_TIMER_RULEBOOK 2
+#define WFS_TIMER_COUNT 3
+int wfs_timing_enable(int32_t on);                        /* also clears the table            */
+int wfs_timing_read(int32_t timer, double *total_ms, int64_t *launches);  /* synchronises     */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFSPARSE_H */

@@ -1,0 +1,273 @@
+"""GPU parity tests: libwfsparse (HIP, through the C ABI and the spconv-surface shim) vs the CPU
+oracle on the same seeded inputs.  Bars (BASELINE.json north_star): rulebook indices BIT-EXACT;
+fp32 features / logits / gradients within 1e-5 relative (stated per assert); bf16 storage is
+compared with the fp32 oracle at a bf16 tolerance.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, norm, rand_coords
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = "cuda:0"
+
+
+def _sp():
+    import waveformml_amd.spconv as sp
+    return sp
+
+
+def _assert_close(got, want, rtol=1e-5, what=""):
+    """|got - want| <= rtol * max|want| + rtol * |want|  (relative to the tensor's scale)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    scale = float(np.abs(want).max()) if want.size else 1.0
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * max(scale, 1e-30), err_msg=what)
+
+
+def _golden():
+    with open(os.path.join(HERE, "golden", "rulebook_small.json")) as f:
+        return json.load(f)
+
+
+def _rulebook_both(idx, B, shape, k, s, p, d, subm):
+    from oracle import ref
+    sp = _sp()
+    want = ref.get_indice_pairs(idx, B, shape, k, s, p, d, 0, subm)
+    got = sp.ops.get_indice_pairs(torch.from_numpy(idx).to(DEV), B, list(shape), k, s, p, d, 0, subm)
+    torch.cuda.synchronize()
+    return [g.cpu().numpy() for g in got], want
+
+
+@pytest.mark.parametrize("case", _golden(), ids=lambda c: "D%d_%s" % (c["ndim"], "subm" if c["subm"] else "conv"))
+def test_rulebook_golden_bitexact(case):
+    """Committed fixture (independent Python transcription of A.3), incl. duplicate coordinates."""
+    sp = _sp()
+    idx = torch.tensor(case["indices"], dtype=torch.int32, device=DEV)
+    out_idx, pairs, num = sp.ops.get_indice_pairs(idx, case["batch_size"], case["spatial_shape"], case["ksize"],
+                                                  case["stride"], case["padding"], case["dilation"], 0, case["subm"])
+    assert num.cpu().tolist() == case["indice_pair_num"]
+    assert pairs.cpu().tolist() == case["indice_pairs"]
+    assert out_idx.cpu().tolist() == case["out_indices"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "D%d_k%s_s%s_p%s_d%s_%s" % (c[0], c[2], c[3], c[4], c[5], "subm" if c[6] else "conv"))
+def test_rulebook_bitexact_vs_oracle(case):
+    ndim, shape, k, s, p, d, subm = case
+    rng = np.random.default_rng(101)
+    B = 5
+    n = min(2000, B * int(np.prod(shape)) // 2)
+    idx = rand_coords(rng, B, shape, n)
+    got, want = _rulebook_both(idx, B, shape, k, s, p, d, subm)
+    for g, w, name in zip(got, want, ("out_indices", "indice_pairs", "indice_pair_num")):
+        assert g.dtype == np.int32 and g.shape == w.shape, name
+        assert np.array_equal(g, w), name
+
+
+def _waveform_like(rng, B, T, n_hits=3):
+    """PMT-grid x time voxels: a few segments per event, each a contiguous run of active samples."""
+    rows = []
+    for b in range(B):
+        for _ in range(1 + rng.integers(0, n_hits)):
+            x, y = rng.integers(0, 14), rng.integers(0, 11)
+            t0 = rng.integers(0, T // 4)
+            t1 = min(T, t0 + rng.integers(T // 8, T // 2))
+            for t in range(t0, t1):
+                rows.append((b, x, y, t))
+    rows = sorted(set(rows))
+    return np.asarray(rows, np.int32)
+
+
+@pytest.mark.parametrize("subm,stride", [(True, 1), (False, (1, 1, 4)), (False, 2)])
+def test_rulebook_bitexact_at_psd_scale(subm, stride):
+    """14x11x256 grid, batch 256 (BASELINE config[1] geometry): hash path for SubM, direct grid for the
+    strided layers; every entry of the rulebook must equal the sequential CPU algorithm's."""
+    rng = np.random.default_rng(202)
+    B, T = 256, 256
+    idx = _waveform_like(rng, B, T)
+    got, want = _rulebook_both(idx, B, (14, 11, T), 3, stride, 0, 1, subm)
+    for g, w, name in zip(got, want, ("out_indices", "indice_pairs", "indice_pair_num")):
+        assert np.array_equal(g, w), name
+    assert want[2].sum() > len(idx)
+
+
+def test_rulebook_empty_and_errors():
+    sp = _sp()
+    idx = torch.zeros((0, 4), dtype=torch.int32, device=DEV)
+    o, p, n = sp.ops.get_indice_pairs(idx, 1, [14, 11, 16], 3, 1, 0, 1, 0, True)
+    assert p.shape == (2, 27, 0) and int(n.sum()) == 0
+    o, p, n = sp.ops.get_indice_pairs(idx, 1, [14, 11, 16], 3, 2, 0, 1, 0, False)
+    assert o.shape == (0, 4) and int(n.sum()) == 0
+    one = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):          # batch * volume >= 2^31, as spconv's C++ assert
+        sp.ops.get_indice_pairs(one, 4096, [1024, 1024, 1024], 3, 1, 0, 1, 0, True)
+    with pytest.raises(AssertionError):        # stride and dilation both > 1
+        sp.ops.get_indice_pairs(one[:, :3].contiguous(), 1, [8, 8], 3, 2, 0, 2, 0, False)
+    bad = torch.tensor([[0, 20, 0, 0]], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):          # coordinate outside spatial_shape
+        sp.ops.get_indice_pairs(bad, 1, [14, 11, 16], 3, 1, 0, 1, 0, True)
+    with pytest.raises(RuntimeError):          # CPU tensors: no fallback
+        sp.ops.get_indice_pairs(one.cpu(), 1, [14, 11, 16], 3, 1, 0, 1, 0, True)
+
+
+def _conv_pair(case, Cin, Cout, n, B, seed, dtype=torch.float32, bias=True):
+    """Builds the same layer in the product (GPU) and in the oracle (CPU) with equal weights."""
+    from oracle import spconv as osp
+    sp = _sp()
+    ndim, shape, k, s, p, d, subm = case
+    rng = np.random.default_rng(seed)
+    idx = rand_coords(rng, B, shape, n)
+    feat = rng.standard_normal((n, Cin)).astype(np.float32)
+    name = ("SubMConv%dd" if subm else "SparseConv%dd") % ndim
+    torch.manual_seed(seed)
+    ref_layer = getattr(osp, name)(Cin, Cout, k, s, p, d, 1, bias)
+    layer = getattr(sp, name)(Cin, Cout, k, s, p, d, 1, bias).to(DEV)
+    layer.load_state_dict(ref_layer.state_dict())
+    xr = osp.SparseConvTensor(torch.from_numpy(feat).requires_grad_(True), torch.from_numpy(idx), list(shape), B)
+    xg = sp.SparseConvTensor(torch.from_numpy(feat).to(DEV).to(dtype).requires_grad_(True),
+                             torch.from_numpy(idx).to(DEV), list(shape), B)
+    return layer, ref_layer, xg, xr, rng
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "D%d_k%s_s%s_p%s_d%s_%s" % (c[0], c[2], c[3], c[4], c[5], "subm" if c[6] else "conv"))
+@pytest.mark.parametrize("chan", [(2, 32), (32, 32), (5, 7)], ids=lambda c: "c%dx%d" % c)
+def test_conv_forward_backward_fp32(case, chan):
+    Cin, Cout = chan
+    B = 3
+    n = min(400, B * int(np.prod(case[1])) // 3)
+    layer, ref_layer, xg, xr, rng = _conv_pair(case, Cin, Cout, n, B, 303)
+    yg, yr = layer(xg), ref_layer(xr)
+    assert np.array_equal(yg.indices.cpu().numpy(), yr.indices.numpy())
+    assert yg.spatial_shape == [int(v) for v in yr.spatial_shape]
+    _assert_close(yg.features.detach().cpu().numpy(), yr.features.detach().numpy(), 1e-5, "forward")
+    g = rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)
+    yr.features.backward(torch.from_numpy(g))
+    yg.features.backward(torch.from_numpy(g).to(DEV))
+    _assert_close(xg.features.grad.cpu().numpy(), xr.features.grad.numpy(), 1e-5, "dX")
+    _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-5, "dW")
+    _assert_close(layer.bias.grad.cpu().numpy(), ref_layer.bias.grad.numpy(), 1e-5, "dbias")
+
+
+def test_conv_bf16_storage_against_fp32_oracle():
+    """bf16 rows in HBM, fp32 accumulate: 8 mantissa bits -> tolerance 2e-2 of the tensor scale."""
+    case = (3, (14, 11, 24), 3, 1, 0, 1, True)
+    layer, ref_layer, xg, xr, rng = _conv_pair(case, 32, 32, 600, 3, 404, dtype=torch.bfloat16)
+    xr.features = xr.features.detach().to(torch.bfloat16).float()     # same rounded inputs
+    yg, yr = layer(xg), ref_layer(xr)
+    assert yg.features.dtype == torch.bfloat16
+    _assert_close(yg.features.detach().float().cpu().numpy(), yr.features.detach().numpy(), 2e-2, "bf16 forward")
+
+
+def test_inverse_conv_and_rulebook_reuse():
+    from oracle import spconv as osp
+    sp = _sp()
+    rng = np.random.default_rng(505)
+    shape, B, n = (14, 11), 4, 150
+    idx = rand_coords(rng, B, shape, n)
+    feat = rng.standard_normal((n, 6)).astype(np.float32)
+    torch.manual_seed(1)
+    ref_net = osp.SparseSequential(osp.SparseConv2d(6, 8, 3, 2, 1, 1, 1, True, indice_key="ind_0"), torch.nn.ReLU(),
+                                   osp.SparseInverseConv2d(8, 5, 3, "ind_0", bias=False))
+    net = sp.SparseSequential(sp.SparseConv2d(6, 8, 3, 2, 1, 1, 1, True, indice_key="ind_0"), torch.nn.ReLU(),
+                              sp.SparseInverseConv2d(8, 5, 3, "ind_0", bias=False)).to(DEV)
+    net.load_state_dict(ref_net.state_dict())
+    fr = torch.from_numpy(feat).requires_grad_(True)
+    fg = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+    yr = ref_net(osp.SparseConvTensor(fr, torch.from_numpy(idx), list(shape), B))
+    xg = sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), list(shape), B)
+    yg = net(xg)
+    assert np.array_equal(yg.indices.cpu().numpy(), idx) and yg.spatial_shape == list(shape)
+    _assert_close(yg.features.detach().cpu().numpy(), yr.features.detach().numpy(), 1e-5, "inverse fwd")
+    yr.features.square().sum().backward()
+    yg.features.square().sum().backward()
+    _assert_close(fg.grad.cpu().numpy(), fr.grad.numpy(), 1e-5, "dX through inverse+conv")
+    for a, b in zip(net.parameters(), ref_net.parameters()):
+        _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-5, "param grad")
+    # the cached entry unpacks like spconv's 5-tuple and holds the oracle's rulebook
+    outids, indices, pairs, num, spatial = xg.indice_dict["ind_0"]
+    from oracle import ref
+    o, p, c = ref.get_indice_pairs(idx, B, shape, 3, 2, 1, 1, 0, False)
+    assert np.array_equal(pairs.cpu().numpy(), p) and np.array_equal(num.cpu().numpy(), c)
+    assert np.array_equal(outids.cpu().numpy(), o) and spatial == list(shape)
+
+
+@pytest.mark.parametrize("subm", [True, False], ids=["subm", "conv"])
+def test_duplicate_coordinates_follow_the_cpu_semantics(subm):
+    """Duplicate sites: SubM's hash keeps the last row, regular conv adds both rows (A.3/A.4)."""
+    case = (2, (7, 6), 3, 1 if subm else 2, 0 if subm else 1, 1, subm)
+    layer, ref_layer, xg, xr, rng = _conv_pair(case, 4, 6, 40, 2, 606)
+    idx = xr.indices.numpy().copy()
+    idx[31] = idx[30]
+    idx[12] = idx[11]
+    idx = idx[np.argsort(idx[:, 0], kind="stable")]
+    xr.indices = torch.from_numpy(idx)
+    xg.indices = torch.from_numpy(idx).to(DEV)
+    yg, yr = layer(xg), ref_layer(xr)
+    assert np.array_equal(yg.indices.cpu().numpy(), yr.indices.numpy())
+    _assert_close(yg.features.detach().cpu().numpy(), yr.features.detach().numpy(), 1e-5, "dup forward")
+    g = rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)
+    yr.features.backward(torch.from_numpy(g))
+    yg.features.backward(torch.from_numpy(g).to(DEV))
+    _assert_close(xg.features.grad.cpu().numpy(), xr.features.grad.numpy(), 1e-5, "dup dX")
+    _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-5, "dup dW")
+
+
+def test_to_dense_and_backward():
+    from oracle import spconv as osp
+    sp = _sp()
+    rng = np.random.default_rng(707)
+    shape, B, n, C = (10, 7, 16), 5, 500, 32
+    idx = rand_coords(rng, B, shape, n)
+    idx[77] = idx[76]                                  # duplicate: the later row must win
+    feat = rng.standard_normal((n, C)).astype(np.float32)
+    fr = torch.from_numpy(feat).requires_grad_(True)
+    fg = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+    dr = osp.SparseConvTensor(fr, torch.from_numpy(idx), list(shape), B).dense()
+    dg = sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), list(shape), B).dense()
+    assert dg.shape == (B, C) + shape and dg.is_contiguous()
+    assert np.array_equal(dg.detach().cpu().numpy(), dr.detach().numpy())
+    w = rng.standard_normal(tuple(dr.shape)).astype(np.float32)
+    (dr * torch.from_numpy(w)).sum().backward()
+    (dg * torch.from_numpy(w).to(DEV)).sum().backward()
+    assert np.array_equal(fg.grad.cpu().numpy(), fr.grad.numpy())
+
+
+def test_small_psd_stack_logits_loss_and_grads():
+    """A C2-shaped stack (SubM 2->32, SubM 32->32 sharing the rulebook, strided conv, ToDense, Linear)
+    against the CPU restatement: logits and loss within 1e-5 relative, every gradient within 1e-5."""
+    from oracle import spconv as osp
+    sp = _sp()
+    rng = np.random.default_rng(808)
+    B, T = 8, 32
+    idx = _waveform_like(rng, B, T)
+    feat = rng.random((len(idx), 2)).astype(np.float32)
+    labels = torch.from_numpy(rng.integers(0, 3, B))
+
+    def build(m):
+        return m.SparseSequential(
+            # no conv bias in front of BatchNorm: its gradient is identically zero up to rounding noise
+            m.SubMConv3d(2, 32, 3, 1, 0, 1, 1, False, "subm0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            m.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "subm0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            m.SparseConv3d(32, 16, 3, (1, 1, 4), 0, 1, 1, True), torch.nn.ReLU(), m.ToDense())
+
+    torch.manual_seed(2)
+    ref_net, ref_head = build(osp), torch.nn.Linear(16 * 12 * 9 * 8, 3)
+    net, head = build(sp).to(DEV), torch.nn.Linear(16 * 12 * 9 * 8, 3).to(DEV)
+    net.load_state_dict(ref_net.state_dict())
+    head.load_state_dict(ref_head.state_dict())
+    crit = torch.nn.CrossEntropyLoss(reduction="mean")
+    lr = ref_head(ref_net(osp.SparseConvTensor(torch.from_numpy(feat), torch.from_numpy(idx), [14, 11, T], B)).view(B, -1))
+    lg = head(net(sp.SparseConvTensor(torch.from_numpy(feat).to(DEV), torch.from_numpy(idx).to(DEV), [14, 11, T], B)).view(B, -1))
+    loss_r, loss_g = crit(lr, labels), crit(lg, labels.to(DEV))
+    _assert_close(lg.detach().cpu().numpy(), lr.detach().numpy(), 1e-5, "logits")
+    assert abs(loss_g.item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
+    loss_r.backward()
+    loss_g.backward()
+    for (name, a), b in zip(net.named_parameters(), ref_net.parameters()):
+        _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-5, name)

@@ -1,0 +1,124 @@
+"""ctypes binding of libwfsparse.so (include/wfsparse.h).  No CPU fallback: if the HIP library is
+missing or a tensor is not on the GPU, calls fail loudly."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwfsparse.so")
+
+WFS_OK, WFS_EINVAL, WFS_EOVERFLOW, WFS_EHIP, WFS_EWORKSPACE = 0, 1, 2, 3, 4
+WFS_F32, WFS_BF16 = 0, 1
+WFS_MAX_DIM = 4
+TIMER_GATHER_CONV, TIMER_GATHER_DW, TIMER_RULEBOOK = 0, 1, 2
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+
+
+class Geometry(ctypes.Structure):
+    """struct wfs_geometry"""
+    _fields_ = [("ndim", _i32), ("batch_size", _i32), ("subm", _i32), ("K", _i32),
+                ("spatial", _i32 * WFS_MAX_DIM), ("out_shape", _i32 * WFS_MAX_DIM),
+                ("ksize", _i32 * WFS_MAX_DIM), ("stride", _i32 * WFS_MAX_DIM),
+                ("padding", _i32 * WFS_MAX_DIM), ("dilation", _i32 * WFS_MAX_DIM)]
+
+
+# name -> (restype, argtypes); mirrors include/wfsparse.h one to one
+SIGNATURES = {
+    "wfs_abi_version": (ctypes.c_int, []),
+    "wfs_last_error": (ctypes.c_char_p, []),
+    "wfs_geometry_init": (ctypes.c_int, [ctypes.POINTER(Geometry)]),
+    "wfs_rulebook_workspace_bytes": (_sz, [ctypes.POINTER(Geometry), _i64]),
+    "wfs_rulebook_plan": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _vp, _sz, c_i64p, _vp]),
+    "wfs_rulebook_emit": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _sz, _vp]),
+    "wfs_indices_check": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _sz, c_i64p, _vp]),
+    "wfs_gather_conv": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _i32,
+                                       _vp, _vp, _i32, _vp]),
+    "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "wfs_gather_dw": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
+                                     _sz, _vp]),
+    "wfs_scatter_conv": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "wfs_to_dense": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "wfs_to_dense_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp]),
+    "wfs_timing_enable": (ctypes.c_int, [_i32]),
+    "wfs_timing_read": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_double), c_i64p]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load libwfsparse.so (built by waveformml_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libwfsparse.so is missing at %s -- build it with `make -C waveformml_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+def last_error():
+    msg = load().wfs_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    if rc != WFS_OK:
+        raise RuntimeError("libwfsparse: %s (status %d)" % (last_error(), rc))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Raw device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("waveformml_amd: tensor must live on the GPU (there is no CPU path); got %s" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("waveformml_amd: tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return WFS_F32
+    if t.dtype == torch.bfloat16:
+        return WFS_BF16
+    raise RuntimeError("waveformml_amd: features must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def i32_array(values):
+    return (ctypes.c_int32 * len(values))(*[int(v) for v in values])
+
+
+def make_geometry(ndim, batch_size, spatial, ksize, stride, padding, dilation, subm):
+    g = Geometry()
+    g.ndim, g.batch_size, g.subm = int(ndim), int(batch_size), int(bool(subm))
+    for i in range(ndim):
+        g.spatial[i], g.ksize[i] = int(spatial[i]), int(ksize[i])
+        g.stride[i], g.padding[i], g.dilation[i] = int(stride[i]), int(padding[i]), int(dilation[i])
+    check(load().wfs_geometry_init(ctypes.byref(g)))
+    return g
+
+
+def timing_enable(on=True):
+    check(load().wfs_timing_enable(1 if on else 0))
+
+
+def timing_read(timer):
+    ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+    check(load().wfs_timing_read(timer, ctypes.byref(ms), ctypes.byref(n)))
+    return ms.value, n.value

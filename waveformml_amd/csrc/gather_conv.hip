@@ -1,0 +1,293 @@
+// gather_conv.hip -- gather - GEMM - (no) scatter: forward, dX and dW of a sparse convolution.
+//
+// Replaces torch.ops.spconv.indice_conv / indice_conv_backward of spconv 1.2.1 (SURVEY.md A.4;
+// reference call sites src/models/SPConvBlocks.py:75,134,498,803-810).  spconv's Native algo is
+// input-stationary: per offset gather -> mm -> scatter-ADD, which on a GPU means float atomics
+// (~1.3 TB/s chip-wide on MI355X, 4-5x below plain stores).  Here the rulebook is kept as gather
+// tables (rulebook.hip) and every kernel is OUTPUT-stationary: a row of the result is owned by one
+// thread group, its <= K source rows are gathered through table[k][row] and contracted with W[k];
+// nothing is scattered, nothing is atomically accumulated, results are run-to-run reproducible.
+//
+// This file holds the shape-generic fp32-accumulate kernels (any Cin/Cout, fp32 or bf16 storage).
+// The shape-specialised MFMA kernels for the PSD net's 32-channel layers live in conv_mfma.hip.
+#include "wfs_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int CT = 8;        // output channels per thread (generic kernel)
+
+struct KMap {                // table column used for filter offset k (identity unless remapped)
+    int v[128];
+};
+
+// ------------------------------------------------------------------------------------------
+// generic gather conv: block = 64 rows x 4 waves; wave w owns output channels
+// [cbase + w*CT, cbase + w*CT + CT) of the 32-channel slice blockIdx.y.  The filter values a wave
+// needs are wave-uniform -> scalar loads; X values are per-lane row gathers (L1/L2 served).
+template <typename T, bool TRANSPOSE_W>
+__global__ void __launch_bounds__(TB) k_gather_conv(const int *__restrict__ table, KMap kmap, int K, int identity_k,
+                                                    long long R, const T *__restrict__ X, int Cx,
+                                                    const float *__restrict__ W, int Cw_in, int Cw_out,
+                                                    const float *__restrict__ bias, T *__restrict__ Y, int Cy) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 64 + lane;
+    const int c0 = blockIdx.y * (4 * CT) + wid * CT;
+    if (c0 >= Cy) return;
+    const bool live = r < R;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = (bias != nullptr && c0 + c < Cy) ? bias[c0 + c] : 0.f;
+    for (int k = 0; k < K; ++k) {
+        int nb = -1;
+        if (live) nb = (k == identity_k) ? (int)r : table[(long long)kmap.v[k] * R + r];
+        if (__ballot(nb >= 0) == 0ull) continue;      // wave-uniform skip of empty offsets
+        const float *Wk = W + (long long)k * Cw_in * Cw_out;
+        const T *xrow = X + (long long)(nb >= 0 ? nb : 0) * Cx;
+        for (int ci = 0; ci < Cx; ++ci) {
+            float x = nb >= 0 ? wfs_ld(xrow + ci) : 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                int co = c0 + c;
+                if (co < Cy) {
+                    float w = TRANSPOSE_W ? Wk[(long long)co * Cw_out + ci] : Wk[(long long)ci * Cw_out + co];
+                    acc[c] = fmaf(x, w, acc[c]);
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (c0 + c < Cy) wfs_st(Y + r * Cy + c0 + c, acc[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// scatter form (float atomics), only for inputs with duplicate coordinates, where the inverse of
+// the gather table is not a function:   Y[table[k][r]] += X[r] . W[k]   (Y fp32, pre-zeroed/biased)
+template <typename T, bool TRANSPOSE_W>
+__global__ void __launch_bounds__(TB) k_scatter_conv(const int *__restrict__ table, int K, int identity_k,
+                                                     long long R, const T *__restrict__ X, int Cx,
+                                                     const float *__restrict__ W, int Cw_in, int Cw_out,
+                                                     float *__restrict__ Y, int Cy) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 64 + lane;
+    const int c0 = blockIdx.y * (4 * CT) + wid * CT;
+    if (c0 >= Cy || r >= R) return;
+    const T *xrow = X + r * Cx;
+    for (int k = 0; k < K; ++k) {
+        int dst = (k == identity_k) ? (int)r : table[(long long)k * R + r];
+        if (dst < 0) continue;
+        const float *Wk = W + (long long)k * Cw_in * Cw_out;
+        float acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+        for (int ci = 0; ci < Cx; ++ci) {
+            float x = wfs_ld(xrow + ci);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                int co = c0 + c;
+                if (co < Cy) {
+                    float w = TRANSPOSE_W ? Wk[(long long)co * Cw_out + ci] : Wk[(long long)ci * Cw_out + co];
+                    acc[c] = fmaf(x, w, acc[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (c0 + c < Cy) atomicAdd(Y + (long long)dst * Cy + c0 + c, acc[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dW:  part[chunk][k][a][b] = sum_{r in chunk} S[r][a] * G[table[k][r]][b]  over a 32x32 (a,b) tile,
+// then a second kernel sums the chunks in fixed order (deterministic).
+constexpr int DW_TA = 32, DW_TBB = 32, DW_ROWS = 64;
+
+template <typename T>
+__global__ void __launch_bounds__(TB) k_gather_dw(const int *__restrict__ table, int K, int identity_k, long long R,
+                                                  long long rows_per_chunk, const T *__restrict__ S, int Cs,
+                                                  const T *__restrict__ G, int Cg, float *__restrict__ part,
+                                                  int tiles_a, int tiles_b) {
+    __shared__ float sS[DW_ROWS][DW_TA + 1];
+    __shared__ float sG[DW_ROWS][DW_TBB + 1];
+    __shared__ int sNb[DW_ROWS];
+    const int k = blockIdx.y;
+    const int ta = blockIdx.z / tiles_b, tb = blockIdx.z % tiles_b;
+    const int a0 = ta * DW_TA, b0 = tb * DW_TBB;
+    const long long chunk = blockIdx.x;
+    const long long r_begin = chunk * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < R ? r_begin + rows_per_chunk : R;
+    // thread -> 2x2 micro tile of the 32x32 output tile
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (long long base = r_begin; base < r_end; base += DW_ROWS) {
+        int nb = -1;
+        if (threadIdx.x < DW_ROWS) {
+            long long r = base + threadIdx.x;
+            if (r < r_end) nb = (k == identity_k) ? (int)r : table[(long long)k * R + r];
+            sNb[threadIdx.x] = nb;
+        }
+        if (!__syncthreads_or(nb >= 0)) continue;      // block-uniform skip of empty row groups
+        for (int e = threadIdx.x; e < DW_ROWS * DW_TA; e += TB) {
+            int rr = e / DW_TA, a = e % DW_TA;
+            long long r = base + rr;
+            float v = 0.f;
+            if (sNb[rr] >= 0 && a0 + a < Cs) v = wfs_ld(S + r * Cs + a0 + a);
+            sS[rr][a] = v;
+        }
+        for (int e = threadIdx.x; e < DW_ROWS * DW_TBB; e += TB) {
+            int rr = e / DW_TBB, b = e % DW_TBB;
+            int src = sNb[rr];
+            float v = 0.f;
+            if (src >= 0 && b0 + b < Cg) v = wfs_ld(G + (long long)src * Cg + b0 + b);
+            sG[rr][b] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < DW_ROWS; ++rr) {
+            float s0 = sS[rr][ty * 2], s1 = sS[rr][ty * 2 + 1];
+            float g0 = sG[rr][tx * 2], g1 = sG[rr][tx * 2 + 1];
+            acc[0][0] = fmaf(s0, g0, acc[0][0]);
+            acc[0][1] = fmaf(s0, g1, acc[0][1]);
+            acc[1][0] = fmaf(s1, g0, acc[1][0]);
+            acc[1][1] = fmaf(s1, g1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    // part layout: [chunk][k][Cs][Cg]
+    float *p = part + ((long long)chunk * K + k) * Cs * Cg;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int a = a0 + ty * 2 + i, b = b0 + tx * 2 + j;
+            if (a < Cs && b < Cg) p[(long long)a * Cg + b] = acc[i][j];
+        }
+}
+
+// dW[k][a][b] (swap==0) or dW[k][b][a] (swap==1) = sum_chunk part[chunk][k][a][b]
+__global__ void k_dw_reduce(const float *__restrict__ part, long long nchunks, int K, int Cs, int Cg, int swap,
+                            float *__restrict__ dW) {
+    long long e = (long long)blockIdx.x * TB + threadIdx.x;
+    long long per = (long long)K * Cs * Cg;
+    if (e >= per) return;
+    float s = 0.f;
+    for (long long c = 0; c < nchunks; ++c) s += part[c * per + e];
+    int k = (int)(e / ((long long)Cs * Cg));
+    int rem = (int)(e % ((long long)Cs * Cg));
+    int a = rem / Cg, b = rem % Cg;
+    if (swap)
+        dW[((long long)k * Cg + b) * Cs + a] = s;
+    else
+        dW[e] = s;
+}
+
+long long dw_chunks(long long R) {
+    long long chunks = wfs_cdiv(R, 4096);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 512) chunks = 512;
+    return chunks;
+}
+
+}  // namespace
+
+extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                               int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
+                               int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
+                               void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)X_rows;
+    WFS_REQUIRE(K >= 1 && K <= 128, WFS_EINVAL, "kernel volume %d not in [1,128]", K);
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    const int Cy = transpose_w ? Cw_in : Cw_out;
+    WFS_REQUIRE(Cx == (transpose_w ? Cw_out : Cw_in), WFS_EINVAL, "channel mismatch: X has %d, filter wants %d", Cx,
+                transpose_w ? Cw_out : Cw_in);
+    if (R == 0) return WFS_OK;
+    WFS_REQUIRE((table || (K == 1 && identity_k == 0)) && X && W && Y, WFS_EINVAL, "NULL device pointer");
+    KMap km;
+    for (int k = 0; k < K; ++k) {
+        km.v[k] = kmap_host ? kmap_host[k] : k;
+        WFS_REQUIRE(km.v[k] >= 0 && km.v[k] < K, WFS_EINVAL, "kmap[%d] out of range", k);
+    }
+    WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
+    dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
+#define WFS_GC(T, TR)                                                                                           \
+    k_gather_conv<T, TR><<<grid, block, 0, stream>>>(table, km, K, identity_k, R, (const T *)X, Cx, W, Cw_in, \
+                                                      Cw_out, bias, (T *)Y, Cy)
+    if (dtype == WFS_F32) {
+        if (transpose_w) WFS_GC(float, true); else WFS_GC(float, false);
+    } else {
+        if (transpose_w) WFS_GC(wfs_bf16, true); else WFS_GC(wfs_bf16, false);
+    }
+#undef WFS_GC
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X,
+                                int32_t Cx, const float *W, int32_t Cw_in, int32_t Cw_out, int32_t transpose_w,
+                                float *Y_accum, int32_t dtype, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(K >= 1, WFS_EINVAL, "bad K");
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    const int Cy = transpose_w ? Cw_in : Cw_out;
+    WFS_REQUIRE(Cx == (transpose_w ? Cw_out : Cw_in), WFS_EINVAL, "channel mismatch");
+    if (R == 0) return WFS_OK;
+    WFS_REQUIRE(table && X && W && Y_accum, WFS_EINVAL, "NULL device pointer");
+    dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
+#define WFS_SC(T, TR)                                                                                          \
+    k_scatter_conv<T, TR><<<grid, block, 0, stream>>>(table, K, identity_k, R, (const T *)X, Cx, W, Cw_in, Cw_out, \
+                                                       Y_accum, Cy)
+    if (dtype == WFS_F32) {
+        if (transpose_w) WFS_SC(float, true); else WFS_SC(float, false);
+    } else {
+        if (transpose_w) WFS_SC(wfs_bf16, true); else WFS_SC(wfs_bf16, false);
+    }
+#undef WFS_SC
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg) {
+    return (size_t)dw_chunks(R) * K * Cs * Cg * sizeof(float);
+}
+
+extern "C" int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *S,
+                             int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
+                             int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)G_rows;
+    WFS_REQUIRE(K >= 1 && K <= 65535, WFS_EINVAL, "bad K");
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(dW, WFS_EINVAL, "NULL dW");
+    if (R == 0) {
+        WFS_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)K * Cs * Cg * sizeof(float), stream));
+        return WFS_OK;
+    }
+    WFS_REQUIRE((table || (K == 1 && identity_k == 0)) && S && G && workspace, WFS_EINVAL, "NULL device pointer");
+    size_t need = wfs_gather_dw_workspace_bytes(K, R, Cs, Cg);
+    WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
+    WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
+    long long chunks = dw_chunks(R);
+    long long rows_per_chunk = wfs_cdiv(wfs_cdiv(R, chunks), DW_ROWS) * DW_ROWS;
+    int tiles_a = (int)wfs_cdiv(Cs, DW_TA), tiles_b = (int)wfs_cdiv(Cg, DW_TBB);
+    WFS_REQUIRE((long long)tiles_a * tiles_b <= 65535, WFS_EINVAL, "channel tile grid too large");
+    dim3 grid((unsigned)chunks, (unsigned)K, (unsigned)(tiles_a * tiles_b)), block(TB);
+    float *part = (float *)workspace;
+    if (dtype == WFS_F32)
+        k_gather_dw<float><<<grid, block, 0, stream>>>(table, K, identity_k, R, rows_per_chunk, (const float *)S, Cs,
+                                                       (const float *)G, Cg, part, tiles_a, tiles_b);
+    else
+        k_gather_dw<wfs_bf16><<<grid, block, 0, stream>>>(table, K, identity_k, R, rows_per_chunk,
+                                                          (const wfs_bf16 *)S, Cs, (const wfs_bf16 *)G, Cg, part,
+                                                          tiles_a, tiles_b);
+    WFS_LAUNCH_CHECK();
+    long long per = (long long)K * Cs * Cg;
+    k_dw_reduce<<<dim3((unsigned)wfs_cdiv(per, TB)), block, 0, stream>>>(part, chunks, K, Cs, Cg, swap, dW);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}

@@ -1,0 +1,583 @@
+// rulebook.hip -- rulebook ("indice pairs") construction on gfx950.
+//
+// Replaces torch.ops.spconv.get_indice_pairs of spconv 1.2.1 (reference requirements.txt:15;
+// call sites src/models/SPConvBlocks.py:75,134,498,803-810).  The CPU algorithm being matched
+// bit-for-bit is sequential; the GPU formulation is order-free by construction:
+//
+//   * the candidate enumeration of getValidOutPos (out position descending per dim, last dim
+//     fastest) visits kernel offsets in INCREASING linear offset k, so "candidate order" ==
+//     "k order" and a candidate is the pair (input row j, offset k);
+//   * SubM: hash[key] = j with "last wins" == atomicMax over j;
+//   * regular conv: an output site's id is the rank of its FIRST ticket t = j*K + k among all
+//     distinct sites == (number of first-tickets in rows < j) + (first-tickets of row j at
+//     offsets < k): one atomicMin per candidate, one row-count, one exclusive scan over rows;
+//   * spconv's indice_pairs[:, k, :n_k] is ordered by input row == stable compaction of the
+//     gather-table column nbr_out[k, :] (wave ballot + popcount prefix, block offsets from a
+//     scan over row tiles).
+//
+// Site lookup uses either a direct grid (slot == key, when batch*volume is small next to N) or an
+// open-addressing hash of 32-bit keys (batch*volume < 2^31 is asserted by the front door).
+#include "wfs_common.h"
+
+namespace {
+
+constexpr int TB = 256;  // threads per block everywhere in this file
+
+struct Geo {
+    int ndim, K;
+    int spatial[4], out_shape[4], ksize[4], stride[4], padding[4], dilation[4];
+    long long in_volume, out_volume;
+};
+
+struct Table {       // site table: hash (direct == 0) or dense grid (direct == 1)
+    int *keys;       // [cap] hash mode only, -1 = empty
+    unsigned shift;  // 32 - log2(cap)
+    unsigned mask;   // cap - 1
+    int direct;
+};
+
+__device__ __forceinline__ unsigned tbl_home(const Table &t, int key) {
+    return ((unsigned)key * 0x9E3779B1u) >> t.shift;
+}
+// find-or-insert; returns the slot
+__device__ __forceinline__ unsigned tbl_insert(const Table &t, int key) {
+    if (t.direct) return (unsigned)key;
+    unsigned s = tbl_home(t, key);
+    while (true) {
+        int prev = atomicCAS(&t.keys[s], -1, key);
+        if (prev == -1 || prev == key) return s;
+        s = (s + 1) & t.mask;
+    }
+}
+// find; returns slot or 0xFFFFFFFF
+__device__ __forceinline__ unsigned tbl_find(const Table &t, int key) {
+    if (t.direct) return (unsigned)key;
+    unsigned s = tbl_home(t, key);
+    while (true) {
+        int cur = t.keys[s];
+        if (cur == key) return s;
+        if (cur == -1) return 0xFFFFFFFFu;
+        s = (s + 1) & t.mask;
+    }
+}
+
+// Per-row candidate walker: offsets k = 0..K-1 in increasing order (last dim fastest).
+struct Walker {
+    int off[4];
+    __device__ __forceinline__ void reset() { off[0] = off[1] = off[2] = off[3] = 0; }
+    __device__ __forceinline__ void next(const Geo &g) {
+#pragma unroll
+        for (int d = 3; d >= 0; --d) {
+            if (d >= g.ndim) continue;
+            if (++off[d] < g.ksize[d]) return;
+            off[d] = 0;
+        }
+    }
+    // output-site key of (row position x, batch b) at the current offset, or -1
+    __device__ __forceinline__ int key(const Geo &g, const int *x, int b) const {
+        long long lin = b;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (d >= g.ndim) break;
+            int t = x[d] + g.padding[d] - off[d] * g.dilation[d];
+            if (t < 0) return -1;
+            int o = t / g.stride[d];
+            if (o * g.stride[d] != t || o >= g.out_shape[d]) return -1;
+            lin = lin * g.out_shape[d] + o;
+        }
+        return (int)lin;
+    }
+};
+
+__device__ __forceinline__ bool load_row(const Geo &g, const int *idx, long long j, int *x, int &b, int batch) {
+    const int *row = idx + j * (g.ndim + 1);
+    b = row[0];
+    bool ok = b >= 0 && b < batch;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d < g.ndim) {
+            x[d] = row[1 + d];
+            ok = ok && x[d] >= 0 && x[d] < g.spatial[d];
+        } else {
+            x[d] = 0;
+        }
+    }
+    return ok;
+}
+
+// key of an INPUT site (row-major over the input spatial shape)
+__device__ __forceinline__ int in_key(const Geo &g, const int *x, int b) {
+    long long lin = b;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        if (d < g.ndim) lin = lin * g.spatial[d] + x[d];
+    return (int)lin;
+}
+
+// ---------------------------------------------------------------- SubM
+// info[0] = M, info[1] = duplicate coordinates seen, info[2] = out-of-range index seen
+__global__ void k_site_insert(Geo g, int batch, const int *idx, long long N, Table t, int *vals, long long *info) {
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    if (j >= N) return;
+    int x[4], b;
+    if (!load_row(g, idx, j, x, b, batch)) {
+        info[2] = 1;
+        return;
+    }
+    unsigned s = tbl_insert(t, in_key(g, x, b));
+    int old = atomicMax(&vals[s], (int)j);      // duplicates: the LAST row wins (A.3)
+    if (old >= 0) info[1] = 1;
+}
+
+__global__ void k_subm_lookup(Geo g, int batch, const int *idx, long long N, Table t, const int *vals,
+                              int *nbr_out) {
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    if (j >= N) return;
+    int x[4], b;
+    bool ok = load_row(g, idx, j, x, b, batch);
+    Walker w;
+    w.reset();
+    for (int k = 0; k < g.K; ++k) {
+        int res = -1;
+        int key = ok ? w.key(g, x, b) : -1;
+        if (key >= 0) {
+            unsigned s = tbl_find(t, key);
+            if (s != 0xFFFFFFFFu) res = vals[s];
+        }
+        nbr_out[(long long)k * N + j] = res;
+        w.next(g);
+    }
+}
+
+// ---------------------------------------------------------------- regular / strided conv
+__global__ void k_conv_insert(Geo g, int batch, const int *idx, long long N, Table t,
+                              unsigned long long *ticket, int *nbr_out, long long *info) {
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    if (j >= N) return;
+    int x[4], b;
+    bool ok = load_row(g, idx, j, x, b, batch);
+    if (!ok) info[2] = 1;
+    Walker w;
+    w.reset();
+    for (int k = 0; k < g.K; ++k) {
+        int key = ok ? w.key(g, x, b) : -1;
+        int slot = -1;
+        if (key >= 0) {
+            unsigned s = tbl_insert(t, key);
+            atomicMin(&ticket[s], (unsigned long long)j * g.K + k);
+            slot = (int)s;
+        }
+        nbr_out[(long long)k * N + j] = slot;   // slot for now; k_conv_finalize turns it into the id
+        w.next(g);
+    }
+}
+
+__global__ void k_conv_rowcount(int K, long long N, const int *nbr_out, const unsigned long long *ticket,
+                                int *rowfirst) {
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    if (j >= N) return;
+    int c = 0;
+    for (int k = 0; k < K; ++k) {
+        int s = nbr_out[(long long)k * N + j];
+        if (s >= 0 && ticket[s] == (unsigned long long)j * K + k) ++c;
+    }
+    rowfirst[j] = c;
+}
+
+__global__ void k_conv_assign(Geo g, long long N, const int *nbr_out, const unsigned long long *ticket,
+                              const int *rowbase, Table t, int *slot_id, int *out_indices) {
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    if (j >= N) return;
+    int id = rowbase[j];
+    for (int k = 0; k < g.K; ++k) {
+        int s = nbr_out[(long long)k * N + j];
+        if (s >= 0 && ticket[s] == (unsigned long long)j * g.K + k) {
+            slot_id[s] = id;
+            long long key = t.direct ? (long long)s : (long long)t.keys[s];
+            int *o = out_indices + (long long)id * (g.ndim + 1);
+            for (int d = g.ndim - 1; d >= 0; --d) {
+                o[1 + d] = (int)(key % g.out_shape[d]);
+                key /= g.out_shape[d];
+            }
+            o[0] = (int)key;
+            ++id;
+        }
+    }
+}
+
+__global__ void k_conv_finalize(int K, long long N, long long M, int *nbr_out, const int *slot_id, int *nbr_in) {
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    if (j >= N) return;
+    for (int k = 0; k < K; ++k) {
+        int s = nbr_out[(long long)k * N + j];
+        if (s >= 0) {
+            int id = slot_id[s];
+            nbr_out[(long long)k * N + j] = id;
+            if (nbr_in) atomicMax(&nbr_in[(long long)k * M + id], (int)j);
+        }
+    }
+}
+
+// SubM with an even kernel or dilation: nbr_in by scatter of nbr_out
+__global__ void k_invert_table(int K, long long N, long long M, const int *nbr_out, int *nbr_in) {
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    if (j >= N) return;
+    for (int k = 0; k < K; ++k) {
+        int i = nbr_out[(long long)k * N + j];
+        if (i >= 0) atomicMax(&nbr_in[(long long)k * M + i], (int)j);
+    }
+}
+
+// ---------------------------------------------------------------- exclusive scan (int32)
+// three launches: per-block sums -> scan of block sums (one block) -> per-block exclusive scan
+constexpr int SCAN_ITEMS = 4;                      // items per thread
+constexpr int SCAN_TILE = TB * SCAN_ITEMS;
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+// block-wide exclusive scan of one int per thread; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int *total) {
+    __shared__ int wsum[TB / 64];
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = wave_incl_scan(v);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w) {
+        int s = wsum[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ void k_scan_blocksum(const int *in, long long n, int *bsum) {
+    long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) v += in[base + i];
+    int tot;
+    block_excl_scan(v, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+// single block: exclusive scan of bsum[0..nb) in place; total -> *total (long long) and total32
+__global__ void k_scan_top(int *bsum, long long nb, long long *total) {
+    int carry = 0;
+    for (long long base = 0; base < nb; base += TB) {
+        long long i = base + threadIdx.x;
+        int v = i < nb ? bsum[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, &tot);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void k_scan_apply(const int *in, long long n, const int *bsum, int *out) {
+    long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int vals[SCAN_ITEMS];
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        vals[i] = base + i < n ? in[base + i] : 0;
+        v += vals[i];
+    }
+    int tot;
+    int ex = block_excl_scan(v, &tot) + bsum[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = ex;
+        ex += vals[i];
+    }
+}
+
+// ---------------------------------------------------------------- compaction to spconv's encoding
+// tile = TB consecutive input rows.  tcount[k * ntiles + tile] = valid entries of column k in tile.
+__global__ void k_compact_count(int K, long long N, long long ntiles, const int *nbr_out, int *tcount) {
+    __shared__ int wsum[TB / 64];
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int k = 0; k < K; ++k) {
+        bool v = j < N && nbr_out[(long long)k * N + j] >= 0;
+        unsigned long long m = __ballot(v);
+        if (lane == 0) wsum[wid] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+#pragma unroll
+            for (int w = 0; w < TB / 64; ++w) s += wsum[w];
+            tcount[(long long)k * ntiles + blockIdx.x] = s;
+        }
+        __syncthreads();
+    }
+}
+// one block per offset k: exclusive scan over tiles in place, total -> pair_num[k]
+__global__ void k_compact_scan(long long ntiles, int *tcount, int *pair_num) {
+    int *row = tcount + (long long)blockIdx.x * ntiles;
+    int carry = 0;
+    for (long long base = 0; base < ntiles; base += TB) {
+        long long i = base + threadIdx.x;
+        int v = i < ntiles ? row[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, &tot);
+        if (i < ntiles) row[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) pair_num[blockIdx.x] = carry;
+}
+__global__ void k_compact_write(int K, long long N, long long ntiles, const int *nbr_out, const int *tcount,
+                                const int *pair_num, int *pairs) {
+    __shared__ int wsum[TB / 64];
+    long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int k = 0; k < K; ++k) {
+        int o = j < N ? nbr_out[(long long)k * N + j] : -1;
+        bool v = o >= 0;
+        unsigned long long m = __ballot(v);
+        if (lane == 0) wsum[wid] = __popcll(m);
+        __syncthreads();
+        int base = tcount[(long long)k * ntiles + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < TB / 64; ++w)
+            if (w < wid) base += wsum[w];
+        int rank = __popcll(m & ((1ull << lane) - 1ull));
+        int *p0 = pairs + (long long)k * N;
+        int *p1 = pairs + ((long long)K + k) * N;
+        if (v) {
+            p0[base + rank] = (int)j;
+            p1[base + rank] = o;
+        }
+        if (j < N && j >= pair_num[k]) {       // the -1 padding of A.2, written once
+            p0[j] = -1;
+            p1[j] = -1;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct Plan {
+    Geo geo;
+    Table tbl;
+    long long cap;
+    // workspace carve-up (byte offsets)
+    size_t off_info, off_keys, off_vals, off_ticket, off_slot_id, off_rowfirst, off_rowbase, off_bsum,
+        off_tcount, total;
+    long long ntiles, nscan;
+};
+
+unsigned log2_ceil(unsigned long long v) {
+    unsigned l = 0;
+    while ((1ull << l) < v) ++l;
+    return l;
+}
+
+void make_plan(const wfs_geometry *g, long long N, Plan *p) {
+    Geo &G = p->geo;
+    G.ndim = g->ndim;
+    G.K = g->K;
+    G.in_volume = G.out_volume = 1;
+    for (int i = 0; i < 4; ++i) {
+        G.spatial[i] = g->spatial[i];
+        G.out_shape[i] = g->out_shape[i];
+        G.ksize[i] = g->ksize[i];
+        G.stride[i] = g->stride[i];
+        G.padding[i] = g->padding[i];
+        G.dilation[i] = g->dilation[i];
+        if (i < g->ndim) {
+            G.in_volume *= g->spatial[i];
+            G.out_volume *= g->out_shape[i];
+        }
+    }
+    long long cells = (long long)g->batch_size * G.out_volume;   // < 2^31
+    long long bound = g->subm ? N : (N * (long long)g->K < cells ? N * (long long)g->K : cells);
+    if (bound < 1) bound = 1;
+    p->tbl.direct = cells <= 4 * bound;
+    if (p->tbl.direct) {
+        p->cap = cells > 0 ? cells : 1;
+        p->tbl.shift = 0;
+        p->tbl.mask = 0;
+    } else {
+        unsigned lg = log2_ceil((unsigned long long)(2 * bound));
+        if (lg < 6) lg = 6;
+        p->cap = 1ll << lg;
+        p->tbl.shift = 32 - lg;
+        p->tbl.mask = (unsigned)(p->cap - 1);
+    }
+    p->ntiles = wfs_cdiv(N > 0 ? N : 1, TB);
+    p->nscan = wfs_cdiv(N > 0 ? N : 1, SCAN_TILE);
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = wfs_align_up(o + bytes, 256);
+        return at;
+    };
+    p->off_info = take(4 * sizeof(long long));
+    p->off_keys = take(p->tbl.direct ? 0 : (size_t)p->cap * 4);
+    if (g->subm) {
+        p->off_vals = take((size_t)p->cap * 4);
+        p->off_ticket = p->off_slot_id = p->off_rowfirst = p->off_rowbase = p->off_bsum = o;
+    } else {
+        p->off_vals = o;
+        p->off_ticket = take((size_t)p->cap * 8);
+        p->off_slot_id = take((size_t)p->cap * 4);
+        p->off_rowfirst = take((size_t)(N + 1) * 4);
+        p->off_rowbase = take((size_t)(N + 1) * 4);
+        p->off_bsum = take((size_t)p->nscan * 4);
+    }
+    p->off_tcount = take((size_t)g->K * p->ntiles * 4);
+    p->total = o;
+}
+
+}  // namespace
+
+extern "C" size_t wfs_rulebook_workspace_bytes(const wfs_geometry *g, int64_t N) {
+    if (!g || N < 0) return 0;
+    Plan p;
+    make_plan(g, N, &p);
+    return p.total;
+}
+
+// Standalone duplicate check for index sets whose uniqueness is unknown before a regular conv
+// (a regular conv's OUTPUT is unique by construction; SubM learns it for free in its plan).
+// workspace: same size as a SubM rulebook over (spatial, batch).  Synchronises `stream`.
+extern "C" int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indices, int64_t N,
+                                 void *workspace, size_t workspace_bytes, int64_t host_info[2], void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(g_subm && g_subm->subm, WFS_EINVAL, "wfs_indices_check wants a SubM geometry");
+    Plan p;
+    make_plan(g_subm, N, &p);
+    WFS_REQUIRE(workspace_bytes >= p.total, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, p.total);
+    char *ws = (char *)workspace;
+    long long *info = (long long *)(ws + p.off_info);
+    p.tbl.keys = (int *)(ws + p.off_keys);
+    int *vals = (int *)(ws + p.off_vals);
+    WFS_HIP_CHECK(hipMemsetAsync(info, 0, 4 * sizeof(long long), stream));
+    if (!p.tbl.direct) WFS_HIP_CHECK(hipMemsetAsync(p.tbl.keys, 0xFF, (size_t)p.cap * 4, stream));
+    WFS_HIP_CHECK(hipMemsetAsync(vals, 0xFF, (size_t)p.cap * 4, stream));
+    if (N > 0) {
+        k_site_insert<<<dim3((unsigned)wfs_cdiv(N, TB)), dim3(TB), 0, stream>>>(p.geo, g_subm->batch_size, indices, N,
+                                                                              p.tbl, vals, info);
+        WFS_LAUNCH_CHECK();
+    }
+    long long h[4];
+    WFS_HIP_CHECK(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
+    WFS_HIP_CHECK(hipStreamSynchronize(stream));
+    WFS_REQUIRE(h[2] == 0, WFS_EINVAL, "an index row lies outside batch_size/spatial_shape");
+    host_info[0] = N;
+    host_info[1] = h[1];
+    return WFS_OK;
+}
+
+extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, int64_t N, int32_t *nbr_out,
+                                 void *workspace, size_t workspace_bytes, int64_t host_info[2], void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(g && host_info, WFS_EINVAL, "NULL argument");
+    WFS_REQUIRE(N >= 0 && N < (1ll << 31), WFS_EINVAL, "N out of range");
+    WFS_REQUIRE(g->K >= 1, WFS_EINVAL, "geometry not initialised (wfs_geometry_init)");
+    host_info[0] = g->subm ? N : 0;
+    host_info[1] = 0;
+    if (N == 0) return WFS_OK;
+    WFS_REQUIRE(indices && nbr_out && workspace, WFS_EINVAL, "NULL device pointer");
+    Plan p;
+    make_plan(g, N, &p);
+    WFS_REQUIRE(workspace_bytes >= p.total, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, p.total);
+    WfsTimerScope timer(WFS_TIMER_RULEBOOK, stream);
+    char *ws = (char *)workspace;
+    long long *info = (long long *)(ws + p.off_info);
+    p.tbl.keys = (int *)(ws + p.off_keys);
+    dim3 grid((unsigned)wfs_cdiv(N, TB)), block(TB);
+    WFS_HIP_CHECK(hipMemsetAsync(info, 0, 4 * sizeof(long long), stream));
+    if (!p.tbl.direct) WFS_HIP_CHECK(hipMemsetAsync(p.tbl.keys, 0xFF, (size_t)p.cap * 4, stream));
+    if (g->subm) {
+        int *vals = (int *)(ws + p.off_vals);
+        WFS_HIP_CHECK(hipMemsetAsync(vals, 0xFF, (size_t)p.cap * 4, stream));
+        k_site_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, p.tbl, vals, info);
+        WFS_LAUNCH_CHECK();
+        k_subm_lookup<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, p.tbl, vals, nbr_out);
+        WFS_LAUNCH_CHECK();
+    } else {
+        unsigned long long *ticket = (unsigned long long *)(ws + p.off_ticket);
+        int *rowfirst = (int *)(ws + p.off_rowfirst);
+        int *rowbase = (int *)(ws + p.off_rowbase);
+        int *bsum = (int *)(ws + p.off_bsum);
+        WFS_HIP_CHECK(hipMemsetAsync(ticket, 0xFF, (size_t)p.cap * 8, stream));
+        k_conv_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, p.tbl, ticket, nbr_out, info);
+        WFS_LAUNCH_CHECK();
+        k_conv_rowcount<<<grid, block, 0, stream>>>(g->K, N, nbr_out, ticket, rowfirst);
+        WFS_LAUNCH_CHECK();
+        dim3 sgrid((unsigned)p.nscan);
+        k_scan_blocksum<<<sgrid, block, 0, stream>>>(rowfirst, N, bsum);
+        WFS_LAUNCH_CHECK();
+        k_scan_top<<<dim3(1), block, 0, stream>>>(bsum, p.nscan, info);      // info[0] = M
+        WFS_LAUNCH_CHECK();
+        k_scan_apply<<<sgrid, block, 0, stream>>>(rowfirst, N, bsum, rowbase);
+        WFS_LAUNCH_CHECK();
+    }
+    long long h[4];
+    WFS_HIP_CHECK(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
+    WFS_HIP_CHECK(hipStreamSynchronize(stream));
+    WFS_REQUIRE(h[2] == 0, WFS_EINVAL, "an index row lies outside batch_size/spatial_shape");
+    host_info[0] = g->subm ? N : h[0];
+    host_info[1] = h[1];
+    return WFS_OK;
+}
+
+extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, int64_t N, int64_t M,
+                                 int32_t *nbr_out, int32_t *out_indices, int32_t *nbr_in, int32_t *indice_pairs,
+                                 int32_t *indice_pair_num, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)indices;
+    WFS_REQUIRE(g, WFS_EINVAL, "NULL geometry");
+    if (N == 0) {
+        if (indice_pair_num) WFS_HIP_CHECK(hipMemsetAsync(indice_pair_num, 0, (size_t)g->K * 4, stream));
+        return WFS_OK;
+    }
+    WFS_REQUIRE(nbr_out && workspace, WFS_EINVAL, "NULL device pointer");
+    Plan p;
+    make_plan(g, N, &p);
+    WFS_REQUIRE(workspace_bytes >= p.total, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, p.total);
+    WfsTimerScope timer(WFS_TIMER_RULEBOOK, stream);
+    char *ws = (char *)workspace;
+    p.tbl.keys = (int *)(ws + p.off_keys);
+    dim3 grid((unsigned)wfs_cdiv(N, TB)), block(TB);
+    if (nbr_in && M > 0) WFS_HIP_CHECK(hipMemsetAsync(nbr_in, 0xFF, (size_t)g->K * M * 4, stream));
+    if (!g->subm) {
+        WFS_REQUIRE(out_indices || M == 0, WFS_EINVAL, "out_indices is NULL");
+        unsigned long long *ticket = (unsigned long long *)(ws + p.off_ticket);
+        int *slot_id = (int *)(ws + p.off_slot_id);
+        int *rowbase = (int *)(ws + p.off_rowbase);
+        k_conv_assign<<<grid, block, 0, stream>>>(p.geo, N, nbr_out, ticket, rowbase, p.tbl, slot_id, out_indices);
+        WFS_LAUNCH_CHECK();
+        k_conv_finalize<<<grid, block, 0, stream>>>(g->K, N, M, nbr_out, slot_id, nbr_in);
+        WFS_LAUNCH_CHECK();
+    } else if (nbr_in) {
+        k_invert_table<<<grid, block, 0, stream>>>(g->K, N, M, nbr_out, nbr_in);
+        WFS_LAUNCH_CHECK();
+    }
+    if (indice_pairs || indice_pair_num) {
+        WFS_REQUIRE(indice_pair_num, WFS_EINVAL, "indice_pair_num is required with indice_pairs");
+        int *tcount = (int *)(ws + p.off_tcount);
+        k_compact_count<<<grid, block, 0, stream>>>(g->K, N, p.ntiles, nbr_out, tcount);
+        WFS_LAUNCH_CHECK();
+        k_compact_scan<<<dim3((unsigned)g->K), block, 0, stream>>>(p.ntiles, tcount, indice_pair_num);
+        WFS_LAUNCH_CHECK();
+        if (indice_pairs) {
+            k_compact_write<<<grid, block, 0, stream>>>(g->K, N, p.ntiles, nbr_out, tcount, indice_pair_num,
+                                                        indice_pairs);
+            WFS_LAUNCH_CHECK();
+        }
+    }
+    return WFS_OK;
+}

@@ -1,0 +1,177 @@
+"""Autograd functions over libwfsparse: counterpart of ``spconv.functional`` (spconv 1.2.1,
+SURVEY.md A.4: ``indice_conv`` / ``indice_subm_conv`` / ``indice_inverse_conv`` and their backward).
+
+All three are the same output-stationary gather kernel with a different table (include/wfsparse.h):
+
+    mode      forward table (rows R)        dX table (rows)          dW stationary / gathered
+    conv      nbr_in  [K,M]  gathers X[N]   nbr_out [K,N] dY[M]      S = X [N],  G = dY, nbr_out
+    subm      nbr_out mirrored (or nbr_in)  nbr_out [K,N] dY[N]      S = X [N],  G = dY, nbr_out
+    inverse   nbr_out [K,N]  gathers X[M]   nbr_in  [K,M] dY[N]      S = dY [N], G = X,  nbr_out (swap)
+
+With duplicate input coordinates the inverse of nbr_out is not a function; the two products that
+need it (conv/subm forward, inverse dX) then use the atomic scatter form.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+CONV, SUBM, INVERSE = 0, 1, 2
+
+
+def _features_ok(t):
+    if not t.is_cuda:
+        raise RuntimeError("waveformml_amd.spconv: features must be on the GPU (there is no CPU path)")
+    return t.contiguous()
+
+
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, out_dtype=None):
+    """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w)."""
+    lib = _lib.load()
+    Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
+    Cy = Cw_in if transpose_w else Cw_out
+    Y = torch.empty((R, Cy), dtype=X.dtype, device=X.device)
+    assert W.dtype == torch.float32 and W.is_contiguous()
+    assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
+    assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
+    _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
+                                   _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
+                                   _lib.dtype_code(X), _lib.stream_ptr()))
+    return Y
+
+
+def scatter_conv(table, K, identity_k, R, X, W, transpose_w, n_out, bias):
+    """fp32-atomic form for duplicate coordinates: Y[table[k, r]] += X[r] . W[k]."""
+    lib = _lib.load()
+    Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
+    Cy = Cw_in if transpose_w else Cw_out
+    Y = torch.zeros((n_out, Cy), dtype=torch.float32, device=X.device)
+    if bias is not None:
+        Y += bias
+    assert table.dtype == torch.int32 and table.shape == (K, R)
+    _lib.check(lib.wfs_scatter_conv(_lib.ptr(table), K, identity_k, R, _lib.ptr(X), X.shape[1], _lib.ptr(W), Cw_in,
+                                    Cw_out, 1 if transpose_w else 0, _lib.ptr(Y), _lib.dtype_code(X),
+                                    _lib.stream_ptr()))
+    return Y.to(X.dtype)
+
+
+def gather_dw(table, K, identity_k, R, S, G, swap):
+    """dW[k,a,b] = sum_r S[r,a] G[table[k,r], b]  (swap: dW[k,b,a])."""
+    lib = _lib.load()
+    Cs, Cg = int(S.shape[1]), int(G.shape[1])
+    dW = torch.empty((K, Cg, Cs) if swap else (K, Cs, Cg), dtype=torch.float32, device=S.device)
+    assert S.dtype == G.dtype and S.shape[0] == R
+    assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
+    nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
+    _lib.check(lib.wfs_gather_dw(_lib.ptr(table), K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0], Cg,
+                                 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
+                                 _lib.stream_ptr()))
+    return dW
+
+
+class SparseConvFunction(Function):
+    """features [n_in, Cin], filters [*k, Cin, Cout] fp32, bias [Cout] or None -> [n_out, Cout]."""
+
+    @staticmethod
+    def forward(ctx, features, filters, bias, rulebook, mode):
+        rb = rulebook
+        features = _features_ok(features)
+        K = rb.K
+        W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        ident = rb.centre_k if rb.subm else -1
+        if mode == INVERSE:
+            assert features.shape[0] == rb.M, "inverse conv input must be the coupled conv's output set"
+            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b)
+        elif rb.has_dup:
+            out = scatter_conv(rb.nbr_out, K, ident, rb.N, features, W, False, rb.M, b)
+        else:
+            assert features.shape[0] == rb.N
+            table, kmap = rb.table_by_out()
+            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b)
+        ctx.save_for_backward(features, filters, bias)
+        ctx.rb, ctx.mode = rb, mode
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, filters, bias = ctx.saved_tensors
+        rb, mode = ctx.rb, ctx.mode
+        K = rb.K
+        dY = grad_output.contiguous()
+        if dY.dtype != features.dtype:
+            dY = dY.to(features.dtype)
+        W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
+        ident = rb.centre_k if rb.subm else -1
+        dX = dW = db = None
+        if mode == INVERSE:
+            if ctx.needs_input_grad[0]:
+                if rb.has_dup:
+                    dX = scatter_conv(rb.nbr_out, K, ident, rb.N, dY, W, True, rb.M, None)
+                else:
+                    dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None)
+            if ctx.needs_input_grad[1]:
+                dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True)
+        else:
+            if ctx.needs_input_grad[0]:
+                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None)
+            if ctx.needs_input_grad[1]:
+                dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False)
+        if dW is not None:
+            dW = dW.reshape(filters.shape).to(filters.dtype)
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = dY.float().sum(0).to(bias.dtype)
+        return dX, dW, db, None, None
+
+
+class ToDenseFunction(Function):
+    """SparseConvTensor.dense(): [M, C] -> [B, C, *spatial] (A.1)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, spatial_shape, batch_size, unique):
+        lib = _lib.load()
+        features = _features_ok(features)
+        indices = indices.contiguous()
+        M, C = features.shape
+        ndim = indices.shape[1] - 1
+        spatial = [int(s) for s in spatial_shape]
+        out = torch.zeros([int(batch_size), C] + spatial, dtype=features.dtype, device=features.device)
+        winner = None
+        if not unique:
+            cells = int(batch_size)
+            for s in spatial:
+                cells *= s
+            winner = torch.empty((cells,), dtype=torch.int32, device=features.device)
+        _lib.check(lib.wfs_to_dense(_lib.ptr(features), _lib.ptr(indices), M, ndim, _lib.i32_array(spatial),
+                                    int(batch_size), C, _lib.ptr(out), _lib.ptr(winner), _lib.dtype_code(features),
+                                    _lib.stream_ptr()))
+        ctx.save_for_backward(indices)
+        ctx.meta = (spatial, int(batch_size), M, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        (indices,) = ctx.saved_tensors
+        spatial, batch_size, M, C = ctx.meta
+        dY = grad_output.contiguous()
+        dX = torch.empty((M, C), dtype=dY.dtype, device=dY.device)
+        _lib.check(lib.wfs_to_dense_bwd(_lib.ptr(dY), _lib.ptr(indices), M, len(spatial), _lib.i32_array(spatial),
+                                        batch_size, C, _lib.ptr(dX), _lib.dtype_code(dY), _lib.stream_ptr()))
+        return dX, None, None, None, None
+
+
+def indice_conv(features, filters, bias, rulebook):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV)
+
+
+def indice_subm_conv(features, filters, bias, rulebook):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM)
+
+
+def indice_inverse_conv(features, filters, bias, rulebook):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE)

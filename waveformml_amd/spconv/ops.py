@@ -1,0 +1,186 @@
+"""Rulebook front door: counterpart of ``spconv.ops`` (spconv 1.2.1).
+
+``get_indice_pairs`` keeps spconv's signature and return value (bit-identical to its CPU algorithm,
+A.3).  The modules in this package use ``build_rulebook`` instead, which returns a :class:`Rulebook`
+holding the gather tables libwfsparse's compute kernels consume (include/wfsparse.h) and
+materialises spconv's ``indice_pairs`` encoding only when somebody asks for it.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _listify(v, ndim):
+    if isinstance(v, (list, tuple, np.ndarray)):
+        v = [int(x) for x in v]
+        assert len(v) == ndim, "expected %d values, got %s" % (ndim, v)
+        return v
+    if torch.is_tensor(v):
+        return _listify(v.tolist(), ndim)
+    return [int(v)] * ndim
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    ndim = len(input_size)
+    out = []
+    for i in range(ndim):
+        size = (int(input_size[i]) + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(int(input_size[i]) if kernel_size[i] == -1 else size)
+    return out
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    ndim = len(input_size)
+    out = []
+    for i in range(ndim):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        out.append((int(input_size[i]) - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i])
+    return out
+
+
+class Rulebook(object):
+    """Device-resident rulebook of one sparse convolution geometry.
+
+    nbr_out int32 [K, N]: output row of (input row j, offset k) or -1
+    nbr_in  int32 [K, M]: input row of (output row i, offset k) or -1; for SubM with odd kernels and
+                          dilation 1 it is nbr_out with the k axis mirrored (``kmap``), not stored.
+    """
+
+    def __init__(self):
+        self.geometry = None
+        self.N = self.M = self.K = 0
+        self.subm = False
+        self.has_dup = False
+        self.indices = None          # input indices [N, D+1]
+        self.out_indices = None      # [M, D+1] (SubM: the input indices)
+        self.nbr_out = None
+        self.nbr_in = None
+        self.kmap_in = None          # ctypes int32[K] or None
+        self.centre_k = -1           # SubM: offset computed as a plain X.W[k] (spconv's k*), else -1
+        self.out_spatial_shape = None
+        self._pairs = None
+        self._pair_num = None
+
+    # gather table addressed by OUTPUT rows, for the forward of conv / SubM
+    def table_by_out(self):
+        if self.nbr_in is not None:
+            return self.nbr_in, None
+        return self.nbr_out, self.kmap_in
+
+    def _emit_pairs(self, want_pairs):
+        lib = _lib.load()
+        dev = self.indices.device
+        if self._pair_num is None or (want_pairs and self._pairs is None):
+            num = torch.empty((self.K,), dtype=torch.int32, device=dev)
+            pairs = torch.empty((2, self.K, self.N), dtype=torch.int32, device=dev) if want_pairs else None
+            if self.N == 0:
+                num.zero_()
+            else:
+                # a finished rulebook is compacted with NULL nbr_in / out_indices under SubM rules, so
+                # that emit runs only the compaction kernels (they read nbr_out and the tile counters)
+                cg = self._compact_geometry()
+                nbytes = lib.wfs_rulebook_workspace_bytes(ctypes.byref(cg), self.N)
+                ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
+                _lib.check(lib.wfs_rulebook_emit(ctypes.byref(cg), _lib.ptr(self.indices),
+                                                 self.N, self.M, _lib.ptr(self.nbr_out), None, None,
+                                                 _lib.ptr(pairs), _lib.ptr(num), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr()))
+            self._pair_num = num
+            if want_pairs:
+                self._pairs = pairs
+
+    def _compact_geometry(self):
+        # compaction only reads nbr_out; a SubM-flagged copy of the geometry makes emit skip the
+        # regular-conv numbering kernels (they already ran)
+        g = _lib.Geometry()
+        ctypes.memmove(ctypes.byref(g), ctypes.byref(self.geometry), ctypes.sizeof(g))
+        g.subm = 1
+        return g
+
+    @property
+    def indice_pair_num(self):
+        self._emit_pairs(False)
+        return self._pair_num
+
+    @property
+    def indice_pairs(self):
+        self._emit_pairs(True)
+        return self._pairs
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
+                   known_unique=None):
+    """Builds the device rulebook.  ``known_unique``: True if the caller knows the index rows are
+    distinct sites (skips the duplicate check a regular conv would otherwise run once)."""
+    if not indices.is_cuda:
+        raise RuntimeError("waveformml_amd.spconv: indices must be on the GPU (no CPU path)")
+    if indices.dtype != torch.int32:
+        raise RuntimeError("waveformml_amd.spconv: indices must be int32")
+    indices = indices.contiguous()
+    lib = _lib.load()
+    N, ndim = indices.shape[0], indices.shape[1] - 1
+    spatial_shape = [int(s) for s in spatial_shape]
+    g = _lib.make_geometry(ndim, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    rb = Rulebook()
+    rb.geometry, rb.N, rb.K, rb.subm, rb.indices = g, N, int(g.K), bool(subm), indices
+    rb.out_spatial_shape = [int(g.out_shape[i]) for i in range(ndim)]
+    dev = indices.device
+    stream = _lib.stream_ptr()
+    nbytes = lib.wfs_rulebook_workspace_bytes(ctypes.byref(g), N)
+    ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
+    rb.nbr_out = torch.empty((rb.K, N), dtype=torch.int32, device=dev)
+    info = (ctypes.c_int64 * 2)(0, 0)
+    _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
+                                     ws.numel(), info, stream))
+    rb.M = int(info[0])
+    rb.has_dup = bool(info[1])
+    symmetric = all(int(g.ksize[i]) % 2 == 1 and int(g.dilation[i]) == 1 for i in range(ndim))
+    if subm:
+        rb.out_indices = indices
+        if symmetric:
+            rb.kmap_in = _lib.i32_array([rb.K - 1 - k for k in range(rb.K)])
+            rb.centre_k = rb.K // 2
+        else:
+            rb.nbr_in = torch.empty((rb.K, rb.M), dtype=torch.int32, device=dev)
+            _lib.check(lib.wfs_rulebook_emit(ctypes.byref(g), _lib.ptr(indices), N, rb.M, _lib.ptr(rb.nbr_out), None,
+                                             _lib.ptr(rb.nbr_in), None, None, _lib.ptr(ws), ws.numel(), stream))
+        if rb.has_dup or not symmetric:
+            # spconv computes offset k* = argmax(indice_pair_num) as a plain X.W[k*] (A.4); with
+            # distinct sites and an odd kernel that is the centre, otherwise it has to be looked up
+            rb.centre_k = int(np.argmax(rb.indice_pair_num.cpu().numpy())) if N > 0 else 0   # first max, as A.4
+    else:
+        if known_unique is None and N > 0:
+            gs = _lib.make_geometry(ndim, batch_size, spatial_shape, [1] * ndim, [1] * ndim, [0] * ndim,
+                                    [1] * ndim, True)
+            nb2 = lib.wfs_rulebook_workspace_bytes(ctypes.byref(gs), N)
+            ws2 = torch.empty((max(int(nb2), 1),), dtype=torch.uint8, device=dev)
+            info2 = (ctypes.c_int64 * 2)(0, 0)
+            _lib.check(lib.wfs_indices_check(ctypes.byref(gs), _lib.ptr(indices), N, _lib.ptr(ws2), ws2.numel(),
+                                             info2, stream))
+            rb.has_dup = bool(info2[1])
+        elif known_unique is not None:
+            rb.has_dup = not known_unique
+        rb.out_indices = torch.empty((rb.M, ndim + 1), dtype=torch.int32, device=dev)
+        rb.nbr_in = torch.empty((rb.K, rb.M), dtype=torch.int32, device=dev)
+        _lib.check(lib.wfs_rulebook_emit(ctypes.byref(g), _lib.ptr(indices), N, rb.M, _lib.ptr(rb.nbr_out),
+                                         _lib.ptr(rb.out_indices), _lib.ptr(rb.nbr_in), None, None, _lib.ptr(ws),
+                                         ws.numel(), stream))
+    return rb
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                     out_padding=0, subm=False, transpose=False, grid=None, use_hash=False):
+    """spconv.ops.get_indice_pairs: returns (out_indices, indice_pairs [2,K,N], indice_pair_num [K])."""
+    ndim = indices.shape[1] - 1
+    ksize, stride = _listify(ksize, ndim), _listify(stride, ndim)
+    padding, dilation = _listify(padding, ndim), _listify(dilation, ndim)
+    for d, s in zip(dilation, stride):
+        assert any([s == 1, d == 1]), "don't support this."
+    if transpose:
+        raise NotImplementedError("transposed (deconv) rulebooks are not on the PSD path")
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    return rb.out_indices, rb.indice_pairs, rb.indice_pair_num
