@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- waveforms/sec of the LitPSD sparse-conv training step on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): SubMConv3d PSD net on the 14x11 PMT grid x
+256-sample waveforms, Cin 2 -> 32 (+ two 32->32 SubM layers sharing the rulebook, two strided
+SparseConv3d k3 s(1,1,4), ToDense, Linear -> 3 classes), 256 synthetic events per rank per step.
+One step = rulebook build + forward + backward + gradient exchange + SGD step on a batch that is
+already resident in HBM.  value = events (waveform readouts) per second over all ranks.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="events per rank per step")
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--config", default=os.path.join(ROOT, "config", "psd_c2_3d.json"))
+    ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def load_cfg(path, samples):
+    with open(path) as f:
+        cfg = json.load(f)
+    cfg["system_config"]["n_samples"] = samples
+    return cfg
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE %d" % (args.gpus, world)
+
+    from waveformml_amd import _lib
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.config import DictionaryUtility
+    from waveformml_amd.psd.ddp import FlatGradAllReducer, broadcast_parameters
+    from waveformml_amd.psd.lit import LitPSD
+    from waveformml_amd.spconv import functional as Fsp
+    _lib.load()
+
+    cfg_dict = load_cfg(args.config, args.samples)
+    torch.manual_seed(1234)
+    module = LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg_dict))).to(dev)
+    module.train()
+    broadcast_parameters(module)
+    init_state = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    opt = module.configure_optimizers()
+    optimizer = opt[0][0] if isinstance(opt, tuple) else opt
+    reducer = FlatGradAllReducer(module.model.parameters())
+
+    # synthetic batch, resident in HBM before the timed region (weak scaling: fixed events per rank)
+    c, f, y = synthetic.generate(args.batch, args.samples, cfg_dict["system_config"]["n_type"], seed=1234, rank=rank)
+    fdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    coords = torch.from_numpy(c).to(dev)
+    feats = torch.from_numpy(f).to(dev).to(fdtype)
+    labels = torch.from_numpy(y).to(dev)
+    batch = ([coords, feats], labels)
+
+    def step():
+        reducer.reset()
+        loss = module.training_step(batch, 0)
+        loss.backward()
+        reducer.finish()
+        optimizer.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # parity snapshot on the un-trained weights (rank 0, N=1): GPU logits/loss for the CPU leg below
+    with torch.no_grad():
+        module.eval()
+        logits0 = module.model([coords.clone(), feats.clone()]).float().cpu()
+        module.train()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_roofline:
+        _lib.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timers = {}
+    if not args.no_roofline:
+        for name, tid in (("gather_conv", _lib.TIMER_GATHER_CONV), ("gather_dw", _lib.TIMER_GATHER_DW),
+                          ("rulebook", _lib.TIMER_RULEBOOK)):
+            timers[name] = _lib.timing_read(tid)
+        _lib.timing_enable(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    result = None
+    if rank == 0:
+        value = args.batch * world * args.steps / elapsed
+        result = {
+            "metric": "waveforms/sec (LitPSD sparse-conv training step)", "value": value, "unit": "events/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "SubMConv3d PSD net, 14x11 PMT grid x %d samples, Cin=2 Cout=32, "
+                                   "%d events/rank/step, rulebook rebuilt every step" % (args.samples, args.batch),
+                       "active_voxels_per_rank": int(coords.shape[0]), "global_batch": args.batch * world,
+                       "parallelism": "dp%d" % world, "final_loss": final_loss},
+        }
+        # ---- roofline of the dominant kernel: algorithmic bytes (accounting pass) / measured duration
+        if not args.no_roofline:
+            Fsp.ACCOUNT = []
+            step()
+            torch.cuda.synchronize()
+            acct, Fsp.ACCOUNT = Fsp.ACCOUNT, None
+            per_kind = {}
+            for a in acct:
+                d = per_kind.setdefault(a["kind"], {"bytes": 0, "flops": 0, "launches": 0})
+                d["bytes"] += a["bytes"]
+                d["flops"] += a["flops"]
+                d["launches"] += 1
+            dom = max(("gather_conv", "gather_dw"), key=lambda k: timers[k][0])
+            ms, n = timers[dom]
+            by = per_kind.get(dom, {"bytes": 0, "flops": 0, "launches": 1})
+            avg_ms = ms / max(n, 1)
+            bytes_per_launch = by["bytes"] / max(by["launches"], 1)
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                  "avg_launch_us": avg_ms * 1e3, "launches_per_step": by["launches"],
+                                  "algorithmic_bytes_per_launch": bytes_per_launch,
+                                  "tflops": by["flops"] / max(by["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                                  "per_step_ms": {k: timers[k][0] / args.steps for k in timers}}
+        # ---- CPU baseline: the oracle's spconv-Native-algo restatement on the host cores, same batch
+        if world == 1 and args.cpu_steps > 0:
+            result["cpu_baseline"], parity = cpu_baseline(cfg_dict, init_state, c, f, y, args.cpu_steps, logits0)
+            result["parity"] = parity
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg_dict, init_state, c, f, y, n_steps, gpu_logits):
+    """Times the CPU restatement of the reference's cpuonly path (oracle/spconv.py: per-offset gather ->
+    torch.mm -> scatter-add under the SparseSequential loop, fp32, all host cores) on the same batch and
+    the same initial weights, and diffs its logits with the GPU's."""
+    from waveformml_amd.psd.config import DictionaryUtility
+    from waveformml_amd.psd.lit import LitPSD
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = copy.deepcopy(cfg_dict)
+    cfg["net_config"]["imports"] = ["oracle.spconv" if m == "waveformml_amd.spconv" else m
+                                    for m in cfg["net_config"]["imports"]]
+    ref = LitPSD(DictionaryUtility.to_object(cfg))
+    ref.load_state_dict(init_state)
+    batch = ([torch.from_numpy(c), torch.from_numpy(f)], torch.from_numpy(y))
+    ref.eval()
+    with torch.no_grad():
+        logits = ref.model([batch[0][0].clone(), batch[0][1].clone()])
+    scale = float(logits.abs().max())
+    parity = {"max_abs_logit_diff": float((logits - gpu_logits).abs().max()), "logit_scale": scale,
+              "max_rel_logit_diff": float((logits - gpu_logits).abs().max()) / max(scale, 1e-30)}
+    ref.train()
+    opt = ref.configure_optimizers()
+    optimizer = opt[0][0] if isinstance(opt, tuple) else opt
+
+    def step():
+        optimizer.zero_grad()
+        loss = ref.training_step(([batch[0][0].clone(), batch[0][1]], batch[1]), 0)
+        loss.backward()
+        optimizer.step()
+
+    step()                                   # warm-up
+    times = []
+    for _ in range(n_steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    nev = len(y)
+    return ({"value": nev / med, "unit": "events/s", "cores": cores, "kind": "port",
+             "sample": "%d timed training steps (after 1 warm-up) on the same %d-event batch, median; "
+                       "restatement of spconv 1.2.1's Native CPU algorithm, fp32, torch threads = %d"
+                       % (n_steps, nev, cores), "ms_per_step": med * 1e3}, parity)
+
+
+if __name__ == "__main__":
+    main()

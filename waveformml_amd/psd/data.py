@@ -1,0 +1,73 @@
+"""Batch assembly for the PSD path: mirror of the reference's ``collate_fn``
+(src/engineering/PSDDataModule.py:10-20) plus a synthetic in-memory dataset with the item structure
+of ``HDF5Dataset.__getitem__`` (src/datasets/HDF5Dataset.py:186-217: ONE item = one file's event
+range, ``[[coords, feats], labels]`` with event ids starting at 0).
+"""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import synthetic
+
+
+def collate_fn(batch):
+    """Concatenate per-item COO chunks; event ids of item i>0 are shifted by the number of events
+    before it -- IN PLACE on column 2, like the reference (which hard-codes column 2 even for the
+    4-column 3-D layout, SURVEY.md 7 "reference quirks"; ``event_column`` below lifts that for callers
+    that need the 3-D batch column, see collate_fn_3d)."""
+    return _collate(batch, 2)
+
+
+def collate_fn_3d(batch):
+    """The same collate with the event id in column 3 (x, y, t, evt), which is what a 3-D
+    ``SPConvNet`` reads its batch size from (reference src/models/SPConvNet.py:63)."""
+    return _collate(batch, 3)
+
+
+def _collate(batch, event_column):
+    offset = 0
+    for i, b in enumerate(batch):
+        if i > 0:
+            b[0][0][:, event_column] += offset
+        offset += b[1].size()[0]
+    coords = torch.cat([b[0][0] for b in batch])
+    if isinstance(batch[0][0][1], list):       # additional per-row fields
+        feats = [torch.cat([b[0][1][i] for b in batch]) for i in range(len(batch[0][0][1]))]
+    else:
+        feats = torch.cat([b[0][1] for b in batch])
+    return [coords, feats], torch.cat([b[1] for b in batch])
+
+
+class SyntheticPulseDataset(Dataset):
+    """``n_items`` chunks of ``events_per_item`` synthetic events each (a chunk stands for one HDF5 file's
+    event range); deterministic in (seed, rank, item)."""
+
+    def __init__(self, n_items, events_per_item, n_samples, n_type=3, layout="3d", seed=1234, rank=0,
+                 use_half=False):
+        self.n_items, self.events_per_item = n_items, events_per_item
+        self.n_samples, self.n_type, self.layout = n_samples, n_type, layout
+        self.seed, self.rank = seed, rank
+        self.valtype = torch.float16 if use_half else torch.float32
+
+    def __len__(self):
+        return self.n_items
+
+    def __getitem__(self, index):
+        c, f, y = synthetic.generate(self.events_per_item, self.n_samples, self.n_type,
+                                     seed=self.seed + 7919 * index, rank=self.rank, layout=self.layout)
+        return [torch.from_numpy(c), torch.from_numpy(f).type(self.valtype)], torch.from_numpy(y)
+
+
+def make_loader(dataset, items_per_batch, num_workers=0, shuffle=False, pin_memory=True):
+    fn = collate_fn_3d if getattr(dataset, "layout", "2d") == "3d" else collate_fn
+    return DataLoader(dataset, batch_size=items_per_batch, shuffle=shuffle, num_workers=num_workers,
+                      collate_fn=fn, pin_memory=pin_memory)
+
+
+def to_device(batch, device, feature_dtype=None, non_blocking=True):
+    (c, f), y = batch
+    c = c.to(device, non_blocking=non_blocking)
+    f = f.to(device, non_blocking=non_blocking)
+    if feature_dtype is not None:
+        f = f.to(feature_dtype)
+    return [c, f], y.to(device, non_blocking=non_blocking)

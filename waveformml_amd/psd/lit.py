@@ -1,0 +1,89 @@
+"""``LitPSD``: host-side mirror of the reference's LightningModule for PSD classification
+(src/engineering/LitBase.py:13-55, src/engineering/LitPSD.py:20-151).
+
+pytorch_lightning 1.2 (which the reference subclasses) is not installable here, so this class keeps
+the same constructor, attributes (``model``, ``criterion``, ``lr``, ``modules``) and step semantics on
+a plain ``nn.Module``; ``waveformml_amd.psd.trainer.Trainer`` plays the part of ``pl.Trainer`` for it.
+Where Lightning IS present, INTEGRATION.md shows the two-line change that makes the reference's own
+LitPSD use the MI355X operators instead (only the ``imports`` list changes).
+"""
+import logging
+
+import torch
+from torch import nn
+
+from .config import DictionaryUtility, ModuleUtility
+
+
+class LitPSD(nn.Module):
+    def __init__(self, config, trial=None):
+        super().__init__()
+        self.trial = trial
+        self.pylog = logging.getLogger(__name__)
+        self.config = config
+        self.n_type = config.system_config.n_type
+        self.lr = config.optimize_config.lr
+        self.modules_util = ModuleUtility(config.net_config.imports + config.dataset_config.imports +
+                                          config.optimize_config.imports)
+        self.model = self.modules_util.retrieve_class(config.net_config.net_class)(config)
+        criterion_class = self.modules_util.retrieve_class(config.net_config.criterion_class)
+        self.criterion = criterion_class(*config.net_config.criterion_params, reduction="mean")
+        self.occlude_index = getattr(config.dataset_config, "occlude_index", None)
+        self.softmax = nn.LogSoftmax(dim=1)
+        self.logged = {}
+
+    def forward(self, x):
+        return self.model(x)
+
+    def log(self, name, value, **kwargs):
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+    def log_dict(self, d, **kwargs):
+        for k, v in d.items():
+            self.log(k, v)
+
+    # reference LitPSD.configure_optimizers, :60-76
+    def configure_optimizers(self):
+        oc = self.config.optimize_config
+        optimizer = self.modules_util.retrieve_class(oc.optimizer_class)(
+            self.model.parameters(), lr=self.lr, **DictionaryUtility.to_dict(oc.optimizer_params))
+        if getattr(oc, "scheduler_class", None):
+            if not hasattr(oc, "scheduler_params"):
+                raise IOError("Optimizer config has a learning scheduler class specified. You must also set "
+                              "lr_schedule_parameters (dictionary of key value pairs).")
+            scheduler = self.modules_util.retrieve_class(oc.scheduler_class)(
+                optimizer, **DictionaryUtility.to_dict(oc.scheduler_params))
+            return [optimizer], [scheduler]
+        return optimizer
+
+    # reference LitPSD.training_step, :94-104
+    def training_step(self, batch, batch_idx):
+        (c, f), target = batch
+        predictions = self.model([c, f])
+        loss = self.criterion.forward(predictions, target)
+        self.log("train_loss", loss, on_epoch=True, prog_bar=True, logger=True)
+        return loss
+
+    # reference LitPSD.validation_step, :106-128
+    def validation_step(self, batch, batch_idx):
+        (c, f), target = batch
+        predictions = self.model([c, f])
+        loss = self.criterion.forward(predictions, target)
+        pred = torch.argmax(self.softmax(predictions), dim=1)
+        acc = (pred == target).float().mean()
+        results = {"val_loss": loss, "val_acc": acc}
+        self.log_dict(results, on_epoch=True, prog_bar=True, logger=True)
+        return results
+
+    # reference LitPSD.test_step, :130-151 (evaluator plumbing is out of scope)
+    def test_step(self, batch, batch_idx):
+        (c, f), target = batch
+        if self.occlude_index:                       # falsy for index 0, exactly as the reference (:134)
+            f[:, self.occlude_index] = 0
+        predictions = self.model([c, f])
+        loss = self.criterion.forward(predictions, target)
+        pred = torch.argmax(self.softmax(predictions), dim=1)
+        acc = (pred == target).float().mean()
+        results = {"test_loss": loss, "test_acc": acc}
+        self.log_dict(results, on_epoch=True, logger=True)
+        return results

@@ -1,0 +1,112 @@
+"""``SPConvNet``: host-side mirror of the reference's PSD network wrapper
+(src/models/SPConvNet.py:29-157).  Builds the sparse stack + linear head from either an explicit
+``algorithm`` list or ``hparams``, wraps ``[coords, feats]`` into a SparseConvTensor (batch column
+moved first), runs the stack, flattens and applies the head.
+
+The operator package is whatever module the config's ``imports`` binds to the key ``spconv``
+(waveformml_amd.spconv on the GPU; tests bind the CPU oracle to compare).
+"""
+import logging
+
+import torch
+from torch import nn
+
+from .blocks import LinearBlock, SparseConv2DBlock
+from .config import DictionaryUtility, ModuleUtility
+
+
+class SPConvNet(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.log = logging.getLogger(__name__)
+        self.system_config = config.system_config
+        self.net_config = config.net_config
+        self.nsamples = self.system_config.n_samples
+        self.ntype = self.system_config.n_type
+        self.modules_util = ModuleUtility(self.net_config.imports)
+        self.spconv = self.modules_util.retrieve_module("spconv")
+        self.sequence_class = self.modules_util.retrieve_class(self.net_config.sequence_class)
+        self._build()
+        net_type = getattr(self.net_config, "net_type", "2DConvolution")
+        if net_type == "3DConvolution":
+            self.ndim = 3
+            self.spatial_size = [14, 11, int(self.nsamples)]
+            self.register_buffer("permute_tensor", torch.LongTensor([3, 0, 1, 2]), persistent=False)
+        else:
+            if net_type != "2DConvolution":
+                self.log.warning("Warning: unknown net_type in net_config: {}".format(net_type))
+            self.ndim = 2
+            self.spatial_size = [14, 11]
+            self.register_buffer("permute_tensor", torch.LongTensor([2, 0, 1]), persistent=False)
+
+    # reference SPConvNet.forward, :54-69
+    def forward(self, x, batch_size=None):
+        coords, feats = x[0], x[1]
+        if hasattr(self, "waveformLayer"):
+            feats = self.waveformLayer(feats.unsqueeze(1)).squeeze(1)
+        if batch_size is None:
+            batch_size = int(coords[-1, -1]) + 1          # one device->host read, as the reference's
+        st = self.spconv.SparseConvTensor(feats, coords[:, self.permute_tensor].contiguous(), self.spatial_size,
+                                          batch_size)
+        out = self.sparseModel(st)
+        out = out.view(-1, self.n_linear)
+        return self.linear(out)
+
+    def _build(self):
+        if hasattr(self.net_config, "algorithm"):
+            self._from_algorithm(self.net_config.algorithm)
+        elif hasattr(self.net_config, "hparams"):
+            try:
+                self._from_hparams(self.net_config.hparams)
+            except AssertionError as e:
+                raise AssertionError("Parameters {0} \nlead to error : {1}".format(
+                    DictionaryUtility.to_dict(self.net_config.hparams), e))
+        else:
+            raise IOError("net_config must contain one of either 'algorithm' or 'hparams'")
+
+    # reference get_algorithm, :124-157: [optional nn.Conv1d front end] sparse layers ... "nn.Linear" head
+    def _from_algorithm(self, algorithm):
+        waveform, sparse, linear = [], [], []
+        in_wf = False
+        for i, f in enumerate(algorithm):
+            if i == 0 and isinstance(f, str) and f == "nn.Conv1d":
+                in_wf = True
+                waveform.append(f)
+                continue
+            if in_wf:
+                if isinstance(f, str) and not f.startswith("nn."):
+                    in_wf = False
+                    sparse.append(f)
+                else:
+                    waveform.append(f)
+                continue
+            if isinstance(f, str) and f == "nn.Linear":
+                linear = algorithm[i:]
+                break
+            sparse.append(f)
+        if waveform:
+            self.waveformLayer = nn.Sequential(*self.modules_util.create_class_instances(waveform))
+        self.sparseModel = self.sequence_class(*self.modules_util.create_class_instances(sparse))
+        self.linear = nn.Sequential(*self.modules_util.create_class_instances(linear))
+        self.n_linear = linear[1][0]
+
+    # reference create_algorithm, :71-109 (2-D only there as well)
+    def _from_hparams(self, hparams):
+        for rq in ["n_dil", "n_conv", "n_lin", "out_planes"]:
+            if not hasattr(hparams, rq):
+                raise IOError(rq + " is required to create the sparse conv algorithm.")
+        size = [14, 11, int(self.nsamples * 2)]
+        if hparams.n_dil > 0:
+            from .tcn import TemporalConvNet
+            params = DictionaryUtility.to_dict(hparams.wf_params) if hasattr(hparams, "wf_params") else {}
+            self.waveformLayer = TemporalConvNet(1, [1] * hparams.n_dil, **params)
+        params = DictionaryUtility.to_dict(hparams.conv_params) if hasattr(hparams, "conv_params") else {}
+        block = SparseConv2DBlock(self.spconv, size[2], hparams.out_planes, hparams.n_conv, size, True, **params)
+        self.sparseModel = block.func
+        self.schedule = block.schedule
+        flat = 1
+        for s in block.out_size:
+            flat *= s
+        self.n_linear = flat
+        head = LinearBlock(flat, self.ntype, hparams.n_lin)
+        self.linear = head.func

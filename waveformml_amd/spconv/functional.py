@@ -20,6 +20,20 @@ from .. import _lib
 
 CONV, SUBM, INVERSE = 0, 1, 2
 
+# bench.py's accounting pass (never active inside a timed region): when this is a list, every launch
+# appends its ALGORITHMIC work as SURVEY.md 8d defines it -- each tensor counted once, the rulebook
+# at 8 bytes per pair (spconv's encoding), filters fp32.
+ACCOUNT = None
+
+
+def _account(kind, table, R, rows_in, c_in, rows_out, c_out, K, cw_in, cw_out, esize):
+    if ACCOUNT is None:
+        return
+    pairs = int((table >= 0).sum().item()) if table is not None else int(R)
+    ACCOUNT.append(dict(kind=kind, pairs=pairs,
+                        bytes=rows_in * c_in * esize + rows_out * c_out * esize + pairs * 8 + K * cw_in * cw_out * 4,
+                        flops=2 * pairs * cw_in * cw_out))
+
 
 def _features_ok(t):
     if not t.is_cuda:
@@ -40,6 +54,7 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, out_dtyp
     _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
                                    _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
                                    _lib.dtype_code(X), _lib.stream_ptr()))
+    _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
     return Y
 
 
@@ -70,6 +85,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap):
     _lib.check(lib.wfs_gather_dw(_lib.ptr(table), K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0], Cg,
                                  1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
                                  _lib.stream_ptr()))
+    _account("gather_dw", table, R, R, Cs, G.shape[0], Cg, K, Cs, Cg, S.element_size())
     return dW
 
 
