@@ -28,6 +28,28 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 
 
+def log(msg):
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %8.2fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,9 +130,11 @@ def main():
         logits0 = module.model([coords.clone(), feats.clone()]).float().cpu()
         module.train()
 
+    log("model + batch ready: %d voxels, eval forward done" % coords.shape[0])
     for _ in range(args.warmup):
         step()
     fence()
+    log("warm-up done")
     if not args.no_roofline:
         _lib.timing_enable(True)
     t0 = time.perf_counter()
@@ -118,6 +142,7 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    log("timed region done: %.3fs for %d steps" % (elapsed, args.steps))
     timers = {}
     if not args.no_roofline:
         for name, tid in (("gather_conv", _lib.TIMER_GATHER_CONV), ("gather_dw", _lib.TIMER_GATHER_DW),
@@ -149,6 +174,7 @@ def main():
             step()
             torch.cuda.synchronize()
             acct, Fsp.ACCOUNT = Fsp.ACCOUNT, None
+            log("accounting pass done")
             per_kind = {}
             for a in acct:
                 d = per_kind.setdefault(a["kind"], {"bytes": 0, "flops": 0, "launches": 0})
@@ -183,8 +209,9 @@ def cpu_baseline(cfg_dict, init_state, c, f, y, n_steps, gpu_logits):
     the same initial weights, and diffs its logits with the GPU's."""
     from waveformml_amd.psd.config import DictionaryUtility
     from waveformml_amd.psd.lit import LitPSD
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log("cpu_baseline: %d host threads (os.cpu_count()=%s)" % (cores, os.cpu_count()))
     cfg = copy.deepcopy(cfg_dict)
     cfg["net_config"]["imports"] = ["oracle.spconv" if m == "waveformml_amd.spconv" else m
                                     for m in cfg["net_config"]["imports"]]
@@ -208,11 +235,17 @@ def cpu_baseline(cfg_dict, init_state, c, f, y, n_steps, gpu_logits):
         optimizer.step()
 
     step()                                   # warm-up
+    log("cpu_baseline: warm-up step done")
     times = []
-    for _ in range(n_steps):
+    budget = time.perf_counter() + 40.0      # bounded sample: stop after ~40 s whatever n_steps says
+    for i in range(n_steps):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
+        log("cpu_baseline: step %d %.3fs" % (i, times[-1]))
+        if time.perf_counter() > budget:
+            break
+    n_steps = len(times)
     med = float(np.median(times))
     nev = len(y)
     return ({"value": nev / med, "unit": "events/s", "cores": cores, "kind": "port",
