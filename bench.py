@@ -124,11 +124,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # parity snapshot on the un-trained weights (rank 0, N=1): GPU logits/loss for the CPU leg below
+    # parity snapshot on the un-trained weights (rank 0, N=1): GPU logits/loss for the CPU leg below.
+    # train mode, so BatchNorm normalises with batch statistics over the active voxels (in eval mode the
+    # fresh running stats leave the activations at ~1e-6 and the logits are just the head's bias).
     with torch.no_grad():
-        module.eval()
-        logits0 = module.model([coords.clone(), feats.clone()]).float().cpu()
-        module.train()
+        logits0 = module.model([coords.clone(), feats.clone()]).float()
+        loss0 = float(module.criterion(logits0, labels).item())
+        logits0 = logits0.cpu()
 
     log("model + batch ready: %d voxels, eval forward done" % coords.shape[0])
     for _ in range(args.warmup):
@@ -195,7 +197,7 @@ def main():
                                   "per_step_ms": {k: timers[k][0] / args.steps for k in timers}}
         # ---- CPU baseline: the oracle's spconv-Native-algo restatement on the host cores, same batch
         if world == 1 and args.cpu_steps > 0:
-            result["cpu_baseline"], parity = cpu_baseline(cfg_dict, init_state, c, f, y, args.cpu_steps, logits0)
+            result["cpu_baseline"], parity = cpu_baseline(cfg_dict, init_state, c, f, y, args.cpu_steps, logits0, loss0)
             result["parity"] = parity
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -203,7 +205,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg_dict, init_state, c, f, y, n_steps, gpu_logits):
+def cpu_baseline(cfg_dict, init_state, c, f, y, n_steps, gpu_logits, gpu_loss):
     """Times the CPU restatement of the reference's cpuonly path (oracle/spconv.py: per-offset gather ->
     torch.mm -> scatter-add under the SparseSequential loop, fp32, all host cores) on the same batch and
     the same initial weights, and diffs its logits with the GPU's."""
@@ -218,13 +220,14 @@ def cpu_baseline(cfg_dict, init_state, c, f, y, n_steps, gpu_logits):
     ref = LitPSD(DictionaryUtility.to_object(cfg))
     ref.load_state_dict(init_state)
     batch = ([torch.from_numpy(c), torch.from_numpy(f)], torch.from_numpy(y))
-    ref.eval()
+    ref.train()
     with torch.no_grad():
         logits = ref.model([batch[0][0].clone(), batch[0][1].clone()])
+        loss = float(ref.criterion(logits, batch[1]).item())
     scale = float(logits.abs().max())
     parity = {"max_abs_logit_diff": float((logits - gpu_logits).abs().max()), "logit_scale": scale,
-              "max_rel_logit_diff": float((logits - gpu_logits).abs().max()) / max(scale, 1e-30)}
-    ref.train()
+              "max_rel_logit_diff": float((logits - gpu_logits).abs().max()) / max(scale, 1e-30),
+              "loss_cpu": loss, "loss_gpu": gpu_loss, "rel_loss_diff": abs(loss - gpu_loss) / max(abs(loss), 1e-30)}
     opt = ref.configure_optimizers()
     optimizer = opt[0][0] if isinstance(opt, tuple) else opt
 
