@@ -271,3 +271,37 @@ def test_small_psd_stack_logits_loss_and_grads():
     loss_g.backward()
     for (name, a), b in zip(net.named_parameters(), ref_net.parameters()):
         _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-5, name)
+
+
+@pytest.mark.parametrize("layer_kind", ["subm32", "conv32_s4", "subm2"])
+def test_layers_at_bench_geometry_fp32(layer_kind):
+    """The bench workload's own layers on synthetic events (many row tiles, every block/XCD range of the
+    MFMA kernels in use): forward, dX and dW against the CPU oracle at 1e-5."""
+    from oracle import spconv as osp
+    from waveformml_amd.psd import synthetic
+    sp = _sp()
+    B, T = 96, 256
+    c, f, _ = synthetic.generate(B, T, 3, seed=4321)
+    idx = np.ascontiguousarray(c[:, [3, 0, 1, 2]])
+    rng = np.random.default_rng(909)
+    cin = 2 if layer_kind == "subm2" else 32
+    feat = f if cin == 2 else rng.standard_normal((len(idx), 32)).astype(np.float32)
+    torch.manual_seed(5)
+    if layer_kind == "conv32_s4":
+        mk = lambda m: m.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, True)
+    else:
+        mk = lambda m: m.SubMConv3d(cin, 32, 3, 1, 0, 1, 1, True, "k")
+    ref_layer = mk(osp)
+    layer = mk(sp).to(DEV)
+    layer.load_state_dict(ref_layer.state_dict())
+    fr = torch.from_numpy(feat).requires_grad_(True)
+    fg = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+    yr = ref_layer(osp.SparseConvTensor(fr, torch.from_numpy(idx), [14, 11, T], B))
+    yg = layer(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), [14, 11, T], B))
+    assert np.array_equal(yg.indices.cpu().numpy(), yr.indices.numpy())
+    _assert_close(yg.features.detach().cpu().numpy(), yr.features.detach().numpy(), 1e-5, "forward")
+    g = rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)
+    yr.features.backward(torch.from_numpy(g))
+    yg.features.backward(torch.from_numpy(g).to(DEV))
+    _assert_close(fg.grad.cpu().numpy(), fr.grad.numpy(), 1e-5, "dX")
+    _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-5, "dW")

@@ -1,0 +1,381 @@
+// conv_mfma.hip -- shape-specialised kernels for the PSD net's layers (fp32 storage, exact fp32 MFMA).
+//
+//   k_gconv32_f32   Cin = Cout = 32 gather conv (forward, and dX with the transposed filter):
+//                   one wave = 32 output rows x 32 channels, v_mfma_f32_32x32x2_f32 (exact fp32 fma
+//                   chain, MI355X_MICROARCH.md "Matrix cores"), all K filters resident in LDS in
+//                   fragment order, per-tile skip of kernel offsets no row of the tile uses.
+//   k_gconv_c2c32   Cin = 2 -> Cout = 32 first layer (VALU; 8 lanes per row -> 1 KiB coalesced stores).
+//   k_gdw32_f32     dW for 32 x 32 channels: rows are the MFMA K dimension, S and gathered G rows are read
+//                   as whole 128-B lines, block-level LDS reduction, deterministic slab reduce.
+//   k_gdw_c2c32     dW for the first layer.
+//
+// Contraction-index trick: the k order inside an MFMA chain is free as long as A and B agree, so lane
+// (r, h = lane>>5) feeds channels h*16 .. h*16+15 of its gathered row (one 64-B contiguous read) instead of
+// the natural even/odd interleave.
+#include "wfs_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct KMap {
+    int v[128];
+};
+
+// ------------------------------------------------------------------------------------------ 32 -> 32
+// LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
+// (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
+template <bool TRANSPOSE_W>
+__global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, KMap kmap, int K, int identity_k,
+                                                      long long R, const float *__restrict__ X,
+                                                      const float *__restrict__ W, const float *__restrict__ bias,
+                                                      float *__restrict__ Y, long long ntiles, long long tiles_per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];
+    const int nthreads = blockDim.x;
+    if (!TRANSPOSE_W) {
+        for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
+            int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;
+            const float *src = W + ((long long)k * 32 + c4 * 4) * 32 + j4 * 4;
+            f32x4 r0 = *(const f32x4 *)(src), r1 = *(const f32x4 *)(src + 32);
+            f32x4 r2 = *(const f32x4 *)(src + 64), r3 = *(const f32x4 *)(src + 96);
+            int h = c4 >> 2, q = c4 & 3;
+            float *dst = sW + ((((k * 2 + h) * 4 + q) * 32) + j4 * 4) * 4;
+            *(f32x4 *)(dst + 0) = f32x4{r0.x, r1.x, r2.x, r3.x};
+            *(f32x4 *)(dst + 4) = f32x4{r0.y, r1.y, r2.y, r3.y};
+            *(f32x4 *)(dst + 8) = f32x4{r0.z, r1.z, r2.z, r3.z};
+            *(f32x4 *)(dst + 12) = f32x4{r0.w, r1.w, r2.w, r3.w};
+        }
+    } else {
+        for (int e = threadIdx.x; e < K * 256; e += nthreads) {
+            int k = e >> 8, j = (e >> 3) & 31, c4 = e & 7;
+            f32x4 v = *(const f32x4 *)(W + ((long long)k * 32 + j) * 32 + c4 * 4);
+            int h = c4 >> 2, q = c4 & 3;
+            *(f32x4 *)(sW + ((((k * 2 + h) * 4 + q) * 32) + j) * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware tile map: blocks with equal blockIdx % 8 share an L2 -> give them one contiguous row range
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const long long t_begin = (long long)xcd * tiles_per_xcd;
+    const long long t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
+    const float bj = bias ? bias[r] : 0.f;
+    for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
+        const long long row = tile * 32 + r;
+        const bool live = row < R;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bj;
+        for (int k = 0; k < K; ++k) {
+            int nb = -1;
+            if (live) nb = (k == identity_k) ? (int)row : table[(long long)kmap.v[k] * R + row];
+            if (__ballot(nb >= 0) == 0ull) continue;          // no row of this tile uses offset k
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            if (nb >= 0) {
+                const f32x4 *xp = (const f32x4 *)(X + (long long)nb * 32 + h * 16);
+                a0 = xp[0];
+                a1 = xp[1];
+                a2 = xp[2];
+                a3 = xp[3];
+            }
+            const f32x4 *bp = (const f32x4 *)(sW + (((k * 2 + h) * 4) * 32 + r) * 4);
+            f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
+#define WFS_MFMA4(a, b)                                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            WFS_MFMA4(a0, b0)
+            WFS_MFMA4(a1, b1)
+            WFS_MFMA4(a2, b2)
+            WFS_MFMA4(a3, b3)
+#undef WFS_MFMA4
+        }
+        // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (orow < R) Y[orow * 32 + r] = acc[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 2 -> 32
+template <typename T>
+__global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ table, KMap kmap, int K, int identity_k,
+                                                     long long R, const T *__restrict__ X,
+                                                     const float *__restrict__ W, const float *__restrict__ bias,
+                                                     T *__restrict__ Y) {
+    __shared__ __attribute__((aligned(16))) float sW[128 * 64];
+    for (int e = threadIdx.x; e < K * 64; e += 256) sW[e] = W[e];
+    __syncthreads();
+    const int rsub = threadIdx.x >> 3, cq = threadIdx.x & 7;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *(const f32x4 *)(bias + cq * 4);
+    for (long long row = (long long)blockIdx.x * 32 + rsub; row < R; row += (long long)gridDim.x * 32) {
+        f32x4 acc = bv;
+        for (int k = 0; k < K; ++k) {
+            int nb = (k == identity_k) ? (int)row : table[(long long)kmap.v[k] * R + row];
+            if (nb < 0) continue;
+            float x0 = wfs_ld(X + (long long)nb * 2), x1 = wfs_ld(X + (long long)nb * 2 + 1);
+            f32x4 w0 = *(const f32x4 *)(sW + k * 64 + cq * 4);
+            f32x4 w1 = *(const f32x4 *)(sW + k * 64 + 32 + cq * 4);
+            acc.x = fmaf(x0, w0.x, acc.x);
+            acc.y = fmaf(x0, w0.y, acc.y);
+            acc.z = fmaf(x0, w0.z, acc.z);
+            acc.w = fmaf(x0, w0.w, acc.w);
+            acc.x = fmaf(x1, w1.x, acc.x);
+            acc.y = fmaf(x1, w1.y, acc.y);
+            acc.z = fmaf(x1, w1.z, acc.z);
+            acc.w = fmaf(x1, w1.w, acc.w);
+        }
+        T *y = Y + row * 32 + cq * 4;
+        wfs_st(y + 0, acc.x);
+        wfs_st(y + 1, acc.y);
+        wfs_st(y + 2, acc.z);
+        wfs_st(y + 3, acc.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dW 32 x 32
+// dW[k][a][b] = sum_r S[r][a] * G[table[k][r]][b].   MFMA: D[i = a][j = b] += A[i][kk] B[kk][j] with the
+// tile's rows as kk:  A[a][kk = 2s+h] = S[row0 + 2s + h][a],  B[kk][b] = G[nb(k, row0 + 2s + h)][b].
+// Both operands are whole 128-B rows per half-wave -> perfectly coalesced loads.
+// Work unit = (block of rows, group of DW_KG offsets {g, g+NG, g+2NG, ...}); the 8 waves of a block take
+// interleaved tiles of the block's row range and are summed through LDS; slabs are reduced afterwards.
+constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator registers)
+constexpr int DW_WAVES = 8;
+
+__global__ void __launch_bounds__(512) k_gdw32_f32(const int *__restrict__ table, int K, int identity_k, long long R,
+                                                   const float *__restrict__ S, const float *__restrict__ G,
+                                                   float *__restrict__ part, int ngroups, long long tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sAcc[];     // [DW_WAVES][DW_KG][32][32]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+    const long long ntiles = (R + 31) >> 5;
+    const long long t_begin = (long long)blockIdx.x * tiles_per_block;
+    const long long t_end = t_begin + tiles_per_block < ntiles ? t_begin + tiles_per_block : ntiles;
+    f32x16 acc[DW_KG];
+#pragma unroll
+    for (int q = 0; q < DW_KG; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    for (long long tile = t_begin + wid; tile < t_end; tile += DW_WAVES) {
+        const long long row0 = tile * 32;
+        // which of this wave's offsets does the tile use at all?  lane r holds row (row0 + r)'s entries
+        int nbv[DW_KG];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < DW_KG; ++q) {
+            int k = g + q * ngroups;
+            int nb = -1;
+            long long row = row0 + j;
+            if (k < K && row < R && h == 0) nb = (k == identity_k) ? (int)row : table[(long long)k * R + row];
+            nbv[q] = nb;
+            any = any || (__ballot(nb >= 0) != 0ull);
+        }
+        if (!any) continue;
+        float a[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            long long row = row0 + 2 * s + h;
+            a[s] = row < R ? S[row * 32 + j] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < DW_KG; ++q) {
+            if (__ballot(nbv[q] >= 0) == 0ull) continue;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                int n0 = __builtin_amdgcn_readlane(nbv[q], 2 * s);
+                int n1 = __builtin_amdgcn_readlane(nbv[q], 2 * s + 1);
+                int nb = h ? n1 : n0;
+                float b = nb >= 0 ? G[(long long)nb * 32 + j] : 0.f;
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc[q], 0, 0, 0);
+            }
+        }
+    }
+    // block reduction through LDS, then one slab per (block, k)
+#pragma unroll
+    for (int q = 0; q < DW_KG; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sAcc[((wid * DW_KG + q) * 32 + arow) * 32 + j] = acc[q][i];
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < DW_KG * 1024; e += 512) {
+        int q = e >> 10, ab = e & 1023;
+        int k = g + q * ngroups;
+        if (k >= K) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < DW_WAVES; ++w) s += sAcc[(w * DW_KG + q) * 1024 + ab];
+        part[((long long)blockIdx.x * K + k) * 1024 + ab] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dW 2 x 32
+// S = X [R, 2] (stationary), G = dY [*, 32] (gathered): part[chunk][k][a][b]; thread = (row slot, b).
+template <typename T>
+__global__ void __launch_bounds__(256) k_gdw_c2c32(const int *__restrict__ table, int K, int identity_k, long long R,
+                                                   long long rows_per_chunk, const T *__restrict__ S,
+                                                   const T *__restrict__ G, float *__restrict__ part) {
+    __shared__ float sRed[8][2][32];
+    const int slot = threadIdx.x >> 5, b = threadIdx.x & 31;
+    const long long r_begin = (long long)blockIdx.x * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < R ? r_begin + rows_per_chunk : R;
+    for (int k = blockIdx.y; k < K; k += gridDim.y) {
+        float acc0 = 0.f, acc1 = 0.f;
+        for (long long row = r_begin + slot; row < r_end; row += 8) {
+            int nb = (k == identity_k) ? (int)row : table[(long long)k * R + row];
+            if (nb < 0) continue;
+            float gv = wfs_ld(G + (long long)nb * 32 + b);
+            acc0 = fmaf(wfs_ld(S + row * 2), gv, acc0);
+            acc1 = fmaf(wfs_ld(S + row * 2 + 1), gv, acc1);
+        }
+        sRed[slot][0][b] = acc0;
+        sRed[slot][1][b] = acc1;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            int a = threadIdx.x >> 5;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += sRed[w][a][b];
+            part[((long long)blockIdx.x * K + k) * 64 + a * 32 + b] = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_slab_reduce(const float *__restrict__ part, long long nslabs, long long per, int K, int Cs, int Cg,
+                              int swap, float *__restrict__ dW) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    float s = 0.f;
+    for (long long c = 0; c < nslabs; ++c) s += part[c * per + e];
+    if (swap) {
+        int k = (int)(e / ((long long)Cs * Cg));
+        int rem = (int)(e % ((long long)Cs * Cg));
+        int a = rem / Cg, b = rem % Cg;
+        dW[((long long)k * Cg + b) * Cs + a] = s;
+    } else {
+        dW[e] = s;
+    }
+}
+
+bool g_attr_done[2] = {false, false};
+
+}  // namespace
+
+// ---- launchers used by gather_conv.hip's C entry points -------------------------------------------------
+bool wfs_mfma_gconv32_ok(int K) { return K >= 1 && K <= 32; }       // K * 4 KiB of LDS <= 128 KiB
+
+int wfs_launch_gconv32_f32(const int *table, const int *kmap, int K, int identity_k, long long R, const float *X,
+                           const float *W, int transpose_w, const float *bias, float *Y, hipStream_t stream) {
+    KMap km;
+    for (int k = 0; k < K; ++k) km.v[k] = kmap ? kmap[k] : k;
+    const long long ntiles = (R + 31) >> 5;
+    // waves per block: enough tiles per SIMD without leaving CUs idle on small inputs
+    int wpb = (int)((ntiles + 255) / 256);
+    wpb = wpb < 4 ? 4 : (wpb > 16 ? 16 : (wpb + 3) / 4 * 4);
+    long long nblk = (ntiles + wpb - 1) / wpb;
+    if (nblk > 256) nblk = 256;
+    nblk = (nblk + 7) / 8 * 8;
+    const long long tiles_per_xcd = (ntiles + 7) / 8;
+    const size_t lds = (size_t)K * 4096;
+    const int which = transpose_w ? 1 : 0;
+    if (!g_attr_done[which]) {
+        const void *fn = transpose_w ? (const void *)k_gconv32_f32<true> : (const void *)k_gconv32_f32<false>;
+        WFS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_attr_done[which] = true;
+    }
+    if (transpose_w)
+        k_gconv32_f32<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, km, K, identity_k, R, X, W,
+                                                                                 bias, Y, ntiles, tiles_per_xcd);
+    else
+        k_gconv32_f32<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, km, K, identity_k, R, X, W,
+                                                                                  bias, Y, ntiles, tiles_per_xcd);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R, const void *X,
+                           const float *W, const float *bias, void *Y, int dtype, hipStream_t stream) {
+    KMap km;
+    for (int k = 0; k < K; ++k) km.v[k] = kmap ? kmap[k] : k;
+    long long nblk = (R + 31) / 32;
+    if (nblk > 8192) nblk = 8192;
+    if (dtype == WFS_F32)
+        k_gconv_c2c32<float><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(table, km, K, identity_k, R,
+                                                                            (const float *)X, W, bias, (float *)Y);
+    else
+        k_gconv_c2c32<wfs_bf16><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(
+            table, km, K, identity_k, R, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+// slabs for the 32x32 dW: blocks over rows; returns the slab count through *nslabs
+static long long dw32_blocks(long long R) {
+    long long ntiles = (R + 31) >> 5;
+    long long nblk = (ntiles + 63) / 64;        // >= 64 tiles (8 per wave) per block
+    if (nblk < 1) nblk = 1;
+    if (nblk > 64) nblk = 64;
+    return nblk;
+}
+static long long dwc2_chunks(long long R) {
+    long long c = (R + 2047) / 2048;
+    if (c < 1) c = 1;
+    if (c > 256) c = 256;
+    return c;
+}
+
+size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
+    if (Cs == 32 && Cg == 32) return (size_t)dw32_blocks(R) * K * 1024 * sizeof(float);
+    if (Cs == 2 && Cg == 32) return (size_t)dwc2_chunks(R) * K * 64 * sizeof(float);
+    return 0;
+}
+
+int wfs_launch_gdw32_f32(const int *table, int K, int identity_k, long long R, const float *S, const float *G,
+                         int swap, float *dW, float *part, hipStream_t stream) {
+    static bool attr = false;
+    const size_t lds = (size_t)DW_WAVES * DW_KG * 1024 * sizeof(float);      // 128 KiB
+    if (!attr) {
+        WFS_HIP_CHECK(hipFuncSetAttribute((const void *)k_gdw32_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024));
+        attr = true;
+    }
+    const long long nblk = dw32_blocks(R);
+    const long long ntiles = (R + 31) >> 5;
+    const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
+    const int ngroups = (K + DW_KG - 1) / DW_KG;
+    k_gdw32_f32<<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), lds, stream>>>(table, K, identity_k, R, S, G, part,
+                                                                                  ngroups, tiles_per_block);
+    WFS_LAUNCH_CHECK();
+    const long long per = (long long)K * 1024;
+    k_slab_reduce<<<dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+int wfs_launch_gdw_c2c32(const int *table, int K, int identity_k, long long R, const void *S, const void *G, int swap,
+                         float *dW, float *part, int dtype, hipStream_t stream) {
+    const long long chunks = dwc2_chunks(R);
+    const long long rows_per_chunk = (R + chunks - 1) / chunks;
+    dim3 grid((unsigned)chunks, (unsigned)(K < 32 ? K : 32));
+    if (dtype == WFS_F32)
+        k_gdw_c2c32<float><<<grid, dim3(256), 0, stream>>>(table, K, identity_k, R, rows_per_chunk, (const float *)S,
+                                                          (const float *)G, part);
+    else
+        k_gdw_c2c32<wfs_bf16><<<grid, dim3(256), 0, stream>>>(table, K, identity_k, R, rows_per_chunk,
+                                                             (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
+    WFS_LAUNCH_CHECK();
+    const long long per = (long long)K * 64;
+    k_slab_reduce<<<dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream>>>(part, chunks, per, K, 2, 32, swap, dW);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}

@@ -214,6 +214,11 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
         WFS_REQUIRE(km.v[k] >= 0 && km.v[k] < K, WFS_EINVAL, "kmap[%d] out of range", k);
     }
     WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
+    if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table)
+        return wfs_launch_gconv32_f32(table, kmap_host, K, identity_k, R, (const float *)X, W, transpose_w, bias,
+                                      (float *)Y, stream);
+    if (Cx == 2 && Cy == 32 && !transpose_w && table)
+        return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, X, W, bias, Y, dtype, stream);
     dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
 #define WFS_GC(T, TR)                                                                                           \
     k_gather_conv<T, TR><<<grid, block, 0, stream>>>(table, km, K, identity_k, R, (const T *)X, Cx, W, Cw_in, \
@@ -253,7 +258,9 @@ extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identit
 }
 
 extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg) {
-    return (size_t)dw_chunks(R) * K * Cs * Cg * sizeof(float);
+    size_t generic = (size_t)dw_chunks(R) * K * Cs * Cg * sizeof(float);
+    size_t fast = wfs_dw_fast_workspace(K, R, Cs, Cg);
+    return generic > fast ? generic : fast;
 }
 
 extern "C" int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *S,
@@ -272,6 +279,11 @@ extern "C" int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k
     size_t need = wfs_gather_dw_workspace_bytes(K, R, Cs, Cg);
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
+    if (dtype == WFS_F32 && Cs == 32 && Cg == 32 && table)
+        return wfs_launch_gdw32_f32(table, K, identity_k, R, (const float *)S, (const float *)G, swap, dW,
+                                    (float *)workspace, stream);
+    if (Cs == 2 && Cg == 32 && table)
+        return wfs_launch_gdw_c2c32(table, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype, stream);
     long long chunks = dw_chunks(R);
     long long rows_per_chunk = wfs_cdiv(wfs_cdiv(R, chunks), DW_ROWS) * DW_ROWS;
     int tiles_a = (int)wfs_cdiv(Cs, DW_TA), tiles_b = (int)wfs_cdiv(Cg, DW_TBB);
