@@ -27,7 +27,7 @@ struct KMap {
 // LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
 // (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
 template <bool TRANSPOSE_W>
-__global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, KMap kmap, int K, int identity_k,
+__global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                       long long R, const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                       float *__restrict__ Y, long long ntiles, long long tiles_per_xcd) {
@@ -63,36 +63,75 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     const long long t_begin = (long long)xcd * tiles_per_xcd;
     const long long t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
     const float bj = bias ? bias[r] : 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
         const long long row = tile * 32 + r;
         const bool live = row < R;
+        const long long rowc = live ? row : R - 1;
+        // ---- phase 1: which kernel offsets does this tile use?  All K table reads are issued together
+        // (unconditional, clamped addresses: a per-element "load or zero" would make hipcc branch around and
+        // wait for every single load), then one ballot each.
+        int v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            int kk = k < K ? k : K - 1;
+            v[k] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+        }
+        unsigned mask = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            bool ok = live && k < K && (k == identity_k || v[k] >= 0);
+            if (__ballot(ok) != 0ull) mask |= 1u << k;
+        }
+        mask = __builtin_amdgcn_readfirstlane(mask);
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = bj;
-        for (int k = 0; k < K; ++k) {
-            int nb = -1;
-            if (live) nb = (k == identity_k) ? (int)row : table[(long long)kmap.v[k] * R + row];
-            if (__ballot(nb >= 0) == 0ull) continue;          // no row of this tile uses offset k
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-            if (nb >= 0) {
-                const f32x4 *xp = (const f32x4 *)(X + (long long)nb * 32 + h * 16);
-                a0 = xp[0];
-                a1 = xp[1];
-                a2 = xp[2];
-                a3 = xp[3];
-            }
-            const f32x4 *bp = (const f32x4 *)(sW + (((k * 2 + h) * 4) * 32 + r) * 4);
-            f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
+        if (mask != 0) {
+            // ---- phase 2: software-pipelined walk over the active offsets: while the 16 MFMAs of offset k
+            // run, the gathered rows of the next active offset and the table entry of the one after are in flight.
+            auto entry = [&](int k) -> int {
+                int t = table[(long long)(mirror ? K - 1 - k : k) * R + rowc];      // L1 hit: phase 1 touched the line
+                t = (k == identity_k) ? (int)rowc : t;
+                return live ? t : -1;
+            };
+            int k_cur = __builtin_ctz(mask);
+            mask &= mask - 1;
+            int nb_cur = entry(k_cur);
+            const f32x4 *xp = (const f32x4 *)(X + (long long)(nb_cur >= 0 ? nb_cur : 0) * 32 + h * 16);
+            f32x4 a0 = xp[0], a1 = xp[1], a2 = xp[2], a3 = xp[3];
+            int k_next = mask ? __builtin_ctz(mask) : k_cur;
+            int nb_next = entry(k_next);
+            while (true) {
+                const f32x4 *xn = (const f32x4 *)(X + (long long)(nb_next >= 0 ? nb_next : 0) * 32 + h * 16);
+                f32x4 n0 = xn[0], n1 = xn[1], n2 = xn[2], n3 = xn[3];
+                unsigned m2 = mask & (mask - 1);
+                int k_nn = m2 ? __builtin_ctz(m2) : k_next;
+                int nb_nn = entry(k_nn);
+                if (nb_cur < 0) a0 = a1 = a2 = a3 = zero4;
+                const f32x4 *bp = (const f32x4 *)(sW + (((k_cur * 2 + h) * 4) * 32 + r) * 4);
+                f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
 #define WFS_MFMA4(a, b)                                                          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-            WFS_MFMA4(a0, b0)
-            WFS_MFMA4(a1, b1)
-            WFS_MFMA4(a2, b2)
-            WFS_MFMA4(a3, b3)
+                WFS_MFMA4(a0, b0)
+                WFS_MFMA4(a1, b1)
+                WFS_MFMA4(a2, b2)
+                WFS_MFMA4(a3, b3)
 #undef WFS_MFMA4
+                if (mask == 0) break;
+                mask &= mask - 1;
+                a0 = n0;
+                a1 = n1;
+                a2 = n2;
+                a3 = n3;
+                k_cur = k_next;
+                nb_cur = nb_next;
+                k_next = k_nn;
+                nb_next = nb_nn;
+            }
         }
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -149,10 +188,10 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
 constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator registers)
 constexpr int DW_WAVES = 8;
 
-__global__ void __launch_bounds__(512) k_gdw32_f32(const int *__restrict__ table, int K, int identity_k, long long R,
-                                                   const float *__restrict__ S, const float *__restrict__ G,
-                                                   float *__restrict__ part, int ngroups, long long tiles_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float sAcc[];     // [DW_WAVES][DW_KG][32][32]
+__global__ void __launch_bounds__(512, 2) k_gdw32_f32(const int *__restrict__ table, int K, int identity_k, long long R,
+                                                      const float *__restrict__ S, const float *__restrict__ G,
+                                                      float *__restrict__ part, int ngroups, long long tiles_per_block) {
+    __shared__ float sAcc[DW_KG * 1024];                              // [DW_KG][32][32], 16 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int g = blockIdx.y;
@@ -164,57 +203,70 @@ __global__ void __launch_bounds__(512) k_gdw32_f32(const int *__restrict__ table
     for (int q = 0; q < DW_KG; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    for (int e = threadIdx.x; e < DW_KG * 1024; e += 512) sAcc[e] = 0.f;
     for (long long tile = t_begin + wid; tile < t_end; tile += DW_WAVES) {
         const long long row0 = tile * 32;
-        // which of this wave's offsets does the tile use at all?  lane r holds row (row0 + r)'s entries
+        // lane j holds the table entries of row (row0 + j) for this wave's offsets.  Loads are unconditional
+        // on clamped addresses (see k_gconv32_f32), validity is applied afterwards.
+        const long long trow = row0 + j < R ? row0 + j : R - 1;
         int nbv[DW_KG];
-        bool any = false;
 #pragma unroll
         for (int q = 0; q < DW_KG; ++q) {
             int k = g + q * ngroups;
-            int nb = -1;
-            long long row = row0 + j;
-            if (k < K && row < R && h == 0) nb = (k == identity_k) ? (int)row : table[(long long)k * R + row];
-            nbv[q] = nb;
-            any = any || (__ballot(nb >= 0) != 0ull);
+            int kk = k < K ? k : K - 1;
+            nbv[q] = table[(long long)kk * R + trow];
         }
-        if (!any) continue;
         float a[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             long long row = row0 + 2 * s + h;
-            a[s] = row < R ? S[row * 32 + j] : 0.f;
+            float t = S[(row < R ? row : R - 1) * 32 + j];
+            a[s] = row < R ? t : 0.f;
         }
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < DW_KG; ++q) {
+            int k = g + q * ngroups;
+            int nb = (k == identity_k) ? (int)trow : nbv[q];
+            nb = (k < K && row0 + j < R) ? nb : -1;
+            nbv[q] = nb;
+            any = any || (__ballot(nb >= 0) != 0ull);
+        }
+        if (!any) continue;
 #pragma unroll
         for (int q = 0; q < DW_KG; ++q) {
             if (__ballot(nbv[q] >= 0) == 0ull) continue;
+            float b[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 int n0 = __builtin_amdgcn_readlane(nbv[q], 2 * s);
                 int n1 = __builtin_amdgcn_readlane(nbv[q], 2 * s + 1);
                 int nb = h ? n1 : n0;
-                float b = nb >= 0 ? G[(long long)nb * 32 + j] : 0.f;
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc[q], 0, 0, 0);
+                float t = G[(long long)(nb >= 0 ? nb : 0) * 32 + j];
+                b[s] = nb >= 0 ? t : 0.f;
             }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[q], 0, 0, 0);
         }
     }
-    // block reduction through LDS, then one slab per (block, k)
-#pragma unroll
-    for (int q = 0; q < DW_KG; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
-            sAcc[((wid * DW_KG + q) * 32 + arow) * 32 + j] = acc[q][i];
-        }
+    // deterministic block reduction: waves add their accumulators into LDS one after the other
     __syncthreads();
+    for (int w = 0; w < DW_WAVES; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int q = 0; q < DW_KG; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    sAcc[(q * 32 + arow) * 32 + j] += acc[q][i];
+                }
+        }
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < DW_KG * 1024; e += 512) {
         int q = e >> 10, ab = e & 1023;
         int k = g + q * ngroups;
-        if (k >= K) continue;
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < DW_WAVES; ++w) s += sAcc[(w * DW_KG + q) * 1024 + ab];
-        part[((long long)blockIdx.x * K + k) * 1024 + ab] = s;
+        if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + ab] = sAcc[e];
     }
 }
 
@@ -274,10 +326,8 @@ bool g_attr_done[2] = {false, false};
 // ---- launchers used by gather_conv.hip's C entry points -------------------------------------------------
 bool wfs_mfma_gconv32_ok(int K) { return K >= 1 && K <= 32; }       // K * 4 KiB of LDS <= 128 KiB
 
-int wfs_launch_gconv32_f32(const int *table, const int *kmap, int K, int identity_k, long long R, const float *X,
+int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const float *X,
                            const float *W, int transpose_w, const float *bias, float *Y, hipStream_t stream) {
-    KMap km;
-    for (int k = 0; k < K; ++k) km.v[k] = kmap ? kmap[k] : k;
     const long long ntiles = (R + 31) >> 5;
     // waves per block: enough tiles per SIMD without leaving CUs idle on small inputs
     int wpb = (int)((ntiles + 255) / 256);
@@ -294,10 +344,10 @@ int wfs_launch_gconv32_f32(const int *table, const int *kmap, int K, int identit
         g_attr_done[which] = true;
     }
     if (transpose_w)
-        k_gconv32_f32<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, km, K, identity_k, R, X, W,
+        k_gconv32_f32<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, mirror, K, identity_k, R, X, W,
                                                                                  bias, Y, ntiles, tiles_per_xcd);
     else
-        k_gconv32_f32<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, km, K, identity_k, R, X, W,
+        k_gconv32_f32<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, mirror, K, identity_k, R, X, W,
                                                                                   bias, Y, ntiles, tiles_per_xcd);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
@@ -322,7 +372,7 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
 // slabs for the 32x32 dW: blocks over rows; returns the slab count through *nslabs
 static long long dw32_blocks(long long R) {
     long long ntiles = (R + 31) >> 5;
-    long long nblk = (ntiles + 63) / 64;        // >= 64 tiles (8 per wave) per block
+    long long nblk = (ntiles + 39) / 40;        // ~40 tiles (5 per wave) per block
     if (nblk < 1) nblk = 1;
     if (nblk > 64) nblk = 64;
     return nblk;
@@ -342,18 +392,11 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
 
 int wfs_launch_gdw32_f32(const int *table, int K, int identity_k, long long R, const float *S, const float *G,
                          int swap, float *dW, float *part, hipStream_t stream) {
-    static bool attr = false;
-    const size_t lds = (size_t)DW_WAVES * DW_KG * 1024 * sizeof(float);      // 128 KiB
-    if (!attr) {
-        WFS_HIP_CHECK(hipFuncSetAttribute((const void *)k_gdw32_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          160 * 1024));
-        attr = true;
-    }
     const long long nblk = dw32_blocks(R);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
-    k_gdw32_f32<<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), lds, stream>>>(table, K, identity_k, R, S, G, part,
+    k_gdw32_f32<<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(table, K, identity_k, R, S, G, part,
                                                                                   ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;

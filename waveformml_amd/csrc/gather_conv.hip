@@ -214,8 +214,14 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
         WFS_REQUIRE(km.v[k] >= 0 && km.v[k] < K, WFS_EINVAL, "kmap[%d] out of range", k);
     }
     WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
-    if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table)
-        return wfs_launch_gconv32_f32(table, kmap_host, K, identity_k, R, (const float *)X, W, transpose_w, bias,
+    // the fast kernels know two column maps: identity, and the SubM mirror k -> K-1-k
+    bool is_ident = true, is_mirror = true;
+    for (int k = 0; k < K; ++k) {
+        is_ident = is_ident && km.v[k] == k;
+        is_mirror = is_mirror && km.v[k] == K - 1 - k;
+    }
+    if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror))
+        return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, (const float *)X, W, transpose_w, bias,
                                       (float *)Y, stream);
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
         return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, X, W, bias, Y, dtype, stream);

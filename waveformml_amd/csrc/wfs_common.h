@@ -56,7 +56,7 @@ struct WfsTimerScope {
 
 // shape-specialised launchers (conv_mfma.hip)
 bool wfs_mfma_gconv32_ok(int K);
-int wfs_launch_gconv32_f32(const int *table, const int *kmap, int K, int identity_k, long long R, const float *X,
+int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const float *X,
                            const float *W, int transpose_w, const float *bias, float *Y, hipStream_t stream);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R, const void *X,
                            const float *W, const float *bias, void *Y, int dtype, hipStream_t stream);
