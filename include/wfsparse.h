@@ -149,6 +149,27 @@ int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_
                      int32_t Cx, const float *W, int32_t Cw_in, int32_t Cw_out, int32_t transpose_w,
                      float *Y_accum, int32_t dtype, void *stream);
 
+/* BatchNorm1d (+ReLU) over the active rows ------------------------------------------------------
+ * What spconv.SparseSequential does with the plain nn.BatchNorm1d / nn.ReLU modules the reference
+ * puts after every sparse conv (src/models/SPConvBlocks.py:505-508): applied to .features [N, C],
+ * statistics over the N active rows.  Two launches per direction (column reduction into per-block
+ * partials; elementwise pass whose blocks fold the partials in a fixed order): deterministic.
+ * training != 0: batch statistics (biased variance), running_mean/var (may be NULL) updated with
+ * `momentum` using the unbiased variance, exactly as torch.  training == 0: running statistics.
+ * relu != 0 fuses y = max(0, .).  save_mean / save_invstd [C] are outputs the backward consumes.
+ * gamma / beta may be NULL (affine=False).  C <= 1024.                                           */
+size_t wfs_bn_workspace_bytes(int64_t N, int32_t C);
+
+int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
+                    float *running_mean, float *running_var, float momentum, float eps,
+                    int32_t training, int32_t relu, void *Y, float *save_mean, float *save_invstd,
+                    void *workspace, size_t workspace_bytes, int32_t dtype, void *stream);
+
+int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
+                    const float *beta, const float *save_mean, const float *save_invstd,
+                    int32_t training, int32_t relu, void *dX, float *dgamma, float *dbeta,
+                    void *workspace, size_t workspace_bytes, int32_t dtype, void *stream);
+
 /* SparseConvTensor.dense() -------------------------------------------------------------------
  * Y is [B, C, *spatial] (channels first, contiguous) and must be zero-filled by the caller;
  * rows are assigned, not accumulated.  winner_ws: NULL when coordinates are unique, else int32

@@ -305,3 +305,50 @@ def test_layers_at_bench_geometry_fp32(layer_kind):
     yg.features.backward(torch.from_numpy(g).to(DEV))
     _assert_close(fg.grad.cpu().numpy(), fr.grad.numpy(), 1e-5, "dX")
     _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-5, "dW")
+
+
+@pytest.mark.parametrize("C,relu,dtype", [(32, True, torch.float32), (32, False, torch.float32), (7, True, torch.float32),
+                                          (252, True, torch.float32), (32, True, torch.bfloat16)],
+                         ids=["c32_relu", "c32", "c7_relu", "c252_relu", "c32_relu_bf16"])
+def test_fused_batchnorm_relu_matches_torch(C, relu, dtype):
+    """The fused BatchNorm1d(+ReLU) kernels against torch's own modules on the CPU in fp32 (what the
+    reference's SparseSequential runs), training mode: output, running stats, dX, dgamma, dbeta."""
+    from waveformml_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(1001)
+    N = 5000
+    x = (rng.standard_normal((N, C)) * rng.uniform(0.5, 3.0, C) + rng.uniform(-20, 20, C)).astype(np.float32)
+    g = rng.standard_normal((N, C)).astype(np.float32)
+    torch.manual_seed(3)
+    ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    bn.load_state_dict(ref.state_dict())
+    xin = torch.from_numpy(x).to(dtype).float()          # the rounded values both sides see
+    xr = xin.clone().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(torch.from_numpy(g))
+    xg = xin.to(DEV).to(dtype).requires_grad_(True)
+    assert Fsp.can_fuse_batch_norm(bn, xg)
+    yg = Fsp.batch_norm_relu(xg, bn, relu)
+    yg.backward(torch.from_numpy(g).to(DEV).to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    _assert_close(yg.detach().float().cpu().numpy(), yr.detach().numpy(), tol, "y")
+    _assert_close(bn.running_mean.cpu().numpy(), ref.running_mean.numpy(), 1e-5, "running_mean")
+    _assert_close(bn.running_var.cpu().numpy(), ref.running_var.numpy(), 1e-5, "running_var")
+    assert int(bn.num_batches_tracked) == 1
+    if dtype == torch.float32:
+        # a ReLU mask can flip where |pre-activation| ~ 1e-7; compare with a few-outliers-tolerant metric
+        dx_g, dx_r = xg.grad.cpu().numpy(), xr.grad.numpy()
+        bad = np.abs(dx_g - dx_r) > 1e-5 * np.abs(dx_r).max()
+        assert bad.mean() < 1e-4, bad.mean()
+        _assert_close(bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), 1e-4, "dgamma")
+        _assert_close(bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), 1e-4, "dbeta")
+    # eval mode uses the running statistics
+    bn.eval(), ref.eval()
+    ye = Fsp.batch_norm_relu(xin.to(DEV).to(dtype), bn, relu)
+    yre = torch.relu(ref(xin)) if relu else ref(xin)
+    _assert_close(ye.detach().float().cpu().numpy(), yre.detach().numpy(), tol, "eval y")

@@ -1,0 +1,70 @@
+"""Micro-benchmark of the conv kernels on the bench workload's layers (run on the GPU box).
+usage: python tools/microbench_conv.py [iters]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from waveformml_amd.psd import synthetic
+from waveformml_amd.spconv import ops, functional as Fsp
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+dev = torch.device("cuda:0")
+c, f, y = synthetic.generate(256, 256, 3, seed=1234)
+idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(dev)
+rb = ops.build_rulebook(idx, 256, [14, 11, 256], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True)
+rb1 = ops.build_rulebook(idx, 256, [14, 11, 256], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, known_unique=True)
+N, M1 = rb.N, rb1.M
+X = torch.randn(N, 32, device=dev)
+dY = torch.randn(N, 32, device=dev)
+dY1 = torch.randn(M1, 32, device=dev)
+X2 = torch.randn(N, 2, device=dev)
+W = torch.randn(27, 32, 32, device=dev) * 0.1
+W2 = torch.randn(27, 2, 32, device=dev) * 0.1
+
+
+def timeit(name, fn, nbytes=None):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / iters * 1e3
+    extra = "  %.0f GB/s algorithmic" % (nbytes / us / 1e3) if nbytes else ""
+    print("%-34s %8.1f us%s" % (name, us, extra), flush=True)
+
+
+P = int((rb.nbr_out >= 0).sum())
+P1 = int((rb1.nbr_out >= 0).sum())
+print("N %d  P %d  M1 %d  P1 %d  dbg=%s" % (N, P, M1, P1, os.environ.get("WFS_DBG", "0")))
+t, km = rb.table_by_out()
+by = N * 128 * 2 + P * 8 + 27 * 4096
+timeit("subm fwd 32->32", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None), by)
+timeit("subm dX 32->32", lambda: Fsp.gather_conv(rb.nbr_out, None, 27, rb.centre_k, N, dY, W, True, None), by)
+timeit("subm dW 32x32", lambda: Fsp.gather_dw(rb.nbr_out, 27, rb.centre_k, N, X, dY, False), by)
+by1 = N * 128 + M1 * 128 + P1 * 8 + 27 * 4096
+timeit("conv s4 fwd 32->32", lambda: Fsp.gather_conv(rb1.nbr_in, None, 27, -1, M1, X, W, False, None), by1)
+timeit("conv s4 dX", lambda: Fsp.gather_conv(rb1.nbr_out, None, 27, -1, N, dY1, W, True, None), by1)
+timeit("conv s4 dW", lambda: Fsp.gather_dw(rb1.nbr_out, 27, -1, N, X, dY1, False), by1)
+timeit("subm fwd 2->32", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X2, W2, False, None), N * 136 + P * 8)
+timeit("subm dW 2x32", lambda: Fsp.gather_dw(rb.nbr_out, 27, rb.centre_k, N, X2, dY, False), N * 136 + P * 8)
+timeit("rulebook subm", lambda: ops.build_rulebook(idx, 256, [14, 11, 256], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True))
+timeit("rulebook conv s4", lambda: ops.build_rulebook(idx, 256, [14, 11, 256], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, known_unique=True))
+
+# --- per-offset cost: synthetic tables with exactly 1 / 10 / 27 active offsets in every tile
+ar = torch.arange(N, device=dev, dtype=torch.int32)
+for nact in (1, 10, 27):
+    tb = torch.full((27, N), -1, dtype=torch.int32, device=dev)
+    for k in range(nact):
+        tb[k] = ar
+    timeit("fwd 32->32, %2d active offsets/tile" % nact, lambda: Fsp.gather_conv(tb, None, 27, -1, N, X, W, False, None))
+    timeit("dW 32x32,   %2d active offsets/tile" % nact, lambda: Fsp.gather_dw(tb, 27, -1, N, X, dY, False))
+# measured tile unions of the real tables
+def unions(tab, R):
+    nt = (R + 31) // 32
+    pad = torch.full((27, nt * 32), -1, dtype=torch.int32, device=dev)
+    pad[:, :R] = tab
+    return float((pad.view(27, nt, 32) >= 0).any(2).sum()) / nt
+print("active offsets per 32-row tile: subm %.2f  conv1 nbr_in %.2f  conv1 nbr_out %.2f" % (unions(rb.nbr_out, N), unions(rb1.nbr_in, M1), unions(rb1.nbr_out, N)))

@@ -1,0 +1,374 @@
+// bn.hip -- BatchNorm1d (+ ReLU) over the active rows of a sparse tensor, forward and backward.
+//
+// The reference applies plain nn.BatchNorm1d / nn.ReLU modules to SparseConvTensor.features inside
+// spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508): batch
+// statistics over the N ACTIVE voxels only, per rank (no SyncBN).  Same arithmetic here, in two launches per
+// direction instead of torch's ~5: a column reduction into per-block partials, and an elementwise pass
+// whose every block first folds the partials in a fixed order (deterministic, no atomics, no extra launch).
+//
+//   forward   mean_c, var_c (biased) over rows;  y = max(0, gamma*(x-mean)*invstd + beta)   [ReLU optional]
+//             running_mean/var updated with momentum (unbiased var), as torch does
+//   backward  g = dy * [y > 0];  dbeta = sum g;  dgamma = sum g*xhat;
+//             dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)              (training)
+//             dx = gamma*invstd*g                                           (eval: running statistics)
+#include "wfs_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int MAXC = 1024;
+
+// thread layout of a block: (row slot, channel group of VEC channels); VEC = 4 when C % 4 == 0, else 1
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T *p, float *out) {
+    if constexpr (VEC == 4 && sizeof(T) == 4) {
+        float4 v = *reinterpret_cast<const float4 *>(p);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else if constexpr (VEC == 4) {
+        uint2 v = *reinterpret_cast<const uint2 *>(p);
+        out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xFFFF0000u);
+        out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    } else {
+        out[0] = wfs_ld(p);
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T *p, const float *in) {
+    if constexpr (VEC == 4 && sizeof(T) == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(in[0], in[1], in[2], in[3]);
+    } else if constexpr (VEC == 4) {
+        wfs_bf16 h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wfs_st(&h[i], in[i]);
+        uint2 v;
+        v.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        v.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+        *reinterpret_cast<uint2 *>(p) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) wfs_st(p + i, in[i]);
+    }
+}
+
+// partial[block][2][C]: column sums of (a, b) where
+//   MODE 0 (forward stats):  a = d, b = d*d with d = x - x[row 0] (shifted sums: no cancellation in the variance)
+//   MODE 1 (backward):       a = g, b = g*xhat with g = dy*[gamma*xhat+beta > 0] (relu), xhat = (x-mean)*invstd
+template <typename T, int VEC, int MODE>
+__global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const T *__restrict__ dY, long long N, int C,
+                                                  long long rows_per_block, const float *__restrict__ mean,
+                                                  const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, int relu,
+                                                  float *__restrict__ partial) {
+    __shared__ float red[2][TB][VEC];
+    const int groups = C / VEC, slots = TB / groups;
+    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
+    const int c0 = grp * VEC;
+    float sa[VEC], sb[VEC], m[VEC], is[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sa[i] = sb[i] = m[i] = is[i] = ga[i] = be[i] = 0.f;
+    const bool active = slot < slots;
+    if (active) {
+        if (MODE == 0) {
+            load_vec<T, VEC>(X + c0, m);                      // the shift: row 0
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                m[i] = mean[c0 + i];
+                is[i] = invstd[c0 + i];
+                ga[i] = gamma ? gamma[c0 + i] : 1.f;
+                be[i] = beta ? beta[c0 + i] : 0.f;
+            }
+        }
+        const long long r_begin = (long long)blockIdx.x * rows_per_block;
+        const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
+        for (long long r = r_begin + slot; r < r_end; r += slots) {
+            float x[VEC], g[VEC];
+            load_vec<T, VEC>(X + r * C + c0, x);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float d = x[i] - m[i];
+                    sa[i] += d;
+                    sb[i] = fmaf(d, d, sb[i]);
+                }
+            } else {
+                load_vec<T, VEC>(dY + r * C + c0, g);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float xh = (x[i] - m[i]) * is[i];
+                    float gi = g[i];
+                    if (relu && !(fmaf(ga[i], xh, be[i]) > 0.f)) gi = 0.f;
+                    sa[i] += gi;
+                    sb[i] = fmaf(gi, xh, sb[i]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        red[0][threadIdx.x][i] = sa[i];
+        red[1][threadIdx.x][i] = sb[i];
+    }
+    __syncthreads();
+    if (active && slot == 0) {                       // fold the row slots in a fixed order
+        for (int s = 1; s < slots; ++s)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sa[i] += red[0][s * groups + grp][i];
+                sb[i] += red[1][s * groups + grp][i];
+            }
+        float *p = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            p[c0 + i] = sa[i];
+            p[C + c0 + i] = sb[i];
+        }
+    }
+}
+
+// every block folds partial[0..nblk) in the same order -> identical statistics in every block, no atomics.
+// All 256 threads take part: thread (slice s, channel c) sums partials p = s, s+S, ... and the S slices are
+// then added in slice order.
+__device__ __forceinline__ void fold_partials(const float *partial, int nblk, int C, float *sA, float *sB) {
+    __shared__ float tA[TB], tB[TB];
+    if (C <= TB) {
+        const int S = TB / C;
+        const int c = threadIdx.x % C, sl = threadIdx.x / C;
+        float a = 0.f, b = 0.f;
+        if (sl < S)
+            for (int p = sl; p < nblk; p += S) {
+                a += partial[(long long)p * 2 * C + c];
+                b += partial[(long long)p * 2 * C + C + c];
+            }
+        tA[threadIdx.x] = a;
+        tB[threadIdx.x] = b;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            a = 0.f;
+            b = 0.f;
+            for (int q = 0; q < S; ++q) {
+                a += tA[q * C + threadIdx.x];
+                b += tB[q * C + threadIdx.x];
+            }
+            sA[threadIdx.x] = a;
+            sB[threadIdx.x] = b;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += TB) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < nblk; ++p) {
+                a += partial[(long long)p * 2 * C + c];
+                b += partial[(long long)p * 2 * C + C + c];
+            }
+            sA[c] = a;
+            sB[c] = b;
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long long N, int C, long long rows_per_block,
+                                                 const float *__restrict__ partial, int nblk_partial,
+                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                 float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                 float momentum, float eps, int training, int relu,
+                                                 T *__restrict__ Y, float *__restrict__ save_mean,
+                                                 float *__restrict__ save_invstd) {
+    __shared__ float sA[MAXC], sB[MAXC];       // mean / invstd
+    if (training) {
+        fold_partials(partial, nblk_partial, C, sA, sB);
+        for (int c = threadIdx.x; c < C; c += TB) {
+            float shift = wfs_ld(X + c);
+            float md = sA[c] / (float)N;                       // mean of (x - shift)
+            float var = sB[c] / (float)N - md * md;            // biased, what torch normalises with
+            var = var > 0.f ? var : 0.f;
+            float mean = shift + md;
+            float invstd = rsqrtf(var + eps);
+            sA[c] = mean;
+            sB[c] = invstd;
+            if (blockIdx.x == 0) {
+                save_mean[c] = mean;
+                save_invstd[c] = invstd;
+                if (running_mean) {
+                    float unbiased = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+                }
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += TB) {
+            float mean = running_mean[c], invstd = rsqrtf(running_var[c] + eps);
+            sA[c] = mean;
+            sB[c] = invstd;
+            if (blockIdx.x == 0) {
+                save_mean[c] = mean;
+                save_invstd[c] = invstd;
+            }
+        }
+    }
+    __syncthreads();
+    const int groups = C / VEC, slots = TB / groups;
+    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
+    if (slot >= slots) return;
+    const int c0 = grp * VEC;
+    float m[VEC], is[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        m[i] = sA[c0 + i];
+        is[i] = sB[c0 + i];
+        ga[i] = gamma ? gamma[c0 + i] : 1.f;
+        be[i] = beta ? beta[c0 + i] : 0.f;
+    }
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
+    for (long long r = r_begin + slot; r < r_end; r += slots) {
+        float x[VEC], y[VEC];
+        load_vec<T, VEC>(X + r * C + c0, x);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float v = fmaf(ga[i], (x[i] - m[i]) * is[i], be[i]);      // same expression as the backward's mask
+            y[i] = (relu && !(v > 0.f)) ? 0.f : v;
+        }
+        store_vec<T, VEC>(Y + r * C + c0, y);
+    }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, const T *__restrict__ dY, long long N,
+                                                     int C, long long rows_per_block,
+                                                     const float *__restrict__ partial, int nblk_partial,
+                                                     const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     int training, int relu, T *__restrict__ dX,
+                                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float sA[MAXC], sB[MAXC];       // sum g, sum g*xhat
+    fold_partials(partial, nblk_partial, C, sA, sB);
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += TB) {
+            if (dbeta) dbeta[c] = sA[c];
+            if (dgamma) dgamma[c] = sB[c];
+        }
+    }
+    const int groups = C / VEC, slots = TB / groups;
+    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
+    if (slot >= slots) return;
+    const int c0 = grp * VEC;
+    float m[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
+    const float invN = 1.f / (float)N;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        m[i] = mean[c0 + i];
+        is[i] = invstd[c0 + i];
+        ga[i] = gamma ? gamma[c0 + i] : 1.f;
+        be[i] = beta ? beta[c0 + i] : 0.f;
+        k1[i] = training ? sA[c0 + i] * invN : 0.f;
+        k2[i] = training ? sB[c0 + i] * invN : 0.f;
+    }
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
+    for (long long r = r_begin + slot; r < r_end; r += slots) {
+        float x[VEC], g[VEC], o[VEC];
+        load_vec<T, VEC>(X + r * C + c0, x);
+        load_vec<T, VEC>(dY + r * C + c0, g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float xh = (x[i] - m[i]) * is[i];
+            float gi = g[i];
+            if (relu && !(fmaf(ga[i], xh, be[i]) > 0.f)) gi = 0.f;
+            o[i] = ga[i] * is[i] * (gi - k1[i] - xh * k2[i]);
+        }
+        store_vec<T, VEC>(dX + r * C + c0, o);
+    }
+}
+
+long long bn_reduce_blocks(long long N) {      // = number of partials every apply block folds
+    long long b = wfs_cdiv(N, 256);
+    if (b < 1) b = 1;
+    if (b > 256) b = 256;
+    return b;
+}
+long long bn_apply_blocks(long long N) {
+    long long b = wfs_cdiv(N, 128);
+    if (b < 1) b = 1;
+    if (b > 512) b = 512;
+    return b;
+}
+
+}  // namespace
+
+extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
+    return (size_t)bn_reduce_blocks(N) * 2 * C * sizeof(float);
+}
+
+extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
+                               float *running_mean, float *running_var, float momentum, float eps, int32_t training,
+                               int32_t relu, void *Y, float *save_mean, float *save_invstd, void *workspace,
+                               size_t workspace_bytes, int32_t dtype, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(training || (running_mean && running_var), WFS_EINVAL, "eval mode needs running statistics");
+    if (N == 0) return WFS_OK;
+    WFS_REQUIRE(X && Y && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
+    const long long nblk = bn_reduce_blocks(N), nblk_a = bn_apply_blocks(N);
+    WFS_REQUIRE(workspace_bytes >= (size_t)nblk * 2 * C * sizeof(float), WFS_EWORKSPACE, "workspace too small");
+    const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
+    float *partial = (float *)workspace;
+    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
+#define WFS_BN_FWD(T, VEC)                                                                                         \
+    do {                                                                                                           \
+        if (training)                                                                                              \
+            k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, C, rpb, nullptr, nullptr,  \
+                                                                nullptr, nullptr, 0, partial);                     \
+        k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, C, rpb_a, partial, (int)nblk, gamma, beta, \
+                                                        running_mean, running_var, momentum, eps, training, relu,  \
+                                                        (T *)Y, save_mean, save_invstd);                           \
+    } while (0)
+    if (dtype == WFS_F32) {
+        if (C % 4 == 0) WFS_BN_FWD(float, 4); else WFS_BN_FWD(float, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_FWD(wfs_bf16, 4); else WFS_BN_FWD(wfs_bf16, 1);
+    }
+#undef WFS_BN_FWD
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
+                               const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
+                               int32_t relu, void *dX, float *dgamma, float *dbeta, void *workspace,
+                               size_t workspace_bytes, int32_t dtype, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    if (N == 0) {
+        if (dgamma) WFS_HIP_CHECK(hipMemsetAsync(dgamma, 0, C * sizeof(float), stream));
+        if (dbeta) WFS_HIP_CHECK(hipMemsetAsync(dbeta, 0, C * sizeof(float), stream));
+        return WFS_OK;
+    }
+    WFS_REQUIRE(X && dY && dX && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
+    const long long nblk = bn_reduce_blocks(N), nblk_a = bn_apply_blocks(N);
+    WFS_REQUIRE(workspace_bytes >= (size_t)nblk * 2 * C * sizeof(float), WFS_EWORKSPACE, "workspace too small");
+    const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
+    float *partial = (float *)workspace;
+    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
+#define WFS_BN_BWD(T, VEC)                                                                                           \
+    do {                                                                                                             \
+        k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, C, rpb, save_mean,          \
+                                                            save_invstd, gamma, beta, relu, partial);                \
+        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, C, rpb_a, partial,        \
+                                                              (int)nblk,                                             \
+                                                            save_mean, save_invstd, gamma, beta, training, relu,     \
+                                                            (T *)dX, dgamma, dbeta);                                 \
+    } while (0)
+    if (dtype == WFS_F32) {
+        if (C % 4 == 0) WFS_BN_BWD(float, 4); else WFS_BN_BWD(float, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_BWD(wfs_bf16, 4); else WFS_BN_BWD(wfs_bf16, 1);
+    }
+#undef WFS_BN_BWD
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}

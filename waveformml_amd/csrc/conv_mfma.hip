@@ -12,6 +12,8 @@
 // Contraction-index trick: the k order inside an MFMA chain is free as long as A and B agree, so lane
 // (r, h = lane>>5) feeds channels h*16 .. h*16+15 of its gathered row (one 64-B contiguous read) instead of
 // the natural even/odd interleave.
+#include <stdlib.h>
+
 #include "wfs_common.h"
 
 namespace {
@@ -30,10 +32,12 @@ template <bool TRANSPOSE_W>
 __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                       long long R, const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
-                                                      float *__restrict__ Y, long long ntiles, long long tiles_per_xcd) {
+                                                      float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
+                                                      int dbg) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
     const int nthreads = blockDim.x;
-    if (!TRANSPOSE_W) {
+    if (dbg & 4) {
+    } else if (!TRANSPOSE_W) {
         for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
             int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;
             const float *src = W + ((long long)k * 32 + c4 * 4) * 32 + j4 * 4;
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
             int k_next = mask ? __builtin_ctz(mask) : k_cur;
             int nb_next = entry(k_next);
             while (true) {
-                const f32x4 *xn = (const f32x4 *)(X + (long long)(nb_next >= 0 ? nb_next : 0) * 32 + h * 16);
+                const f32x4 *xn = (const f32x4 *)(X + (long long)(nb_next >= 0 && !(dbg & 2) ? nb_next : 0) * 32 + h * 16);
                 f32x4 n0 = xn[0], n1 = xn[1], n2 = xn[2], n3 = xn[3];
                 unsigned m2 = mask & (mask - 1);
                 int k_nn = m2 ? __builtin_ctz(m2) : k_next;
@@ -116,10 +120,14 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-                WFS_MFMA4(a0, b0)
-                WFS_MFMA4(a1, b1)
-                WFS_MFMA4(a2, b2)
-                WFS_MFMA4(a3, b3)
+                if (dbg & 1) {
+                    acc[0] += a0.x * b0.x + a1.y * b1.y + a2.z * b2.z + a3.w * b3.w;
+                } else {
+                    WFS_MFMA4(a0, b0)
+                    WFS_MFMA4(a1, b1)
+                    WFS_MFMA4(a2, b2)
+                    WFS_MFMA4(a3, b3)
+                }
 #undef WFS_MFMA4
                 if (mask == 0) break;
                 mask &= mask - 1;
@@ -337,6 +345,8 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     nblk = (nblk + 7) / 8 * 8;
     const long long tiles_per_xcd = (ntiles + 7) / 8;
     const size_t lds = (size_t)K * 4096;
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("WFS_DBG") ? atoi(getenv("WFS_DBG")) : 0;
     const int which = transpose_w ? 1 : 0;
     if (!g_attr_done[which]) {
         const void *fn = transpose_w ? (const void *)k_gconv32_f32<true> : (const void *)k_gconv32_f32<false>;
@@ -345,10 +355,10 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     }
     if (transpose_w)
         k_gconv32_f32<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, mirror, K, identity_k, R, X, W,
-                                                                                 bias, Y, ntiles, tiles_per_xcd);
+                                                                                 bias, Y, ntiles, tiles_per_xcd, dbg);
     else
         k_gconv32_f32<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, mirror, K, identity_k, R, X, W,
-                                                                                  bias, Y, ntiles, tiles_per_xcd);
+                                                                                  bias, Y, ntiles, tiles_per_xcd, dbg);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

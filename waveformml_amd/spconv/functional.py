@@ -181,6 +181,70 @@ class ToDenseFunction(Function):
         return dX, None, None, None, None
 
 
+class BatchNormReLUFunction(Function):
+    """nn.BatchNorm1d (+ nn.ReLU) over the active rows [N, C] in two launches per direction
+    (reference: the plain modules inside spconv.SparseSequential, src/models/SPConvBlocks.py:505-508)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu):
+        lib = _lib.load()
+        x = _features_ok(x)
+        N, C = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
+        for t in (weight, bias, running_mean, running_var):
+            assert t is None or (t.dtype == torch.float32 and t.numel() == C and t.is_contiguous())
+        _lib.check(lib.wfs_bn_relu_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
+                                       _lib.ptr(running_var), float(momentum), float(eps), 1 if training else 0,
+                                       1 if relu else 0, _lib.ptr(y), _lib.ptr(save_mean), _lib.ptr(save_invstd),
+                                       _lib.ptr(ws), ws.numel(), _lib.dtype_code(x), _lib.stream_ptr()))
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
+        ctx.flags = (bool(training), bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        training, relu = ctx.flags
+        N, C = x.shape
+        dy = grad_output.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if weight is not None else None
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if bias is not None else None
+        ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.wfs_bn_relu_bwd(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
+                                       _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
+                                       1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
+                                       ws.numel(), _lib.dtype_code(x), _lib.stream_ptr()))
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm_relu(features, bn, relu):
+    """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features."""
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormReLUFunction.apply(features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                       bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps,
+                                       training, relu)
+
+
+def can_fuse_batch_norm(bn, features):
+    """The fused kernels cover what the reference's nets use: float32 parameters, a fixed momentum,
+    fp32/bf16 features on the GPU, C <= 1024."""
+    c = bn.num_features
+    return (type(bn) is torch.nn.BatchNorm1d and bn.momentum is not None and features.is_cuda and features.dim() == 2
+            and features.dtype in (torch.float32, torch.bfloat16) and features.shape[0] > 0
+            and (c <= 256 or (c % 4 == 0 and c <= 1024))
+            and (bn.weight is None or bn.weight.dtype == torch.float32)
+            and (bn.training or bn.running_mean is not None))
+
+
 def indice_conv(features, filters, bias, rulebook):
     return SparseConvFunction.apply(features, filters, bias, rulebook, CONV)
 

@@ -55,15 +55,26 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        from . import functional as Fsp
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if isinstance(module, SparseModule):
                 input = module(input)
-            else:
-                if _is_sparse_tensor(input):
-                    if input.indices.shape[0] != 0:
+            elif _is_sparse_tensor(input):
+                if input.indices.shape[0] != 0:
+                    if isinstance(module, nn.BatchNorm1d) and Fsp.can_fuse_batch_norm(module, input.features):
+                        # BatchNorm1d [+ ReLU] over the active rows: one fused pair of HIP launches
+                        relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                        input.features = Fsp.batch_norm_relu(input.features, module, relu)
+                        if relu:
+                            i += 1
+                    else:
                         input.features = module(input.features)
-                else:
-                    input = module(input)
+            else:
+                input = module(input)
+            i += 1
         return input
 
 
