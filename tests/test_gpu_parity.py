@@ -352,3 +352,42 @@ def test_fused_batchnorm_relu_matches_torch(C, relu, dtype):
     ye = Fsp.batch_norm_relu(xin.to(DEV).to(dtype), bn, relu)
     yre = torch.relu(ref(xin)) if relu else ref(xin)
     _assert_close(ye.detach().float().cpu().numpy(), yre.detach().numpy(), tol, "eval y")
+
+
+@pytest.mark.parametrize("layer_kind", ["subm32", "conv32_s4", "subm2"])
+def test_layers_at_bench_geometry_bf16(layer_kind):
+    """bf16 storage / bf16 MFMA with fp32 accumulate against the fp32 oracle fed the same bf16-rounded
+    inputs and bf16-rounded filters: what is left is accumulation order and the bf16 rounding of the
+    outputs (2^-9 relative) -> 1e-2 of the tensor scale."""
+    from oracle import spconv as osp
+    from waveformml_amd.psd import synthetic
+    sp = _sp()
+    B, T = 96, 256
+    c, f, _ = synthetic.generate(B, T, 3, seed=4321)
+    idx = np.ascontiguousarray(c[:, [3, 0, 1, 2]])
+    rng = np.random.default_rng(910)
+    cin = 2 if layer_kind == "subm2" else 32
+    feat = f if cin == 2 else rng.standard_normal((len(idx), 32)).astype(np.float32)
+    feat = torch.from_numpy(feat).to(torch.bfloat16)
+    torch.manual_seed(6)
+    if layer_kind == "conv32_s4":
+        mk = lambda m: m.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, True)
+    else:
+        mk = lambda m: m.SubMConv3d(cin, 32, 3, 1, 0, 1, 1, True, "k")
+    ref_layer = mk(osp)
+    layer = mk(sp).to(DEV)
+    layer.load_state_dict(ref_layer.state_dict())
+    if cin == 32:                      # the MFMA kernels round the filters to bf16
+        with torch.no_grad():
+            ref_layer.weight.copy_(ref_layer.weight.to(torch.bfloat16).float())
+    fr = feat.float().requires_grad_(True)
+    fg = feat.to(DEV).requires_grad_(True)
+    yr = ref_layer(osp.SparseConvTensor(fr, torch.from_numpy(idx), [14, 11, T], B))
+    yg = layer(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), [14, 11, T], B))
+    assert yg.features.dtype == torch.bfloat16
+    _assert_close(yg.features.detach().float().cpu().numpy(), yr.features.detach().numpy(), 1e-2, "forward")
+    g = torch.from_numpy(rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)).to(torch.bfloat16)
+    yr.features.backward(g.float())
+    yg.features.backward(g.to(DEV))
+    _assert_close(fg.grad.float().cpu().numpy(), fr.grad.numpy(), 1e-2, "dX")
+    _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-2, "dW")

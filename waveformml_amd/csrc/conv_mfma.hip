@@ -150,6 +150,137 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     }
 }
 
+// ------------------------------------------------------------------------------------------ 32 -> 32, bf16
+// bf16 rows in HBM (64 B per voxel), fp32 master filters converted to bf16 while they are staged into LDS,
+// fp32 accumulation: v_mfma_f32_32x32x16_bf16, 2 MFMAs per kernel offset and 32-row tile.  At 1/16 of the fp32
+// MFMA cost the kernel is bound by memory latency, so it is organised for memory-level parallelism:
+//   phase 1  the tile's K table entries are read once (coalesced) and parked in LDS; ballots give the mask of
+//            offsets the tile uses;
+//   phase 2  active offsets are taken GROUP (8) at a time: all their row gathers are issued back to back
+//            (2 x 16 B per lane and offset), then the 16 MFMAs run while the next group's gathers are in flight.
+// Channel order inside the contraction: lane (r, h), k-step s, element j <-> channel 16h + 8s + j, i.e. one
+// contiguous 32-B read per lane and gathered row; the LDS filter image is built to match:
+//   sWb[k][s][h][col][j] = B[16h + 8s + j][col],  B[c][col] = W[k][c][col] (forward) or W[k][col][c] (dX).
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF_GROUP = 6;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    wfs_bf16 a, b;
+    wfs_st(&a, lo);
+    wfs_st(&b, hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+template <bool TRANSPOSE_W>
+__global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                       long long R, const wfs_bf16 *__restrict__ X,
+                                                       const float *__restrict__ W, const float *__restrict__ bias,
+                                                       wfs_bf16 *__restrict__ Y, long long ntiles,
+                                                       long long tiles_per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *sWb = reinterpret_cast<uint4 *>(smem);                           // K * 128 fragments of 16 B
+    int *sNb = reinterpret_cast<int *>(smem + (size_t)K * 2048);            // [waves][K][32]
+    const int nthreads = blockDim.x;
+    for (int u = threadIdx.x; u < K * 128; u += nthreads) {
+        int k = u >> 7, s = (u >> 6) & 1, h = (u >> 5) & 1, col = u & 31;
+        int c0 = 16 * h + 8 * s;
+        float w[8];
+        if (!TRANSPOSE_W) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = W[((long long)k * 32 + c0 + j) * 32 + col];
+        } else {
+            const f32x4 *src = (const f32x4 *)(W + ((long long)k * 32 + col) * 32 + c0);
+            f32x4 lo = src[0], hi = src[1];
+            w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+            w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+        }
+        uint4 v;
+        v.x = pack_bf16x2(w[0], w[1]);
+        v.y = pack_bf16x2(w[2], w[3]);
+        v.z = pack_bf16x2(w[4], w[5]);
+        v.w = pack_bf16x2(w[6], w[7]);
+        sWb[u] = v;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int *myNb = sNb + (size_t)wid * K * 32;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const long long t_begin = (long long)xcd * tiles_per_xcd;
+    const long long t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
+    const float bj = bias ? bias[r] : 0.f;
+    for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
+        const long long row = tile * 32 + r;
+        const bool live = row < R;
+        const long long rowc = live ? row : R - 1;
+        // ---- phase 1
+        int v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            int kk = k < K ? k : K - 1;
+            v[k] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+        }
+        unsigned mask = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            int nb = (k == identity_k) ? (int)rowc : v[k];
+            nb = (live && k < K) ? nb : -1;
+            if (k < K && h == 0) myNb[k * 32 + r] = nb;
+            if (__ballot(nb >= 0) != 0ull) mask |= 1u << k;
+        }
+        mask = __builtin_amdgcn_readfirstlane(mask);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bj;
+        // ---- phase 2 (the wave's own LDS writes above are visible to its later reads: same wave, in order)
+        while (mask != 0) {
+            int ks[BF_GROUP];
+            uint4 a_lo[BF_GROUP], a_hi[BF_GROUP];
+            int nbs[BF_GROUP];
+#pragma unroll
+            for (int g = 0; g < BF_GROUP; ++g) {
+                ks[g] = mask ? __builtin_ctz(mask) : -1;
+                mask = mask ? (mask & (mask - 1)) : 0u;
+            }
+#pragma unroll
+            for (int g = 0; g < BF_GROUP; ++g)
+                if (ks[g] >= 0) {
+                    nbs[g] = myNb[ks[g] * 32 + r];
+                    const uint4 *xp = (const uint4 *)(X + (long long)(nbs[g] >= 0 ? nbs[g] : 0) * 32 + h * 16);
+                    a_lo[g] = xp[0];
+                    a_hi[g] = xp[1];
+                }
+#pragma unroll
+            for (int g = 0; g < BF_GROUP; ++g)
+                if (ks[g] >= 0) {
+                    uint4 lo = a_lo[g], hi = a_hi[g];
+                    if (nbs[g] < 0) lo = hi = uint4{0u, 0u, 0u, 0u};
+                    const uint4 *bp = sWb + (size_t)ks[g] * 128 + h * 32 + r;
+                    uint4 b0 = bp[0], b1 = bp[64];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, lo),
+                                                                  __builtin_bit_cast(bf16x8, b0), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hi),
+                                                                  __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+                }
+        }
+        // ---- epilogue: reg i holds (row (i&3) + 8(i>>2) + 4h, col r).  Neighbouring columns are paired with one
+        // lane exchange so that every lane stores one packed dword: even lanes row(i), odd lanes row(i+1).
+        unsigned *Yw = reinterpret_cast<unsigned *>(Y);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            float mine0 = acc[i], mine1 = acc[i + 1];
+            float send = (lane & 1) ? mine0 : mine1;
+            float got = __shfl_xor(send, 1, 64);
+            unsigned packed = (lane & 1) ? pack_bf16x2(got, mine1) : pack_bf16x2(mine0, got);
+            int ri = (lane & 1) ? i + 1 : i;
+            long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
+            if (orow < R) Yw[orow * 16 + (r >> 1)] = packed;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 2 -> 32
 template <typename T>
 __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ table, KMap kmap, int K, int identity_k,
@@ -180,10 +311,14 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
             acc.w = fmaf(x1, w1.w, acc.w);
         }
         T *y = Y + row * 32 + cq * 4;
-        wfs_st(y + 0, acc.x);
-        wfs_st(y + 1, acc.y);
-        wfs_st(y + 2, acc.z);
-        wfs_st(y + 3, acc.w);
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4 *>(y) = acc;
+        } else {
+            uint2 pk;
+            pk.x = pack_bf16x2(acc.x, acc.y);
+            pk.y = pack_bf16x2(acc.z, acc.w);
+            *reinterpret_cast<uint2 *>(y) = pk;
+        }
     }
 }
 
@@ -196,9 +331,10 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
 constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator registers)
 constexpr int DW_WAVES = 8;
 
-__global__ void __launch_bounds__(512, 2) k_gdw32_f32(const int *__restrict__ table, int K, int identity_k, long long R,
-                                                      const float *__restrict__ S, const float *__restrict__ G,
-                                                      float *__restrict__ part, int ngroups, long long tiles_per_block) {
+template <typename T>
+__global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long R,
+                                                  const T *__restrict__ S, const T *__restrict__ G,
+                                                  float *__restrict__ part, int ngroups, long long tiles_per_block) {
     __shared__ float sAcc[DW_KG * 1024];                              // [DW_KG][32][32], 16 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -228,7 +364,7 @@ __global__ void __launch_bounds__(512, 2) k_gdw32_f32(const int *__restrict__ ta
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             long long row = row0 + 2 * s + h;
-            float t = S[(row < R ? row : R - 1) * 32 + j];
+            float t = wfs_ld(S + (row < R ? row : R - 1) * 32 + j);
             a[s] = row < R ? t : 0.f;
         }
         bool any = false;
@@ -250,7 +386,7 @@ __global__ void __launch_bounds__(512, 2) k_gdw32_f32(const int *__restrict__ ta
                 int n0 = __builtin_amdgcn_readlane(nbv[q], 2 * s);
                 int n1 = __builtin_amdgcn_readlane(nbv[q], 2 * s + 1);
                 int nb = h ? n1 : n0;
-                float t = G[(long long)(nb >= 0 ? nb : 0) * 32 + j];
+                float t = wfs_ld(G + (long long)(nb >= 0 ? nb : 0) * 32 + j);
                 b[s] = nb >= 0 ? t : 0.f;
             }
 #pragma unroll
@@ -363,6 +499,33 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     return WFS_OK;
 }
 
+int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const void *X,
+                            const float *W, int transpose_w, const float *bias, void *Y, hipStream_t stream) {
+    static bool attr[2] = {false, false};
+    const long long ntiles = (R + 31) >> 5;
+    int wpb = (int)((ntiles + 255) / 256);
+    wpb = wpb < 4 ? 4 : (wpb > 16 ? 16 : (wpb + 3) / 4 * 4);
+    long long nblk = (ntiles + wpb - 1) / wpb;
+    if (nblk > 256) nblk = 256;
+    nblk = (nblk + 7) / 8 * 8;
+    const long long tiles_per_xcd = (ntiles + 7) / 8;
+    const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
+    const int which = transpose_w ? 1 : 0;
+    if (!attr[which]) {
+        const void *fn = transpose_w ? (const void *)k_gconv32_bf16<true> : (const void *)k_gconv32_bf16<false>;
+        WFS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr[which] = true;
+    }
+    if (transpose_w)
+        k_gconv32_bf16<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
+            table, mirror, K, identity_k, R, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
+    else
+        k_gconv32_bf16<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
+            table, mirror, K, identity_k, R, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R, const void *X,
                            const float *W, const float *bias, void *Y, int dtype, hipStream_t stream) {
     KMap km;
@@ -400,14 +563,18 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
     return 0;
 }
 
-int wfs_launch_gdw32_f32(const int *table, int K, int identity_k, long long R, const float *S, const float *G,
-                         int swap, float *dW, float *part, hipStream_t stream) {
+int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const void *S, const void *G, int swap,
+                     float *dW, float *part, int dtype, hipStream_t stream) {
     const long long nblk = dw32_blocks(R);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
-    k_gdw32_f32<<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(table, K, identity_k, R, S, G, part,
-                                                                                  ngroups, tiles_per_block);
+    if (dtype == WFS_F32)
+        k_gdw32<float><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(
+            table, K, identity_k, R, (const float *)S, (const float *)G, part, ngroups, tiles_per_block);
+    else
+        k_gdw32<wfs_bf16><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(
+            table, K, identity_k, R, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
     k_slab_reduce<<<dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);

@@ -223,6 +223,8 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
     if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror))
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, (const float *)X, W, transpose_w, bias,
                                       (float *)Y, stream);
+    if (dtype == WFS_BF16 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror))
+        return wfs_launch_gconv32_bf16(table, is_ident ? 0 : 1, K, identity_k, R, X, W, transpose_w, bias, Y, stream);
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
         return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, X, W, bias, Y, dtype, stream);
     dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
@@ -285,9 +287,8 @@ extern "C" int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k
     size_t need = wfs_gather_dw_workspace_bytes(K, R, Cs, Cg);
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
-    if (dtype == WFS_F32 && Cs == 32 && Cg == 32 && table)
-        return wfs_launch_gdw32_f32(table, K, identity_k, R, (const float *)S, (const float *)G, swap, dW,
-                                    (float *)workspace, stream);
+    if (Cs == 32 && Cg == 32 && table)
+        return wfs_launch_gdw32(table, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype, stream);
     if (Cs == 2 && Cg == 32 && table)
         return wfs_launch_gdw_c2c32(table, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype, stream);
     long long chunks = dw_chunks(R);

@@ -50,6 +50,9 @@ class SPConvNet(nn.Module):
                                           batch_size)
         out = self.sparseModel(st)
         out = out.view(-1, self.n_linear)
+        head_dtype = next(self.linear.parameters()).dtype
+        if out.dtype != head_dtype:          # bf16 activations, fp32 master weights in the dense head
+            out = out.to(head_dtype)
         return self.linear(out)
 
     def _build(self):
