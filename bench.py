@@ -99,9 +99,14 @@ def main():
     module.train()
     broadcast_parameters(module)
     init_state = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    reducer = FlatGradAllReducer(module.model.parameters())          # flat parameter + flat gradient buffers
+    module.optimizer_parameters = reducer.optimizer_parameters()
     opt = module.configure_optimizers()
     optimizer = opt[0][0] if isinstance(opt, tuple) else opt
-    reducer = FlatGradAllReducer(module.model.parameters())
+    # synthetic events are distinct in-range sites by construction (psd/synthetic.py): skip the index
+    # validation read-backs, exactly as spconv (which never validates) does
+    from waveformml_amd.spconv import ops as _ops
+    _ops.ASSUME_VALID_UNIQUE_INDICES = True
 
     # synthetic batch, resident in HBM before the timed region (weak scaling: fixed events per rank)
     c, f, y = synthetic.generate(args.batch, args.samples, cfg_dict["system_config"]["n_type"], seed=1234, rank=rank)

@@ -88,7 +88,9 @@ int wfs_geometry_init(wfs_geometry *g);
  * Phase 1  wfs_rulebook_plan : site table build (hash or direct grid), candidate lookup,
  *          first-seen numbering.  SubM: nbr_out is final.  Regular conv: nbr_out holds table
  *          slots until phase 2.  Synchronises `stream` ONCE to return, on the host,
- *          host_info = {M, input_has_duplicate_coordinates (SubM only)}.
+ *          host_info = {M, input_has_duplicate_coordinates (SubM only)}.  For SubM host_info may
+ *          be NULL: no read-back, no synchronisation -- the caller then vouches that every index
+ *          row is in range and that sites are distinct (spconv itself checks neither).
  * Phase 2  wfs_rulebook_emit : regular conv: writes out_indices [M, ndim+1], finalises nbr_out,
  *          fills nbr_in [K, M] if given.  SubM: fills nbr_in if given (needed only for even
  *          kernels / dilation).  Both: spconv's indice_pairs / indice_pair_num if given
@@ -134,13 +136,16 @@ int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, i
 /* Replaces the dW half of torch.ops.spconv.indice_conv_backward:
  *     dW[k, a, b] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 0)
  *     dW[k, b, a] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 1)
- * S = the stationary rows [R, Cs], G = the gathered rows [*, Cg].  Deterministic two-stage
- * reduction through `workspace` (wfs_gather_dw_workspace_bytes).                             */
+ * S = the stationary rows [R, Cs], G = the gathered rows [*, Cg]; table column kmap[k] serves
+ * offset k (kmap_host NULL = identity; the SubM mirror is accepted for Cs = 32, Cg = 2, which lets
+ * the first layer keep its wide dY rows stationary).  Deterministic two-stage reduction through
+ * `workspace` (wfs_gather_dw_workspace_bytes).                                                 */
 size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg);
 
-int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *S,
-                  int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
-                  int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
+int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                  int64_t R, const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg,
+                  int32_t swap, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
+                  void *stream);
 
 /* Scatter form with fp32 atomics, used ONLY when the input holds duplicate coordinates (then
  * the inverse of a gather table is not a function):

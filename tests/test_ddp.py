@@ -1,0 +1,121 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the data-parallel gradient exchange
+(waveformml_amd/psd/ddp.py): flat parameter / flat gradient buffers, bucketed asynchronous all-reduce
+launched from gradient hooks, averaging, identical replicas after the optimizer step.
+The GPU path differs only in the backend name ("nccl" == RCCL) -- see bench.py."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _net():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(),
+                               torch.nn.Linear(16, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(12, 6, generator=g), torch.randint(0, 3, (12,), generator=g)
+
+
+def _worker(rank, world, port, n_buckets, out):
+    from waveformml_amd.psd.ddp import FlatGradAllReducer, broadcast_parameters
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = _net()
+        if rank != 0:                       # replicas start different; the broadcast must fix that
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(1.0)
+        broadcast_parameters(net)
+        red = FlatGradAllReducer(net.parameters(), n_buckets=n_buckets)
+        opt = torch.optim.SGD(red.optimizer_parameters(), lr=0.1, momentum=0.9, nesterov=True)
+        crit = torch.nn.CrossEntropyLoss()
+        x, y = _data(rank)
+        for _ in range(3):
+            red.reset()
+            crit(net(x), y).backward()
+            red.finish()
+            opt.step()
+        out[rank] = (red.flat_grad.clone(), [p.detach().clone() for p in net.parameters()],
+                     [p.data_ptr() for p in net.parameters()], red.flat_param.data_ptr(),
+                     [(s, e, list(i)) for s, e, i in red.buckets])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_buckets", [1, 3])
+def test_two_rank_gloo_matches_single_process_average(n_buckets):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_buckets, out), nprocs=world, join=True)
+    g0, p0, ptr0, fp0, buckets = out[0]
+    g1, p1, _, _, _ = out[1]
+    assert torch.equal(g0, g1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)                     # replicas stay bit-identical
+    # parameters are views of the flat parameter, laid out in reverse order
+    assert min(ptr0) == fp0 and len(buckets) == n_buckets
+    assert buckets[0][0] == 0 and buckets[-1][1] == g0.numel()
+    assert sorted(i for _, _, idxs in buckets for i in idxs) == list(range(len(p0)))
+    # single-process reference: per-rank BatchNorm statistics (no SyncBN), gradients averaged over ranks
+    net = _net()
+    nets = [net, _net()]
+    nets[1].load_state_dict(net.state_dict())
+    opts = [torch.optim.SGD(n.parameters(), lr=0.1, momentum=0.9, nesterov=True) for n in nets]
+    crit = torch.nn.CrossEntropyLoss()
+    for _ in range(3):
+        for r in range(2):
+            opts[r].zero_grad()
+            x, y = _data(r)
+            crit(nets[r](x), y).backward()
+        for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
+            avg = (pa.grad + pb.grad) / 2
+            pa.grad, pb.grad = avg.clone(), avg.clone()
+        for o in opts:
+            o.step()
+    for a, b in zip(p0, nets[0].parameters()):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_single_process_reducer_packs_gradients_and_flat_optimizer_step():
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    net, ref = _net(), _net()
+    red = FlatGradAllReducer(net.parameters(), n_buckets=2, world_size=1)
+    assert red.world == 1 and len(red.optimizer_parameters()) == 1
+    opt = torch.optim.SGD(red.optimizer_parameters(), lr=0.05, momentum=0.9)
+    opt_ref = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9)
+    x, y = _data(0)
+    crit = torch.nn.CrossEntropyLoss()
+    for _ in range(2):
+        red.reset()
+        crit(net(x), y).backward()
+        red.finish()
+        opt.step()
+        opt_ref.zero_grad()
+        crit(ref(x), y).backward()
+        opt_ref.step()
+    for i, (a, b) in enumerate(zip(net.parameters(), ref.parameters())):
+        o, n = red.slices[i]
+        torch.testing.assert_close(red.flat_grad[o:o + n].view_as(b), b.grad)
+        torch.testing.assert_close(a.detach(), b.detach())
+    assert set(net.state_dict()) == set(ref.state_dict())        # checkpoints keep the module's own names

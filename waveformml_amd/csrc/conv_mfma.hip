@@ -414,52 +414,86 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
     }
 }
 
-// ------------------------------------------------------------------------------------------ dW 2 x 32
-// S = X [R, 2] (stationary), G = dY [*, 32] (gathered): part[chunk][k][a][b]; thread = (row slot, b).
+// ------------------------------------------------------------------------------------------ dW 32 x 2
+// First layer (Cin = 2): the STATIONARY rows are the 32-channel ones (dY, read once, coalesced) and the 2-channel
+// input rows are gathered through the by-output table:  part[chunk][k][c][b] = sum_i G[table[km(k)][i]][c] * S[i][b]
+// with c in {0,1}.  Thread = (row slot, b); 2*K accumulators in registers (K <= 27).
 template <typename T>
-__global__ void __launch_bounds__(256) k_gdw_c2c32(const int *__restrict__ table, int K, int identity_k, long long R,
-                                                   long long rows_per_chunk, const T *__restrict__ S,
+__global__ void __launch_bounds__(256) k_gdw_c32c2(const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                   long long R, long long rows_per_chunk, const T *__restrict__ S,
                                                    const T *__restrict__ G, float *__restrict__ part) {
-    __shared__ float sRed[8][2][32];
+    __shared__ float sRed[8][32];
     const int slot = threadIdx.x >> 5, b = threadIdx.x & 31;
     const long long r_begin = (long long)blockIdx.x * rows_per_chunk;
     const long long r_end = r_begin + rows_per_chunk < R ? r_begin + rows_per_chunk : R;
-    for (int k = blockIdx.y; k < K; k += gridDim.y) {
-        float acc0 = 0.f, acc1 = 0.f;
-        for (long long row = r_begin + slot; row < r_end; row += 8) {
-            int nb = (k == identity_k) ? (int)row : table[(long long)k * R + row];
-            if (nb < 0) continue;
-            float gv = wfs_ld(G + (long long)nb * 32 + b);
-            acc0 = fmaf(wfs_ld(S + row * 2), gv, acc0);
-            acc1 = fmaf(wfs_ld(S + row * 2 + 1), gv, acc1);
-        }
-        sRed[slot][0][b] = acc0;
-        sRed[slot][1][b] = acc1;
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            int a = threadIdx.x >> 5;
-            float s = 0.f;
+    float acc0[27], acc1[27];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += sRed[w][a][b];
-            part[((long long)blockIdx.x * K + k) * 64 + a * 32 + b] = s;
+    for (int k = 0; k < 27; ++k) acc0[k] = acc1[k] = 0.f;
+    for (long long row = r_begin + slot; row < r_end; row += 8) {
+        const float gv = wfs_ld(S + row * 32 + b);
+        int nb[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            int kk = k < K ? k : K - 1;
+            nb[k] = table[(long long)(mirror ? K - 1 - kk : kk) * R + row];
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            int n = (k == identity_k) ? (int)row : nb[k];
+            bool ok = k < K && n >= 0;
+            const T *xp = G + (long long)(ok ? n : 0) * 2;
+            float x0 = wfs_ld(xp), x1 = wfs_ld(xp + 1);
+            x0 = ok ? x0 : 0.f;
+            x1 = ok ? x1 : 0.f;
+            acc0[k] = fmaf(x0, gv, acc0[k]);
+            acc1[k] = fmaf(x1, gv, acc1[k]);
+        }
+    }
+    // fold the 8 row slots in a fixed order, one (k, c) plane at a time
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 27; ++q)
+                if (q == k) v = c ? acc1[q] : acc0[q];
+            sRed[slot][b] = v;
+            __syncthreads();
+            if (slot == 0) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s += sRed[w][b];
+                part[((long long)blockIdx.x * K + k) * 64 + c * 32 + b] = s;
+            }
+            __syncthreads();
+        }
     }
 }
 
-__global__ void k_slab_reduce(const float *__restrict__ part, long long nslabs, long long per, int K, int Cs, int Cg,
-                              int swap, float *__restrict__ dW) {
-    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= per) return;
+// dW[k][a][b] (swap==0) or dW[k][b][a] (swap==1) = sum over slabs of part[slab][k][a][b]; 8 slab slices per
+// output are summed in parallel and folded in slice order (deterministic).
+__global__ void __launch_bounds__(256) k_slab_reduce(const float *__restrict__ part, long long nslabs, long long per,
+                                                     int K, int Cs, int Cg, int swap, float *__restrict__ dW) {
+    __shared__ float sR[8][32];
+    const int sl = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const long long e = (long long)blockIdx.x * 32 + lane;
     float s = 0.f;
-    for (long long c = 0; c < nslabs; ++c) s += part[c * per + e];
-    if (swap) {
-        int k = (int)(e / ((long long)Cs * Cg));
-        int rem = (int)(e % ((long long)Cs * Cg));
-        int a = rem / Cg, b = rem % Cg;
-        dW[((long long)k * Cg + b) * Cs + a] = s;
-    } else {
-        dW[e] = s;
+    if (e < per)
+        for (long long c = sl; c < nslabs; c += 8) s += part[c * per + e];
+    sR[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && e < per) {
+        s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += sR[q][lane];
+        if (swap) {
+            int k = (int)(e / ((long long)Cs * Cg));
+            int rem = (int)(e % ((long long)Cs * Cg));
+            int a = rem / Cg, b = rem % Cg;
+            dW[((long long)k * Cg + b) * Cs + a] = s;
+        } else {
+            dW[e] = s;
+        }
     }
 }
 
@@ -551,15 +585,15 @@ static long long dw32_blocks(long long R) {
     return nblk;
 }
 static long long dwc2_chunks(long long R) {
-    long long c = (R + 2047) / 2048;
+    long long c = (R + 127) / 128;
     if (c < 1) c = 1;
-    if (c > 256) c = 256;
+    if (c > 512) c = 512;
     return c;
 }
 
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
     if (Cs == 32 && Cg == 32) return (size_t)dw32_blocks(R) * K * 1024 * sizeof(float);
-    if (Cs == 2 && Cg == 32) return (size_t)dwc2_chunks(R) * K * 64 * sizeof(float);
+    if (Cs == 32 && Cg == 2) return (size_t)dwc2_chunks(R) * K * 64 * sizeof(float);
     return 0;
 }
 
@@ -577,25 +611,25 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
             table, K, identity_k, R, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
-    k_slab_reduce<<<dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
+    k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
 
-int wfs_launch_gdw_c2c32(const int *table, int K, int identity_k, long long R, const void *S, const void *G, int swap,
-                         float *dW, float *part, int dtype, hipStream_t stream) {
+int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const void *S,
+                         const void *G, int swap, float *dW, float *part, int dtype, hipStream_t stream) {
     const long long chunks = dwc2_chunks(R);
     const long long rows_per_chunk = (R + chunks - 1) / chunks;
-    dim3 grid((unsigned)chunks, (unsigned)(K < 32 ? K : 32));
     if (dtype == WFS_F32)
-        k_gdw_c2c32<float><<<grid, dim3(256), 0, stream>>>(table, K, identity_k, R, rows_per_chunk, (const float *)S,
-                                                          (const float *)G, part);
+        k_gdw_c32c2<float><<<dim3((unsigned)chunks), dim3(256), 0, stream>>>(
+            table, mirror, K, identity_k, R, rows_per_chunk, (const float *)S, (const float *)G, part);
     else
-        k_gdw_c2c32<wfs_bf16><<<grid, dim3(256), 0, stream>>>(table, K, identity_k, R, rows_per_chunk,
-                                                             (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
+        k_gdw_c32c2<wfs_bf16><<<dim3((unsigned)chunks), dim3(256), 0, stream>>>(
+            table, mirror, K, identity_k, R, rows_per_chunk, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
     WFS_LAUNCH_CHECK();
+    // part is [chunk][k][c (gathered, 2)][b (stationary, 32)] = the "swap" orientation of (S=32, G=2)
     const long long per = (long long)K * 64;
-    k_slab_reduce<<<dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream>>>(part, chunks, per, K, 2, 32, swap, dW);
+    k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(256), 0, stream>>>(part, chunks, per, K, 2, 32, swap ? 0 : 1, dW);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

@@ -271,7 +271,7 @@ extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs
     return generic > fast ? generic : fast;
 }
 
-extern "C" int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *S,
+extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R, const void *S,
                              int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
                              int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -287,10 +287,18 @@ extern "C" int wfs_gather_dw(const int32_t *table, int32_t K, int32_t identity_k
     size_t need = wfs_gather_dw_workspace_bytes(K, R, Cs, Cg);
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
-    if (Cs == 32 && Cg == 32 && table)
+    if (Cs == 32 && Cg == 32 && table && !kmap_host)
         return wfs_launch_gdw32(table, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype, stream);
-    if (Cs == 2 && Cg == 32 && table)
-        return wfs_launch_gdw_c2c32(table, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype, stream);
+    bool is_ident = true, is_mirror = true;
+    for (int k = 0; k < K && kmap_host; ++k) {
+        is_ident = is_ident && kmap_host[k] == k;
+        is_mirror = is_mirror && kmap_host[k] == K - 1 - k;
+    }
+    if (!kmap_host) is_mirror = false;
+    if (Cs == 32 && Cg == 2 && K <= 27 && table && (is_ident || is_mirror))
+        return wfs_launch_gdw_c32c2(table, is_ident ? 0 : 1, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype,
+                                    stream);
+    WFS_REQUIRE(is_ident, WFS_EINVAL, "a column map is only supported by the 32 x 2 dW kernel");
     long long chunks = dw_chunks(R);
     long long rows_per_chunk = wfs_cdiv(wfs_cdiv(R, chunks), DW_ROWS) * DW_ROWS;
     int tiles_a = (int)wfs_cdiv(Cs, DW_TA), tiles_b = (int)wfs_cdiv(Cg, DW_TBB);

@@ -483,11 +483,14 @@ extern "C" int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indi
 extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, int64_t N, int32_t *nbr_out,
                                  void *workspace, size_t workspace_bytes, int64_t host_info[2], void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    WFS_REQUIRE(g && host_info, WFS_EINVAL, "NULL argument");
+    WFS_REQUIRE(g, WFS_EINVAL, "NULL argument");
+    WFS_REQUIRE(host_info || g->subm, WFS_EINVAL, "a regular conv must read M back: host_info is required");
     WFS_REQUIRE(N >= 0 && N < (1ll << 31), WFS_EINVAL, "N out of range");
     WFS_REQUIRE(g->K >= 1, WFS_EINVAL, "geometry not initialised (wfs_geometry_init)");
-    host_info[0] = g->subm ? N : 0;
-    host_info[1] = 0;
+    if (host_info) {
+        host_info[0] = g->subm ? N : 0;
+        host_info[1] = 0;
+    }
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(indices && nbr_out && workspace, WFS_EINVAL, "NULL device pointer");
     Plan p;
@@ -525,6 +528,7 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         k_scan_apply<<<sgrid, block, 0, stream>>>(rowfirst, N, bsum, rowbase);
         WFS_LAUNCH_CHECK();
     }
+    if (!host_info) return WFS_OK;          // SubM, caller vouches for the indices: fully asynchronous
     long long h[4];
     WFS_HIP_CHECK(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
     WFS_HIP_CHECK(hipStreamSynchronize(stream));

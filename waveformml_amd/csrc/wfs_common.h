@@ -65,5 +65,5 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg);
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const void *S, const void *G, int swap,
                      float *dW, float *part, int dtype, hipStream_t stream);
-int wfs_launch_gdw_c2c32(const int *table, int K, int identity_k, long long R, const void *S, const void *G, int swap,
-                         float *dW, float *part, int dtype, hipStream_t stream);
+int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const void *S,
+                         const void *G, int swap, float *dW, float *part, int dtype, hipStream_t stream);

@@ -4,17 +4,22 @@ The reference gets data parallelism from Lightning's DDPPlugin -> torch DDP -> N
 (src/utils/util.py:228-239; no explicit collective call sites, SURVEY.md 2 "Parallelism inventory").
 Events are independent units: each rank runs its own shard of the global batch, the
 only exchange is the gradient all-reduce.  The PSD nets are tiny (0.03-1 M parameters), so the
-exchange is latency-bound: all gradients live in ONE flat fp32 buffer cut into a few contiguous
-buckets in reverse layer order; a bucket's all-reduce is launched asynchronously (RCCL runs it on its
-own stream) the moment its last gradient has been accumulated, so it overlaps the rest of backward.
-BatchNorm statistics stay per rank, exactly as under the reference's DDP (no SyncBN).
+exchange is latency-bound.  Layout:
+
+  * all parameters live in ONE flat fp32 buffer (the module's parameters are views of it), so the
+    optimizer updates a single tensor -- a handful of launches instead of one per parameter;
+  * all gradients land in ONE flat buffer cut into a few contiguous buckets in reverse layer order.
+    A bucket is packed (one concatenation kernel) and its all-reduce launched asynchronously -- RCCL
+    runs it on its own stream -- the moment its last gradient has been produced, so the exchange
+    overlaps the rest of backward;
+  * BatchNorm statistics stay per rank, exactly as under the reference's DDP (no SyncBN).
 """
 import torch
 import torch.distributed as dist
 
 
 class FlatGradAllReducer(object):
-    def __init__(self, parameters, n_buckets=2, process_group=None, world_size=None):
+    def __init__(self, parameters, n_buckets=2, process_group=None, world_size=None, flatten=True):
         self.params = [p for p in parameters if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -23,21 +28,28 @@ class FlatGradAllReducer(object):
             dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1)
         dev, dtype = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=dtype, device=dev)
         # reverse order: the LAST layer's gradients are produced first and sit at the front
         order = list(reversed(range(len(self.params))))
         off = 0
         self.slices = {}
         for i in order:
-            p = self.params[i]
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            self.slices[i] = (off, n)
-            off += n
+            self.slices[i] = (off, self.params[i].numel())
+            off += self.params[i].numel()
+        self.flat_grad = torch.zeros(total, dtype=dtype, device=dev)
+        self.flat_param = None
+        if flatten:
+            flat = torch.empty(total, dtype=dtype, device=dev)
+            with torch.no_grad():
+                for i, p in enumerate(self.params):
+                    o, n = self.slices[i]
+                    flat[o:o + n].copy_(p.data.reshape(-1))
+                    p.data = flat[o:o + n].view_as(p)
+            self.flat_param = torch.nn.Parameter(flat)
+            self.flat_param.grad = self.flat_grad
         # contiguous buckets of roughly equal size over that order
         n_buckets = max(1, min(n_buckets, len(self.params)))
         target = total / n_buckets
-        self.buckets = []          # (start, end, [param indices])
+        self.buckets = []          # (start, end, [param indices in flat order])
         cur, start, acc = [], 0, 0
         for i in order:
             cur.append(i)
@@ -57,46 +69,63 @@ class FlatGradAllReducer(object):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
 
+    # flat view of the gradient buffer (tests / diagnostics)
+    @property
+    def flat(self):
+        return self.flat_grad
+
+    def optimizer_parameters(self):
+        """What to hand the optimizer: the single flat parameter (or the original list if not flattened)."""
+        return [self.flat_param] if self.flat_param is not None else self.params
+
+    def _pack(self, b):
+        s, e, idxs = self.buckets[b]
+        grads = []
+        for i in idxs:
+            g = self.params[i].grad
+            grads.append(g.reshape(-1) if g is not None else self.flat_grad.new_zeros(self.slices[i][1]))
+        torch.cat(grads, out=self.flat_grad[s:e])
+
     def _make_hook(self, i):
         def hook(param):
-            if param.grad.data_ptr() != self.flat.data_ptr() + self.slices[i][0] * self.flat.element_size():
-                # something re-pointed .grad (e.g. zero_grad(set_to_none=True)): copy into the flat buffer
-                off, n = self.slices[i]
-                self.flat[off:off + n].copy_(param.grad.reshape(-1))
-                param.grad = self.flat[off:off + n].view_as(param)
             b = self.bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0:
+                self._pack(b)
                 s, e, _ = self.buckets[b]
-                self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
         return hook
 
     def reset(self):
-        """Call before each backward: zero the flat gradient buffer and re-arm the buckets."""
-        self.flat.zero_()
-        for i, p in enumerate(self.params):
-            off, n = self.slices[i]
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
-                p.grad = self.flat[off:off + n].view_as(p)
+        """Call before each backward: drop the per-parameter gradients (autograd then ASSIGNS fresh ones
+        instead of launching an add per parameter) and re-arm the buckets."""
+        for p in self.params:
+            p.grad = None
         self._pending = [len(idxs) for (_, _, idxs) in self.buckets]
         self._handles = []
 
     def finish(self):
-        """Call after backward, before optimizer.step(): wait for the exchanges, average."""
-        if self.world <= 1:
-            return
-        # a parameter that received no gradient never fires its hook: flush whatever is left
+        """Call after backward, before optimizer.step(): pack what is not packed yet, wait for the
+        exchanges, average.  Afterwards flat_grad (== flat_param.grad) holds the step's gradient."""
         for b, left in enumerate(self._pending):
-            if left > 0:
-                s, e, _ = self.buckets[b]
-                self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
+            if left > 0 or self.world <= 1:
+                # world == 1: no hooks ran; world > 1: a parameter without gradient never fires its hook
+                self._pack(b)
+                if self.world > 1:
+                    s, e, _ = self.buckets[b]
+                    self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
                 self._pending[b] = 0
         for h in self._handles:
             h.wait()
         self._handles = []
-        self.flat.div_(self.world)
+        if self.world > 1:
+            self.flat_grad.div_(self.world)
+        if self.flat_param is None:
+            for i, p in enumerate(self.params):
+                o, n = self.slices[i]
+                p.grad = self.flat_grad[o:o + n].view_as(p)
 
     def remove(self):
         for h in self._hooks:

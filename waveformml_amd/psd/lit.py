@@ -31,9 +31,17 @@ class LitPSD(nn.Module):
         self.occlude_index = getattr(config.dataset_config, "occlude_index", None)
         self.softmax = nn.LogSoftmax(dim=1)
         self.logged = {}
+        self.optimizer_parameters = None      # set to [flat parameter] by ddp.FlatGradAllReducer(flatten=True)
 
     def forward(self, x):
         return self.model(x)
+
+    def _predict(self, c, f, target):
+        # the reference reads the batch size back from the last coordinate row (SPConvNet.py:63, a device->host
+        # sync); one label per event means it equals len(target), which is known on the host
+        if hasattr(self.model, "batch_size_hint"):
+            self.model.batch_size_hint = int(target.shape[0])
+        return self.model([c, f])
 
     def log(self, name, value, **kwargs):
         self.logged[name] = value.detach() if torch.is_tensor(value) else value
@@ -45,8 +53,9 @@ class LitPSD(nn.Module):
     # reference LitPSD.configure_optimizers, :60-76
     def configure_optimizers(self):
         oc = self.config.optimize_config
+        params = self.optimizer_parameters if self.optimizer_parameters is not None else self.model.parameters()
         optimizer = self.modules_util.retrieve_class(oc.optimizer_class)(
-            self.model.parameters(), lr=self.lr, **DictionaryUtility.to_dict(oc.optimizer_params))
+            params, lr=self.lr, **DictionaryUtility.to_dict(oc.optimizer_params))
         if getattr(oc, "scheduler_class", None):
             if not hasattr(oc, "scheduler_params"):
                 raise IOError("Optimizer config has a learning scheduler class specified. You must also set "
@@ -59,7 +68,7 @@ class LitPSD(nn.Module):
     # reference LitPSD.training_step, :94-104
     def training_step(self, batch, batch_idx):
         (c, f), target = batch
-        predictions = self.model([c, f])
+        predictions = self._predict(c, f, target)
         loss = self.criterion.forward(predictions, target)
         self.log("train_loss", loss, on_epoch=True, prog_bar=True, logger=True)
         return loss
@@ -67,7 +76,7 @@ class LitPSD(nn.Module):
     # reference LitPSD.validation_step, :106-128
     def validation_step(self, batch, batch_idx):
         (c, f), target = batch
-        predictions = self.model([c, f])
+        predictions = self._predict(c, f, target)
         loss = self.criterion.forward(predictions, target)
         pred = torch.argmax(self.softmax(predictions), dim=1)
         acc = (pred == target).float().mean()
@@ -80,7 +89,7 @@ class LitPSD(nn.Module):
         (c, f), target = batch
         if self.occlude_index:                       # falsy for index 0, exactly as the reference (:134)
             f[:, self.occlude_index] = 0
-        predictions = self.model([c, f])
+        predictions = self._predict(c, f, target)
         loss = self.criterion.forward(predictions, target)
         pred = torch.argmax(self.softmax(predictions), dim=1)
         acc = (pred == target).float().mean()

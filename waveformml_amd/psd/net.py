@@ -26,6 +26,7 @@ class SPConvNet(nn.Module):
         self.modules_util = ModuleUtility(self.net_config.imports)
         self.spconv = self.modules_util.retrieve_module("spconv")
         self.sequence_class = self.modules_util.retrieve_class(self.net_config.sequence_class)
+        self.batch_size_hint = None
         self._build()
         net_type = getattr(self.net_config, "net_type", "2DConvolution")
         if net_type == "3DConvolution":
@@ -44,6 +45,8 @@ class SPConvNet(nn.Module):
         coords, feats = x[0], x[1]
         if hasattr(self, "waveformLayer"):
             feats = self.waveformLayer(feats.unsqueeze(1)).squeeze(1)
+        if batch_size is None:
+            batch_size = getattr(self, "batch_size_hint", None)
         if batch_size is None:
             batch_size = int(coords[-1, -1]) + 1          # one device->host read, as the reference's
         st = self.spconv.SparseConvTensor(feats, coords[:, self.permute_tensor].contiguous(), self.spatial_size,

@@ -29,9 +29,10 @@ class Trainer(object):
     def fit(self, module, train_loader, val_loader=None):
         module.to(self.device)
         broadcast_parameters(module)
+        reducer = FlatGradAllReducer(module.model.parameters())
+        module.optimizer_parameters = reducer.optimizer_parameters()
         opt = module.configure_optimizers()
         optimizer, scheduler = (opt[0][0], opt[1][0]) if isinstance(opt, tuple) else (opt, None)
-        reducer = FlatGradAllReducer(module.model.parameters())
         best = float("inf")
         for epoch in range(self.max_epochs):
             module.train()

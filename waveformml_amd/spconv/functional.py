@@ -73,8 +73,8 @@ def scatter_conv(table, K, identity_k, R, X, W, transpose_w, n_out, bias):
     return Y.to(X.dtype)
 
 
-def gather_dw(table, K, identity_k, R, S, G, swap):
-    """dW[k,a,b] = sum_r S[r,a] G[table[k,r], b]  (swap: dW[k,b,a])."""
+def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None):
+    """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a])."""
     lib = _lib.load()
     Cs, Cg = int(S.shape[1]), int(G.shape[1])
     dW = torch.empty((K, Cg, Cs) if swap else (K, Cs, Cg), dtype=torch.float32, device=S.device)
@@ -82,7 +82,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap):
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
     nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
-    _lib.check(lib.wfs_gather_dw(_lib.ptr(table), K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0], Cg,
+    _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0], Cg,
                                  1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
                                  _lib.stream_ptr()))
     _account("gather_dw", table, R, R, Cs, G.shape[0], Cg, K, Cs, Cg, S.element_size())
@@ -136,7 +136,12 @@ class SparseConvFunction(Function):
             if ctx.needs_input_grad[0]:
                 dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None)
             if ctx.needs_input_grad[1]:
-                dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False)
+                if features.shape[1] == 2 and dY.shape[1] == 32 and K <= 27 and not rb.has_dup:
+                    # narrow input, wide output (first layer): keep the wide dY rows stationary
+                    table, kmap = rb.table_by_out()
+                    dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap)
+                else:
+                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:

@@ -13,6 +13,12 @@ import torch
 from .. import _lib
 
 
+# When True, index rows are taken to be in range and distinct (what the reference's datasets deliver and
+# what spconv silently assumes): SubM rulebook builds then never synchronise with the host and regular
+# convs skip their duplicate scan.  Default False = every build validates the indices it is given.
+ASSUME_VALID_UNIQUE_INDICES = False
+
+
 def _listify(v, ndim):
     if isinstance(v, (list, tuple, np.ndarray)):
         v = [int(x) for x in v]
@@ -133,11 +139,18 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     nbytes = lib.wfs_rulebook_workspace_bytes(ctypes.byref(g), N)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
     rb.nbr_out = torch.empty((rb.K, N), dtype=torch.int32, device=dev)
-    info = (ctypes.c_int64 * 2)(0, 0)
-    _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
-                                     ws.numel(), info, stream))
-    rb.M = int(info[0])
-    rb.has_dup = bool(info[1])
+    if known_unique is None and ASSUME_VALID_UNIQUE_INDICES:
+        known_unique = True
+    if subm and known_unique:
+        _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
+                                         ws.numel(), None, stream))
+        rb.M, rb.has_dup = N, False
+    else:
+        info = (ctypes.c_int64 * 2)(0, 0)
+        _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
+                                         ws.numel(), info, stream))
+        rb.M = int(info[0])
+        rb.has_dup = bool(info[1])
     symmetric = all(int(g.ksize[i]) % 2 == 1 and int(g.dilation[i]) == 1 for i in range(ndim))
     if subm:
         rb.out_indices = indices
