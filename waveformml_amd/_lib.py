@@ -83,7 +83,8 @@ def check(rc):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream on the current device (kernels are launched there)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def ptr(t):

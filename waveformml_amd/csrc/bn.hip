@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const
         }
         const long long r_begin = (long long)blockIdx.x * rows_per_block;
         const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
+#pragma unroll 4
         for (long long r = r_begin + slot; r < r_end; r += slots) {
             float x[VEC], g[VEC];
             load_vec<T, VEC>(X + r * C + c0, x);
@@ -134,12 +135,28 @@ __device__ __forceinline__ void fold_partials(const float *partial, int nblk, in
     if (C <= TB) {
         const int S = TB / C;
         const int c = threadIdx.x % C, sl = threadIdx.x / C;
-        float a = 0.f, b = 0.f;
-        if (sl < S)
-            for (int p = sl; p < nblk; p += S) {
-                a += partial[(long long)p * 2 * C + c];
-                b += partial[(long long)p * 2 * C + C + c];
+        // four independent chains in a fixed interleave: the loads of one slice overlap instead of
+        // waiting on each other, and the summation order is still the same in every block and run
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        if (sl < S) {
+            int p = sl;
+            for (; p + 3 * S < nblk; p += 4 * S) {
+                const float *q = partial + (long long)p * 2 * C + c;
+                a0 += q[0];
+                b0 += q[C];
+                a1 += q[(long long)S * 2 * C];
+                b1 += q[(long long)S * 2 * C + C];
+                a2 += q[(long long)2 * S * 2 * C];
+                b2 += q[(long long)2 * S * 2 * C + C];
+                a3 += q[(long long)3 * S * 2 * C];
+                b3 += q[(long long)3 * S * 2 * C + C];
             }
+            for (; p < nblk; p += S) {
+                a0 += partial[(long long)p * 2 * C + c];
+                b0 += partial[(long long)p * 2 * C + C + c];
+            }
+        }
+        float a = (a0 + a1) + (a2 + a3), b = (b0 + b1) + (b2 + b3);
         tA[threadIdx.x] = a;
         tB[threadIdx.x] = b;
         __syncthreads();
@@ -223,6 +240,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
     }
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
+#pragma unroll 4
     for (long long r = r_begin + slot; r < r_end; r += slots) {
         float x[VEC], y[VEC];
         load_vec<T, VEC>(X + r * C + c0, x);
@@ -268,6 +286,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
     }
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
+#pragma unroll 4
     for (long long r = r_begin + slot; r < r_end; r += slots) {
         float x[VEC], g[VEC], o[VEC];
         load_vec<T, VEC>(X + r * C + c0, x);
@@ -286,7 +305,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
 long long bn_reduce_blocks(long long N) {      // = number of partials every apply block folds
     long long b = wfs_cdiv(N, 256);
     if (b < 1) b = 1;
-    if (b > 256) b = 256;
+    if (b > 128) b = 128;
     return b;
 }
 long long bn_apply_blocks(long long N) {

@@ -54,8 +54,14 @@ class LitPSD(nn.Module):
     def configure_optimizers(self):
         oc = self.config.optimize_config
         params = self.optimizer_parameters if self.optimizer_parameters is not None else self.model.parameters()
-        optimizer = self.modules_util.retrieve_class(oc.optimizer_class)(
-            params, lr=self.lr, **DictionaryUtility.to_dict(oc.optimizer_params))
+        kwargs = DictionaryUtility.to_dict(oc.optimizer_params)
+        opt_class = self.modules_util.retrieve_class(oc.optimizer_class)
+        if self.optimizer_parameters is not None and len(self.optimizer_parameters) == 1:
+            # one flat tensor: torch's multi-tensor ("foreach") kernels would run it on a handful of blocks
+            import inspect
+            if "foreach" in inspect.signature(opt_class.__init__).parameters and "foreach" not in kwargs:
+                kwargs["foreach"] = False
+        optimizer = opt_class(params, lr=self.lr, **kwargs)
         if getattr(oc, "scheduler_class", None):
             if not hasattr(oc, "scheduler_params"):
                 raise IOError("Optimizer config has a learning scheduler class specified. You must also set "
