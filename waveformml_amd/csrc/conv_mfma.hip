@@ -172,6 +172,14 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return (unsigned)a | ((unsigned)b << 16);
 }
 
+__device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-wise: a vector select goes through scratch
+    v.x = ok ? v.x : 0u;
+    v.y = ok ? v.y : 0u;
+    v.z = ok ? v.z : 0u;
+    v.w = ok ? v.w : 0u;
+    return v;
+}
+
 template <bool TRANSPOSE_W>
 __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                        long long R, const wfs_bf16 *__restrict__ X,
@@ -256,7 +264,8 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
             for (int g = 0; g < BF_GROUP; ++g)
                 if (ks[g] >= 0) {
                     uint4 lo = a_lo[g], hi = a_hi[g];
-                    if (nbs[g] < 0) lo = hi = uint4{0u, 0u, 0u, 0u};
+                    lo = keep_if(lo, nbs[g] >= 0);
+                    hi = keep_if(hi, nbs[g] >= 0);
                     const uint4 *bp = sWb + (size_t)ks[g] * 128 + h * 32 + r;
                     uint4 b0 = bp[0], b1 = bp[64];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, lo),
@@ -408,6 +417,114 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
         __syncthreads();
     }
     for (int e = threadIdx.x; e < DW_KG * 1024; e += 512) {
+        int q = e >> 10, ab = e & 1023;
+        int k = g + q * ngroups;
+        if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + ab] = sAcc[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dW 32 x 32, bf16
+// dW[k][a][b] = sum_r S[r][a] * G[table[k][r]][b] with bf16 rows and v_mfma_f32_32x32x16_bf16.  The contraction
+// runs over ROWS, while memory holds a row's 32 channels contiguously, so both operands need a transpose: each
+// wave parks the 32-row S tile and the gathered G tile in its own LDS region ([row][32 ch], written as whole
+// 16-B chunks) and reads its fragments column-wise (lane (c, h), k-step s, element j <-> row 16s + 8h + j).
+// Work unit: block = (row split, set of 4 offsets {g, g+7, g+14, g+21}); its 16 waves take interleaved tiles,
+// skip (tile, offset) pairs without neighbours, and are summed through LDS in wave order (deterministic).
+constexpr int DWB_WAVES = 16;
+constexpr int DWB_KG = 4;
+
+__device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, int col, int row0) {
+    unsigned w[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        unsigned lo = tile[(row0 + 2 * m) * 32 + col];
+        unsigned hi = tile[(row0 + 2 * m + 1) * 32 + col];
+        w[m] = lo | (hi << 16);
+    }
+    uint4 v = {w[0], w[1], w[2], w[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int K, int identity_k, long long R,
+                                                     const wfs_bf16 *__restrict__ S, const wfs_bf16 *__restrict__ G,
+                                                     float *__restrict__ part, int ngroups, long long tiles_per_block) {
+    __shared__ __attribute__((aligned(16))) unsigned short sTiles[DWB_WAVES][2][32 * 32];   // per wave: S tile, G tile
+    __shared__ float sAcc[DWB_KG * 1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;          // fragment coordinates
+    const int grow = lane >> 2, gchunk = lane & 3;   // staging coordinates: rows grow and grow+16, 16-B chunk gchunk
+    unsigned short *sS = sTiles[wid][0], *sG = sTiles[wid][1];
+    const int g = blockIdx.y;
+    const long long ntiles = (R + 31) >> 5;
+    const long long t_begin = (long long)blockIdx.x * tiles_per_block;
+    const long long t_end = t_begin + tiles_per_block < ntiles ? t_begin + tiles_per_block : ntiles;
+    f32x16 acc[DWB_KG];
+#pragma unroll
+    for (int q = 0; q < DWB_KG; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    for (int e = threadIdx.x; e < DWB_KG * 1024; e += 1024) sAcc[e] = 0.f;
+    for (long long tile = t_begin + wid; tile < t_end; tile += DWB_WAVES) {
+        const long long row0 = tile * 32;
+        const long long ra = row0 + grow, rb = row0 + grow + 16;
+        const bool la = ra < R, lb = rb < R;
+        const long long rac = la ? ra : R - 1, rbc = lb ? rb : R - 1;
+        // table entries of the two rows this lane stages, for the block's 4 offsets (unconditional loads)
+        int ta[DWB_KG], tb[DWB_KG];
+#pragma unroll
+        for (int q = 0; q < DWB_KG; ++q) {
+            int k = g + q * ngroups;
+            int kk = k < K ? k : K - 1;
+            ta[q] = table[(long long)kk * R + rac];
+            tb[q] = table[(long long)kk * R + rbc];
+        }
+        // the S tile is needed whenever any offset is active; issue its loads together with the table reads
+        uint4 s0 = *(const uint4 *)(S + rac * 32 + gchunk * 8);
+        uint4 s1 = *(const uint4 *)(S + rbc * 32 + gchunk * 8);
+        unsigned long long act[DWB_KG];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < DWB_KG; ++q) {
+            int k = g + q * ngroups;
+            int na = (k == identity_k) ? (int)rac : ta[q], nb = (k == identity_k) ? (int)rbc : tb[q];
+            ta[q] = (k < K && la) ? na : -1;
+            tb[q] = (k < K && lb) ? nb : -1;
+            act[q] = __ballot(ta[q] >= 0 || tb[q] >= 0);
+            any = any || act[q] != 0ull;
+        }
+        if (!any) continue;
+        *(uint4 *)(sS + grow * 32 + gchunk * 8) = keep_if(s0, la);
+        *(uint4 *)(sS + (grow + 16) * 32 + gchunk * 8) = keep_if(s1, lb);
+        __builtin_amdgcn_wave_barrier();
+        const bf16x8 a0 = lds_column_frag(sS, c, 8 * h), a1 = lds_column_frag(sS, c, 16 + 8 * h);
+#pragma unroll
+        for (int q = 0; q < DWB_KG; ++q) {
+            if (act[q] == 0ull) continue;
+            uint4 g0 = *(const uint4 *)(G + (long long)(ta[q] >= 0 ? ta[q] : 0) * 32 + gchunk * 8);
+            uint4 g1 = *(const uint4 *)(G + (long long)(tb[q] >= 0 ? tb[q] : 0) * 32 + gchunk * 8);
+            __builtin_amdgcn_wave_barrier();           // the previous offset's fragment reads are done (in order)
+            *(uint4 *)(sG + grow * 32 + gchunk * 8) = keep_if(g0, ta[q] >= 0);
+            *(uint4 *)(sG + (grow + 16) * 32 + gchunk * 8) = keep_if(g1, tb[q] >= 0);
+            __builtin_amdgcn_wave_barrier();
+            const bf16x8 b0 = lds_column_frag(sG, c, 8 * h), b1 = lds_column_frag(sG, c, 16 + 8 * h);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[q], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < DWB_WAVES; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int q = 0; q < DWB_KG; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    sAcc[(q * 32 + arow) * 32 + c] += acc[q][i];
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < DWB_KG * 1024; e += 1024) {
         int q = e >> 10, ab = e & 1023;
         int k = g + q * ngroups;
         if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + ab] = sAcc[e];
@@ -581,7 +698,7 @@ static long long dw32_blocks(long long R) {
     long long ntiles = (R + 31) >> 5;
     long long nblk = (ntiles + 39) / 40;        // ~40 tiles (5 per wave) per block
     if (nblk < 1) nblk = 1;
-    if (nblk > 64) nblk = 64;
+    if (nblk > 36) nblk = 36;                   // x 7 offset sets = 252 blocks: one round on 256 CUs
     return nblk;
 }
 static long long dwc2_chunks(long long R) {
@@ -607,7 +724,7 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
         k_gdw32<float><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(
             table, K, identity_k, R, (const float *)S, (const float *)G, part, ngroups, tiles_per_block);
     else
-        k_gdw32<wfs_bf16><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(
+        k_gdw32_bf16<<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(1024), 0, stream>>>(
             table, K, identity_k, R, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
