@@ -1,0 +1,149 @@
+"""CPU tests of the host-side mirror (waveformml_amd/psd) against golden data captured from the
+REFERENCE's own Python callers (tests/golden/reference_callers.json, generated in the build container by
+tests/golden/make_reference_goldens.py: layer schedules, head widths, output sizes, collate_fn, plugin loader)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_callers.json")) as _f:
+    GOLD = json.load(_f)
+
+
+class _Rec(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.rec = dict(cls=type(self).__name__, args=[a if not isinstance(a, (list, tuple)) else list(a) for a in args],
+                        kwargs=kwargs)
+
+
+def _recording_spconv():
+    sp = types.SimpleNamespace()
+    for name in ["SparseConv2d", "ToDense"]:
+        setattr(sp, name, type(name, (_Rec,), {}))
+
+    class SparseSequential(nn.Module):
+        def __init__(self, *layers):
+            super().__init__()
+            self.layers = list(layers)
+    sp.SparseSequential = SparseSequential
+    return sp
+
+
+@pytest.mark.parametrize("case", GOLD["sparse_conv2d_block_v0"], ids=lambda c: "nin%d_n%d" % (c["inputs"]["nin"], c["inputs"]["n"]))
+def test_layer_schedule_matches_reference_generator(case):
+    from waveformml_amd.psd.blocks import SparseConv2DBlock
+    c = case["inputs"]
+    blk = SparseConv2DBlock(_recording_spconv(), c["nin"], c["nout"], c["n"], list(c["size"]), True, **c["params"])
+    layers = []
+    for m in blk.alg:
+        if isinstance(m, _Rec):
+            layers.append(m.rec)
+        elif isinstance(m, nn.BatchNorm1d):
+            layers.append(dict(cls="BatchNorm1d", args=[m.num_features]))
+        elif isinstance(m, nn.Dropout):
+            layers.append(dict(cls="Dropout", args=[m.p]))
+        else:
+            layers.append(dict(cls=type(m).__name__, args=[]))
+    assert layers == case["layers"]
+    assert [int(v) for v in blk.out_size] == case["out_size"]
+
+
+def test_gep_schedule_is_the_one_survey_quotes():
+    """GEP.json: 300 -> 252 (1x1) -> 158 -> 64 (3x3), dense [10, 7, 64], head 4480 -> 116 -> 3."""
+    g = GOLD["sparse_conv2d_block_v0"][0]
+    convs = [l for l in g["layers"] if l["cls"] == "SparseConv2d"]
+    assert [(l["args"][0], l["args"][1], l["args"][2]) for l in convs] == [(300, 252, 1), (252, 158, 3), (158, 64, 3)]
+    assert g["out_size"] == [10, 7, 64]
+    assert GOLD["linear_block"][0]["widths"] == [[4480, 116], [116, 3]]
+
+
+@pytest.mark.parametrize("case", GOLD["linear_block"], ids=lambda c: "%d_%d_%d" % (c["nin"], c["nout"], c["n"]))
+def test_linear_block_widths(case):
+    from waveformml_amd.psd.blocks import LinearBlock
+    lb = LinearBlock(case["nin"], case["nout"], case["n"])
+    assert [[m.in_features, m.out_features] for m in lb.alg] == case["widths"]
+
+
+def test_output_size_table():
+    from waveformml_amd.psd.blocks import conv_output_size
+    for c in GOLD["calc_output_size"]:
+        assert conv_output_size(c["size"], c["nout"], c["fs"], c["stride"], c["pad"], c["dil"], c["ndim"]) == c["out"], c
+
+
+def test_collate_fn_matches_reference_and_shifts_in_place():
+    from waveformml_amd.psd.data import collate_fn
+    g = GOLD["collate_fn"]
+    batch = [[[torch.tensor(i["coords"], dtype=torch.int32), torch.tensor(i["feats"])], torch.tensor(i["labels"])]
+             for i in g["inputs"]]
+    (c, f), l = collate_fn(batch)
+    assert c.tolist() == g["coords"] and l.tolist() == g["labels"]
+    np.testing.assert_array_equal(f.numpy(), np.asarray(g["feats"], np.float32))
+    assert c.dtype == torch.int32 and int(c[-1, 2]) + 1 == len(g["labels"])
+    assert batch[1][0][0][:, 2].min() >= len(g["inputs"][0]["labels"])       # the inputs were shifted IN PLACE
+
+
+def test_collate_3d_keeps_event_ids_contiguous():
+    from waveformml_amd.psd.data import SyntheticPulseDataset, make_loader
+    ds = SyntheticPulseDataset(3, 4, 32, layout="3d", seed=1)
+    (c, f), y = next(iter(make_loader(ds, 3, pin_memory=False)))
+    assert c.shape[1] == 4 and f.shape[1] == 2 and y.shape[0] == 12
+    ev = c[:, 3]
+    assert int(ev[0]) == 0 and int(ev[-1]) == 11 and bool((ev[1:] >= ev[:-1]).all())
+
+
+def test_plugin_loader_matches_reference():
+    from waveformml_amd.psd.config import DictionaryUtility, ModuleUtility
+    g = GOLD["module_utility"]
+    mu = ModuleUtility(["torch.nn", "collections"])
+    inst = mu.create_class_instances(g["spec"])
+    got = [("class:" + x.__name__) if isinstance(x, type) else ("instance:" + type(x).__name__) for x in inst]
+    assert got == g["result"] and sorted(mu.modules) == g["keys"]
+    with pytest.raises(IOError):
+        mu.retrieve_class("nosuch.Thing")
+    d = GOLD["dictionary_utility"]
+    obj = DictionaryUtility.to_object(d["input"])
+    assert DictionaryUtility.to_dict(obj) == d["roundtrip"] and [obj.a, obj.b.c[1].d] == d["attr"]
+    # the plugin key of a dotted module name is its LAST component: this is how the MI355X operators bind
+    assert "spconv" in ModuleUtility(["waveformml_amd.spconv"]).modules
+
+
+def test_litpsd_builds_from_reference_style_config_and_exposes_the_lightning_surface():
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.lit import LitPSD
+    root = os.path.dirname(HERE)
+    m = LitPSD(load_config(os.path.join(root, "config", "psd_c2_3d.json")))
+    for attr in ["model", "criterion", "lr", "training_step", "validation_step", "test_step", "configure_optimizers"]:
+        assert hasattr(m, attr)
+    assert m.model.n_linear == 35840 and m.model.ndim == 3 and m.model.spatial_size == [14, 11, 256]
+    assert m.model.permute_tensor.tolist() == [3, 0, 1, 2]
+    opt, sched = m.configure_optimizers()
+    assert type(opt[0]).__name__ == "SGD" and opt[0].defaults["nesterov"] and type(sched[0]).__name__ == "ExponentialLR"
+    names = [n for n, _ in m.model.sparseModel.named_parameters()]
+    assert names[0] == "0.weight" and tuple(m.model.sparseModel[0].weight.shape) == (3, 3, 3, 2, 32)
+
+
+def test_gep_hparams_config_builds_the_2d_net():
+    """reference config/examples/GEP.json with only the `imports` changed."""
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.lit import LitPSD
+    cfg = json.load(open(os.path.join(HERE, "golden", "gep_config.json")))
+    m = LitPSD(load_config(cfg))
+    assert [s["nout"] for s in m.model.schedule] == [252, 158, 64] and m.model.n_linear == 4480
+    assert [tuple(l.weight.shape) for l in m.model.linear] == [(116, 4480), (3, 116)]
+
+
+def test_synthetic_generator_is_seeded_and_well_formed():
+    from waveformml_amd.psd import synthetic
+    c1, f1, y1 = synthetic.generate(16, 64, 3, seed=5)
+    c2, f2, y2 = synthetic.generate(16, 64, 3, seed=5)
+    assert np.array_equal(c1, c2) and np.array_equal(f1, f2) and np.array_equal(y1, y2)
+    assert c1.dtype == np.int32 and f1.dtype == np.float32 and c1.shape[1] == 4 and f1.shape[1] == 2
+    assert c1[:, 0].max() < 14 and c1[:, 1].max() < 11 and c1[:, 2].max() < 64 and set(c1[:, 3]) == set(range(16))
+    assert len({tuple(r) for r in c1.tolist()}) == len(c1)            # distinct sites
+    assert 0 < f1.max() <= 1.0 and (f1.max(1) >= 8 / (2 ** 14 - 1) - 1e-9).all()   # zero-suppression threshold
