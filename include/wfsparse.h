@@ -29,6 +29,11 @@
  *     permutes its (x,y[,t],evt) columns to batch-first at src/models/SPConvNet.py:47-52,64).
  *   - feature dtype codes: WFS_F32 (fp32 storage, fp32 accumulate) and WFS_BF16 (bf16 storage,
  *     fp32 accumulate).  Filters [K, Cin, Cout] are fp32 in both cases (master weights).
+ *   - device-side row counts: every row-dimensioned call takes its row count BY VALUE (array
+ *     strides, grid size, = the capacity) and an optional `const int64_t *..._dev` that, when not
+ *     NULL, holds the number of VALID rows (<= the capacity) in device memory.  Rows beyond it are
+ *     neither read nor written.  With device counts no call needs the host to know a data-dependent
+ *     size, so a whole training step can be captured into one HIP graph and replayed.
  */
 #ifndef WFSPARSE_H
 #define WFSPARSE_H
@@ -97,17 +102,24 @@ int wfs_geometry_init(wfs_geometry *g);
  *          (indice_pair_num alone is allowed; pass NULL for both to skip the compaction).
  *
  * `workspace` must hold wfs_rulebook_workspace_bytes(g, N) bytes and stay untouched between
- * the two phases.  WFS_EINVAL if an index row lies outside batch_size / spatial.             */
+ * the two phases.  WFS_EINVAL if an index row lies outside batch_size / spatial.
+ *
+ * Device-count mode (no host synchronisation at all): host_info = NULL, n_dev = valid input rows,
+ * m_dev = where the plan writes min(M, M_cap) for the consumers of the outputs, M_cap = the caller's
+ * output capacity (rows of out_indices / nbr_in handed to emit as M); emit sets *overflow_dev != 0
+ * if the true M exceeded it (the step's results are then invalid and must be redone with room). */
 size_t wfs_rulebook_workspace_bytes(const wfs_geometry *g, int64_t N);
 
 int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, int64_t N,
                       int32_t *nbr_out, void *workspace, size_t workspace_bytes,
-                      int64_t host_info[2], void *stream);
+                      int64_t host_info[2], const int64_t *n_dev, int64_t *m_dev, int64_t M_cap,
+                      void *stream);
 
 int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, int64_t N, int64_t M,
                       int32_t *nbr_out, int32_t *out_indices, int32_t *nbr_in,
                       int32_t *indice_pairs, int32_t *indice_pair_num,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      void *workspace, size_t workspace_bytes, const int64_t *n_dev,
+                      int32_t *overflow_dev, void *stream);
 
 /* Duplicate-coordinate / range check of an index set whose uniqueness is unknown before a
  * REGULAR conv (SubM learns it for free in its plan; a regular conv's output is unique by
@@ -131,7 +143,7 @@ int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indices, int64_
 int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                     int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
-                    int32_t dtype, void *stream);
+                    int32_t dtype, const int64_t *r_dev, void *stream);
 
 /* Replaces the dW half of torch.ops.spconv.indice_conv_backward:
  *     dW[k, a, b] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 0)
@@ -145,7 +157,7 @@ size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t C
 int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                   int64_t R, const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg,
                   int32_t swap, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
-                  void *stream);
+                  const int64_t *r_dev, void *stream);
 
 /* Scatter form with fp32 atomics, used ONLY when the input holds duplicate coordinates (then
  * the inverse of a gather table is not a function):
@@ -168,12 +180,14 @@ size_t wfs_bn_workspace_bytes(int64_t N, int32_t C);
 int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float momentum, float eps,
                     int32_t training, int32_t relu, void *Y, float *save_mean, float *save_invstd,
-                    void *workspace, size_t workspace_bytes, int32_t dtype, void *stream);
+                    void *workspace, size_t workspace_bytes, int32_t dtype, const int64_t *n_dev,
+                    void *stream);
 
 int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
                     const float *beta, const float *save_mean, const float *save_invstd,
                     int32_t training, int32_t relu, void *dX, float *dgamma, float *dbeta,
-                    void *workspace, size_t workspace_bytes, int32_t dtype, void *stream);
+                    void *workspace, size_t workspace_bytes, int32_t dtype, const int64_t *n_dev,
+                    void *stream);
 
 /* SparseConvTensor.dense() -------------------------------------------------------------------
  * Y is [B, C, *spatial] (channels first, contiguous) and must be zero-filled by the caller;
@@ -182,11 +196,11 @@ int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const f
  * assignment order does (A.1).  wfs_to_dense_bwd gathers dX[m,c] = dY[b,c,pos] for every row. */
 int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, int32_t ndim,
                  const int32_t *spatial_host, int32_t batch_size, int32_t C, void *Y,
-                 int32_t *winner_ws, int32_t dtype, void *stream);
+                 int32_t *winner_ws, int32_t dtype, const int64_t *m_dev, void *stream);
 
 int wfs_to_dense_bwd(const void *dY, const int32_t *indices, int64_t M, int32_t ndim,
                      const int32_t *spatial_host, int32_t batch_size, int32_t C, void *dX,
-                     int32_t dtype, void *stream);
+                     int32_t dtype, const int64_t *m_dev, void *stream);
 
 /* opt-in per-kernel timing (HIP events on the launch stream), used by bench.py's roofline ---- */
 #define WFS_TIMER_GATHER_CONV 0

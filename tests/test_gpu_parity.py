@@ -391,3 +391,89 @@ def test_layers_at_bench_geometry_bf16(layer_kind):
     yg.features.backward(g.to(DEV))
     _assert_close(fg.grad.float().cpu().numpy(), fr.grad.numpy(), 1e-2, "dX")
     _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-2, "dW")
+
+
+def _c2_module(T, n_lin, dtype_seed=0):
+    import copy
+    import json
+    from waveformml_amd.psd.config import DictionaryUtility
+    from waveformml_amd.psd.lit import LitPSD
+    root = os.path.dirname(HERE)
+    cfg = json.load(open(os.path.join(root, "config", "psd_c2_3d.json")))
+    cfg["system_config"]["n_samples"] = T
+    cfg["net_config"]["algorithm"][-1] = [n_lin, 3]
+    torch.manual_seed(11 + dtype_seed)
+    return LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg)))
+
+
+def test_device_count_mode_equals_exact_size_mode():
+    """Capacity-padded tensors + device-side row counts (no host read-back anywhere) must give the same
+    logits, loss and gradients as the ordinary exact-size path -- bit for bit in the sparse stack, because the
+    kernels visit the same rows in the same order."""
+    from waveformml_amd.psd import synthetic
+    T, B = 64, 24
+    mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
+    c, f, y = synthetic.generate(B, T, 3, seed=77)
+    coords, feats, labels = torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV), torch.from_numpy(y).to(DEV)
+    mod.zero_grad()
+    loss_a = mod.training_step(([coords, feats], labels), 0)
+    loss_a.backward()
+    grads_a = [p.grad.clone() for p in mod.model.parameters()]
+    stats_a = [b.clone() for b in mod.model.buffers()]
+    # padded: 30 % spare rows filled with garbage that must never be touched
+    mod2 = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
+    n, cap = coords.shape[0], int(coords.shape[0] * 1.3) + 17
+    pc = torch.randint(0, 10, (cap, 4), dtype=torch.int32, device=DEV)
+    pf = torch.full((cap, 2), float("nan"), device=DEV)
+    pc[:n], pf[:n] = coords, feats
+    n_valid = torch.tensor([n], dtype=torch.int64, device=DEV)
+    loss_b = mod2.training_step(([pc, pf, n_valid], labels), 0)
+    loss_b.backward()
+    assert loss_a.item() == loss_b.item()
+    for ga, p in zip(grads_a, mod2.model.parameters()):
+        assert torch.equal(ga, p.grad)
+    for sa, b in zip(stats_a, mod2.model.buffers()):
+        assert torch.equal(sa, b)
+    convs = [m for m in mod2.modules() if getattr(m, "last_rulebook", None) is not None and not m.subm]
+    assert convs and all(int(m.last_rulebook.overflow) == 0 for m in convs)
+    assert all(int(m.last_rulebook.m_dev) <= m.last_rulebook.M for m in convs)
+
+
+def test_graph_captured_step_matches_eager_steps():
+    """The HIP-graph replay of the whole training step (psd/graph.py) against the same steps run eagerly."""
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    from waveformml_amd.psd.graph import GraphedTrainStep
+    T, B = 64, 24
+    batches = []
+    for s in (5, 6, 7):
+        c, f, y = synthetic.generate(B, T, 3, seed=s)
+        batches.append(([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV)))
+
+    def make():
+        mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
+        red = FlatGradAllReducer(mod.model.parameters(), world_size=1)
+        mod.optimizer_parameters = red.optimizer_parameters()
+        opt = mod.configure_optimizers()[0][0]
+        return mod, red, opt
+
+    mod_e, red_e, opt_e = make()
+    mod_g, red_g, opt_g = make()
+    # the graphed runner spends one calibration + two warm-up steps on its example batch before capturing
+    step = GraphedTrainStep(mod_g, opt_g, red_g, batches[0], warmup=2)
+    for _ in range(3):
+        red_e.reset()
+        mod_e.training_step(batches[0], 0).backward()
+        red_e.finish()
+        opt_e.step()
+    for b in batches:
+        red_e.reset()
+        le = mod_e.training_step(b, 0)
+        le.backward()
+        red_e.finish()
+        opt_e.step()
+        lg = step(b)
+        step.check()
+        assert abs(lg.item() - le.item()) <= 1e-6 * max(abs(le.item()), 1e-6), (lg.item(), le.item())
+    for a, b in zip(mod_e.model.parameters(), mod_g.model.parameters()):
+        _assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 1e-6, "parameters after 6 steps")

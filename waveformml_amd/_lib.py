@@ -32,23 +32,24 @@ SIGNATURES = {
     "wfs_last_error": (ctypes.c_char_p, []),
     "wfs_geometry_init": (ctypes.c_int, [ctypes.POINTER(Geometry)]),
     "wfs_rulebook_workspace_bytes": (_sz, [ctypes.POINTER(Geometry), _i64]),
-    "wfs_rulebook_plan": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _vp, _sz, c_i64p, _vp]),
+    "wfs_rulebook_plan": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _vp, _sz, c_i64p, _vp, _vp, _i64,
+                                         _vp]),
     "wfs_rulebook_emit": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
-                                         _vp, _sz, _vp]),
+                                         _vp, _sz, _vp, _vp, _vp]),
     "wfs_indices_check": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _sz, c_i64p, _vp]),
     "wfs_gather_conv": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _i32,
-                                       _vp, _vp, _i32, _vp]),
+                                       _vp, _vp, _i32, _vp, _vp]),
     "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "wfs_gather_dw": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
-                                     _sz, _vp]),
+                                     _sz, _vp, _vp]),
     "wfs_scatter_conv": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "wfs_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "wfs_bn_relu_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32, _i32,
-                                       _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+                                       _vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp]),
     "wfs_bn_relu_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
-                                       _i32, _vp]),
-    "wfs_to_dense": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _vp, _i32, _vp]),
-    "wfs_to_dense_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp]),
+                                       _i32, _vp, _vp]),
+    "wfs_to_dense": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "wfs_to_dense_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp, _vp]),
     "wfs_timing_enable": (ctypes.c_int, [_i32]),
     "wfs_timing_read": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_double), c_i64p]),
 }

@@ -18,6 +18,12 @@ namespace {
 constexpr int TB = 256;
 constexpr int MAXC = 1024;
 
+// N = capacity (grid sizing); the number of valid rows comes from device memory when n_dev is given
+__device__ __forceinline__ long long valid_rows(long long N, const long long *n_dev) {
+    long long v = n_dev ? *n_dev : N;
+    return v < N ? v : N;
+}
+
 // thread layout of a block: (row slot, channel group of VEC channels); VEC = 4 when C % 4 == 0, else 1
 template <typename T, int VEC>
 __device__ __forceinline__ void load_vec(const T *p, float *out) {
@@ -54,12 +60,13 @@ __device__ __forceinline__ void store_vec(T *p, const float *in) {
 //   MODE 0 (forward stats):  a = d, b = d*d with d = x - x[row 0] (shifted sums: no cancellation in the variance)
 //   MODE 1 (backward):       a = g, b = g*xhat with g = dy*[gamma*xhat+beta > 0] (relu), xhat = (x-mean)*invstd
 template <typename T, int VEC, int MODE>
-__global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const T *__restrict__ dY, long long N, int C,
-                                                  long long rows_per_block, const float *__restrict__ mean,
+__global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const T *__restrict__ dY, long long Ncap,
+                                                  const long long *__restrict__ n_dev, int C, long long rows_per_block, const float *__restrict__ mean,
                                                   const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                   const float *__restrict__ beta, int relu,
                                                   float *__restrict__ partial) {
     __shared__ float red[2][TB][VEC];
+    const long long N = valid_rows(Ncap, n_dev);
     const int groups = C / VEC, slots = TB / groups;
     const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
     const int c0 = grp * VEC;
@@ -185,7 +192,8 @@ __device__ __forceinline__ void fold_partials(const float *partial, int nblk, in
 }
 
 template <typename T, int VEC>
-__global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long long N, int C, long long rows_per_block,
+__global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long long Ncap,
+                                                 const long long *__restrict__ n_dev, int C, long long rows_per_block,
                                                  const float *__restrict__ partial, int nblk_partial,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                  float *__restrict__ running_mean, float *__restrict__ running_var,
@@ -193,6 +201,8 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
                                                  T *__restrict__ Y, float *__restrict__ save_mean,
                                                  float *__restrict__ save_invstd) {
     __shared__ float sA[MAXC], sB[MAXC];       // mean / invstd
+    const long long N = valid_rows(Ncap, n_dev);
+    if (N <= 0) return;
     if (training) {
         fold_partials(partial, nblk_partial, C, sA, sB);
         for (int c = threadIdx.x; c < C; c += TB) {
@@ -254,14 +264,16 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
 }
 
 template <typename T, int VEC>
-__global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, const T *__restrict__ dY, long long N,
-                                                     int C, long long rows_per_block,
+__global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, const T *__restrict__ dY,
+                                                     long long Ncap, const long long *__restrict__ n_dev, int C,
+                                                     long long rows_per_block,
                                                      const float *__restrict__ partial, int nblk_partial,
                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                      int training, int relu, T *__restrict__ dX,
                                                      float *__restrict__ dgamma, float *__restrict__ dbeta) {
     __shared__ float sA[MAXC], sB[MAXC];       // sum g, sum g*xhat
+    const long long N = valid_rows(Ncap, n_dev);
     fold_partials(partial, nblk_partial, C, sA, sB);
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += TB) {
@@ -274,7 +286,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
     if (slot >= slots) return;
     const int c0 = grp * VEC;
     float m[VEC], is[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
-    const float invN = 1.f / (float)N;
+    const float invN = N > 0 ? 1.f / (float)N : 0.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         m[i] = mean[c0 + i];
@@ -324,8 +336,9 @@ extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
 extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
                                float *running_mean, float *running_var, float momentum, float eps, int32_t training,
                                int32_t relu, void *Y, float *save_mean, float *save_invstd, void *workspace,
-                               size_t workspace_bytes, int32_t dtype, void *stream_) {
+                               size_t workspace_bytes, int32_t dtype, const int64_t *n_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const long long *n_dev = (const long long *)n_dev_;
     WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
     WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(training || (running_mean && running_var), WFS_EINVAL, "eval mode needs running statistics");
@@ -339,9 +352,10 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
 #define WFS_BN_FWD(T, VEC)                                                                                         \
     do {                                                                                                           \
         if (training)                                                                                              \
-            k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, C, rpb, nullptr, nullptr,  \
-                                                                nullptr, nullptr, 0, partial);                     \
-        k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, C, rpb_a, partial, (int)nblk, gamma, beta, \
+            k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,   \
+                                                                nullptr, nullptr, nullptr, 0, partial);            \
+        k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, rpb_a, partial, (int)nblk,       \
+                                                          gamma, beta,                                             \
                                                         running_mean, running_var, momentum, eps, training, relu,  \
                                                         (T *)Y, save_mean, save_invstd);                           \
     } while (0)
@@ -358,8 +372,9 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
 extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
                                const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
                                int32_t relu, void *dX, float *dgamma, float *dbeta, void *workspace,
-                               size_t workspace_bytes, int32_t dtype, void *stream_) {
+                               size_t workspace_bytes, int32_t dtype, const int64_t *n_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const long long *n_dev = (const long long *)n_dev_;
     WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
     WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
     if (N == 0) {
@@ -375,9 +390,9 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
 #define WFS_BN_BWD(T, VEC)                                                                                           \
     do {                                                                                                             \
-        k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, C, rpb, save_mean,          \
+        k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb, save_mean,   \
                                                             save_invstd, gamma, beta, relu, partial);                \
-        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, C, rpb_a, partial,        \
+        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb_a, partial, \
                                                               (int)nblk,                                             \
                                                             save_mean, save_invstd, gamma, beta, training, relu,     \
                                                             (T *)dX, dgamma, dbeta);                                 \

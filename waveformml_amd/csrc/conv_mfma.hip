@@ -25,12 +25,19 @@ struct KMap {
     int v[128];
 };
 
+// R = capacity (strides, grid); the number of valid rows comes from device memory when r_dev is given
+__device__ __forceinline__ long long valid_rows(long long R, const long long *r_dev) {
+    long long v = r_dev ? *r_dev : R;
+    return v < R ? v : R;
+}
+
 // ------------------------------------------------------------------------------------------ 32 -> 32
 // LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
 // (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
 template <bool TRANSPOSE_W>
 __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
-                                                      long long R, const float *__restrict__ X,
+                                                      long long R, const long long *__restrict__ r_dev,
+                                                      const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                       float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
                                                       int dbg) {
@@ -68,10 +75,12 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     const long long t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
     const float bj = bias ? bias[r] : 0.f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long Rv = valid_rows(R, r_dev);
     for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
+        if (tile * 32 >= Rv) break;
         const long long row = tile * 32 + r;
-        const bool live = row < R;
-        const long long rowc = live ? row : R - 1;
+        const bool live = row < Rv;
+        const long long rowc = live ? row : 0;
         // ---- phase 1: which kernel offsets does this tile use?  All K table reads are issued together
         // (unconditional, clamped addresses: a per-element "load or zero" would make hipcc branch around and
         // wait for every single load), then one ballot each.
@@ -145,7 +154,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (orow < R) Y[orow * 32 + r] = acc[i];
+            if (orow < Rv) Y[orow * 32 + r] = acc[i];
         }
     }
 }
@@ -182,7 +191,8 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 
 template <bool TRANSPOSE_W>
 __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K, int identity_k,
-                                                       long long R, const wfs_bf16 *__restrict__ X,
+                                                       long long R, const long long *__restrict__ r_dev,
+                                                       const wfs_bf16 *__restrict__ X,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                        wfs_bf16 *__restrict__ Y, long long ntiles,
                                                        long long tiles_per_xcd) {
@@ -219,10 +229,12 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
     const long long t_begin = (long long)xcd * tiles_per_xcd;
     const long long t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
     const float bj = bias ? bias[r] : 0.f;
+    const long long Rv = valid_rows(R, r_dev);
     for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
+        if (tile * 32 >= Rv) break;
         const long long row = tile * 32 + r;
-        const bool live = row < R;
-        const long long rowc = live ? row : R - 1;
+        const bool live = row < Rv;
+        const long long rowc = live ? row : 0;
         // ---- phase 1
         int v[32];
 #pragma unroll
@@ -285,7 +297,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
             unsigned packed = (lane & 1) ? pack_bf16x2(got, mine1) : pack_bf16x2(mine0, got);
             int ri = (lane & 1) ? i + 1 : i;
             long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
-            if (orow < R) Yw[orow * 16 + (r >> 1)] = packed;
+            if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
         }
     }
 }
@@ -293,7 +305,8 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
 // ------------------------------------------------------------------------------------------ 2 -> 32
 template <typename T>
 __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ table, KMap kmap, int K, int identity_k,
-                                                     long long R, const T *__restrict__ X,
+                                                     long long R, const long long *__restrict__ r_dev,
+                                                     const T *__restrict__ X,
                                                      const float *__restrict__ W, const float *__restrict__ bias,
                                                      T *__restrict__ Y) {
     __shared__ __attribute__((aligned(16))) float sW[128 * 64];
@@ -302,7 +315,8 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
     const int rsub = threadIdx.x >> 3, cq = threadIdx.x & 7;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *(const f32x4 *)(bias + cq * 4);
-    for (long long row = (long long)blockIdx.x * 32 + rsub; row < R; row += (long long)gridDim.x * 32) {
+    const long long Rv = valid_rows(R, r_dev);
+    for (long long row = (long long)blockIdx.x * 32 + rsub; row < Rv; row += (long long)gridDim.x * 32) {
         f32x4 acc = bv;
         for (int k = 0; k < K; ++k) {
             int nb = (k == identity_k) ? (int)row : table[(long long)kmap.v[k] * R + row];
@@ -341,13 +355,15 @@ constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator register
 constexpr int DW_WAVES = 8;
 
 template <typename T>
-__global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long R,
-                                                  const T *__restrict__ S, const T *__restrict__ G,
+__global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
+                                                  const long long *__restrict__ r_dev, const T *__restrict__ S,
+                                                  const T *__restrict__ G,
                                                   float *__restrict__ part, int ngroups, long long tiles_per_block) {
     __shared__ float sAcc[DW_KG * 1024];                              // [DW_KG][32][32], 16 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int g = blockIdx.y;
+    const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
     const long long t_begin = (long long)blockIdx.x * tiles_per_block;
     const long long t_end = t_begin + tiles_per_block < ntiles ? t_begin + tiles_per_block : ntiles;
@@ -367,7 +383,7 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
         for (int q = 0; q < DW_KG; ++q) {
             int k = g + q * ngroups;
             int kk = k < K ? k : K - 1;
-            nbv[q] = table[(long long)kk * R + trow];
+            nbv[q] = table[(long long)kk * Rcap + trow];
         }
         float a[16];
 #pragma unroll
@@ -445,7 +461,8 @@ __device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int K, int identity_k, long long R,
+__global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int K, int identity_k,
+                                                     long long Rcap, const long long *__restrict__ r_dev,
                                                      const wfs_bf16 *__restrict__ S, const wfs_bf16 *__restrict__ G,
                                                      float *__restrict__ part, int ngroups, long long tiles_per_block) {
     __shared__ __attribute__((aligned(16))) unsigned short sTiles[DWB_WAVES][2][32 * 32];   // per wave: S tile, G tile
@@ -455,6 +472,7 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
     const int grow = lane >> 2, gchunk = lane & 3;   // staging coordinates: rows grow and grow+16, 16-B chunk gchunk
     unsigned short *sS = sTiles[wid][0], *sG = sTiles[wid][1];
     const int g = blockIdx.y;
+    const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
     const long long t_begin = (long long)blockIdx.x * tiles_per_block;
     const long long t_end = t_begin + tiles_per_block < ntiles ? t_begin + tiles_per_block : ntiles;
@@ -475,8 +493,8 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
         for (int q = 0; q < DWB_KG; ++q) {
             int k = g + q * ngroups;
             int kk = k < K ? k : K - 1;
-            ta[q] = table[(long long)kk * R + rac];
-            tb[q] = table[(long long)kk * R + rbc];
+            ta[q] = table[(long long)kk * Rcap + rac];
+            tb[q] = table[(long long)kk * Rcap + rbc];
         }
         // the S tile is needed whenever any offset is active; issue its loads together with the table reads
         uint4 s0 = *(const uint4 *)(S + rac * 32 + gchunk * 8);
@@ -537,12 +555,14 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
 // with c in {0,1}.  Thread = (row slot, b); 2*K accumulators in registers (K <= 27).
 template <typename T>
 __global__ void __launch_bounds__(256) k_gdw_c32c2(const int *__restrict__ table, int mirror, int K, int identity_k,
-                                                   long long R, long long rows_per_chunk, const T *__restrict__ S,
+                                                   long long R, const long long *__restrict__ r_dev,
+                                                   long long rows_per_chunk, const T *__restrict__ S,
                                                    const T *__restrict__ G, float *__restrict__ part) {
     __shared__ float sRed[8][32];
     const int slot = threadIdx.x >> 5, b = threadIdx.x & 31;
+    const long long Rv = valid_rows(R, r_dev);
     const long long r_begin = (long long)blockIdx.x * rows_per_chunk;
-    const long long r_end = r_begin + rows_per_chunk < R ? r_begin + rows_per_chunk : R;
+    const long long r_end = r_begin + rows_per_chunk < Rv ? r_begin + rows_per_chunk : Rv;
     float acc0[27], acc1[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc0[k] = acc1[k] = 0.f;
@@ -621,8 +641,9 @@ bool g_attr_done[2] = {false, false};
 // ---- launchers used by gather_conv.hip's C entry points -------------------------------------------------
 bool wfs_mfma_gconv32_ok(int K) { return K >= 1 && K <= 32; }       // K * 4 KiB of LDS <= 128 KiB
 
-int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const float *X,
-                           const float *W, int transpose_w, const float *bias, float *Y, hipStream_t stream) {
+int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                           const float *X, const float *W, int transpose_w, const float *bias, float *Y,
+                           hipStream_t stream) {
     const long long ntiles = (R + 31) >> 5;
     // waves per block: enough tiles per SIMD without leaving CUs idle on small inputs
     int wpb = (int)((ntiles + 255) / 256);
@@ -641,17 +662,18 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
         g_attr_done[which] = true;
     }
     if (transpose_w)
-        k_gconv32_f32<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, mirror, K, identity_k, R, X, W,
-                                                                                 bias, Y, ntiles, tiles_per_xcd, dbg);
+        k_gconv32_f32<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
+            table, mirror, K, identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg);
     else
-        k_gconv32_f32<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(table, mirror, K, identity_k, R, X, W,
-                                                                                  bias, Y, ntiles, tiles_per_xcd, dbg);
+        k_gconv32_f32<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
+            table, mirror, K, identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
 
-int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const void *X,
-                            const float *W, int transpose_w, const float *bias, void *Y, hipStream_t stream) {
+int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                            const void *X, const float *W, int transpose_w, const float *bias, void *Y,
+                            hipStream_t stream) {
     static bool attr[2] = {false, false};
     const long long ntiles = (R + 31) >> 5;
     int wpb = (int)((ntiles + 255) / 256);
@@ -669,26 +691,27 @@ int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k,
     }
     if (transpose_w)
         k_gconv32_bf16<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
-            table, mirror, K, identity_k, R, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
+            table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
     else
         k_gconv32_bf16<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
-            table, mirror, K, identity_k, R, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
+            table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
 
-int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R, const void *X,
-                           const float *W, const float *bias, void *Y, int dtype, hipStream_t stream) {
+int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
+                           const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
+                           hipStream_t stream) {
     KMap km;
     for (int k = 0; k < K; ++k) km.v[k] = kmap ? kmap[k] : k;
     long long nblk = (R + 31) / 32;
     if (nblk > 8192) nblk = 8192;
     if (dtype == WFS_F32)
-        k_gconv_c2c32<float><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(table, km, K, identity_k, R,
+        k_gconv_c2c32<float><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(table, km, K, identity_k, R, r_dev,
                                                                             (const float *)X, W, bias, (float *)Y);
     else
         k_gconv_c2c32<wfs_bf16><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(
-            table, km, K, identity_k, R, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y);
+            table, km, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
@@ -714,18 +737,18 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
     return 0;
 }
 
-int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const void *S, const void *G, int swap,
-                     float *dW, float *part, int dtype, hipStream_t stream) {
+int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
+                     const void *G, int swap, float *dW, float *part, int dtype, hipStream_t stream) {
     const long long nblk = dw32_blocks(R);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
     if (dtype == WFS_F32)
         k_gdw32<float><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(
-            table, K, identity_k, R, (const float *)S, (const float *)G, part, ngroups, tiles_per_block);
+            table, K, identity_k, R, r_dev, (const float *)S, (const float *)G, part, ngroups, tiles_per_block);
     else
         k_gdw32_bf16<<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(1024), 0, stream>>>(
-            table, K, identity_k, R, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
+            table, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
     k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
@@ -733,16 +756,17 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
     return WFS_OK;
 }
 
-int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const void *S,
-                         const void *G, int swap, float *dW, float *part, int dtype, hipStream_t stream) {
+int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                         const void *S, const void *G, int swap, float *dW, float *part, int dtype,
+                         hipStream_t stream) {
     const long long chunks = dwc2_chunks(R);
     const long long rows_per_chunk = (R + chunks - 1) / chunks;
     if (dtype == WFS_F32)
         k_gdw_c32c2<float><<<dim3((unsigned)chunks), dim3(256), 0, stream>>>(
-            table, mirror, K, identity_k, R, rows_per_chunk, (const float *)S, (const float *)G, part);
+            table, mirror, K, identity_k, R, r_dev, rows_per_chunk, (const float *)S, (const float *)G, part);
     else
         k_gdw_c32c2<wfs_bf16><<<dim3((unsigned)chunks), dim3(256), 0, stream>>>(
-            table, mirror, K, identity_k, R, rows_per_chunk, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
+            table, mirror, K, identity_k, R, r_dev, rows_per_chunk, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
     WFS_LAUNCH_CHECK();
     // part is [chunk][k][c (gathered, 2)][b (stationary, 32)] = the "swap" orientation of (S=32, G=2)
     const long long per = (long long)K * 64;

@@ -25,19 +25,26 @@ __device__ __forceinline__ long long cell_of(const Shape &s, const int *row, int
     return pos;
 }
 
-__global__ void k_dense_winner(Shape s, const int *__restrict__ idx, long long M, int *__restrict__ winner) {
+// M = capacity (grid); the number of valid rows comes from device memory when m_dev is given
+__device__ __forceinline__ long long valid_rows(long long M, const long long *m_dev) {
+    long long v = m_dev ? *m_dev : M;
+    return v < M ? v : M;
+}
+
+__global__ void k_dense_winner(Shape s, const int *__restrict__ idx, long long M, const long long *m_dev,
+                               int *__restrict__ winner) {
     long long m = (long long)blockIdx.x * TB + threadIdx.x;
-    if (m >= M) return;
+    if (m >= valid_rows(M, m_dev)) return;
     int b;
     long long pos = cell_of(s, idx + m * (s.ndim + 1), b);
     atomicMax(&winner[(long long)b * s.volume + pos], (int)m);
 }
 
 template <typename T>
-__global__ void k_to_dense(Shape s, const T *__restrict__ X, const int *__restrict__ idx, long long M, int C,
-                           const int *__restrict__ winner, T *__restrict__ Y) {
+__global__ void k_to_dense(Shape s, const T *__restrict__ X, const int *__restrict__ idx, long long M,
+                           const long long *m_dev, int C, const int *__restrict__ winner, T *__restrict__ Y) {
     long long e = (long long)blockIdx.x * TB + threadIdx.x;
-    if (e >= M * C) return;
+    if (e >= valid_rows(M, m_dev) * C) return;
     long long m = e / C;
     int c = (int)(e % C);
     int b;
@@ -47,10 +54,10 @@ __global__ void k_to_dense(Shape s, const T *__restrict__ X, const int *__restri
 }
 
 template <typename T>
-__global__ void k_to_dense_bwd(Shape s, const T *__restrict__ dY, const int *__restrict__ idx, long long M, int C,
-                               T *__restrict__ dX) {
+__global__ void k_to_dense_bwd(Shape s, const T *__restrict__ dY, const int *__restrict__ idx, long long M,
+                               const long long *m_dev, int C, T *__restrict__ dX) {
     long long e = (long long)blockIdx.x * TB + threadIdx.x;
-    if (e >= M * C) return;
+    if (e >= valid_rows(M, m_dev) * C) return;
     long long m = e / C;
     int c = (int)(e % C);
     int b;
@@ -76,8 +83,9 @@ int make_shape(Shape *s, int ndim, const int32_t *spatial_host) {
 // which makes "last row wins" deterministic.
 extern "C" int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, int32_t ndim,
                             const int32_t *spatial_host, int32_t batch_size, int32_t C, void *Y, int32_t *winner_ws,
-                            int32_t dtype, void *stream_) {
+                            int32_t dtype, const int64_t *m_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const long long *m_dev = (const long long *)m_dev_;
     Shape s;
     int rc = make_shape(&s, ndim, spatial_host);
     if (rc) return rc;
@@ -86,14 +94,14 @@ extern "C" int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, in
     WFS_REQUIRE(X && indices && Y, WFS_EINVAL, "NULL device pointer");
     if (winner_ws) {
         WFS_HIP_CHECK(hipMemsetAsync(winner_ws, 0xFF, (size_t)batch_size * s.volume * 4, stream));
-        k_dense_winner<<<dim3((unsigned)wfs_cdiv(M, TB)), dim3(TB), 0, stream>>>(s, indices, M, winner_ws);
+        k_dense_winner<<<dim3((unsigned)wfs_cdiv(M, TB)), dim3(TB), 0, stream>>>(s, indices, M, m_dev, winner_ws);
         WFS_LAUNCH_CHECK();
     }
     dim3 grid((unsigned)wfs_cdiv(M * C, TB)), block(TB);
     if (dtype == WFS_F32)
-        k_to_dense<float><<<grid, block, 0, stream>>>(s, (const float *)X, indices, M, C, winner_ws, (float *)Y);
+        k_to_dense<float><<<grid, block, 0, stream>>>(s, (const float *)X, indices, M, m_dev, C, winner_ws, (float *)Y);
     else
-        k_to_dense<wfs_bf16><<<grid, block, 0, stream>>>(s, (const wfs_bf16 *)X, indices, M, C, winner_ws,
+        k_to_dense<wfs_bf16><<<grid, block, 0, stream>>>(s, (const wfs_bf16 *)X, indices, M, m_dev, C, winner_ws,
                                                          (wfs_bf16 *)Y);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
@@ -101,8 +109,9 @@ extern "C" int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, in
 
 extern "C" int wfs_to_dense_bwd(const void *dY, const int32_t *indices, int64_t M, int32_t ndim,
                                 const int32_t *spatial_host, int32_t batch_size, int32_t C, void *dX,
-                                int32_t dtype, void *stream_) {
+                                int32_t dtype, const int64_t *m_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const long long *m_dev = (const long long *)m_dev_;
     (void)batch_size;
     Shape s;
     int rc = make_shape(&s, ndim, spatial_host);
@@ -112,9 +121,10 @@ extern "C" int wfs_to_dense_bwd(const void *dY, const int32_t *indices, int64_t 
     WFS_REQUIRE(dY && indices && dX, WFS_EINVAL, "NULL device pointer");
     dim3 grid((unsigned)wfs_cdiv(M * C, TB)), block(TB);
     if (dtype == WFS_F32)
-        k_to_dense_bwd<float><<<grid, block, 0, stream>>>(s, (const float *)dY, indices, M, C, (float *)dX);
+        k_to_dense_bwd<float><<<grid, block, 0, stream>>>(s, (const float *)dY, indices, M, m_dev, C, (float *)dX);
     else
-        k_to_dense_bwd<wfs_bf16><<<grid, block, 0, stream>>>(s, (const wfs_bf16 *)dY, indices, M, C, (wfs_bf16 *)dX);
+        k_to_dense_bwd<wfs_bf16><<<grid, block, 0, stream>>>(s, (const wfs_bf16 *)dY, indices, M, m_dev, C,
+                                                             (wfs_bf16 *)dX);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

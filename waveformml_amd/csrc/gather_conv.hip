@@ -21,13 +21,20 @@ struct KMap {                // table column used for filter offset k (identity 
     int v[128];
 };
 
+// R = capacity (strides, grid); the number of valid rows comes from device memory when r_dev is given
+__device__ __forceinline__ long long valid_rows(long long R, const long long *r_dev) {
+    long long v = r_dev ? *r_dev : R;
+    return v < R ? v : R;
+}
+
 // ------------------------------------------------------------------------------------------
 // generic gather conv: block = 64 rows x 4 waves; wave w owns output channels
 // [cbase + w*CT, cbase + w*CT + CT) of the 32-channel slice blockIdx.y.  The filter values a wave
 // needs are wave-uniform -> scalar loads; X values are per-lane row gathers (L1/L2 served).
 template <typename T, bool TRANSPOSE_W>
 __global__ void __launch_bounds__(TB) k_gather_conv(const int *__restrict__ table, KMap kmap, int K, int identity_k,
-                                                    long long R, const T *__restrict__ X, int Cx,
+                                                    long long R, const long long *__restrict__ r_dev,
+                                                    const T *__restrict__ X, int Cx,
                                                     const float *__restrict__ W, int Cw_in, int Cw_out,
                                                     const float *__restrict__ bias, T *__restrict__ Y, int Cy) {
     const int lane = threadIdx.x & 63;
@@ -35,7 +42,7 @@ __global__ void __launch_bounds__(TB) k_gather_conv(const int *__restrict__ tabl
     const long long r = (long long)blockIdx.x * 64 + lane;
     const int c0 = blockIdx.y * (4 * CT) + wid * CT;
     if (c0 >= Cy) return;
-    const bool live = r < R;
+    const bool live = r < valid_rows(R, r_dev);
     float acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = (bias != nullptr && c0 + c < Cy) ? bias[c0 + c] : 0.f;
@@ -109,9 +116,9 @@ constexpr int DW_TA = 32, DW_TBB = 32, DW_ROWS = 64;
 
 template <typename T>
 __global__ void __launch_bounds__(TB) k_gather_dw(const int *__restrict__ table, int K, int identity_k, long long R,
-                                                  long long rows_per_chunk, const T *__restrict__ S, int Cs,
-                                                  const T *__restrict__ G, int Cg, float *__restrict__ part,
-                                                  int tiles_a, int tiles_b) {
+                                                  const long long *__restrict__ r_dev, long long rows_per_chunk,
+                                                  const T *__restrict__ S, int Cs, const T *__restrict__ G, int Cg,
+                                                  float *__restrict__ part, int tiles_a, int tiles_b) {
     __shared__ float sS[DW_ROWS][DW_TA + 1];
     __shared__ float sG[DW_ROWS][DW_TBB + 1];
     __shared__ int sNb[DW_ROWS];
@@ -119,8 +126,9 @@ __global__ void __launch_bounds__(TB) k_gather_dw(const int *__restrict__ table,
     const int ta = blockIdx.z / tiles_b, tb = blockIdx.z % tiles_b;
     const int a0 = ta * DW_TA, b0 = tb * DW_TBB;
     const long long chunk = blockIdx.x;
+    const long long Rv = valid_rows(R, r_dev);
     const long long r_begin = chunk * rows_per_chunk;
-    const long long r_end = r_begin + rows_per_chunk < R ? r_begin + rows_per_chunk : R;
+    const long long r_end = r_begin + rows_per_chunk < Rv ? r_begin + rows_per_chunk : Rv;
     // thread -> 2x2 micro tile of the 32x32 output tile
     const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
@@ -198,8 +206,9 @@ long long dw_chunks(long long R) {
 extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                                int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
                                int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
-                               void *stream_) {
+                               const int64_t *r_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const long long *r_dev = (const long long *)r_dev_;
     (void)X_rows;
     WFS_REQUIRE(K >= 1 && K <= 128, WFS_EINVAL, "kernel volume %d not in [1,128]", K);
     WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
@@ -221,16 +230,17 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
         is_mirror = is_mirror && km.v[k] == K - 1 - k;
     }
     if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror))
-        return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, (const float *)X, W, transpose_w, bias,
-                                      (float *)Y, stream);
+        return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
+                                      bias, (float *)Y, stream);
     if (dtype == WFS_BF16 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror))
-        return wfs_launch_gconv32_bf16(table, is_ident ? 0 : 1, K, identity_k, R, X, W, transpose_w, bias, Y, stream);
+        return wfs_launch_gconv32_bf16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
+                                       stream);
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
-        return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, X, W, bias, Y, dtype, stream);
+        return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stream);
     dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
 #define WFS_GC(T, TR)                                                                                           \
-    k_gather_conv<T, TR><<<grid, block, 0, stream>>>(table, km, K, identity_k, R, (const T *)X, Cx, W, Cw_in, \
-                                                      Cw_out, bias, (T *)Y, Cy)
+    k_gather_conv<T, TR><<<grid, block, 0, stream>>>(table, km, K, identity_k, R, r_dev, (const T *)X, Cx, W,  \
+                                                      Cw_in, Cw_out, bias, (T *)Y, Cy)
     if (dtype == WFS_F32) {
         if (transpose_w) WFS_GC(float, true); else WFS_GC(float, false);
     } else {
@@ -273,8 +283,10 @@ extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs
 
 extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R, const void *S,
                              int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
-                             int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
+                             int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev_,
+                             void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const long long *r_dev = (const long long *)r_dev_;
     (void)G_rows;
     WFS_REQUIRE(K >= 1 && K <= 65535, WFS_EINVAL, "bad K");
     WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
@@ -288,7 +300,7 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
     if (Cs == 32 && Cg == 32 && table && !kmap_host)
-        return wfs_launch_gdw32(table, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype, stream);
+        return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, stream);
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K && kmap_host; ++k) {
         is_ident = is_ident && kmap_host[k] == k;
@@ -296,8 +308,8 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     }
     if (!kmap_host) is_mirror = false;
     if (Cs == 32 && Cg == 2 && K <= 27 && table && (is_ident || is_mirror))
-        return wfs_launch_gdw_c32c2(table, is_ident ? 0 : 1, K, identity_k, R, S, G, swap, dW, (float *)workspace, dtype,
-                                    stream);
+        return wfs_launch_gdw_c32c2(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace,
+                                    dtype, stream);
     WFS_REQUIRE(is_ident, WFS_EINVAL, "a column map is only supported by the 32 x 2 dW kernel");
     long long chunks = dw_chunks(R);
     long long rows_per_chunk = wfs_cdiv(wfs_cdiv(R, chunks), DW_ROWS) * DW_ROWS;
@@ -306,10 +318,10 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     dim3 grid((unsigned)chunks, (unsigned)K, (unsigned)(tiles_a * tiles_b)), block(TB);
     float *part = (float *)workspace;
     if (dtype == WFS_F32)
-        k_gather_dw<float><<<grid, block, 0, stream>>>(table, K, identity_k, R, rows_per_chunk, (const float *)S, Cs,
-                                                       (const float *)G, Cg, part, tiles_a, tiles_b);
+        k_gather_dw<float><<<grid, block, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk, (const float *)S,
+                                                       Cs, (const float *)G, Cg, part, tiles_a, tiles_b);
     else
-        k_gather_dw<wfs_bf16><<<grid, block, 0, stream>>>(table, K, identity_k, R, rows_per_chunk,
+        k_gather_dw<wfs_bf16><<<grid, block, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk,
                                                           (const wfs_bf16 *)S, Cs, (const wfs_bf16 *)G, Cg, part,
                                                           tiles_a, tiles_b);
     WFS_LAUNCH_CHECK();

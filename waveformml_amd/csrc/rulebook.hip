@@ -116,9 +116,17 @@ __device__ __forceinline__ int in_key(const Geo &g, const int *x, int b) {
 
 // ---------------------------------------------------------------- SubM
 // info[0] = M, info[1] = duplicate coordinates seen, info[2] = out-of-range index seen
-__global__ void k_site_insert(Geo g, int batch, const int *idx, long long N, Table t, int *vals, long long *info) {
+// Row counts: N is the CAPACITY (array strides, grid size); when n_dev is given the number of valid rows is
+// read from device memory, so that a build never needs the host to know it (HIP-graph capturable steps).
+__device__ __forceinline__ long long valid_rows(long long N, const long long *n_dev) {
+    long long v = n_dev ? *n_dev : N;
+    return v < N ? v : N;
+}
+
+__global__ void k_site_insert(Geo g, int batch, const int *idx, long long N, const long long *n_dev, Table t, int *vals,
+                              long long *info) {
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
-    if (j >= N) return;
+    if (j >= valid_rows(N, n_dev)) return;
     int x[4], b;
     if (!load_row(g, idx, j, x, b, batch)) {
         info[2] = 1;
@@ -129,10 +137,10 @@ __global__ void k_site_insert(Geo g, int batch, const int *idx, long long N, Tab
     if (old >= 0) info[1] = 1;
 }
 
-__global__ void k_subm_lookup(Geo g, int batch, const int *idx, long long N, Table t, const int *vals,
-                              int *nbr_out) {
+__global__ void k_subm_lookup(Geo g, int batch, const int *idx, long long N, const long long *n_dev, Table t,
+                              const int *vals, int *nbr_out) {
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
-    if (j >= N) return;
+    if (j >= valid_rows(N, n_dev)) return;
     int x[4], b;
     bool ok = load_row(g, idx, j, x, b, batch);
     Walker w;
@@ -150,10 +158,10 @@ __global__ void k_subm_lookup(Geo g, int batch, const int *idx, long long N, Tab
 }
 
 // ---------------------------------------------------------------- regular / strided conv
-__global__ void k_conv_insert(Geo g, int batch, const int *idx, long long N, Table t,
+__global__ void k_conv_insert(Geo g, int batch, const int *idx, long long N, const long long *n_dev, Table t,
                               unsigned long long *ticket, int *nbr_out, long long *info) {
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
-    if (j >= N) return;
+    if (j >= valid_rows(N, n_dev)) return;
     int x[4], b;
     bool ok = load_row(g, idx, j, x, b, batch);
     if (!ok) info[2] = 1;
@@ -172,10 +180,14 @@ __global__ void k_conv_insert(Geo g, int batch, const int *idx, long long N, Tab
     }
 }
 
-__global__ void k_conv_rowcount(int K, long long N, const int *nbr_out, const unsigned long long *ticket,
-                                int *rowfirst) {
+__global__ void k_conv_rowcount(int K, long long N, const long long *n_dev, const int *nbr_out,
+                                const unsigned long long *ticket, int *rowfirst) {
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
     if (j >= N) return;
+    if (j >= valid_rows(N, n_dev)) {       // the scan runs over the capacity
+        rowfirst[j] = 0;
+        return;
+    }
     int c = 0;
     for (int k = 0; k < K; ++k) {
         int s = nbr_out[(long long)k * N + j];
@@ -184,15 +196,21 @@ __global__ void k_conv_rowcount(int K, long long N, const int *nbr_out, const un
     rowfirst[j] = c;
 }
 
-__global__ void k_conv_assign(Geo g, long long N, const int *nbr_out, const unsigned long long *ticket,
-                              const int *rowbase, Table t, int *slot_id, int *out_indices) {
+__global__ void k_conv_assign(Geo g, long long N, const long long *n_dev, long long M_cap, const int *nbr_out,
+                              const unsigned long long *ticket, const int *rowbase, Table t, int *slot_id,
+                              int *out_indices, long long *info) {
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
-    if (j >= N) return;
+    if (j >= valid_rows(N, n_dev)) return;
     int id = rowbase[j];
     for (int k = 0; k < g.K; ++k) {
         int s = nbr_out[(long long)k * N + j];
         if (s >= 0 && ticket[s] == (unsigned long long)j * g.K + k) {
             slot_id[s] = id;
+            if (id >= M_cap) {                 // output capacity exceeded (device-count mode): flag, do not write
+                info[3] = 1;
+                ++id;
+                continue;
+            }
             long long key = t.direct ? (long long)s : (long long)t.keys[s];
             int *o = out_indices + (long long)id * (g.ndim + 1);
             for (int d = g.ndim - 1; d >= 0; --d) {
@@ -205,23 +223,26 @@ __global__ void k_conv_assign(Geo g, long long N, const int *nbr_out, const unsi
     }
 }
 
-__global__ void k_conv_finalize(int K, long long N, long long M, int *nbr_out, const int *slot_id, int *nbr_in) {
+__global__ void k_conv_finalize(int K, long long N, const long long *n_dev, long long M, int *nbr_out,
+                                const int *slot_id, int *nbr_in) {
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
-    if (j >= N) return;
+    if (j >= valid_rows(N, n_dev)) return;
     for (int k = 0; k < K; ++k) {
         int s = nbr_out[(long long)k * N + j];
         if (s >= 0) {
             int id = slot_id[s];
+            if (id >= M) id = -1;              // beyond the output capacity (flagged by k_conv_assign)
             nbr_out[(long long)k * N + j] = id;
-            if (nbr_in) atomicMax(&nbr_in[(long long)k * M + id], (int)j);
+            if (nbr_in && id >= 0) atomicMax(&nbr_in[(long long)k * M + id], (int)j);
         }
     }
 }
 
 // SubM with an even kernel or dilation: nbr_in by scatter of nbr_out
-__global__ void k_invert_table(int K, long long N, long long M, const int *nbr_out, int *nbr_in) {
+__global__ void k_invert_table(int K, long long N, const long long *n_dev, long long M, const int *nbr_out,
+                               int *nbr_in) {
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
-    if (j >= N) return;
+    if (j >= valid_rows(N, n_dev)) return;
     for (int k = 0; k < K; ++k) {
         int i = nbr_out[(long long)k * N + j];
         if (i >= 0) atomicMax(&nbr_in[(long long)k * M + i], (int)j);
@@ -272,7 +293,7 @@ __global__ void k_scan_blocksum(const int *in, long long n, int *bsum) {
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 // single block: exclusive scan of bsum[0..nb) in place; total -> *total (long long) and total32
-__global__ void k_scan_top(int *bsum, long long nb, long long *total) {
+__global__ void k_scan_top(int *bsum, long long nb, long long *total, long long *total2, long long cap) {
     int carry = 0;
     for (long long base = 0; base < nb; base += TB) {
         long long i = base + threadIdx.x;
@@ -282,7 +303,10 @@ __global__ void k_scan_top(int *bsum, long long nb, long long *total) {
         if (i < nb) bsum[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) {
+        *total = carry;
+        if (total2) *total2 = carry < cap ? carry : cap;       // the row count downstream kernels bound by
+    }
 }
 __global__ void k_scan_apply(const int *in, long long n, const int *bsum, int *out) {
     long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -304,12 +328,14 @@ __global__ void k_scan_apply(const int *in, long long n, const int *bsum, int *o
 
 // ---------------------------------------------------------------- compaction to spconv's encoding
 // tile = TB consecutive input rows.  tcount[k * ntiles + tile] = valid entries of column k in tile.
-__global__ void k_compact_count(int K, long long N, long long ntiles, const int *nbr_out, int *tcount) {
+__global__ void k_compact_count(int K, long long N, const long long *n_dev, long long ntiles, const int *nbr_out,
+                                int *tcount) {
     __shared__ int wsum[TB / 64];
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    const long long Nv = valid_rows(N, n_dev);
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int k = 0; k < K; ++k) {
-        bool v = j < N && nbr_out[(long long)k * N + j] >= 0;
+        bool v = j < Nv && nbr_out[(long long)k * N + j] >= 0;
         unsigned long long m = __ballot(v);
         if (lane == 0) wsum[wid] = __popcll(m);
         __syncthreads();
@@ -336,13 +362,14 @@ __global__ void k_compact_scan(long long ntiles, int *tcount, int *pair_num) {
     }
     if (threadIdx.x == 0) pair_num[blockIdx.x] = carry;
 }
-__global__ void k_compact_write(int K, long long N, long long ntiles, const int *nbr_out, const int *tcount,
-                                const int *pair_num, int *pairs) {
+__global__ void k_compact_write(int K, long long N, const long long *n_dev, long long ntiles, const int *nbr_out,
+                                const int *tcount, const int *pair_num, int *pairs) {
     __shared__ int wsum[TB / 64];
     long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    const long long Nv = valid_rows(N, n_dev);
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int k = 0; k < K; ++k) {
-        int o = j < N ? nbr_out[(long long)k * N + j] : -1;
+        int o = j < Nv ? nbr_out[(long long)k * N + j] : -1;
         bool v = o >= 0;
         unsigned long long m = __ballot(v);
         if (lane == 0) wsum[wid] = __popcll(m);
@@ -468,7 +495,7 @@ extern "C" int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indi
     WFS_HIP_CHECK(hipMemsetAsync(vals, 0xFF, (size_t)p.cap * 4, stream));
     if (N > 0) {
         k_site_insert<<<dim3((unsigned)wfs_cdiv(N, TB)), dim3(TB), 0, stream>>>(p.geo, g_subm->batch_size, indices, N,
-                                                                              p.tbl, vals, info);
+                                                                              nullptr, p.tbl, vals, info);
         WFS_LAUNCH_CHECK();
     }
     long long h[4];
@@ -481,22 +508,28 @@ extern "C" int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indi
 }
 
 extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, int64_t N, int32_t *nbr_out,
-                                 void *workspace, size_t workspace_bytes, int64_t host_info[2], void *stream_) {
+                                 void *workspace, size_t workspace_bytes, int64_t host_info[2],
+                                 const int64_t *n_dev, int64_t *m_dev, int64_t M_cap, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(g, WFS_EINVAL, "NULL argument");
-    WFS_REQUIRE(host_info || g->subm, WFS_EINVAL, "a regular conv must read M back: host_info is required");
+    WFS_REQUIRE(host_info || g->subm || m_dev, WFS_EINVAL,
+                "a regular conv must hand M back: give host_info (synchronises) or m_dev (device)");
     WFS_REQUIRE(N >= 0 && N < (1ll << 31), WFS_EINVAL, "N out of range");
     WFS_REQUIRE(g->K >= 1, WFS_EINVAL, "geometry not initialised (wfs_geometry_init)");
     if (host_info) {
         host_info[0] = g->subm ? N : 0;
         host_info[1] = 0;
     }
-    if (N == 0) return WFS_OK;
+    if (N == 0) {
+        if (m_dev) WFS_HIP_CHECK(hipMemsetAsync(m_dev, 0, sizeof(int64_t), stream));
+        return WFS_OK;
+    }
     WFS_REQUIRE(indices && nbr_out && workspace, WFS_EINVAL, "NULL device pointer");
     Plan p;
     make_plan(g, N, &p);
     WFS_REQUIRE(workspace_bytes >= p.total, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, p.total);
     WfsTimerScope timer(WFS_TIMER_RULEBOOK, stream);
+    const long long *nd = (const long long *)n_dev;
     char *ws = (char *)workspace;
     long long *info = (long long *)(ws + p.off_info);
     p.tbl.keys = (int *)(ws + p.off_keys);
@@ -506,29 +539,33 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
     if (g->subm) {
         int *vals = (int *)(ws + p.off_vals);
         WFS_HIP_CHECK(hipMemsetAsync(vals, 0xFF, (size_t)p.cap * 4, stream));
-        k_site_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, p.tbl, vals, info);
+        k_site_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, info);
         WFS_LAUNCH_CHECK();
-        k_subm_lookup<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, p.tbl, vals, nbr_out);
+        k_subm_lookup<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, nbr_out);
         WFS_LAUNCH_CHECK();
+        if (m_dev && n_dev && m_dev != n_dev)
+            WFS_HIP_CHECK(hipMemcpyAsync(m_dev, n_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
     } else {
         unsigned long long *ticket = (unsigned long long *)(ws + p.off_ticket);
         int *rowfirst = (int *)(ws + p.off_rowfirst);
         int *rowbase = (int *)(ws + p.off_rowbase);
         int *bsum = (int *)(ws + p.off_bsum);
         WFS_HIP_CHECK(hipMemsetAsync(ticket, 0xFF, (size_t)p.cap * 8, stream));
-        k_conv_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, p.tbl, ticket, nbr_out, info);
+        k_conv_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, ticket, nbr_out, info);
         WFS_LAUNCH_CHECK();
-        k_conv_rowcount<<<grid, block, 0, stream>>>(g->K, N, nbr_out, ticket, rowfirst);
+        k_conv_rowcount<<<grid, block, 0, stream>>>(g->K, N, nd, nbr_out, ticket, rowfirst);
         WFS_LAUNCH_CHECK();
         dim3 sgrid((unsigned)p.nscan);
         k_scan_blocksum<<<sgrid, block, 0, stream>>>(rowfirst, N, bsum);
         WFS_LAUNCH_CHECK();
-        k_scan_top<<<dim3(1), block, 0, stream>>>(bsum, p.nscan, info);      // info[0] = M
+        // info[0] = M; m_dev = min(M, M_cap) = the row count every consumer of the outputs is bounded by
+        k_scan_top<<<dim3(1), block, 0, stream>>>(bsum, p.nscan, info, (long long *)m_dev,
+                                                  M_cap > 0 ? M_cap : (1ll << 62));
         WFS_LAUNCH_CHECK();
         k_scan_apply<<<sgrid, block, 0, stream>>>(rowfirst, N, bsum, rowbase);
         WFS_LAUNCH_CHECK();
     }
-    if (!host_info) return WFS_OK;          // SubM, caller vouches for the indices: fully asynchronous
+    if (!host_info) return WFS_OK;          // caller vouches for the indices / works with device counts: asynchronous
     long long h[4];
     WFS_HIP_CHECK(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
     WFS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -540,7 +577,8 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
 
 extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, int64_t N, int64_t M,
                                  int32_t *nbr_out, int32_t *out_indices, int32_t *nbr_in, int32_t *indice_pairs,
-                                 int32_t *indice_pair_num, void *workspace, size_t workspace_bytes, void *stream_) {
+                                 int32_t *indice_pair_num, void *workspace, size_t workspace_bytes,
+                                 const int64_t *n_dev, int32_t *overflow_dev, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     (void)indices;
     WFS_REQUIRE(g, WFS_EINVAL, "NULL geometry");
@@ -553,7 +591,9 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
     make_plan(g, N, &p);
     WFS_REQUIRE(workspace_bytes >= p.total, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, p.total);
     WfsTimerScope timer(WFS_TIMER_RULEBOOK, stream);
+    const long long *nd = (const long long *)n_dev;
     char *ws = (char *)workspace;
+    long long *info = (long long *)(ws + p.off_info);
     p.tbl.keys = (int *)(ws + p.off_keys);
     dim3 grid((unsigned)wfs_cdiv(N, TB)), block(TB);
     if (nbr_in && M > 0) WFS_HIP_CHECK(hipMemsetAsync(nbr_in, 0xFF, (size_t)g->K * M * 4, stream));
@@ -562,23 +602,26 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
         unsigned long long *ticket = (unsigned long long *)(ws + p.off_ticket);
         int *slot_id = (int *)(ws + p.off_slot_id);
         int *rowbase = (int *)(ws + p.off_rowbase);
-        k_conv_assign<<<grid, block, 0, stream>>>(p.geo, N, nbr_out, ticket, rowbase, p.tbl, slot_id, out_indices);
+        k_conv_assign<<<grid, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, ticket, rowbase, p.tbl, slot_id, out_indices,
+                                                  info);
         WFS_LAUNCH_CHECK();
-        k_conv_finalize<<<grid, block, 0, stream>>>(g->K, N, M, nbr_out, slot_id, nbr_in);
+        k_conv_finalize<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
         WFS_LAUNCH_CHECK();
+        if (overflow_dev)       // info[3] (8 bytes) -> the caller's flag: non-zero = M exceeded the capacity
+            WFS_HIP_CHECK(hipMemcpyAsync(overflow_dev, info + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     } else if (nbr_in) {
-        k_invert_table<<<grid, block, 0, stream>>>(g->K, N, M, nbr_out, nbr_in);
+        k_invert_table<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, nbr_in);
         WFS_LAUNCH_CHECK();
     }
     if (indice_pairs || indice_pair_num) {
         WFS_REQUIRE(indice_pair_num, WFS_EINVAL, "indice_pair_num is required with indice_pairs");
         int *tcount = (int *)(ws + p.off_tcount);
-        k_compact_count<<<grid, block, 0, stream>>>(g->K, N, p.ntiles, nbr_out, tcount);
+        k_compact_count<<<grid, block, 0, stream>>>(g->K, N, nd, p.ntiles, nbr_out, tcount);
         WFS_LAUNCH_CHECK();
         k_compact_scan<<<dim3((unsigned)g->K), block, 0, stream>>>(p.ntiles, tcount, indice_pair_num);
         WFS_LAUNCH_CHECK();
         if (indice_pairs) {
-            k_compact_write<<<grid, block, 0, stream>>>(g->K, N, p.ntiles, nbr_out, tcount, indice_pair_num,
+            k_compact_write<<<grid, block, 0, stream>>>(g->K, N, nd, p.ntiles, nbr_out, tcount, indice_pair_num,
                                                         indice_pairs);
             WFS_LAUNCH_CHECK();
         }

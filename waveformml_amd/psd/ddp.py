@@ -127,6 +127,20 @@ class FlatGradAllReducer(object):
                 o, n = self.slices[i]
                 p.grad = self.flat_grad[o:o + n].view_as(p)
 
+    def pack_all(self):
+        """Pack every bucket into the flat gradient buffer without communicating (graph-captured steps pack
+        inside the graph and exchange afterwards)."""
+        for b in range(len(self.buckets)):
+            self._pack(b)
+            self._pending[b] = 0
+
+    def exchange_packed(self):
+        """All-reduce + average an already packed flat gradient buffer (one collective: the PSD nets' gradients
+        are well under a megabyte, i.e. latency-bound)."""
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.div_(self.world)
+
     def remove(self):
         for h in self._hooks:
             h.remove()

@@ -1,0 +1,99 @@
+"""HIP-graph capture of the whole PSD training step.
+
+At the reference's batch sizes a step is ~100 small kernels (a 256-event batch is ~10^5 voxels, a layer
+moves ~10 MB), so eager execution is bound by Python/launch latency and by the two host read-backs a
+data-dependent output size normally needs.  libwfsparse's device-side row counts (include/wfsparse.h)
+remove the read-backs: every tensor has a fixed CAPACITY of rows, the valid count lives in device memory.
+With that the step -- rulebook builds, forward, backward, gradient packing, optimizer -- has static
+shapes and is captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed per batch.
+
+    step = GraphedTrainStep(module, optimizer, reducer, example_batch)
+    loss = step(batch)            # copies the batch into the static buffers, replays the graph
+    step.check()                  # occasionally: raises if a capacity was exceeded (results invalid)
+"""
+import torch
+import torch.distributed as dist
+
+
+def _round_up(v, m):
+    return int((int(v) + m - 1) // m * m)
+
+
+class GraphedTrainStep(object):
+    def __init__(self, module, optimizer, reducer, example_batch, headroom=1.25, granule=4096, warmup=2):
+        (coords, feats), labels = example_batch
+        assert coords.is_cuda and feats.is_cuda and labels.is_cuda
+        self.module, self.optimizer, self.reducer = module, optimizer, reducer
+        dev = coords.device
+        self.n_cap = _round_up(headroom * coords.shape[0], granule)
+        self.coords = torch.zeros((self.n_cap, coords.shape[1]), dtype=coords.dtype, device=dev)
+        self.feats = torch.zeros((self.n_cap, feats.shape[1]), dtype=feats.dtype, device=dev)
+        self.labels = torch.zeros_like(labels)
+        self.n_valid = torch.zeros((1,), dtype=torch.int64, device=dev)
+        self.world = reducer.world
+        self.in_graph_optimizer = self.world == 1
+        self._convs = [m for m in module.modules()
+                       if hasattr(m, "subm") and hasattr(m, "conv1x1") and not m.subm and not m.conv1x1 and not m.inverse]
+        # ---- calibration: one ordinary (exact-size) step tells how many rows each strided layer produces
+        reducer.reset()
+        loss = module.training_step(([coords, feats], labels), 0)
+        loss.backward()
+        reducer.finish()
+        optimizer.step()
+        for m in self._convs:
+            m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
+        if self.world > 1:
+            reducer.remove()              # no collectives inside the graph: gradients are exchanged after the replay
+        # ---- warm-up in device-count mode on a side stream, then capture
+        self._load(example_batch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body()
+                if not self.in_graph_optimizer:
+                    self._after()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+        self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
+
+    def _static_batch(self):
+        return ([self.coords, self.feats, self.n_valid], self.labels)
+
+    def _body(self):
+        self.reducer.reset()
+        loss = self.module.training_step(self._static_batch(), 0)
+        loss.backward()
+        self.reducer.pack_all()
+        if self.in_graph_optimizer:
+            self.optimizer.step()
+        return loss.detach()
+
+    def _after(self):
+        self.reducer.exchange_packed()
+        self.optimizer.step()
+
+    def _load(self, batch):
+        (coords, feats), labels = batch
+        n = coords.shape[0]
+        if n > self.n_cap:
+            raise RuntimeError("batch has %d voxels, the captured step holds %d" % (n, self.n_cap))
+        self.coords[:n].copy_(coords, non_blocking=True)
+        self.feats[:n].copy_(feats, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        self.n_valid.fill_(n)
+
+    def __call__(self, batch):
+        self._load(batch)
+        self.graph.replay()
+        if not self.in_graph_optimizer:
+            self._after()
+        return self.loss
+
+    def check(self):
+        """Synchronises; raises if any strided layer produced more rows than its capacity in the last step."""
+        if self._overflow and bool(torch.stack([o.reshape(()) for o in self._overflow]).any().item()):
+            raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")

@@ -36,12 +36,19 @@ class LitPSD(nn.Module):
     def forward(self, x):
         return self.model(x)
 
-    def _predict(self, c, f, target):
+    def _predict(self, c, f, target, n_valid=None):
         # the reference reads the batch size back from the last coordinate row (SPConvNet.py:63, a device->host
         # sync); one label per event means it equals len(target), which is known on the host
         if hasattr(self.model, "batch_size_hint"):
             self.model.batch_size_hint = int(target.shape[0])
-        return self.model([c, f])
+        return self.model([c, f, n_valid] if n_valid is not None else [c, f])
+
+    @staticmethod
+    def _unpack(batch):
+        """((coords, feats), target) as the reference's collate_fn builds it; a third element of the inner
+        list is the device-side count of valid rows of a capacity-padded batch (psd/graph.py)."""
+        inputs, target = batch
+        return inputs[0], inputs[1], (inputs[2] if len(inputs) > 2 else None), target
 
     def log(self, name, value, **kwargs):
         self.logged[name] = value.detach() if torch.is_tensor(value) else value
@@ -73,16 +80,16 @@ class LitPSD(nn.Module):
 
     # reference LitPSD.training_step, :94-104
     def training_step(self, batch, batch_idx):
-        (c, f), target = batch
-        predictions = self._predict(c, f, target)
+        c, f, n_valid, target = self._unpack(batch)
+        predictions = self._predict(c, f, target, n_valid)
         loss = self.criterion.forward(predictions, target)
         self.log("train_loss", loss, on_epoch=True, prog_bar=True, logger=True)
         return loss
 
     # reference LitPSD.validation_step, :106-128
     def validation_step(self, batch, batch_idx):
-        (c, f), target = batch
-        predictions = self._predict(c, f, target)
+        c, f, n_valid, target = self._unpack(batch)
+        predictions = self._predict(c, f, target, n_valid)
         loss = self.criterion.forward(predictions, target)
         pred = torch.argmax(self.softmax(predictions), dim=1)
         acc = (pred == target).float().mean()
@@ -92,10 +99,10 @@ class LitPSD(nn.Module):
 
     # reference LitPSD.test_step, :130-151 (evaluator plumbing is out of scope)
     def test_step(self, batch, batch_idx):
-        (c, f), target = batch
+        c, f, n_valid, target = self._unpack(batch)
         if self.occlude_index:                       # falsy for index 0, exactly as the reference (:134)
             f[:, self.occlude_index] = 0
-        predictions = self._predict(c, f, target)
+        predictions = self._predict(c, f, target, n_valid)
         loss = self.criterion.forward(predictions, target)
         pred = torch.argmax(self.softmax(predictions), dim=1)
         acc = (pred == target).float().mean()

@@ -51,6 +51,8 @@ class SPConvNet(nn.Module):
             batch_size = int(coords[-1, -1]) + 1          # one device->host read, as the reference's
         st = self.spconv.SparseConvTensor(feats, coords[:, self.permute_tensor].contiguous(), self.spatial_size,
                                           batch_size)
+        if len(x) > 2 and x[2] is not None:       # [coords, feats, n_valid]: rows beyond n_valid[0] are padding
+            st.n_valid = x[2]
         out = self.sparseModel(st)
         out = out.view(-1, self.n_linear)
         head_dtype = next(self.linear.parameters()).dtype

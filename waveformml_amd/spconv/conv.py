@@ -74,6 +74,7 @@ class SparseConvolution(SparseModule):
             out_tensor.indice_dict = input.indice_dict
             out_tensor.grid = input.grid
             out_tensor.unique = input.unique
+            out_tensor.n_valid = input.n_valid
             return out_tensor
         datas = input.find_indice_pair(self.indice_key)
         if self.inverse:
@@ -84,12 +85,15 @@ class SparseConvolution(SparseModule):
             out_indices = rb.indices
             out_features = Fsp.indice_inverse_conv(features, self.weight, self.bias, rb)
             out_unique = None if rb.has_dup else True
+            out_n_valid = rb.n_dev
         else:
             if self.indice_key is not None and datas is not None:
                 rb = datas.rulebook
             else:
                 rb = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
-                                        self.padding, self.dilation, self.subm, known_unique=input.unique)
+                                        self.padding, self.dilation, self.subm, known_unique=input.unique,
+                                        n_dev=input.n_valid, out_capacity=getattr(self, "out_capacity", None))
+                self.last_rulebook = rb          # capacity calibration / overflow checks of graph-captured steps
                 input.unique = not rb.has_dup
                 input.indice_dict[self.indice_key] = IndiceData(rb, spatial_shape)
             out_indices = rb.out_indices
@@ -99,10 +103,12 @@ class SparseConvolution(SparseModule):
             else:
                 out_features = Fsp.indice_conv(features, self.weight, self.bias, rb)
                 out_unique = True      # a regular conv numbers DISTINCT output sites
+            out_n_valid = rb.m_dev
         out_tensor = SparseConvTensor(out_features, out_indices, out_spatial_shape, batch_size)
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid
         out_tensor.unique = out_unique
+        out_tensor.n_valid = out_n_valid
         return out_tensor
 
 

@@ -41,19 +41,28 @@ def _features_ok(t):
     return t.contiguous()
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, out_dtype=None):
+def _rows(shape, like, r_dev):
+    """Row-dimensioned output.  In device-count mode the rows beyond the valid count are never written by
+    the kernels, so they are zero-filled once here (torch-side column sums such as the bias gradient run
+    over the whole capacity)."""
+    if r_dev is None:
+        return torch.empty(shape, dtype=like.dtype, device=like.device)
+    return torch.zeros(shape, dtype=like.dtype, device=like.device)
+
+
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
     Cy = Cw_in if transpose_w else Cw_out
-    Y = torch.empty((R, Cy), dtype=X.dtype, device=X.device)
+    Y = _rows((R, Cy), X, r_dev)
     assert W.dtype == torch.float32 and W.is_contiguous()
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
     _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
                                    _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
-                                   _lib.dtype_code(X), _lib.stream_ptr()))
+                                   _lib.dtype_code(X), _lib.ptr(r_dev), _lib.stream_ptr()))
     _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
     return Y
 
@@ -73,7 +82,7 @@ def scatter_conv(table, K, identity_k, R, X, W, transpose_w, n_out, bias):
     return Y.to(X.dtype)
 
 
-def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None):
+def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None):
     """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a])."""
     lib = _lib.load()
     Cs, Cg = int(S.shape[1]), int(G.shape[1])
@@ -84,7 +93,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None):
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
     _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0], Cg,
                                  1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
-                                 _lib.stream_ptr()))
+                                 _lib.ptr(r_dev), _lib.stream_ptr()))
     _account("gather_dw", table, R, R, Cs, G.shape[0], Cg, K, Cs, Cg, S.element_size())
     return dW
 
@@ -102,13 +111,13 @@ class SparseConvFunction(Function):
         ident = rb.centre_k if rb.subm else -1
         if mode == INVERSE:
             assert features.shape[0] == rb.M, "inverse conv input must be the coupled conv's output set"
-            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b)
+            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b, rb.n_dev)
         elif rb.has_dup:
             out = scatter_conv(rb.nbr_out, K, ident, rb.N, features, W, False, rb.M, b)
         else:
             assert features.shape[0] == rb.N
             table, kmap = rb.table_by_out()
-            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b)
+            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev)
         ctx.save_for_backward(features, filters, bias)
         ctx.rb, ctx.mode = rb, mode
         return out
@@ -129,19 +138,19 @@ class SparseConvFunction(Function):
                 if rb.has_dup:
                     dX = scatter_conv(rb.nbr_out, K, ident, rb.N, dY, W, True, rb.M, None)
                 else:
-                    dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None)
+                    dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev)
             if ctx.needs_input_grad[1]:
-                dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True)
+                dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev)
         else:
             if ctx.needs_input_grad[0]:
-                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None)
+                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
             if ctx.needs_input_grad[1]:
                 if features.shape[1] == 2 and dY.shape[1] == 32 and K <= 27 and not rb.has_dup:
                     # narrow input, wide output (first layer): keep the wide dY rows stationary
                     table, kmap = rb.table_by_out()
-                    dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap)
+                    dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap, rb.m_dev)
                 else:
-                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False)
+                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
@@ -153,7 +162,7 @@ class ToDenseFunction(Function):
     """SparseConvTensor.dense(): [M, C] -> [B, C, *spatial] (A.1)."""
 
     @staticmethod
-    def forward(ctx, features, indices, spatial_shape, batch_size, unique):
+    def forward(ctx, features, indices, spatial_shape, batch_size, unique, m_dev=None):
         lib = _lib.load()
         features = _features_ok(features)
         indices = indices.contiguous()
@@ -169,9 +178,10 @@ class ToDenseFunction(Function):
             winner = torch.empty((cells,), dtype=torch.int32, device=features.device)
         _lib.check(lib.wfs_to_dense(_lib.ptr(features), _lib.ptr(indices), M, ndim, _lib.i32_array(spatial),
                                     int(batch_size), C, _lib.ptr(out), _lib.ptr(winner), _lib.dtype_code(features),
-                                    _lib.stream_ptr()))
+                                    _lib.ptr(m_dev), _lib.stream_ptr()))
         ctx.save_for_backward(indices)
         ctx.meta = (spatial, int(batch_size), M, C)
+        ctx.m_dev = m_dev
         return out
 
     @staticmethod
@@ -180,10 +190,11 @@ class ToDenseFunction(Function):
         (indices,) = ctx.saved_tensors
         spatial, batch_size, M, C = ctx.meta
         dY = grad_output.contiguous()
-        dX = torch.empty((M, C), dtype=dY.dtype, device=dY.device)
+        dX = _rows((M, C), dY, ctx.m_dev)
         _lib.check(lib.wfs_to_dense_bwd(_lib.ptr(dY), _lib.ptr(indices), M, len(spatial), _lib.i32_array(spatial),
-                                        batch_size, C, _lib.ptr(dX), _lib.dtype_code(dY), _lib.stream_ptr()))
-        return dX, None, None, None, None
+                                        batch_size, C, _lib.ptr(dX), _lib.dtype_code(dY), _lib.ptr(ctx.m_dev),
+                                        _lib.stream_ptr()))
+        return dX, None, None, None, None, None
 
 
 class BatchNormReLUFunction(Function):
@@ -191,11 +202,11 @@ class BatchNormReLUFunction(Function):
     (reference: the plain modules inside spconv.SparseSequential, src/models/SPConvBlocks.py:505-508)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, n_dev=None):
         lib = _lib.load()
         x = _features_ok(x)
         N, C = x.shape
-        y = torch.empty_like(x)
+        y = _rows(tuple(x.shape), x, n_dev)
         save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
@@ -204,9 +215,11 @@ class BatchNormReLUFunction(Function):
         _lib.check(lib.wfs_bn_relu_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
                                        _lib.ptr(running_var), float(momentum), float(eps), 1 if training else 0,
                                        1 if relu else 0, _lib.ptr(y), _lib.ptr(save_mean), _lib.ptr(save_invstd),
-                                       _lib.ptr(ws), ws.numel(), _lib.dtype_code(x), _lib.stream_ptr()))
+                                       _lib.ptr(ws), ws.numel(), _lib.dtype_code(x), _lib.ptr(n_dev),
+                                       _lib.stream_ptr()))
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.flags = (bool(training), bool(relu))
+        ctx.n_dev = n_dev
         return y
 
     @staticmethod
@@ -218,25 +231,26 @@ class BatchNormReLUFunction(Function):
         dy = grad_output.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        dx = torch.empty_like(x)
+        dx = _rows(tuple(x.shape), x, ctx.n_dev)
         dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if weight is not None else None
         dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if bias is not None else None
         ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
         _lib.check(lib.wfs_bn_relu_bwd(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
                                        _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
                                        1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
-                                       ws.numel(), _lib.dtype_code(x), _lib.stream_ptr()))
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+                                       ws.numel(), _lib.dtype_code(x), _lib.ptr(ctx.n_dev), _lib.stream_ptr()))
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def batch_norm_relu(features, bn, relu):
-    """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features."""
+def batch_norm_relu(features, bn, relu, n_dev=None):
+    """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features
+    (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts")."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return BatchNormReLUFunction.apply(features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps,
-                                       training, relu)
+                                       training, relu, n_dev)
 
 
 def can_fuse_batch_norm(bn, features):

@@ -67,10 +67,13 @@ class SparseSequential(SparseModule):
                     if isinstance(module, nn.BatchNorm1d) and Fsp.can_fuse_batch_norm(module, input.features):
                         # BatchNorm1d [+ ReLU] over the active rows: one fused pair of HIP launches
                         relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                        input.features = Fsp.batch_norm_relu(input.features, module, relu)
+                        input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid)
                         if relu:
                             i += 1
                     else:
+                        if input.n_valid is not None and type(module) is not nn.ReLU:      # ReLU is row-local
+                            raise RuntimeError("device-count (padded) SparseConvTensors only support the fused "
+                                               "BatchNorm1d/ReLU pair between sparse layers, got %s" % type(module).__name__)
                         input.features = module(input.features)
             else:
                 input = module(input)

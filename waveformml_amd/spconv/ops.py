@@ -68,6 +68,10 @@ class Rulebook(object):
         self.kmap_in = None          # ctypes int32[K] or None
         self.centre_k = -1           # SubM: offset computed as a plain X.W[k] (spconv's k*), else -1
         self.out_spatial_shape = None
+        # device-count mode (HIP-graph capturable): N / M above are CAPACITIES, the valid row counts live here
+        self.n_dev = None            # int64 [1] on the GPU: valid input rows
+        self.m_dev = None            # int64 [1]: valid output rows (SubM: n_dev itself)
+        self.overflow = None         # int32 [1]: set by the build if M exceeded the output capacity
         self._pairs = None
         self._pair_num = None
 
@@ -94,7 +98,7 @@ class Rulebook(object):
                 _lib.check(lib.wfs_rulebook_emit(ctypes.byref(cg), _lib.ptr(self.indices),
                                                  self.N, self.M, _lib.ptr(self.nbr_out), None, None,
                                                  _lib.ptr(pairs), _lib.ptr(num), _lib.ptr(ws), ws.numel(),
-                                                 _lib.stream_ptr()))
+                                                 _lib.ptr(self.n_dev), None, _lib.stream_ptr()))
             self._pair_num = num
             if want_pairs:
                 self._pairs = pairs
@@ -118,10 +122,21 @@ class Rulebook(object):
         return self._pairs
 
 
+def default_out_capacity(n_cap, K, cells):
+    """Rows to reserve for a regular conv's outputs when their number is not read back: every input can
+    open at most K sites and there are at most `cells` sites."""
+    return int(min(n_cap * K, cells))
+
+
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                   known_unique=None):
+                   known_unique=None, n_dev=None, out_capacity=None):
     """Builds the device rulebook.  ``known_unique``: True if the caller knows the index rows are
-    distinct sites (skips the duplicate check a regular conv would otherwise run once)."""
+    distinct sites (skips the duplicate check a regular conv would otherwise run once).
+
+    ``n_dev`` (int64 [1] device tensor) switches to device-count mode: ``indices`` holds a CAPACITY of
+    rows of which the first ``n_dev[0]`` are valid, nothing is read back to the host (the build is
+    asynchronous and HIP-graph capturable), indices are trusted, and a regular conv's outputs get
+    ``out_capacity`` rows (default: min(N*K, batch*volume)) with the true count in ``rulebook.m_dev``."""
     if not indices.is_cuda:
         raise RuntimeError("waveformml_amd.spconv: indices must be on the GPU (no CPU path)")
     if indices.dtype != torch.int32:
@@ -139,16 +154,32 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     nbytes = lib.wfs_rulebook_workspace_bytes(ctypes.byref(g), N)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
     rb.nbr_out = torch.empty((rb.K, N), dtype=torch.int32, device=dev)
-    if known_unique is None and ASSUME_VALID_UNIQUE_INDICES:
+    if known_unique is None and (ASSUME_VALID_UNIQUE_INDICES or n_dev is not None):
         known_unique = True
-    if subm and known_unique:
+    if n_dev is not None:
+        assert n_dev.dtype == torch.int64 and n_dev.is_cuda and n_dev.numel() == 1
+        rb.n_dev = n_dev
+        if subm:
+            rb.M, rb.m_dev = N, n_dev
+            m_cap = 0
+        else:
+            cells = int(batch_size) * int(np.prod(rb.out_spatial_shape))
+            m_cap = int(out_capacity) if out_capacity else default_out_capacity(N, rb.K, cells)
+            rb.M = m_cap
+            rb.m_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
+            rb.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
         _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
-                                         ws.numel(), None, stream))
+                                         ws.numel(), None, _lib.ptr(n_dev), None if subm else _lib.ptr(rb.m_dev),
+                                         m_cap, stream))
+        rb.has_dup = False
+    elif subm and known_unique:
+        _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
+                                         ws.numel(), None, None, None, 0, stream))
         rb.M, rb.has_dup = N, False
     else:
         info = (ctypes.c_int64 * 2)(0, 0)
         _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
-                                         ws.numel(), info, stream))
+                                         ws.numel(), info, None, None, 0, stream))
         rb.M = int(info[0])
         rb.has_dup = bool(info[1])
     symmetric = all(int(g.ksize[i]) % 2 == 1 and int(g.dilation[i]) == 1 for i in range(ndim))
@@ -160,13 +191,14 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
         else:
             rb.nbr_in = torch.empty((rb.K, rb.M), dtype=torch.int32, device=dev)
             _lib.check(lib.wfs_rulebook_emit(ctypes.byref(g), _lib.ptr(indices), N, rb.M, _lib.ptr(rb.nbr_out), None,
-                                             _lib.ptr(rb.nbr_in), None, None, _lib.ptr(ws), ws.numel(), stream))
-        if rb.has_dup or not symmetric:
+                                             _lib.ptr(rb.nbr_in), None, None, _lib.ptr(ws), ws.numel(),
+                                             _lib.ptr(rb.n_dev), None, stream))
+        if (rb.has_dup or not symmetric) and n_dev is None:
             # spconv computes offset k* = argmax(indice_pair_num) as a plain X.W[k*] (A.4); with
             # distinct sites and an odd kernel that is the centre, otherwise it has to be looked up
             rb.centre_k = int(np.argmax(rb.indice_pair_num.cpu().numpy())) if N > 0 else 0   # first max, as A.4
     else:
-        if known_unique is None and N > 0:
+        if known_unique is None and N > 0 and n_dev is None:
             gs = _lib.make_geometry(ndim, batch_size, spatial_shape, [1] * ndim, [1] * ndim, [0] * ndim,
                                     [1] * ndim, True)
             nb2 = lib.wfs_rulebook_workspace_bytes(ctypes.byref(gs), N)
@@ -181,7 +213,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
         rb.nbr_in = torch.empty((rb.K, rb.M), dtype=torch.int32, device=dev)
         _lib.check(lib.wfs_rulebook_emit(ctypes.byref(g), _lib.ptr(indices), N, rb.M, _lib.ptr(rb.nbr_out),
                                          _lib.ptr(rb.out_indices), _lib.ptr(rb.nbr_in), None, None, _lib.ptr(ws),
-                                         ws.numel(), stream))
+                                         ws.numel(), _lib.ptr(rb.n_dev), _lib.ptr(rb.overflow), stream))
     return rb
 
 

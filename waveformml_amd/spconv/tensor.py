@@ -62,6 +62,9 @@ class SparseConvTensor(object):
         self.indice_dict = {}
         self.grid = grid
         self.unique = None          # True/False once a rulebook build has looked; None = unknown
+        # device-count mode: `features`/`indices` hold a CAPACITY of rows, the first n_valid[0] are real
+        # (int64 [1] device tensor).  None = every row is valid (spconv's normal contract).
+        self.n_valid = None
 
     @property
     def spatial_size(self):
@@ -76,7 +79,7 @@ class SparseConvTensor(object):
 
     def dense(self, channels_first=True):
         out = Fsp.ToDenseFunction.apply(self.features, self.indices, self.spatial_shape, self.batch_size,
-                                        self.unique is True)
+                                        self.unique is True or self.n_valid is not None, self.n_valid)
         if channels_first:
             return out
         ndim = len(self.spatial_shape)
