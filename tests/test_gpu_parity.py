@@ -408,8 +408,8 @@ def _c2_module(T, n_lin, dtype_seed=0):
 
 def test_device_count_mode_equals_exact_size_mode():
     """Capacity-padded tensors + device-side row counts (no host read-back anywhere) must give the same
-    logits, loss and gradients as the ordinary exact-size path -- bit for bit in the sparse stack, because the
-    kernels visit the same rows in the same order."""
+    loss and gradients as the ordinary exact-size path.  The forward is bit-identical; reductions over rows
+    (dW, BatchNorm sums) are split by CAPACITY, so their fp32 summation order differs -> 1e-6."""
     from waveformml_amd.psd import synthetic
     T, B = 64, 24
     mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
@@ -431,9 +431,9 @@ def test_device_count_mode_equals_exact_size_mode():
     loss_b.backward()
     assert loss_a.item() == loss_b.item()
     for ga, p in zip(grads_a, mod2.model.parameters()):
-        assert torch.equal(ga, p.grad)
+        _assert_close(p.grad.cpu().numpy(), ga.cpu().numpy(), 1e-6, "gradient")
     for sa, b in zip(stats_a, mod2.model.buffers()):
-        assert torch.equal(sa, b)
+        _assert_close(b.float().cpu().numpy(), sa.float().cpu().numpy(), 1e-6, "BatchNorm running statistics")
     convs = [m for m in mod2.modules() if getattr(m, "last_rulebook", None) is not None and not m.subm]
     assert convs and all(int(m.last_rulebook.overflow) == 0 for m in convs)
     assert all(int(m.last_rulebook.m_dev) <= m.last_rulebook.M for m in convs)
