@@ -409,7 +409,7 @@ def _c2_module(T, n_lin, dtype_seed=0):
 def test_device_count_mode_equals_exact_size_mode():
     """Capacity-padded tensors + device-side row counts (no host read-back anywhere) must give the same
     loss and gradients as the ordinary exact-size path.  The forward is bit-identical; reductions over rows
-    (dW, BatchNorm sums) are split by CAPACITY, so their fp32 summation order differs -> 1e-6."""
+    (dW, BatchNorm sums) are split by CAPACITY, so their fp32 summation order differs -> 1e-5 of each tensor's scale."""
     from waveformml_amd.psd import synthetic
     T, B = 64, 24
     mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
@@ -431,7 +431,7 @@ def test_device_count_mode_equals_exact_size_mode():
     loss_b.backward()
     assert loss_a.item() == loss_b.item()
     for ga, p in zip(grads_a, mod2.model.parameters()):
-        _assert_close(p.grad.cpu().numpy(), ga.cpu().numpy(), 1e-6, "gradient")
+        _assert_close(p.grad.cpu().numpy(), ga.cpu().numpy(), 1e-5, "gradient")
     for sa, b in zip(stats_a, mod2.model.buffers()):
         _assert_close(b.float().cpu().numpy(), sa.float().cpu().numpy(), 1e-6, "BatchNorm running statistics")
     convs = [m for m in mod2.modules() if getattr(m, "last_rulebook", None) is not None and not m.subm]
