@@ -34,21 +34,24 @@ class GraphedTrainStep(object):
         self.in_graph_optimizer = self.world == 1
         self._convs = [m for m in module.modules()
                        if hasattr(m, "subm") and hasattr(m, "conv1x1") and not m.subm and not m.conv1x1 and not m.inverse]
-        # ---- calibration: one ordinary (exact-size) step tells how many rows each strided layer produces
-        reducer.reset()
-        loss = module.training_step(([coords, feats], labels), 0)
-        loss.backward()
-        reducer.finish()
-        optimizer.step()
-        for m in self._convs:
-            m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
-        if self.world > 1:
-            reducer.remove()              # no collectives inside the graph: gradients are exchanged after the replay
-        # ---- warm-up in device-count mode on a side stream, then capture
-        self._load(example_batch)
+        # Everything below runs on ONE side stream: autograd's AccumulateGrad nodes remember the stream they
+        # were created on, and a node born on the default (legacy) stream cannot take part in a capture.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            # ---- calibration: one ordinary (exact-size) step tells how many rows each strided layer produces
+            reducer.reset()
+            loss = module.training_step(([coords, feats], labels), 0)
+            loss.backward()
+            reducer.finish()
+            optimizer.step()
+            del loss
+            for m in self._convs:
+                m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
+            if self.world > 1:
+                reducer.remove()          # no collectives inside the graph: gradients are exchanged after the replay
+            # ---- warm-up in device-count mode, then capture
+            self._load(example_batch)
             for _ in range(warmup):
                 self._body()
                 if not self.in_graph_optimizer:
@@ -56,7 +59,7 @@ class GraphedTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._body()
         self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
 
