@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "psd_c2_3d.json"))
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-baseline steps (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run the step eagerly instead of replaying it as one captured HIP graph")
     return ap.parse_args()
 
 
@@ -116,13 +118,15 @@ def main():
     labels = torch.from_numpy(y).to(dev)
     batch = ([coords, feats], labels)
 
-    def step():
+    def eager_step():
         reducer.reset()
         loss = module.training_step(batch, 0)
         loss.backward()
         reducer.finish()
         optimizer.step()
         return loss
+
+    step = eager_step
 
     def fence():
         if world > 1:
@@ -137,21 +141,43 @@ def main():
         loss0 = float(module.criterion(logits0, labels).item())
         logits0 = logits0.cpu()
 
-    log("model + batch ready: %d voxels, eval forward done" % coords.shape[0])
+    log("model + batch ready: %d voxels, parity forward done" % coords.shape[0])
+    mode = "eager"
+    gstep = None
+    if not args.no_graph:
+        # the whole step (rulebook builds, forward, backward, gradient packing, optimizer) captured once as a HIP
+        # graph over capacity-padded buffers with device-side row counts, replayed per step (psd/graph.py)
+        from waveformml_amd.psd.graph import GraphedTrainStep
+        try:
+            gstep = GraphedTrainStep(module, optimizer, reducer, batch)
+            step = lambda: gstep(batch)
+            mode = "hipgraph"
+        except Exception as e:          # noqa: BLE001 -- report and fall back, the number is then an eager one
+            log("graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
     for _ in range(args.warmup):
         step()
     fence()
-    log("warm-up done")
-    if not args.no_roofline:
-        _lib.timing_enable(True)
+    log("warm-up done (%s)" % mode)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
     log("timed region done: %.3fs for %d steps" % (elapsed, args.steps))
+    if gstep is not None:
+        gstep.check()                   # raises if a captured capacity was exceeded (it cannot be, same batch)
     timers = {}
     if not args.no_roofline:
+        # per-kernel HIP-event timing.  Event pairs cannot be re-recorded inside a graph replay, so the kernels
+        # are timed in an eager pass of the same step right after the timed region (same kernels, same shapes);
+        # profiles/ holds the rocprofv3 kernel trace of the graph replay itself.
+        nprof = max(5, min(args.steps, 20))
+        eager_step()
+        torch.cuda.synchronize()
+        _lib.timing_enable(True)
+        for _ in range(nprof):
+            eager_step()
+        torch.cuda.synchronize()
         for name, tid in (("gather_conv", _lib.TIMER_GATHER_CONV), ("gather_dw", _lib.TIMER_GATHER_DW),
                           ("rulebook", _lib.TIMER_RULEBOOK)):
             timers[name] = _lib.timing_read(tid)
@@ -173,12 +199,12 @@ def main():
             "config": {"workload": "SubMConv3d PSD net, 14x11 PMT grid x %d samples, Cin=2 Cout=32, "
                                    "%d events/rank/step, rulebook rebuilt every step" % (args.samples, args.batch),
                        "active_voxels_per_rank": int(coords.shape[0]), "global_batch": args.batch * world,
-                       "parallelism": "dp%d" % world, "final_loss": final_loss},
+                       "parallelism": "dp%d" % world, "final_loss": final_loss, "execution": mode},
         }
         # ---- roofline of the dominant kernel: algorithmic bytes (accounting pass) / measured duration
         if not args.no_roofline:
             Fsp.ACCOUNT = []
-            step()
+            eager_step()
             torch.cuda.synchronize()
             acct, Fsp.ACCOUNT = Fsp.ACCOUNT, None
             log("accounting pass done")
@@ -199,7 +225,7 @@ def main():
                                   "avg_launch_us": avg_ms * 1e3, "launches_per_step": by["launches"],
                                   "algorithmic_bytes_per_launch": bytes_per_launch,
                                   "tflops": by["flops"] / max(by["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-                                  "per_step_ms": {k: timers[k][0] / args.steps for k in timers}}
+                                  "per_step_ms": {k: timers[k][0] / nprof for k in timers}}
         # ---- CPU baseline: the oracle's spconv-Native-algo restatement on the host cores, same batch
         if world == 1 and args.cpu_steps > 0:
             result["cpu_baseline"], parity = cpu_baseline(cfg_dict, init_state, c, f, y, args.cpu_steps, logits0, loss0)
