@@ -82,6 +82,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # everything runs on an ordinary stream: on ROCm 7.2 eager work on the legacy default stream between two
+    # HIP-graph replays hangs the next replay (psd/graph.py "Stream discipline")
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

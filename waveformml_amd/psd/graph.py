@@ -34,32 +34,36 @@ class GraphedTrainStep(object):
         self.in_graph_optimizer = self.world == 1
         self._convs = [m for m in module.modules()
                        if hasattr(m, "subm") and hasattr(m, "conv1x1") and not m.subm and not m.conv1x1 and not m.inverse]
-        # Everything below runs on ONE side stream: autograd's AccumulateGrad nodes remember the stream they
-        # were created on, and a node born on the default (legacy) stream cannot take part in a capture.
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            # ---- calibration: one ordinary (exact-size) step tells how many rows each strided layer produces
-            reducer.reset()
-            loss = module.training_step(([coords, feats], labels), 0)
-            loss.backward()
-            reducer.finish()
-            optimizer.step()
-            del loss
-            for m in self._convs:
-                m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
-            if self.world > 1:
-                reducer.remove()          # no collectives inside the graph: gradients are exchanged after the replay
-            # ---- warm-up in device-count mode, then capture
-            self._load(example_batch)
-            for _ in range(warmup):
-                self._body()
-                if not self.in_graph_optimizer:
-                    self._after()
-        torch.cuda.current_stream().wait_stream(side)
+        # Stream discipline.  (1) Autograd's AccumulateGrad nodes remember the stream they were created on, and a
+        # node born on the legacy default stream cannot take part in a capture.  (2) On ROCm 7.2 ANY eager work on
+        # the legacy default (null) stream between two replays makes the next replay hang.  So the runner moves the
+        # calling thread onto an ordinary stream for good -- calibration, warm-up, capture, replays and whatever
+        # eager work the caller does afterwards (loss.item(), logging, the next batch's copies) all run there.
+        if torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
+            st = torch.cuda.Stream(dev)
+            st.wait_stream(torch.cuda.default_stream(dev))
+            torch.cuda.set_stream(st)
+        self.stream = torch.cuda.current_stream(dev)
+        # ---- calibration: one ordinary (exact-size) step tells how many rows each strided layer produces
+        reducer.reset()
+        loss = module.training_step(([coords, feats], labels), 0)
+        loss.backward()
+        reducer.finish()
+        optimizer.step()
+        del loss
+        for m in self._convs:
+            m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
+        if self.world > 1:
+            reducer.remove()              # no collectives inside the graph: gradients are exchanged after the replay
+        # ---- warm-up in device-count mode, then capture
+        self._load(example_batch)
+        for _ in range(warmup):
+            self._body()
+            if not self.in_graph_optimizer:
+                self._after()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with torch.cuda.graph(self.graph, stream=self.stream):
             self.loss = self._body()
         self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
 
@@ -90,6 +94,8 @@ class GraphedTrainStep(object):
         self.n_valid.fill_(n)
 
     def __call__(self, batch):
+        if torch.cuda.current_stream(self.coords.device) == torch.cuda.default_stream(self.coords.device):
+            torch.cuda.set_stream(self.stream)         # see "Stream discipline" in __init__
         self._load(batch)
         self.graph.replay()
         if not self.in_graph_optimizer:
