@@ -169,16 +169,18 @@ int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_
 /* BatchNorm1d (+ReLU) over the active rows ------------------------------------------------------
  * What spconv.SparseSequential does with the plain nn.BatchNorm1d / nn.ReLU modules the reference
  * puts after every sparse conv (src/models/SPConvBlocks.py:505-508): applied to .features [N, C],
- * statistics over the N active rows.  Two launches per direction (column reduction into per-block
- * partials; elementwise pass whose blocks fold the partials in a fixed order): deterministic.
+ * statistics over the N active rows.  Three small launches per direction (column reduction into per-block
+ * partials; fold of the partials in a fixed order; elementwise pass): deterministic.
  * training != 0: batch statistics (biased variance), running_mean/var (may be NULL) updated with
- * `momentum` using the unbiased variance, exactly as torch.  training == 0: running statistics.
+ * `momentum` using the unbiased variance and *num_batches_tracked (device int64, may be NULL)
+ * incremented, exactly as torch.  training == 0: running statistics.
  * relu != 0 fuses y = max(0, .).  save_mean / save_invstd [C] are outputs the backward consumes.
  * gamma / beta may be NULL (affine=False).  C <= 1024.                                           */
 size_t wfs_bn_workspace_bytes(int64_t N, int32_t C);
 
 int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
-                    float *running_mean, float *running_var, float momentum, float eps,
+                    float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                    float momentum, float eps,
                     int32_t training, int32_t relu, void *Y, float *save_mean, float *save_invstd,
                     void *workspace, size_t workspace_bytes, int32_t dtype, const int64_t *n_dev,
                     void *stream);

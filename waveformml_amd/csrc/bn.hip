@@ -2,9 +2,10 @@
 //
 // The reference applies plain nn.BatchNorm1d / nn.ReLU modules to SparseConvTensor.features inside
 // spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508): batch
-// statistics over the N ACTIVE voxels only, per rank (no SyncBN).  Same arithmetic here, in two launches per
-// direction instead of torch's ~5: a column reduction into per-block partials, and an elementwise pass
-// whose every block first folds the partials in a fixed order (deterministic, no atomics, no extra launch).
+// statistics over the N ACTIVE voxels only, per rank (no SyncBN).  Same arithmetic here, in three small launches
+// per direction: a column reduction into per-block partials (many blocks, bandwidth), a one-block-per-32-channels
+// fold of the partials in a fixed order (deterministic, no atomics) that also finalises the statistics, and the
+// elementwise pass.
 //
 //   forward   mean_c, var_c (biased) over rows;  y = max(0, gamma*(x-mean)*invstd + beta)   [ReLU optional]
 //             running_mean/var updated with momentum (unbiased var), as torch does
@@ -134,108 +135,82 @@ __global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const
     }
 }
 
-// every block folds partial[0..nblk) in the same order -> identical statistics in every block, no atomics.
-// All 256 threads take part: thread (slice s, channel c) sums partials p = s, s+S, ... and the S slices are
-// then added in slice order.
-__device__ __forceinline__ void fold_partials(const float *partial, int nblk, int C, float *sA, float *sB) {
-    __shared__ float tA[TB], tB[TB];
-    if (C <= TB) {
-        const int S = TB / C;
-        const int c = threadIdx.x % C, sl = threadIdx.x / C;
-        // four independent chains in a fixed interleave: the loads of one slice overlap instead of
-        // waiting on each other, and the summation order is still the same in every block and run
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        if (sl < S) {
-            int p = sl;
-            for (; p + 3 * S < nblk; p += 4 * S) {
-                const float *q = partial + (long long)p * 2 * C + c;
-                a0 += q[0];
-                b0 += q[C];
-                a1 += q[(long long)S * 2 * C];
-                b1 += q[(long long)S * 2 * C + C];
-                a2 += q[(long long)2 * S * 2 * C];
-                b2 += q[(long long)2 * S * 2 * C + C];
-                a3 += q[(long long)3 * S * 2 * C];
-                b3 += q[(long long)3 * S * 2 * C + C];
-            }
-            for (; p < nblk; p += S) {
-                a0 += partial[(long long)p * 2 * C + c];
-                b0 += partial[(long long)p * 2 * C + C + c];
-            }
+// Fold of the partials: block = 8 slices x 32 channels; slice s sums partials s, s+8, ... on four interleaved
+// chains (loads overlap, order fixed), slices are added in slice order.
+//   MODE 0: (sum d, sum d^2) -> mean, invstd (+ running statistics, num_batches_tracked)
+//   MODE 1: (sum g, sum g*xhat) -> sums[2][C] (= dbeta, dgamma)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(TB) k_bn_fold(const float *__restrict__ partial, int nblk, int C,
+                                                const T *__restrict__ X, long long Ncap,
+                                                const long long *__restrict__ n_dev, float *__restrict__ running_mean,
+                                                float *__restrict__ running_var, long long *__restrict__ batches_tracked,
+                                                float momentum, float eps, float *__restrict__ out_a,
+                                                float *__restrict__ out_b) {
+    __shared__ float tA[8][32], tB[8][32];
+    const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (c < C) {
+        int p = sl;
+        const long long st = 2ll * C;
+        for (; p + 24 < nblk; p += 32) {
+            const float *q = partial + (long long)p * st + c;
+            a0 += q[0];
+            b0 += q[C];
+            a1 += q[8 * st];
+            b1 += q[8 * st + C];
+            a2 += q[16 * st];
+            b2 += q[16 * st + C];
+            a3 += q[24 * st];
+            b3 += q[24 * st + C];
         }
-        float a = (a0 + a1) + (a2 + a3), b = (b0 + b1) + (b2 + b3);
-        tA[threadIdx.x] = a;
-        tB[threadIdx.x] = b;
-        __syncthreads();
-        if (threadIdx.x < C) {
-            a = 0.f;
-            b = 0.f;
-            for (int q = 0; q < S; ++q) {
-                a += tA[q * C + threadIdx.x];
-                b += tB[q * C + threadIdx.x];
-            }
-            sA[threadIdx.x] = a;
-            sB[threadIdx.x] = b;
-        }
-    } else {
-        for (int c = threadIdx.x; c < C; c += TB) {
-            float a = 0.f, b = 0.f;
-            for (int p = 0; p < nblk; ++p) {
-                a += partial[(long long)p * 2 * C + c];
-                b += partial[(long long)p * 2 * C + C + c];
-            }
-            sA[c] = a;
-            sB[c] = b;
+        for (; p < nblk; p += 8) {
+            a0 += partial[(long long)p * st + c];
+            b0 += partial[(long long)p * st + C + c];
         }
     }
+    tA[sl][lane] = (a0 + a1) + (a2 + a3);
+    tB[sl][lane] = (b0 + b1) + (b2 + b3);
     __syncthreads();
+    if (sl == 0 && c < C) {
+        float a = 0.f, bb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            a += tA[q][lane];
+            bb += tB[q][lane];
+        }
+        if (MODE == 0) {
+            const long long N = valid_rows(Ncap, n_dev);
+            const float n = N > 0 ? (float)N : 1.f;
+            float shift = wfs_ld(X + c);
+            float md = a / n;                           // mean of (x - shift)
+            float var = bb / n - md * md;               // biased, what torch normalises with
+            var = var > 0.f ? var : 0.f;
+            float mean = shift + md;
+            out_a[c] = mean;
+            out_b[c] = rsqrtf(var + eps);
+            if (running_mean) {
+                float unbiased = N > 1 ? var * (n / (n - 1.f)) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        } else {
+            out_a[c] = a;
+            out_b[c] = bb;
+        }
+    }
+    if (MODE == 0 && batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;
 }
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long long Ncap,
                                                  const long long *__restrict__ n_dev, int C, long long rows_per_block,
-                                                 const float *__restrict__ partial, int nblk_partial,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                 float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                 float momentum, float eps, int training, int relu,
-                                                 T *__restrict__ Y, float *__restrict__ save_mean,
+                                                 const float *__restrict__ running_mean,
+                                                 const float *__restrict__ running_var, float eps, int training,
+                                                 int relu, T *__restrict__ Y, float *__restrict__ save_mean,
                                                  float *__restrict__ save_invstd) {
-    __shared__ float sA[MAXC], sB[MAXC];       // mean / invstd
     const long long N = valid_rows(Ncap, n_dev);
-    if (N <= 0) return;
-    if (training) {
-        fold_partials(partial, nblk_partial, C, sA, sB);
-        for (int c = threadIdx.x; c < C; c += TB) {
-            float shift = wfs_ld(X + c);
-            float md = sA[c] / (float)N;                       // mean of (x - shift)
-            float var = sB[c] / (float)N - md * md;            // biased, what torch normalises with
-            var = var > 0.f ? var : 0.f;
-            float mean = shift + md;
-            float invstd = rsqrtf(var + eps);
-            sA[c] = mean;
-            sB[c] = invstd;
-            if (blockIdx.x == 0) {
-                save_mean[c] = mean;
-                save_invstd[c] = invstd;
-                if (running_mean) {
-                    float unbiased = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-                }
-            }
-        }
-    } else {
-        for (int c = threadIdx.x; c < C; c += TB) {
-            float mean = running_mean[c], invstd = rsqrtf(running_var[c] + eps);
-            sA[c] = mean;
-            sB[c] = invstd;
-            if (blockIdx.x == 0) {
-                save_mean[c] = mean;
-                save_invstd[c] = invstd;
-            }
-        }
-    }
-    __syncthreads();
     const int groups = C / VEC, slots = TB / groups;
     const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
     if (slot >= slots) return;
@@ -243,8 +218,17 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
     float m[VEC], is[VEC], ga[VEC], be[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        m[i] = sA[c0 + i];
-        is[i] = sB[c0 + i];
+        if (training) {
+            m[i] = save_mean[c0 + i];
+            is[i] = save_invstd[c0 + i];
+        } else {
+            m[i] = running_mean[c0 + i];
+            is[i] = rsqrtf(running_var[c0 + i] + eps);
+            if (blockIdx.x == 0 && slot == 0) {
+                save_mean[c0 + i] = m[i];
+                save_invstd[c0 + i] = is[i];
+            }
+        }
         ga[i] = gamma ? gamma[c0 + i] : 1.f;
         be[i] = beta ? beta[c0 + i] : 0.f;
     }
@@ -266,19 +250,17 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
 template <typename T, int VEC>
 __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, const T *__restrict__ dY,
                                                      long long Ncap, const long long *__restrict__ n_dev, int C,
-                                                     long long rows_per_block,
-                                                     const float *__restrict__ partial, int nblk_partial,
+                                                     long long rows_per_block, const float *__restrict__ sum_g,
+                                                     const float *__restrict__ sum_gx,
                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                      int training, int relu, T *__restrict__ dX,
                                                      float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ float sA[MAXC], sB[MAXC];       // sum g, sum g*xhat
     const long long N = valid_rows(Ncap, n_dev);
-    fold_partials(partial, nblk_partial, C, sA, sB);
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += TB) {
-            if (dbeta) dbeta[c] = sA[c];
-            if (dgamma) dgamma[c] = sB[c];
+            if (dbeta) dbeta[c] = sum_g[c];
+            if (dgamma) dgamma[c] = sum_gx[c];
         }
     }
     const int groups = C / VEC, slots = TB / groups;
@@ -293,8 +275,8 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
         is[i] = invstd[c0 + i];
         ga[i] = gamma ? gamma[c0 + i] : 1.f;
         be[i] = beta ? beta[c0 + i] : 0.f;
-        k1[i] = training ? sA[c0 + i] * invN : 0.f;
-        k2[i] = training ? sB[c0 + i] * invN : 0.f;
+        k1[i] = training ? sum_g[c0 + i] * invN : 0.f;
+        k2[i] = training ? sum_gx[c0 + i] * invN : 0.f;
     }
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
@@ -314,29 +296,30 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
     }
 }
 
-long long bn_reduce_blocks(long long N) {      // = number of partials every apply block folds
-    long long b = wfs_cdiv(N, 256);
+long long bn_reduce_blocks(long long N) {      // = number of partials the fold kernel sums
+    long long b = wfs_cdiv(N, 64);
     if (b < 1) b = 1;
-    if (b > 128) b = 128;
+    if (b > 1024) b = 1024;
     return b;
 }
 long long bn_apply_blocks(long long N) {
-    long long b = wfs_cdiv(N, 128);
+    long long b = wfs_cdiv(N, 64);
     if (b < 1) b = 1;
-    if (b > 512) b = 512;
+    if (b > 2048) b = 2048;
     return b;
 }
 
 }  // namespace
 
 extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
-    return (size_t)bn_reduce_blocks(N) * 2 * C * sizeof(float);
+    return ((size_t)bn_reduce_blocks(N) + 1) * 2 * C * sizeof(float);     // partials + the folded sums
 }
 
 extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
-                               float *running_mean, float *running_var, float momentum, float eps, int32_t training,
-                               int32_t relu, void *Y, float *save_mean, float *save_invstd, void *workspace,
-                               size_t workspace_bytes, int32_t dtype, const int64_t *n_dev_, void *stream_) {
+                               float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
+                               float eps, int32_t training, int32_t relu, void *Y, float *save_mean,
+                               float *save_invstd, void *workspace, size_t workspace_bytes, int32_t dtype,
+                               const int64_t *n_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long *n_dev = (const long long *)n_dev_;
     WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
@@ -345,19 +328,23 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(X && Y && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
     const long long nblk = bn_reduce_blocks(N), nblk_a = bn_apply_blocks(N);
-    WFS_REQUIRE(workspace_bytes >= (size_t)nblk * 2 * C * sizeof(float), WFS_EWORKSPACE, "workspace too small");
+    WFS_REQUIRE(workspace_bytes >= wfs_bn_workspace_bytes(N, C), WFS_EWORKSPACE, "workspace too small");
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
-    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
-#define WFS_BN_FWD(T, VEC)                                                                                         \
-    do {                                                                                                           \
-        if (training)                                                                                              \
-            k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,   \
-                                                                nullptr, nullptr, nullptr, 0, partial);            \
-        k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, rpb_a, partial, (int)nblk,       \
-                                                          gamma, beta,                                             \
-                                                        running_mean, running_var, momentum, eps, training, relu,  \
-                                                        (T *)Y, save_mean, save_invstd);                           \
+    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), grid_f((unsigned)wfs_cdiv(C, 32)), block(TB);
+#define WFS_BN_FWD(T, VEC)                                                                                          \
+    do {                                                                                                            \
+        if (training) {                                                                                             \
+            k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,    \
+                                                                nullptr, nullptr, nullptr, 0, partial);             \
+            k_bn_fold<T, 0><<<grid_f, block, 0, stream>>>(partial, (int)nblk, C, (const T *)X, N, n_dev,            \
+                                                           running_mean, running_var,                               \
+                                                           (long long *)num_batches_tracked, momentum, eps,         \
+                                                           save_mean, save_invstd);                                 \
+        }                                                                                                           \
+        k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, rpb_a, gamma, beta,             \
+                                                          running_mean, running_var, eps, training, relu, (T *)Y,   \
+                                                          save_mean, save_invstd);                                  \
     } while (0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_FWD(float, 4); else WFS_BN_FWD(float, 1);
@@ -384,18 +371,20 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     }
     WFS_REQUIRE(X && dY && dX && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
     const long long nblk = bn_reduce_blocks(N), nblk_a = bn_apply_blocks(N);
-    WFS_REQUIRE(workspace_bytes >= (size_t)nblk * 2 * C * sizeof(float), WFS_EWORKSPACE, "workspace too small");
+    WFS_REQUIRE(workspace_bytes >= wfs_bn_workspace_bytes(N, C), WFS_EWORKSPACE, "workspace too small");
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
-    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
-#define WFS_BN_BWD(T, VEC)                                                                                           \
-    do {                                                                                                             \
-        k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb, save_mean,   \
-                                                            save_invstd, gamma, beta, relu, partial);                \
-        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb_a, partial, \
-                                                              (int)nblk,                                             \
-                                                            save_mean, save_invstd, gamma, beta, training, relu,     \
-                                                            (T *)dX, dgamma, dbeta);                                 \
+    float *sums = partial + (size_t)nblk * 2 * C;            // [2][C]: sum g, sum g*xhat
+    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), grid_f((unsigned)wfs_cdiv(C, 32)), block(TB);
+#define WFS_BN_BWD(T, VEC)                                                                                          \
+    do {                                                                                                            \
+        k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb, save_mean,  \
+                                                            save_invstd, gamma, beta, relu, partial);               \
+        k_bn_fold<T, 1><<<grid_f, block, 0, stream>>>(partial, (int)nblk, C, nullptr, N, n_dev, nullptr, nullptr,   \
+                                                       nullptr, 0.f, 0.f, sums, sums + C);                          \
+        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb_a, sums,  \
+                                                              sums + C, save_mean, save_invstd, gamma, beta,        \
+                                                              training, relu, (T *)dX, dgamma, dbeta);              \
     } while (0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_BWD(float, 4); else WFS_BN_BWD(float, 1);

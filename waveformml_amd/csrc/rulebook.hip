@@ -157,6 +157,120 @@ __global__ void k_subm_lookup(Geo g, int batch, const int *idx, long long N, con
     }
 }
 
+// ---------------------------------------------------------------- (row, offset)-parallel forms
+// grid = (rows / 64, ceil(K / 4)), block = 256: lane = row, wave = offset -> every thread does ONE site lookup /
+// insert, writes of nbr_out[k][j] are coalesced over j, and the per-offset arithmetic is wave-uniform (scalar).
+// K <= 32 lets a row's "first ticket" flags live in one 32-bit mask.
+__device__ __forceinline__ int offset_key(const Geo &g, int k, const int *x, int b) {
+    int rem = k;
+    int off[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+        if (d >= g.ndim) continue;
+        off[d] = rem % g.ksize[d];
+        rem /= g.ksize[d];
+    }
+    long long lin = b;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d >= g.ndim) break;
+        int t = x[d] + g.padding[d] - off[d] * g.dilation[d];
+        if (t < 0) return -1;
+        int o = t / g.stride[d];
+        if (o * g.stride[d] != t || o >= g.out_shape[d]) return -1;
+        lin = lin * g.out_shape[d] + o;
+    }
+    return (int)lin;
+}
+
+__global__ void __launch_bounds__(TB) k_subm_lookup2(Geo g, int batch, const int *__restrict__ idx, long long N,
+                                                     const long long *n_dev, Table t, const int *__restrict__ vals,
+                                                     int *__restrict__ nbr_out) {
+    const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (k >= g.K || j >= valid_rows(N, n_dev)) return;
+    int x[4], b;
+    bool ok = load_row(g, idx, j, x, b, batch);
+    int res = -1;
+    int key = ok ? offset_key(g, k, x, b) : -1;
+    if (key >= 0) {
+        unsigned s = tbl_find(t, key);
+        if (s != 0xFFFFFFFFu) res = vals[s];
+    }
+    nbr_out[(long long)k * N + j] = res;
+}
+
+__global__ void __launch_bounds__(TB) k_conv_insert2(Geo g, int batch, const int *__restrict__ idx, long long N,
+                                                     const long long *n_dev, Table t,
+                                                     unsigned long long *__restrict__ ticket, int *__restrict__ nbr_out,
+                                                     long long *info) {
+    const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (k >= g.K || j >= valid_rows(N, n_dev)) return;
+    int x[4], b;
+    bool ok = load_row(g, idx, j, x, b, batch);
+    if (!ok) info[2] = 1;
+    int key = ok ? offset_key(g, k, x, b) : -1;
+    int slot = -1;
+    if (key >= 0) {
+        unsigned s = tbl_insert(t, key);
+        atomicMin(&ticket[s], (unsigned long long)j * g.K + k);
+        slot = (int)s;
+    }
+    nbr_out[(long long)k * N + j] = slot;
+}
+
+// rowmask[j] bit k = candidate (j, k) holds the first ticket of its site (rowmask zeroed by the caller)
+__global__ void __launch_bounds__(TB) k_conv_first2(int K, long long N, const long long *n_dev,
+                                                    const int *__restrict__ nbr_out,
+                                                    const unsigned long long *__restrict__ ticket,
+                                                    unsigned *__restrict__ rowmask) {
+    const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (k >= K || j >= valid_rows(N, n_dev)) return;
+    int s = nbr_out[(long long)k * N + j];
+    if (s >= 0 && ticket[s] == (unsigned long long)j * K + k) atomicOr(&rowmask[j], 1u << k);
+}
+
+__global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const long long *n_dev, long long M_cap,
+                                                     const int *__restrict__ nbr_out, const unsigned *__restrict__ rowmask,
+                                                     const int *__restrict__ rowbase, Table t, int *__restrict__ slot_id,
+                                                     int *__restrict__ out_indices, long long *info) {
+    const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (k >= g.K || j >= valid_rows(N, n_dev)) return;
+    const unsigned m = rowmask[j];
+    if (!((m >> k) & 1u)) return;
+    const int s = nbr_out[(long long)k * N + j];
+    const int id = rowbase[j] + __popc(m & ((1u << k) - 1u));       // first-seen order: rows, then offsets
+    slot_id[s] = id;
+    if (id >= M_cap) {
+        info[3] = 1;
+        return;
+    }
+    long long key = t.direct ? (long long)s : (long long)t.keys[s];
+    int *o = out_indices + (long long)id * (g.ndim + 1);
+    for (int d = g.ndim - 1; d >= 0; --d) {
+        o[1 + d] = (int)(key % g.out_shape[d]);
+        key /= g.out_shape[d];
+    }
+    o[0] = (int)key;
+}
+
+__global__ void __launch_bounds__(TB) k_conv_finalize2(int K, long long N, const long long *n_dev, long long M,
+                                                       int *__restrict__ nbr_out, const int *__restrict__ slot_id,
+                                                       int *__restrict__ nbr_in) {
+    const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (k >= K || j >= valid_rows(N, n_dev)) return;
+    int s = nbr_out[(long long)k * N + j];
+    if (s < 0) return;
+    int id = slot_id[s];
+    if (id >= M) id = -1;
+    nbr_out[(long long)k * N + j] = id;
+    if (nbr_in && id >= 0) atomicMax(&nbr_in[(long long)k * M + id], (int)j);
+}
+
 // ---------------------------------------------------------------- regular / strided conv
 __global__ void k_conv_insert(Geo g, int batch, const int *idx, long long N, const long long *n_dev, Table t,
                               unsigned long long *ticket, int *nbr_out, long long *info) {
@@ -282,12 +396,20 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total) {
     return base + inc - v;
 }
 
-__global__ void k_scan_blocksum(const int *in, long long n, int *bsum) {
+// popc != 0: the scanned quantity is the popcount of each input word (row masks of first tickets); rows at or
+// beyond the valid count contribute 0
+__device__ __forceinline__ int scan_item(const int *in, long long i, long long n, long long nv, int popc) {
+    if (i >= n) return 0;
+    if (!popc) return in[i];
+    return i < nv ? __popc((unsigned)in[i]) : 0;
+}
+
+__global__ void k_scan_blocksum(const int *in, long long n, const long long *n_dev, int popc, int *bsum) {
     long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    const long long nv = valid_rows(n, n_dev);
     int v = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < n) v += in[base + i];
+    for (int i = 0; i < SCAN_ITEMS; ++i) v += scan_item(in, base + i, n, nv, popc);
     int tot;
     block_excl_scan(v, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
@@ -308,13 +430,14 @@ __global__ void k_scan_top(int *bsum, long long nb, long long *total, long long 
         if (total2) *total2 = carry < cap ? carry : cap;       // the row count downstream kernels bound by
     }
 }
-__global__ void k_scan_apply(const int *in, long long n, const int *bsum, int *out) {
+__global__ void k_scan_apply(const int *in, long long n, const long long *n_dev, int popc, const int *bsum, int *out) {
     long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    const long long nv = valid_rows(n, n_dev);
     int vals[SCAN_ITEMS];
     int v = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        vals[i] = base + i < n ? in[base + i] : 0;
+        vals[i] = scan_item(in, base + i, n, nv, popc);
         v += vals[i];
     }
     int tot;
@@ -541,7 +664,8 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         WFS_HIP_CHECK(hipMemsetAsync(vals, 0xFF, (size_t)p.cap * 4, stream));
         k_site_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, info);
         WFS_LAUNCH_CHECK();
-        k_subm_lookup<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, nbr_out);
+        dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
+        k_subm_lookup2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, nbr_out);
         WFS_LAUNCH_CHECK();
         if (m_dev && n_dev && m_dev != n_dev)
             WFS_HIP_CHECK(hipMemcpyAsync(m_dev, n_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
@@ -551,18 +675,28 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         int *rowbase = (int *)(ws + p.off_rowbase);
         int *bsum = (int *)(ws + p.off_bsum);
         WFS_HIP_CHECK(hipMemsetAsync(ticket, 0xFF, (size_t)p.cap * 8, stream));
-        k_conv_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, ticket, nbr_out, info);
-        WFS_LAUNCH_CHECK();
-        k_conv_rowcount<<<grid, block, 0, stream>>>(g->K, N, nd, nbr_out, ticket, rowfirst);
-        WFS_LAUNCH_CHECK();
+        const int wide = g->K <= 32;         // (row, offset)-parallel kernels; rowfirst[] then holds first-ticket masks
+        dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
+        if (wide) {
+            WFS_HIP_CHECK(hipMemsetAsync(rowfirst, 0, (size_t)(N + 1) * 4, stream));
+            k_conv_insert2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, ticket, nbr_out, info);
+            WFS_LAUNCH_CHECK();
+            k_conv_first2<<<grid2, block, 0, stream>>>(g->K, N, nd, nbr_out, ticket, (unsigned *)rowfirst);
+            WFS_LAUNCH_CHECK();
+        } else {
+            k_conv_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, ticket, nbr_out, info);
+            WFS_LAUNCH_CHECK();
+            k_conv_rowcount<<<grid, block, 0, stream>>>(g->K, N, nd, nbr_out, ticket, rowfirst);
+            WFS_LAUNCH_CHECK();
+        }
         dim3 sgrid((unsigned)p.nscan);
-        k_scan_blocksum<<<sgrid, block, 0, stream>>>(rowfirst, N, bsum);
+        k_scan_blocksum<<<sgrid, block, 0, stream>>>(rowfirst, N, nd, wide, bsum);
         WFS_LAUNCH_CHECK();
         // info[0] = M; m_dev = min(M, M_cap) = the row count every consumer of the outputs is bounded by
         k_scan_top<<<dim3(1), block, 0, stream>>>(bsum, p.nscan, info, (long long *)m_dev,
                                                   M_cap > 0 ? M_cap : (1ll << 62));
         WFS_LAUNCH_CHECK();
-        k_scan_apply<<<sgrid, block, 0, stream>>>(rowfirst, N, bsum, rowbase);
+        k_scan_apply<<<sgrid, block, 0, stream>>>(rowfirst, N, nd, wide, bsum, rowbase);
         WFS_LAUNCH_CHECK();
     }
     if (!host_info) return WFS_OK;          // caller vouches for the indices / works with device counts: asynchronous
@@ -602,11 +736,21 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
         unsigned long long *ticket = (unsigned long long *)(ws + p.off_ticket);
         int *slot_id = (int *)(ws + p.off_slot_id);
         int *rowbase = (int *)(ws + p.off_rowbase);
-        k_conv_assign<<<grid, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, ticket, rowbase, p.tbl, slot_id, out_indices,
-                                                  info);
-        WFS_LAUNCH_CHECK();
-        k_conv_finalize<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
-        WFS_LAUNCH_CHECK();
+        if (g->K <= 32) {
+            int *rowmask = (int *)(ws + p.off_rowfirst);
+            dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
+            k_conv_assign2<<<grid2, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, (const unsigned *)rowmask, rowbase, p.tbl,
+                                                        slot_id, out_indices, info);
+            WFS_LAUNCH_CHECK();
+            k_conv_finalize2<<<grid2, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
+            WFS_LAUNCH_CHECK();
+        } else {
+            k_conv_assign<<<grid, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, ticket, rowbase, p.tbl, slot_id,
+                                                      out_indices, info);
+            WFS_LAUNCH_CHECK();
+            k_conv_finalize<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
+            WFS_LAUNCH_CHECK();
+        }
         if (overflow_dev)       // info[3] (8 bytes) -> the caller's flag: non-zero = M exceeded the capacity
             WFS_HIP_CHECK(hipMemcpyAsync(overflow_dev, info + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     } else if (nbr_in) {

@@ -42,12 +42,18 @@ def _features_ok(t):
 
 
 def _rows(shape, like, r_dev):
-    """Row-dimensioned output.  In device-count mode the rows beyond the valid count are never written by
-    the kernels, so they are zero-filled once here (torch-side column sums such as the bias gradient run
-    over the whole capacity)."""
+    """Row-dimensioned output.  In device-count mode rows beyond the valid count are never written NOR read
+    by the kernels, so they can stay uninitialised; the one torch-side reduction over rows (the conv bias
+    gradient) masks them itself (_masked_column_sum)."""
+    return torch.empty(shape, dtype=like.dtype, device=like.device)
+
+
+def _masked_column_sum(t, r_dev):
+    """sum over the valid rows of t [R, C] (fp32)."""
     if r_dev is None:
-        return torch.empty(shape, dtype=like.dtype, device=like.device)
-    return torch.zeros(shape, dtype=like.dtype, device=like.device)
+        return t.float().sum(0)
+    valid = (torch.arange(t.shape[0], device=t.device) < r_dev).unsqueeze(1)
+    return torch.where(valid, t.float(), torch.zeros((), device=t.device)).sum(0)
 
 
 def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None):
@@ -154,7 +160,8 @@ class SparseConvFunction(Function):
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
-            db = dY.float().sum(0).to(bias.dtype)
+            # dY has one row per OUTPUT of this product: rb.N rows for an inverse conv, rb.M otherwise
+            db = _masked_column_sum(dY, rb.n_dev if mode == INVERSE else rb.m_dev).to(bias.dtype)
         return dX, dW, db, None, None
 
 
@@ -202,7 +209,8 @@ class BatchNormReLUFunction(Function):
     (reference: the plain modules inside spconv.SparseSequential, src/models/SPConvBlocks.py:505-508)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, n_dev=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, n_dev=None,
+                batches_tracked=None):
         lib = _lib.load()
         x = _features_ok(x)
         N, C = x.shape
@@ -213,7 +221,8 @@ class BatchNormReLUFunction(Function):
         for t in (weight, bias, running_mean, running_var):
             assert t is None or (t.dtype == torch.float32 and t.numel() == C and t.is_contiguous())
         _lib.check(lib.wfs_bn_relu_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
-                                       _lib.ptr(running_var), float(momentum), float(eps), 1 if training else 0,
+                                       _lib.ptr(running_var), _lib.ptr(batches_tracked) if training else None,
+                                       float(momentum), float(eps), 1 if training else 0,
                                        1 if relu else 0, _lib.ptr(y), _lib.ptr(save_mean), _lib.ptr(save_invstd),
                                        _lib.ptr(ws), ws.numel(), _lib.dtype_code(x), _lib.ptr(n_dev),
                                        _lib.stream_ptr()))
@@ -239,18 +248,17 @@ class BatchNormReLUFunction(Function):
                                        _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
                                        1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
                                        ws.numel(), _lib.dtype_code(x), _lib.ptr(ctx.n_dev), _lib.stream_ptr()))
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def batch_norm_relu(features, bn, relu, n_dev=None):
     """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features
     (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts")."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # bumped by the kernel
     return BatchNormReLUFunction.apply(features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps,
-                                       training, relu, n_dev)
+                                       training, relu, n_dev, tracked)
 
 
 def can_fuse_batch_norm(bn, features):
