@@ -135,36 +135,37 @@ __global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const
     }
 }
 
-// Fold of the partials: block = 8 slices x 32 channels; slice s sums partials s, s+8, ... on four interleaved
-// chains (loads overlap, order fixed), slices are added in slice order.
+// Fold of the partials: block = 32 slices x 32 channels (1024 threads); slice s sums partials s, s+32, ... on four
+// interleaved chains (loads overlap, order fixed), slices are added in slice order.
 //   MODE 0: (sum d, sum d^2) -> mean, invstd (+ running statistics, num_batches_tracked)
 //   MODE 1: (sum g, sum g*xhat) -> sums[2][C] (= dbeta, dgamma)
+constexpr int FOLD_SL = 32;
 template <typename T, int MODE>
-__global__ void __launch_bounds__(TB) k_bn_fold(const float *__restrict__ partial, int nblk, int C,
+__global__ void __launch_bounds__(FOLD_SL * 32) k_bn_fold(const float *__restrict__ partial, int nblk, int C,
                                                 const T *__restrict__ X, long long Ncap,
                                                 const long long *__restrict__ n_dev, float *__restrict__ running_mean,
                                                 float *__restrict__ running_var, long long *__restrict__ batches_tracked,
                                                 float momentum, float eps, float *__restrict__ out_a,
                                                 float *__restrict__ out_b) {
-    __shared__ float tA[8][32], tB[8][32];
+    __shared__ float tA[FOLD_SL][32], tB[FOLD_SL][32];
     const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + lane;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
     if (c < C) {
         int p = sl;
         const long long st = 2ll * C;
-        for (; p + 24 < nblk; p += 32) {
+        for (; p + 3 * FOLD_SL < nblk; p += 4 * FOLD_SL) {
             const float *q = partial + (long long)p * st + c;
             a0 += q[0];
             b0 += q[C];
-            a1 += q[8 * st];
-            b1 += q[8 * st + C];
-            a2 += q[16 * st];
-            b2 += q[16 * st + C];
-            a3 += q[24 * st];
-            b3 += q[24 * st + C];
+            a1 += q[FOLD_SL * st];
+            b1 += q[FOLD_SL * st + C];
+            a2 += q[2 * FOLD_SL * st];
+            b2 += q[2 * FOLD_SL * st + C];
+            a3 += q[3 * FOLD_SL * st];
+            b3 += q[3 * FOLD_SL * st + C];
         }
-        for (; p < nblk; p += 8) {
+        for (; p < nblk; p += FOLD_SL) {
             a0 += partial[(long long)p * st + c];
             b0 += partial[(long long)p * st + C + c];
         }
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(TB) k_bn_fold(const float *__restrict__ partia
     if (sl == 0 && c < C) {
         float a = 0.f, bb = 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < FOLD_SL; ++q) {
             a += tA[q][lane];
             bb += tB[q][lane];
         }
@@ -337,7 +338,7 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
         if (training) {                                                                                             \
             k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,    \
                                                                 nullptr, nullptr, nullptr, 0, partial);             \
-            k_bn_fold<T, 0><<<grid_f, block, 0, stream>>>(partial, (int)nblk, C, (const T *)X, N, n_dev,            \
+            k_bn_fold<T, 0><<<grid_f, dim3(FOLD_SL * 32), 0, stream>>>(partial, (int)nblk, C, (const T *)X, N, n_dev,            \
                                                            running_mean, running_var,                               \
                                                            (long long *)num_batches_tracked, momentum, eps,         \
                                                            save_mean, save_invstd);                                 \
@@ -380,7 +381,7 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     do {                                                                                                            \
         k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb, save_mean,  \
                                                             save_invstd, gamma, beta, relu, partial);               \
-        k_bn_fold<T, 1><<<grid_f, block, 0, stream>>>(partial, (int)nblk, C, nullptr, N, n_dev, nullptr, nullptr,   \
+        k_bn_fold<T, 1><<<grid_f, dim3(FOLD_SL * 32), 0, stream>>>(partial, (int)nblk, C, nullptr, N, n_dev, nullptr, nullptr,   \
                                                        nullptr, 0.f, 0.f, sums, sums + C);                          \
         k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb_a, sums,  \
                                                               sums + C, save_mean, save_invstd, gamma, beta,        \

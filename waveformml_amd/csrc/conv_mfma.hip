@@ -607,6 +607,112 @@ __global__ void __launch_bounds__(256) k_gdw_c32c2(const int *__restrict__ table
     }
 }
 
+// bf16 form of the first-layer dW on the matrix cores.  Per 32-row tile the wave builds, in its own LDS region,
+//   A [32 rows][64]: column k*2+c = channel c of the row gathered through table[km(k)][row] (2 x bf16 = one dword
+//                    per (row, k); columns 54..63 are zero padding), row stride 33 dwords (conflict-free fill),
+//   B [32 rows][32]: the stationary dY rows,
+// and accumulates D[col][b] += sum_rows A[row][col] * B[row][b] with 4 x v_mfma_f32_32x32x16_bf16 (two 32-column
+// halves x two 16-row steps; both operands are read column-wise from LDS, as in k_gdw32_bf16).  All of a tile's
+// table reads are issued together, then all gathers: two memory latencies per tile, one tile per wave in flight.
+constexpr int C2_WAVES = 8;
+
+__global__ void __launch_bounds__(512, 4) k_gdw_c32c2_bf16(const int *__restrict__ table, int mirror, int K,
+                                                          int identity_k, long long Rcap,
+                                                          const long long *__restrict__ r_dev,
+                                                          const wfs_bf16 *__restrict__ S, const wfs_bf16 *__restrict__ G,
+                                                          float *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) unsigned sA[C2_WAVES][32 * 33];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[C2_WAVES][32 * 32];
+    __shared__ float sAcc[64 * 32];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int grow = lane >> 2, gchunk = lane & 3;
+    unsigned *myA = sA[wid];
+    unsigned short *myB = sB[wid];
+    const long long R = valid_rows(Rcap, r_dev);
+    const long long ntiles = (R + 31) >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+    for (int e = threadIdx.x; e < 64 * 32; e += 512) sAcc[e] = 0.f;
+    const unsigned *Gw = reinterpret_cast<const unsigned *>(G);          // one dword = the 2 bf16 channels of a row
+    for (long long tile = (long long)blockIdx.x * C2_WAVES + wid; tile < ntiles; tile += (long long)gridDim.x * C2_WAVES) {
+        const long long row0 = tile * 32;
+        // ---- table entries: slot t covers offsets 2t (lanes 0..31) and 2t+1 (lanes 32..63), row = lane & 31
+        const long long trow = row0 + c < R ? row0 + c : R - 1;
+        const bool tlive = row0 + c < R;
+        int nb[14];
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            int k = 2 * t + h;
+            int kk = k < K ? k : K - 1;
+            nb[t] = table[(long long)(mirror ? K - 1 - kk : kk) * Rcap + trow];
+        }
+        // ---- stationary rows (issued before the gathers' addresses are known)
+        const long long ra = row0 + grow, rb = row0 + grow + 16;
+        uint4 s0 = *(const uint4 *)(S + (ra < R ? ra : R - 1) * 32 + gchunk * 8);
+        uint4 s1 = *(const uint4 *)(S + (rb < R ? rb : R - 1) * 32 + gchunk * 8);
+        unsigned xv[14];
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            int k = 2 * t + h;
+            int n = (k == identity_k) ? (int)trow : nb[t];
+            bool ok = tlive && k < K && n >= 0;
+            nb[t] = ok ? n : -1;
+            xv[t] = Gw[ok ? n : 0];
+        }
+        __builtin_amdgcn_wave_barrier();            // the previous tile's fragment reads are done (LDS is in order)
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            int k = 2 * t + h;
+            myA[c * 33 + k] = nb[t] >= 0 ? xv[t] : 0u;          // k = 27 (h = 1, t = 13) lands in the zero padding
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int k = 28; k < 32; ++k) myA[c * 33 + k] = 0u;
+        }
+        *(uint4 *)(myB + grow * 32 + gchunk * 8) = keep_if(s0, ra < R);
+        *(uint4 *)(myB + (grow + 16) * 32 + gchunk * 8) = keep_if(s1, rb < R);
+        __builtin_amdgcn_wave_barrier();
+        // ---- fragments: A^T (columns of the [row][66 u16] image), B (columns of the [row][32] image)
+        const unsigned short *A16 = reinterpret_cast<const unsigned short *>(myA);
+        unsigned wa[2][2][4], wb[2][4];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                int r0 = 16 * st + 8 * h + 2 * m;
+                wa[0][st][m] = (unsigned)A16[r0 * 66 + c] | ((unsigned)A16[(r0 + 1) * 66 + c] << 16);
+                wa[1][st][m] = (unsigned)A16[r0 * 66 + 32 + c] | ((unsigned)A16[(r0 + 1) * 66 + 32 + c] << 16);
+                wb[st][m] = (unsigned)myB[r0 * 32 + c] | ((unsigned)myB[(r0 + 1) * 32 + c] << 16);
+            }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            uint4 a_lo = {wa[0][st][0], wa[0][st][1], wa[0][st][2], wa[0][st][3]};
+            uint4 a_hi = {wa[1][st][0], wa[1][st][1], wa[1][st][2], wa[1][st][3]};
+            uint4 bb = {wb[st][0], wb[st][1], wb[st][2], wb[st][3]};
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo), __builtin_bit_cast(bf16x8, bb),
+                                                           acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bb),
+                                                           acc1, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < C2_WAVES; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int col = (i & 3) + 8 * (i >> 2) + 4 * h;
+                sAcc[col * 32 + c] += acc0[i];
+                sAcc[(32 + col) * 32 + c] += acc1[i];
+            }
+        }
+        __syncthreads();
+    }
+    // part[block][k][ch][b] = sAcc[k*2 + ch][b] for the first 2K columns
+    for (int e = threadIdx.x; e < K * 64; e += 512) part[(long long)blockIdx.x * K * 64 + e] = sAcc[e];
+}
+
 // dW[k][a][b] (swap==0) or dW[k][b][a] (swap==1) = sum over slabs of part[slab][k][a][b]; 8 slab slices per
 // output are summed in parallel and folded in slice order (deterministic).
 __global__ void __launch_bounds__(256) k_slab_reduce(const float *__restrict__ part, long long nslabs, long long per,
@@ -759,14 +865,18 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
 int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                          const void *S, const void *G, int swap, float *dW, float *part, int dtype,
                          hipStream_t stream) {
-    const long long chunks = dwc2_chunks(R);
+    long long chunks = dwc2_chunks(R);
     const long long rows_per_chunk = (R + chunks - 1) / chunks;
-    if (dtype == WFS_F32)
+    if (dtype == WFS_F32) {
         k_gdw_c32c2<float><<<dim3((unsigned)chunks), dim3(256), 0, stream>>>(
             table, mirror, K, identity_k, R, r_dev, rows_per_chunk, (const float *)S, (const float *)G, part);
-    else
-        k_gdw_c32c2<wfs_bf16><<<dim3((unsigned)chunks), dim3(256), 0, stream>>>(
-            table, mirror, K, identity_k, R, r_dev, rows_per_chunk, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
+    } else {
+        const long long ntiles = (R + 31) >> 5;
+        chunks = (ntiles + C2_WAVES - 1) / C2_WAVES;          // one tile per wave, at most 512 blocks (= slabs)
+        if (chunks > 512) chunks = 512;
+        k_gdw_c32c2_bf16<<<dim3((unsigned)chunks), dim3(512), 0, stream>>>(
+            table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
+    }
     WFS_LAUNCH_CHECK();
     // part is [chunk][k][c (gathered, 2)][b (stationary, 32)] = the "swap" orientation of (S=32, G=2)
     const long long per = (long long)K * 64;

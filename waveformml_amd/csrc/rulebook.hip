@@ -200,10 +200,10 @@ __global__ void __launch_bounds__(TB) k_subm_lookup2(Geo g, int batch, const int
     nbr_out[(long long)k * N + j] = res;
 }
 
+// the (row, offset)-parallel kernels keep 32-bit tickets (the host checks N*K < 2^32): native 32-bit atomicMin
 __global__ void __launch_bounds__(TB) k_conv_insert2(Geo g, int batch, const int *__restrict__ idx, long long N,
-                                                     const long long *n_dev, Table t,
-                                                     unsigned long long *__restrict__ ticket, int *__restrict__ nbr_out,
-                                                     long long *info) {
+                                                     const long long *n_dev, Table t, unsigned *__restrict__ ticket,
+                                                     int *__restrict__ nbr_out, long long *info) {
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     if (k >= g.K || j >= valid_rows(N, n_dev)) return;
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(TB) k_conv_insert2(Geo g, int batch, const int
     int slot = -1;
     if (key >= 0) {
         unsigned s = tbl_insert(t, key);
-        atomicMin(&ticket[s], (unsigned long long)j * g.K + k);
+        atomicMin(&ticket[s], (unsigned)(j * g.K + k));
         slot = (int)s;
     }
     nbr_out[(long long)k * N + j] = slot;
@@ -223,19 +223,20 @@ __global__ void __launch_bounds__(TB) k_conv_insert2(Geo g, int batch, const int
 // rowmask[j] bit k = candidate (j, k) holds the first ticket of its site (rowmask zeroed by the caller)
 __global__ void __launch_bounds__(TB) k_conv_first2(int K, long long N, const long long *n_dev,
                                                     const int *__restrict__ nbr_out,
-                                                    const unsigned long long *__restrict__ ticket,
+                                                    const unsigned *__restrict__ ticket,
                                                     unsigned *__restrict__ rowmask) {
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     if (k >= K || j >= valid_rows(N, n_dev)) return;
     int s = nbr_out[(long long)k * N + j];
-    if (s >= 0 && ticket[s] == (unsigned long long)j * K + k) atomicOr(&rowmask[j], 1u << k);
+    if (s >= 0 && ticket[s] == (unsigned)(j * K + k)) atomicOr(&rowmask[j], 1u << k);
 }
 
 __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const long long *n_dev, long long M_cap,
                                                      const int *__restrict__ nbr_out, const unsigned *__restrict__ rowmask,
                                                      const int *__restrict__ rowbase, Table t, int *__restrict__ slot_id,
-                                                     int *__restrict__ out_indices, long long *info) {
+                                                     int *__restrict__ out_indices, long long *info,
+                                                     int *__restrict__ overflow) {
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     if (k >= g.K || j >= valid_rows(N, n_dev)) return;
@@ -246,6 +247,7 @@ __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const l
     slot_id[s] = id;
     if (id >= M_cap) {
         info[3] = 1;
+        if (overflow) *overflow = 1;
         return;
     }
     long long key = t.direct ? (long long)s : (long long)t.keys[s];
@@ -675,13 +677,16 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         int *rowbase = (int *)(ws + p.off_rowbase);
         int *bsum = (int *)(ws + p.off_bsum);
         WFS_HIP_CHECK(hipMemsetAsync(ticket, 0xFF, (size_t)p.cap * 8, stream));
-        const int wide = g->K <= 32;         // (row, offset)-parallel kernels; rowfirst[] then holds first-ticket masks
+        // (row, offset)-parallel kernels; rowfirst[] then holds first-ticket masks, tickets are 32-bit
+        const int wide = g->K <= 32 && (long long)N * g->K < (1ll << 32);
         dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
         if (wide) {
             WFS_HIP_CHECK(hipMemsetAsync(rowfirst, 0, (size_t)(N + 1) * 4, stream));
-            k_conv_insert2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, ticket, nbr_out, info);
+            k_conv_insert2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, (unsigned *)ticket,
+                                                        nbr_out, info);
             WFS_LAUNCH_CHECK();
-            k_conv_first2<<<grid2, block, 0, stream>>>(g->K, N, nd, nbr_out, ticket, (unsigned *)rowfirst);
+            k_conv_first2<<<grid2, block, 0, stream>>>(g->K, N, nd, nbr_out, (const unsigned *)ticket,
+                                                       (unsigned *)rowfirst);
             WFS_LAUNCH_CHECK();
         } else {
             k_conv_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, ticket, nbr_out, info);
@@ -736,11 +741,12 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
         unsigned long long *ticket = (unsigned long long *)(ws + p.off_ticket);
         int *slot_id = (int *)(ws + p.off_slot_id);
         int *rowbase = (int *)(ws + p.off_rowbase);
-        if (g->K <= 32) {
+        if (g->K <= 32 && (long long)N * g->K < (1ll << 32)) {
             int *rowmask = (int *)(ws + p.off_rowfirst);
+            if (overflow_dev) WFS_HIP_CHECK(hipMemsetAsync(overflow_dev, 0, sizeof(int32_t), stream));
             dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
             k_conv_assign2<<<grid2, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, (const unsigned *)rowmask, rowbase, p.tbl,
-                                                        slot_id, out_indices, info);
+                                                        slot_id, out_indices, info, overflow_dev);
             WFS_LAUNCH_CHECK();
             k_conv_finalize2<<<grid2, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
             WFS_LAUNCH_CHECK();
@@ -750,9 +756,9 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
             WFS_LAUNCH_CHECK();
             k_conv_finalize<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
             WFS_LAUNCH_CHECK();
+            if (overflow_dev)   // info[3] (8 bytes) -> the caller's flag: non-zero = M exceeded the capacity
+                WFS_HIP_CHECK(hipMemcpyAsync(overflow_dev, info + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
         }
-        if (overflow_dev)       // info[3] (8 bytes) -> the caller's flag: non-zero = M exceeded the capacity
-            WFS_HIP_CHECK(hipMemcpyAsync(overflow_dev, info + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
     } else if (nbr_in) {
         k_invert_table<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, nbr_in);
         WFS_LAUNCH_CHECK();

@@ -166,8 +166,8 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
             cells = int(batch_size) * int(np.prod(rb.out_spatial_shape))
             m_cap = int(out_capacity) if out_capacity else default_out_capacity(N, rb.K, cells)
             rb.M = m_cap
-            rb.m_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
-            rb.overflow = torch.zeros((1,), dtype=torch.int32, device=dev)
+            rb.m_dev = torch.empty((1,), dtype=torch.int64, device=dev)        # written by the plan
+            rb.overflow = torch.empty((1,), dtype=torch.int32, device=dev)     # cleared, then set, by the emit
         _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
                                          ws.numel(), None, _lib.ptr(n_dev), None if subm else _lib.ptr(rb.m_dev),
                                          m_cap, stream))
