@@ -477,3 +477,28 @@ def test_graph_captured_step_matches_eager_steps():
         assert abs(lg.item() - le.item()) <= 1e-6 * max(abs(le.item()), 1e-6), (lg.item(), le.item())
     for a, b in zip(mod_e.model.parameters(), mod_g.model.parameters()):
         _assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 1e-6, "parameters after 6 steps")
+
+
+@pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.bfloat16, 3), (torch.float32, 8), (torch.float32, 1)],
+                         ids=["f32_o3", "bf16_o3", "f32_o8", "f32_o1"])
+def test_skinny_linear_head_matches_torch(dtype, O):
+    from waveformml_amd.spconv import functional as Fsp
+    torch.manual_seed(4)
+    B, I = 37, 35840
+    lin = torch.nn.Linear(I, O)
+    x = torch.randn(B, I).to(dtype)
+    g = torch.randn(B, O)
+    xr = x.float().clone().requires_grad_(True)
+    yr = lin(xr)
+    yr.backward(g)
+    ling = torch.nn.Linear(I, O).to(DEV)
+    ling.load_state_dict(lin.state_dict())
+    xg = x.to(DEV).requires_grad_(True)
+    assert Fsp.can_use_skinny_linear(ling, xg)
+    yg = Fsp.skinny_linear(xg, ling)
+    yg.backward(g.to(DEV))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    _assert_close(yg.detach().cpu().numpy(), yr.detach().numpy(), 1e-5, "y")
+    _assert_close(xg.grad.float().cpu().numpy(), xr.grad.numpy(), tol, "dx")
+    _assert_close(ling.weight.grad.cpu().numpy(), lin.weight.grad.numpy(), 1e-5, "dW")
+    _assert_close(ling.bias.grad.cpu().numpy(), lin.bias.grad.numpy(), 1e-5, "db")

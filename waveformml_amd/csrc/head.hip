@@ -1,0 +1,214 @@
+// head.hip -- the PSD net's classification head: a dense layer with very few outputs.
+//
+// Reference: SPConvNet.forward flattens ToDense's [B, C, *spatial] to [B, n_linear] and applies the LinearBlock
+// (src/models/SPConvNet.py:67-68, src/models/ConvBlocks.py:82-102); with n_type = 2..4 classes the last (often
+// the only) nn.Linear is [B, 35840] x [35840, 3].  A GEMM library tiles that for large N and spends ~55 us on a
+// 16x16 macro-tile kernel; it is a bandwidth problem (read X once): three small streaming kernels here.
+//   forward   Y[b][o] = bias[o] + sum_i X[b][i] W[o][i]          (X fp32 or bf16, W/Y fp32, O <= 8)
+//   backward  dX[b][i] = sum_o g[b][o] W[o][i];   dW[o][i] = sum_b g[b][o] X[b][i];   (db is left to the caller)
+#include "wfs_common.h"
+
+namespace {
+constexpr int TB = 256;
+constexpr int MAXO = 8;
+
+template <typename T>
+__device__ __forceinline__ void load8(const T *p, float *v) {
+    if constexpr (sizeof(T) == 4) {
+        float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        uint4 u = *reinterpret_cast<const uint4 *>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+        v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xFFFF0000u);
+        v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T *p, const float *v) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        wfs_bf16 h[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wfs_st(&h[i], v[i]);
+        uint4 u;
+        u.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        u.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+        u.z = (unsigned)h[4] | ((unsigned)h[5] << 16);
+        u.w = (unsigned)h[6] | ((unsigned)h[7] << 16);
+        *reinterpret_cast<uint4 *>(p) = u;
+    }
+}
+
+// one block per batch row; I % 8 == 0
+template <typename T, int O>
+__global__ void __launch_bounds__(TB) k_head_fwd(const T *__restrict__ X, const float *__restrict__ W,
+                                                 const float *__restrict__ bias, float *__restrict__ Y, long long I) {
+    __shared__ float red[TB / 64][O];
+    const long long b = blockIdx.x;
+    float acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) acc[o] = 0.f;
+    const T *x = X + b * I;
+    for (long long i = (long long)threadIdx.x * 8; i < I; i += TB * 8) {
+        float xv[8];
+        load8<T>(x + i, xv);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float wv[8];
+            load8<float>(W + (long long)o * I + i, wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o] = fmaf(xv[e], wv[e], acc[o]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        float v = acc[o];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < O) {
+        float v = bias ? bias[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int w = 0; w < TB / 64; ++w) v += red[w][threadIdx.x];
+        Y[b * O + threadIdx.x] = v;
+    }
+}
+
+// dX: grid = (I / (TB*8) rounded up, B)
+template <typename T, int O>
+__global__ void __launch_bounds__(TB) k_head_dx(const float *__restrict__ G, const float *__restrict__ W,
+                                                T *__restrict__ dX, long long I) {
+    const long long b = blockIdx.y;
+    const long long i = ((long long)blockIdx.x * TB + threadIdx.x) * 8;
+    if (i >= I) return;
+    float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        float g = G[b * O + o];
+        float wv[8];
+        load8<float>(W + (long long)o * I + i, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = fmaf(g, wv[e], out[e]);
+    }
+    store8<T>(dX + b * I + i, out);
+}
+
+// dW partials: grid = (I / (TB*8) rounded up, NCHUNK); part[chunk][o][i] = sum over the chunk's batch rows
+template <typename T, int O>
+__global__ void __launch_bounds__(TB) k_head_dw(const float *__restrict__ G, const T *__restrict__ X,
+                                                float *__restrict__ part, long long B, long long I, int rows_per_chunk) {
+    const long long i = ((long long)blockIdx.x * TB + threadIdx.x) * 8;
+    if (i >= I) return;
+    const long long b0 = (long long)blockIdx.y * rows_per_chunk;
+    const long long b1 = b0 + rows_per_chunk < B ? b0 + rows_per_chunk : B;
+    float acc[O][8];
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+#pragma unroll 4
+    for (long long b = b0; b < b1; ++b) {
+        float xv[8];
+        load8<T>(X + b * I + i, xv);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float g = G[b * O + o];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(g, xv[e], acc[o][e]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) store8<float>(part + ((long long)blockIdx.y * O + o) * I + i, acc[o]);
+}
+
+__global__ void k_head_dw_reduce(const float *__restrict__ part, int nchunk, long long OI, float *__restrict__ dW) {
+    long long e = (long long)blockIdx.x * TB + threadIdx.x;
+    if (e >= OI) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += part[(long long)c * OI + e];
+    dW[e] = s;
+}
+
+int head_chunks(long long B) {
+    long long c = (B + 31) / 32;
+    return (int)(c < 1 ? 1 : (c > 16 ? 16 : c));
+}
+}  // namespace
+
+extern "C" size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O) {
+    return (size_t)head_chunks(B) * O * I * sizeof(float);
+}
+
+#define WFS_HEAD_DISPATCH(O, CALL)                    \
+    switch (O) {                                      \
+        case 1: { constexpr int OO = 1; CALL; } break; \
+        case 2: { constexpr int OO = 2; CALL; } break; \
+        case 3: { constexpr int OO = 3; CALL; } break; \
+        case 4: { constexpr int OO = 4; CALL; } break; \
+        case 5: { constexpr int OO = 5; CALL; } break; \
+        case 6: { constexpr int OO = 6; CALL; } break; \
+        case 7: { constexpr int OO = 7; CALL; } break; \
+        default: { constexpr int OO = 8; CALL; } break; \
+    }
+
+extern "C" int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W, const float *bias, int32_t O,
+                            float *Y, int32_t dtype, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    if (B == 0) return WFS_OK;
+    WFS_REQUIRE(X && W && Y, WFS_EINVAL, "NULL device pointer");
+    dim3 grid((unsigned)B), block(TB);
+    if (dtype == WFS_F32) {
+        WFS_HEAD_DISPATCH(O, (k_head_fwd<float, OO><<<grid, block, 0, stream>>>((const float *)X, W, bias, Y, I)));
+    } else {
+        WFS_HEAD_DISPATCH(O, (k_head_fwd<wfs_bf16, OO><<<grid, block, 0, stream>>>((const wfs_bf16 *)X, W, bias, Y, I)));
+    }
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const float *W, int32_t O, void *dX,
+                            float *dW, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    if (B == 0) {
+        if (dW) WFS_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)O * I * sizeof(float), stream));
+        return WFS_OK;
+    }
+    WFS_REQUIRE(X && G && W, WFS_EINVAL, "NULL device pointer");
+    const unsigned gx = (unsigned)wfs_cdiv(I, TB * 8);
+    if (dX) {
+        dim3 grid(gx, (unsigned)B), block(TB);
+        if (dtype == WFS_F32) {
+            WFS_HEAD_DISPATCH(O, (k_head_dx<float, OO><<<grid, block, 0, stream>>>(G, W, (float *)dX, I)));
+        } else {
+            WFS_HEAD_DISPATCH(O, (k_head_dx<wfs_bf16, OO><<<grid, block, 0, stream>>>(G, W, (wfs_bf16 *)dX, I)));
+        }
+        WFS_LAUNCH_CHECK();
+    }
+    if (dW) {
+        const int nchunk = head_chunks(B);
+        WFS_REQUIRE(workspace && workspace_bytes >= wfs_head_workspace_bytes(B, I, O), WFS_EWORKSPACE, "workspace too small");
+        const int rpc = (int)wfs_cdiv(B, nchunk);
+        dim3 grid(gx, (unsigned)nchunk), block(TB);
+        float *part = (float *)workspace;
+        if (dtype == WFS_F32) {
+            WFS_HEAD_DISPATCH(O, (k_head_dw<float, OO><<<grid, block, 0, stream>>>(G, (const float *)X, part, B, I, rpc)));
+        } else {
+            WFS_HEAD_DISPATCH(O, (k_head_dw<wfs_bf16, OO><<<grid, block, 0, stream>>>(G, (const wfs_bf16 *)X, part, B, I, rpc)));
+        }
+        WFS_LAUNCH_CHECK();
+        const long long OI = (long long)O * I;
+        k_head_dw_reduce<<<dim3((unsigned)wfs_cdiv(OI, TB)), dim3(TB), 0, stream>>>(part, nchunk, OI, dW);
+        WFS_LAUNCH_CHECK();
+    }
+    return WFS_OK;
+}

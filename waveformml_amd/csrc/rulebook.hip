@@ -235,8 +235,7 @@ __global__ void __launch_bounds__(TB) k_conv_first2(int K, long long N, const lo
 __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const long long *n_dev, long long M_cap,
                                                      const int *__restrict__ nbr_out, const unsigned *__restrict__ rowmask,
                                                      const int *__restrict__ rowbase, Table t, int *__restrict__ slot_id,
-                                                     int *__restrict__ out_indices, long long *info,
-                                                     int *__restrict__ overflow) {
+                                                     int *__restrict__ out_indices, long long *info) {
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     if (k >= g.K || j >= valid_rows(N, n_dev)) return;
@@ -247,7 +246,6 @@ __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const l
     slot_id[s] = id;
     if (id >= M_cap) {
         info[3] = 1;
-        if (overflow) *overflow = 1;
         return;
     }
     long long key = t.direct ? (long long)s : (long long)t.keys[s];
@@ -261,9 +259,11 @@ __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const l
 
 __global__ void __launch_bounds__(TB) k_conv_finalize2(int K, long long N, const long long *n_dev, long long M,
                                                        int *__restrict__ nbr_out, const int *__restrict__ slot_id,
-                                                       int *__restrict__ nbr_in) {
+                                                       int *__restrict__ nbr_in, const long long *__restrict__ info,
+                                                       int *__restrict__ overflow) {
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (overflow && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *overflow = info[0] > M ? 1 : 0;
     if (k >= K || j >= valid_rows(N, n_dev)) return;
     int s = nbr_out[(long long)k * N + j];
     if (s < 0) return;
@@ -525,7 +525,7 @@ struct Plan {
     long long cap;
     // workspace carve-up (byte offsets)
     size_t off_info, off_keys, off_vals, off_ticket, off_slot_id, off_rowfirst, off_rowbase, off_bsum,
-        off_tcount, total;
+        off_tcount, total, zero_bytes, ones_bytes;
     long long ntiles, nscan;
 };
 
@@ -575,16 +575,21 @@ void make_plan(const wfs_geometry *g, long long N, Plan *p) {
         o = wfs_align_up(o + bytes, 256);
         return at;
     };
+    // zero region: info, then (regular conv) the per-row first-ticket words
     p->off_info = take(4 * sizeof(long long));
+    p->off_rowfirst = g->subm ? o : take((size_t)(N + 1) * 4);
+    p->zero_bytes = o - p->off_info;
+    // 0xFF region: hash keys, then SubM values or regular-conv tickets
     p->off_keys = take(p->tbl.direct ? 0 : (size_t)p->cap * 4);
     if (g->subm) {
         p->off_vals = take((size_t)p->cap * 4);
-        p->off_ticket = p->off_slot_id = p->off_rowfirst = p->off_rowbase = p->off_bsum = o;
+        p->ones_bytes = o - p->off_keys;
+        p->off_ticket = p->off_slot_id = p->off_rowbase = p->off_bsum = o;
     } else {
         p->off_vals = o;
         p->off_ticket = take((size_t)p->cap * 8);
+        p->ones_bytes = o - p->off_keys;
         p->off_slot_id = take((size_t)p->cap * 4);
-        p->off_rowfirst = take((size_t)(N + 1) * 4);
         p->off_rowbase = take((size_t)(N + 1) * 4);
         p->off_bsum = take((size_t)p->nscan * 4);
     }
@@ -615,9 +620,8 @@ extern "C" int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indi
     long long *info = (long long *)(ws + p.off_info);
     p.tbl.keys = (int *)(ws + p.off_keys);
     int *vals = (int *)(ws + p.off_vals);
-    WFS_HIP_CHECK(hipMemsetAsync(info, 0, 4 * sizeof(long long), stream));
-    if (!p.tbl.direct) WFS_HIP_CHECK(hipMemsetAsync(p.tbl.keys, 0xFF, (size_t)p.cap * 4, stream));
-    WFS_HIP_CHECK(hipMemsetAsync(vals, 0xFF, (size_t)p.cap * 4, stream));
+    WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_info, 0, p.zero_bytes, stream));
+    WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_keys, 0xFF, p.ones_bytes, stream));
     if (N > 0) {
         k_site_insert<<<dim3((unsigned)wfs_cdiv(N, TB)), dim3(TB), 0, stream>>>(p.geo, g_subm->batch_size, indices, N,
                                                                               nullptr, p.tbl, vals, info);
@@ -659,11 +663,10 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
     long long *info = (long long *)(ws + p.off_info);
     p.tbl.keys = (int *)(ws + p.off_keys);
     dim3 grid((unsigned)wfs_cdiv(N, TB)), block(TB);
-    WFS_HIP_CHECK(hipMemsetAsync(info, 0, 4 * sizeof(long long), stream));
-    if (!p.tbl.direct) WFS_HIP_CHECK(hipMemsetAsync(p.tbl.keys, 0xFF, (size_t)p.cap * 4, stream));
+    WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_info, 0, p.zero_bytes, stream));        // info (+ first-ticket words)
+    WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_keys, 0xFF, p.ones_bytes, stream));     // keys + values / tickets
     if (g->subm) {
         int *vals = (int *)(ws + p.off_vals);
-        WFS_HIP_CHECK(hipMemsetAsync(vals, 0xFF, (size_t)p.cap * 4, stream));
         k_site_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, info);
         WFS_LAUNCH_CHECK();
         dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
@@ -676,12 +679,10 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         int *rowfirst = (int *)(ws + p.off_rowfirst);
         int *rowbase = (int *)(ws + p.off_rowbase);
         int *bsum = (int *)(ws + p.off_bsum);
-        WFS_HIP_CHECK(hipMemsetAsync(ticket, 0xFF, (size_t)p.cap * 8, stream));
         // (row, offset)-parallel kernels; rowfirst[] then holds first-ticket masks, tickets are 32-bit
         const int wide = g->K <= 32 && (long long)N * g->K < (1ll << 32);
         dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
         if (wide) {
-            WFS_HIP_CHECK(hipMemsetAsync(rowfirst, 0, (size_t)(N + 1) * 4, stream));
             k_conv_insert2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, (unsigned *)ticket,
                                                         nbr_out, info);
             WFS_LAUNCH_CHECK();
@@ -743,12 +744,11 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
         int *rowbase = (int *)(ws + p.off_rowbase);
         if (g->K <= 32 && (long long)N * g->K < (1ll << 32)) {
             int *rowmask = (int *)(ws + p.off_rowfirst);
-            if (overflow_dev) WFS_HIP_CHECK(hipMemsetAsync(overflow_dev, 0, sizeof(int32_t), stream));
             dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
             k_conv_assign2<<<grid2, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, (const unsigned *)rowmask, rowbase, p.tbl,
-                                                        slot_id, out_indices, info, overflow_dev);
+                                                        slot_id, out_indices, info);
             WFS_LAUNCH_CHECK();
-            k_conv_finalize2<<<grid2, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
+            k_conv_finalize2<<<grid2, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in, info, overflow_dev);
             WFS_LAUNCH_CHECK();
         } else {
             k_conv_assign<<<grid, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, ticket, rowbase, p.tbl, slot_id,

@@ -272,6 +272,51 @@ def can_fuse_batch_norm(bn, features):
             and (bn.training or bn.running_mean is not None))
 
 
+class SkinnyLinearFunction(Function):
+    """nn.Linear with a handful of outputs over a long input row (the PSD head: [B, 35840] -> [B, 3]):
+    Y = X W^T + b with X fp32/bf16, W/b/Y fp32 (reference src/models/SPConvNet.py:67-68)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x = _features_ok(x)
+        B, I = x.shape
+        O = weight.shape[0]
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        _lib.check(lib.wfs_head_fwd(_lib.ptr(x), B, I, _lib.ptr(w), _lib.ptr(b), O, _lib.ptr(y), _lib.dtype_code(x),
+                                    _lib.stream_ptr()))
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        x, weight, bias = ctx.saved_tensors
+        B, I = x.shape
+        O = weight.shape[0]
+        g = grad_output.float().contiguous()
+        w = weight.detach().float().contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty((O, I), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        ws = torch.empty((max(int(lib.wfs_head_workspace_bytes(B, I, O)), 1),), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.wfs_head_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw),
+                                    _lib.dtype_code(x), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        db = g.sum(0).to(bias.dtype) if (bias is not None and ctx.needs_input_grad[2]) else None
+        return dx, (dw.to(weight.dtype) if dw is not None else None), db
+
+
+def can_use_skinny_linear(linear, x):
+    return (type(linear) is torch.nn.Linear and x.is_cuda and x.dim() == 2 and linear.out_features <= 8
+            and x.shape[1] % 8 == 0 and x.shape[1] >= 1024 and x.dtype in (torch.float32, torch.bfloat16)
+            and linear.weight.dtype == torch.float32)
+
+
+def skinny_linear(x, linear):
+    return SkinnyLinearFunction.apply(x, linear.weight, linear.bias)
+
+
 def indice_conv(features, filters, bias, rulebook):
     return SparseConvFunction.apply(features, filters, bias, rulebook, CONV)
 
