@@ -502,3 +502,60 @@ def test_skinny_linear_head_matches_torch(dtype, O):
     _assert_close(xg.grad.float().cpu().numpy(), xr.grad.numpy(), tol, "dx")
     _assert_close(ling.weight.grad.cpu().numpy(), lin.weight.grad.numpy(), 1e-5, "dW")
     _assert_close(ling.bias.grad.cpu().numpy(), lin.bias.grad.numpy(), 1e-5, "db")
+
+
+def test_side_stream_overlap_gives_identical_results():
+    """Rulebook prefetch + dW on a side stream (ops.PREFETCH_RULEBOOKS / OVERLAP_DW) only reorder launches across
+    streams: loss and every gradient must be bit-identical to the single-stream run, eagerly and under graph replay."""
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    from waveformml_amd.psd.graph import GraphedTrainStep
+    from waveformml_amd.spconv import functional as Fsp, ops
+    T, B = 64, 24
+    c, f, y = synthetic.generate(B, T, 3, seed=31)
+    coords, feats, labels = torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV), torch.from_numpy(y).to(DEV)
+    n = coords.shape[0]
+    cap = n + 333
+    pc = torch.zeros((cap, 4), dtype=torch.int32, device=DEV)
+    pf = torch.zeros((cap, 2), device=DEV)
+    pc[:n], pf[:n] = coords, feats
+    nv = torch.tensor([n], dtype=torch.int64, device=DEV)
+    results = []
+    for flags in (False, True):
+        ops.PREFETCH_RULEBOOKS = ops.OVERLAP_DW = flags
+        try:
+            mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
+            for p in mod.model.parameters():
+                p.grad = None
+            loss = mod.training_step(([pc, pf, nv], labels), 0)
+            loss.backward()
+            Fsp.join_side_streams()
+            torch.cuda.synchronize()
+            results.append((loss.item(), [p.grad.clone() for p in mod.model.parameters()]))
+        finally:
+            ops.PREFETCH_RULEBOOKS = ops.OVERLAP_DW = False
+    assert results[0][0] == results[1][0]
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
+    # graph replay with the overlaps on vs off: same losses over three different batches
+    losses = []
+    for flags in (False, True):
+        ops.PREFETCH_RULEBOOKS = ops.OVERLAP_DW = flags
+        try:
+            mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
+            red = FlatGradAllReducer(mod.model.parameters(), world_size=1)
+            mod.optimizer_parameters = red.optimizer_parameters()
+            opt = mod.configure_optimizers()[0][0]
+            batches = []
+            for s in (41, 42, 43):
+                cc, ff, yy = synthetic.generate(B, T, 3, seed=s)
+                batches.append(([torch.from_numpy(cc).to(DEV), torch.from_numpy(ff).to(DEV)], torch.from_numpy(yy).to(DEV)))
+            step = GraphedTrainStep(mod, opt, red, batches[0])
+            ls = []
+            for bt in batches:
+                ls.append(float(step(bt)))
+                step.check()
+            losses.append(ls)
+        finally:
+            ops.PREFETCH_RULEBOOKS = ops.OVERLAP_DW = False
+    assert losses[0] == losses[1], losses

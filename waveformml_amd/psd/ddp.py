@@ -79,6 +79,8 @@ class FlatGradAllReducer(object):
         return [self.flat_param] if self.flat_param is not None else self.params
 
     def _pack(self, b):
+        from ..spconv import functional as _fsp
+        _fsp.join_side_streams()          # weight gradients may still be in flight on the dW side stream
         s, e, idxs = self.buckets[b]
         grads = []
         for i in idxs:

@@ -75,6 +75,7 @@ class SparseConvolution(SparseModule):
             out_tensor.grid = input.grid
             out_tensor.unique = input.unique
             out_tensor.n_valid = input.n_valid
+            out_tensor.prefetched = getattr(input, "prefetched", None)
             return out_tensor
         datas = input.find_indice_pair(self.indice_key)
         if self.inverse:
@@ -87,7 +88,16 @@ class SparseConvolution(SparseModule):
             out_unique = None if rb.has_dup else True
             out_n_valid = rb.n_dev
         else:
-            if self.indice_key is not None and datas is not None:
+            pre = getattr(input, "prefetched", None)
+            if pre is not None and id(self) in pre:
+                rb = pre[id(self)]                  # built on the side stream by SparseSequential's prefetch
+                if rb.ready is not None:
+                    torch.cuda.current_stream().wait_event(rb.ready)
+                self.last_rulebook = rb
+                input.unique = not rb.has_dup
+                if datas is None:
+                    input.indice_dict[self.indice_key] = IndiceData(rb, spatial_shape)
+            elif self.indice_key is not None and datas is not None:
                 rb = datas.rulebook
             else:
                 rb = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
@@ -109,6 +119,7 @@ class SparseConvolution(SparseModule):
         out_tensor.grid = input.grid
         out_tensor.unique = out_unique
         out_tensor.n_valid = out_n_valid
+        out_tensor.prefetched = getattr(input, "prefetched", None)
         return out_tensor
 
 

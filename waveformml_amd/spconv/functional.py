@@ -88,8 +88,23 @@ def scatter_conv(table, K, identity_k, R, X, W, transpose_w, n_out, bias):
     return Y.to(X.dtype)
 
 
-def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None):
-    """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a])."""
+_PENDING_SIDE = []          # (event, tensors kept alive until the join) of launches made on a side stream
+
+
+def join_side_streams():
+    """Make the current stream wait for everything launched on side streams (OVERLAP_DW) and release the
+    tensors that were kept alive for them."""
+    if _PENDING_SIDE:
+        cur = torch.cuda.current_stream()
+        for ev, _keep in _PENDING_SIDE:
+            cur.wait_event(ev)
+        del _PENDING_SIDE[:]
+
+
+def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False):
+    """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a]).
+    overlap=True launches on the side stream (see ops.OVERLAP_DW): memory is allocated on the calling stream
+    and every operand is kept alive until join_side_streams()."""
     lib = _lib.load()
     Cs, Cg = int(S.shape[1]), int(G.shape[1])
     dW = torch.empty((K, Cg, Cs) if swap else (K, Cs, Cg), dtype=torch.float32, device=S.device)
@@ -97,9 +112,27 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None):
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
     nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
-    _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0], Cg,
-                                 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
-                                 _lib.ptr(r_dev), _lib.stream_ptr()))
+
+    def launch():
+        _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0],
+                                     Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(r_dev), _lib.stream_ptr()))
+
+    if overlap and ACCOUNT is None:
+        from . import ops
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(S.device, 1)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            launch()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        if not _PENDING_SIDE:
+            # fallback join at the end of this backward pass (the reducer normally joins earlier, before packing)
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        _PENDING_SIDE.append((ev, (table, S, G, dW, ws, r_dev)))
+    else:
+        launch()
     _account("gather_dw", table, R, R, Cs, G.shape[0], Cg, K, Cs, Cg, S.element_size())
     return dW
 
@@ -139,6 +172,8 @@ class SparseConvFunction(Function):
         W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
         ident = rb.centre_k if rb.subm else -1
         dX = dW = db = None
+        from . import ops as _ops
+        ov = _ops.OVERLAP_DW
         if mode == INVERSE:
             if ctx.needs_input_grad[0]:
                 if rb.has_dup:
@@ -146,17 +181,18 @@ class SparseConvFunction(Function):
                 else:
                     dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev)
             if ctx.needs_input_grad[1]:
-                dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev)
+                dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev, ov)
         else:
-            if ctx.needs_input_grad[0]:
-                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
+            # dW first: with OVERLAP_DW it goes to the side stream and runs beside the dX launched next
             if ctx.needs_input_grad[1]:
                 if features.shape[1] == 2 and dY.shape[1] == 32 and K <= 27 and not rb.has_dup:
                     # narrow input, wide output (first layer): keep the wide dY rows stationary
                     table, kmap = rb.table_by_out()
-                    dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap, rb.m_dev)
+                    dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap, rb.m_dev, ov)
                 else:
-                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev)
+                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov)
+            if ctx.needs_input_grad[0]:
+                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:

@@ -54,9 +54,49 @@ class SparseSequential(SparseModule):
                 raise KeyError("name exists")
         self.add_module(name, module)
 
+    @staticmethod
+    def _prefetch_rulebooks(mods, x):
+        """Build every layer's rulebook on a side stream now (device-count mode: nothing synchronises with the
+        host).  Rulebooks depend on indices only, so the strided layers' builds run while the first layers
+        compute; each conv waits for its own rulebook's event."""
+        from . import ops
+        from .conv import SparseConvolution
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(x.features.device)
+        side.wait_stream(main)
+        plan, keyed = {}, {}
+        indices, spatial, n_dev = x.indices, x.spatial_shape, x.n_valid
+        with torch.cuda.stream(side):
+            for m in mods:
+                if isinstance(m, SparseConvolution):
+                    if m.conv1x1:
+                        continue
+                    if m.inverse or m.transposed:
+                        break                       # geometry comes from a coupled layer: leave the rest to the layers
+                    if m.indice_key is not None and m.indice_key in keyed:
+                        rb = keyed[m.indice_key]
+                    else:
+                        rb = ops.build_rulebook(indices, x.batch_size, spatial, m.kernel_size, m.stride, m.padding,
+                                                m.dilation, m.subm, known_unique=True, n_dev=n_dev,
+                                                out_capacity=getattr(m, "out_capacity", None))
+                        rb.ready = torch.cuda.Event()
+                        rb.ready.record(side)
+                        if m.indice_key is not None:
+                            keyed[m.indice_key] = rb
+                    plan[id(m)] = rb
+                    if not m.subm:
+                        indices, spatial, n_dev = rb.out_indices, rb.out_spatial_shape, rb.m_dev
+                elif isinstance(m, SparseModule):
+                    break                           # ToDense or an unknown sparse module ends the sparse stack
+        x.prefetched = plan
+
     def forward(self, input):
         from . import functional as Fsp
+        from . import ops
         mods = list(self._modules.values())
+        if (ops.PREFETCH_RULEBOOKS and _is_sparse_tensor(input) and input.n_valid is not None
+                and getattr(input, "prefetched", None) is None and input.features.is_cuda):
+            self._prefetch_rulebooks(mods, input)
         i = 0
         while i < len(mods):
             module = mods[i]

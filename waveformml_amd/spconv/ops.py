@@ -19,6 +19,28 @@ from .. import _lib
 ASSUME_VALID_UNIQUE_INDICES = False
 
 
+# Concurrency switches (both need a caller that follows the stated contract, so both default to off):
+#   PREFETCH_RULEBOOKS  in device-count mode SparseSequential builds the rulebooks of ALL its layers on a side
+#                       stream at the start of forward, so the strided layers' builds overlap the first layers'
+#                       compute (the builds depend on indices only).
+#   OVERLAP_DW          conv backward launches dW on a side stream while dX and the previous layers' backward
+#                       continue on the main stream.  Contract: parameter .grad is None when backward starts
+#                       (autograd then just stores the tensor) and whoever reads the gradients first calls
+#                       functional.join_side_streams() (psd/ddp.FlatGradAllReducer does; a fallback join also runs
+#                       when the backward pass ends).
+PREFETCH_RULEBOOKS = False
+OVERLAP_DW = False
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, which=0):
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), which)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
+
+
 def _listify(v, ndim):
     if isinstance(v, (list, tuple, np.ndarray)):
         v = [int(x) for x in v]
@@ -72,6 +94,7 @@ class Rulebook(object):
         self.n_dev = None            # int64 [1] on the GPU: valid input rows
         self.m_dev = None            # int64 [1]: valid output rows (SubM: n_dev itself)
         self.overflow = None         # int32 [1]: set by the build if M exceeded the output capacity
+        self.ready = None            # torch.cuda.Event when the build ran on a side stream (prefetch)
         self._pairs = None
         self._pair_num = None
 
