@@ -113,7 +113,7 @@ def main():
     from waveformml_amd.spconv import ops as _ops
     _ops.ASSUME_VALID_UNIQUE_INDICES = True
     _ops.PREFETCH_RULEBOOKS = True        # strided layers' rulebooks build on a side stream beside the first layers
-    _ops.OVERLAP_DW = True                # dW beside dX / the previous layers' backward (joined before packing)
+    # _ops.OVERLAP_DW stays off: dW and dX each fill the CUs' LDS, run side by side they just take twice as long
 
     # synthetic batch, resident in HBM before the timed region (weak scaling: fixed events per rank)
     c, f, y = synthetic.generate(args.batch, args.samples, cfg_dict["system_config"]["n_type"], seed=1234, rank=rank)

@@ -64,7 +64,8 @@ class SparseSequential(SparseModule):
         main = torch.cuda.current_stream()
         side = ops.side_stream(x.features.device)
         side.wait_stream(main)
-        plan, keyed = {}, {}
+        plan = {}
+        keyed = {k: v.rulebook for k, v in x.indice_dict.items() if hasattr(v, "rulebook")}      # already built
         indices, spatial, n_dev = x.indices, x.spatial_shape, x.n_valid
         with torch.cuda.stream(side):
             for m in mods:
@@ -94,14 +95,18 @@ class SparseSequential(SparseModule):
         from . import functional as Fsp
         from . import ops
         mods = list(self._modules.values())
-        if (ops.PREFETCH_RULEBOOKS and _is_sparse_tensor(input) and input.n_valid is not None
-                and getattr(input, "prefetched", None) is None and input.features.is_cuda):
-            self._prefetch_rulebooks(mods, input)
+        want_prefetch = (ops.PREFETCH_RULEBOOKS and _is_sparse_tensor(input) and input.n_valid is not None
+                         and getattr(input, "prefetched", None) is None and input.features.is_cuda)
         i = 0
         while i < len(mods):
             module = mods[i]
             if isinstance(module, SparseModule):
                 input = module(input)
+                if want_prefetch and _is_sparse_tensor(input):
+                    # the first layer has built its own rulebook and launched its conv on this stream; the
+                    # remaining layers' rulebooks now build on the side stream beside what follows
+                    want_prefetch = False
+                    self._prefetch_rulebooks(mods[i + 1:], input)
             elif _is_sparse_tensor(input):
                 if input.indices.shape[0] != 0:
                     if isinstance(module, nn.BatchNorm1d) and Fsp.can_fuse_batch_norm(module, input.features):
