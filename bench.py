@@ -80,6 +80,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
+    if os.environ.get("WFS_REHEARSAL_ONE_GPU"):      # N ranks on ONE card over gloo: a dry run of the N-rank code path
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # everything runs on an ordinary stream: on ROCm 7.2 eager work on the legacy default stream between two
@@ -87,7 +89,10 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("WFS_REHEARSAL_ONE_GPU"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL over xGMI
     assert args.gpus == world, "--gpus %d but WORLD_SIZE %d" % (args.gpus, world)
 
     from waveformml_amd import _lib
