@@ -75,6 +75,9 @@ def load_cfg(path, samples):
 
 def main():
     args = parse()
+    if os.environ.get("WFS_WATCHDOG"):         # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["WFS_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
