@@ -195,6 +195,12 @@ def main():
                           ("rulebook", _lib.TIMER_RULEBOOK)):
             timers[name] = _lib.timing_read(tid)
         _lib.timing_enable(False)
+        # accounting pass (every rank: the eager step contains the gradient collectives): algorithmic work per launch
+        Fsp.ACCOUNT = []
+        eager_step()
+        torch.cuda.synchronize()
+        acct, Fsp.ACCOUNT = Fsp.ACCOUNT, None
+        log("accounting pass done")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,11 +222,6 @@ def main():
         }
         # ---- roofline of the dominant kernel: algorithmic bytes (accounting pass) / measured duration
         if not args.no_roofline:
-            Fsp.ACCOUNT = []
-            eager_step()
-            torch.cuda.synchronize()
-            acct, Fsp.ACCOUNT = Fsp.ACCOUNT, None
-            log("accounting pass done")
             per_kind = {}
             for a in acct:
                 d = per_kind.setdefault(a["kind"], {"bytes": 0, "flops": 0, "launches": 0})
