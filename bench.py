@@ -190,14 +190,40 @@ def measure(env, args, dtype, steps, warmup, roofline):
         avg_ms = ms / max(n, 1)
         bytes_per_launch = by["bytes"] / max(by["launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = pmc_traffic(dom, dtype)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_ms * 1e3,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0], "traffic_source": traffic[1],
+                           "avg_launch_us": avg_ms * 1e3,
                            "launches_per_step": by["launches"], "algorithmic_bytes_per_launch": bytes_per_launch,
                            "tflops": by["flops"] / max(by["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                            "timed_in": "eager pass after the timed region (HIP events on the launch stream)",
                            "per_step_ms": {k: timers[k][0] / nprof for k in timers}}
     extras = {"init_state": init_state, "batch_np": (c, f, y), "logits0": logits0, "loss0": loss0}
     return out, extras
+
+
+def pmc_traffic(kind, dtype):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for 16-B-per-lane reads on gfx950),
+    launch-weighted over the kernels of that class.  None when no PMC summary for this dtype is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_%s.json" % dtype)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        pmc = json.load(f)
+    prefixes = {"gather_conv": ("k_gconv", "k_gather_conv"), "gather_dw": ("k_gdw", "k_gather_dw", "k_slab_reduce")}[kind]
+    tot, launches = 0.0, 0
+    for name, rec in pmc.items():
+        if name.startswith(prefixes):
+            kb = rec["fetch_kb_corrected_x2"] + rec["write_size_kb_per_launch"]
+            if name.startswith("k_slab_reduce"):          # the reduce pass belongs to its dW launch
+                tot += kb * rec["launches"]
+                continue
+            tot += kb * rec["launches"]
+            launches += rec["launches"]
+    if launches == 0:
+        return None, None
+    return tot / launches * 1024.0, "profiles/%s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, FETCH x2)" % os.path.basename(path)
 
 
 def cpu_reference(env, extras, n_steps):
