@@ -439,6 +439,85 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
     }
 }
 
+// ------------------------------------------------------------------------------------------ 2 -> 32, bf16 MFMA
+// First layer on the matrix cores: the K offsets x 2 input channels form a 64-wide contraction (54 used), so one
+// 32-row tile is 4 x v_mfma_f32_32x32x16_bf16.  A-fragment of lane (r, h), k-step s = the 4 gathered dwords
+// (2 bf16 channels each) of offsets 8s + 4h + {0,1,2,3} of row r -- read straight from global memory, no LDS, no
+// transpose; all 16 table entries of a lane are loaded together, then all 16 gathers.  The filter image
+// sWc[s][h][co][j] = W[k = 8s + 4h + j/2][c = j & 1][co] (zero for k >= K) is 4 KiB.
+__global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict__ table, int mirror, int K,
+                                                         int identity_k, long long R,
+                                                         const long long *__restrict__ r_dev,
+                                                         const wfs_bf16 *__restrict__ X, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, wfs_bf16 *__restrict__ Y) {
+    __shared__ __attribute__((aligned(16))) uint4 sWc[4 * 2 * 32];
+    {
+        const int u = threadIdx.x;                 // 256 threads = 4 steps x 2 halves x 32 output channels
+        const int st = u >> 6, hh = (u >> 5) & 1, co = u & 31;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = 8 * st + 4 * hh + (j >> 1);
+            w[j] = k < K ? W[((long long)k * 2 + (j & 1)) * 32 + co] : 0.f;
+        }
+        uint4 v;
+        v.x = pack_bf16x2(w[0], w[1]);
+        v.y = pack_bf16x2(w[2], w[3]);
+        v.z = pack_bf16x2(w[4], w[5]);
+        v.w = pack_bf16x2(w[6], w[7]);
+        sWc[u] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long Rv = valid_rows(R, r_dev);
+    const long long ntiles = (Rv + 31) >> 5;
+    const float bj = bias ? bias[r] : 0.f;
+    const unsigned *Xw = reinterpret_cast<const unsigned *>(X);
+    for (long long tile = (long long)blockIdx.x * 4 + wid; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long row = tile * 32 + r;
+        const bool live = row < Rv;
+        const long long rowc = live ? row : 0;
+        int nb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int k = 8 * (q >> 2) + 4 * h + (q & 3);
+            int kk = k < K ? k : K - 1;
+            nb[q] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+        }
+        unsigned xv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int k = 8 * (q >> 2) + 4 * h + (q & 3);
+            int n = (k == identity_k) ? (int)rowc : nb[q];
+            bool ok = live && k < K && n >= 0;
+            unsigned v = Xw[ok ? n : 0];
+            xv[q] = ok ? v : 0u;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bj;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            uint4 a = {xv[4 * st], xv[4 * st + 1], xv[4 * st + 2], xv[4 * st + 3]};
+            uint4 b = sWc[(st * 2 + h) * 32 + r];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                          0, 0, 0);
+        }
+        unsigned *Yw = reinterpret_cast<unsigned *>(Y);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            float mine0 = acc[i], mine1 = acc[i + 1];
+            float send = (lane & 1) ? mine0 : mine1;
+            float got = __shfl_xor(send, 1, 64);
+            unsigned packed = (lane & 1) ? pack_bf16x2(got, mine1) : pack_bf16x2(mine0, got);
+            int ri = (lane & 1) ? i + 1 : i;
+            long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
+            if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dW 32 x 32, bf16
 // dW[k][a][b] = sum_r S[r][a] * G[table[k][r]][b] with bf16 rows and v_mfma_f32_32x32x16_bf16.  The contraction
 // runs over ROWS, while memory holds a row's 32 channels contiguously, so both operands need a transpose: each
@@ -809,7 +888,20 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
                            hipStream_t stream) {
     KMap km;
-    for (int k = 0; k < K; ++k) km.v[k] = kmap ? kmap[k] : k;
+    bool is_ident = true, is_mirror = true;
+    for (int k = 0; k < K; ++k) {
+        km.v[k] = kmap ? kmap[k] : k;
+        is_ident = is_ident && km.v[k] == k;
+        is_mirror = is_mirror && km.v[k] == K - 1 - k;
+    }
+    if (dtype == WFS_BF16 && K <= 32 && (is_ident || is_mirror)) {
+        long long nb = ((R + 31) / 32 + 3) / 4;
+        if (nb > 4096) nb = 4096;
+        k_gconv_c2c32_bf16<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(table, is_ident ? 0 : 1, K, identity_k, R, r_dev,
+                                                                        (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y);
+        WFS_LAUNCH_CHECK();
+        return WFS_OK;
+    }
     long long nblk = (R + 31) / 32;
     if (nblk > 8192) nblk = 8192;
     if (dtype == WFS_F32)
