@@ -451,40 +451,6 @@ __global__ void k_scan_apply(const int *in, long long n, const long long *n_dev,
     }
 }
 
-// Single-launch form for small inputs (n <= 1024 * SCAN1_MAX): one 1024-thread block, thread t owns the
-// contiguous chunk [t*per, (t+1)*per): chunk sums -> block scan -> chunk-local exclusive prefixes.
-constexpr int SCAN1_MAX = 256;
-__global__ void __launch_bounds__(1024) k_scan_single(const int *__restrict__ in, long long n, const long long *n_dev,
-                                                      int popc, int *__restrict__ out, long long *total,
-                                                      long long *total2, long long cap) {
-    __shared__ int wsum[16];
-    const long long nv = valid_rows(n, n_dev);
-    const long long per = (n + 1023) / 1024;
-    const long long b0 = (long long)threadIdx.x * per;
-    int sum = 0;
-    for (long long i = 0; i < per; ++i) sum += scan_item(in, b0 + i, n, nv, popc);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int inc = wave_incl_scan(sum);
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        int v = wsum[w];
-        if (w < wid) base += v;
-        tot += v;
-    }
-    int ex = base + inc - sum;
-    for (long long i = 0; i < per; ++i) {
-        if (b0 + i < n) out[b0 + i] = ex;
-        ex += scan_item(in, b0 + i, n, nv, popc);
-    }
-    if (threadIdx.x == 0) {
-        *total = tot;
-        if (total2) *total2 = tot < cap ? tot : cap;
-    }
-}
-
 // ---------------------------------------------------------------- compaction to spconv's encoding
 // tile = TB consecutive input rows.  tcount[k * ntiles + tile] = valid entries of column k in tile.
 __global__ void k_compact_count(int K, long long N, const long long *n_dev, long long ntiles, const int *nbr_out,
@@ -731,10 +697,7 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         }
         // info[0] = M; m_dev = min(M, M_cap) = the row count every consumer of the outputs is bounded by
         const long long mcap = M_cap > 0 ? M_cap : (1ll << 62);
-        if (N <= 1024ll * SCAN1_MAX) {
-            k_scan_single<<<dim3(1), dim3(1024), 0, stream>>>(rowfirst, N, nd, wide, rowbase, info, (long long *)m_dev, mcap);
-            WFS_LAUNCH_CHECK();
-        } else {
+        {
             dim3 sgrid((unsigned)p.nscan);
             k_scan_blocksum<<<sgrid, block, 0, stream>>>(rowfirst, N, nd, wide, bsum);
             WFS_LAUNCH_CHECK();
