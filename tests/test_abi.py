@@ -10,10 +10,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    text = open(os.path.join(ROOT, "include", "wfsparse.h")).read()
+def _header_functions(header="wfsparse.h", prefix="wfs_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(wfs_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -29,6 +29,16 @@ def test_ctypes_table_mirrors_header():
     from waveformml_amd import _lib
     assert sorted(_lib.SIGNATURES) == _header_functions()
     assert _lib.load().wfs_abi_version() == 1
+
+
+def test_h5_reader_library_exports_and_ctypes_table_mirror_its_header():
+    from waveformml_amd.psd import h5data
+    names = _header_functions("wfh5.h", "wfh5_")
+    assert len(names) == 7 and sorted(h5data.SIGNATURES) == names
+    lib = ctypes.CDLL(h5data.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libwfh5.so does not export %s" % n
+    assert ctypes.sizeof(h5data.Info) == 40          # struct wfh5_info: 3 x int64 + 4 x int32
 
 
 def test_geometry_front_door():

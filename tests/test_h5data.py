@@ -1,0 +1,148 @@
+"""Native HDF5 -> COO reader (include/wfh5.h, waveformml_amd/psd/h5data.py) against the committed fixtures
+tests/golden/h5/ (written by tests/golden/make_h5_fixtures.py with h5py; expected arrays in expected.npz).
+
+Behaviour under test is the reference's HDF5Dataset (src/datasets/HDF5Dataset.py:152-217, 225-347): file ordering
+and per-directory event budget, event-range slicing, directory-index / dataset labels, 1/(2^14-1) normalisation, and
+the collate of src/engineering/PSDDataModule.py:10-20 over the items.  CPU only: the reader is host code.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from waveformml_amd.psd import data, h5data
+
+H5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h5")
+EXP = np.load(os.path.join(H5, "expected.npz"))
+
+
+def _slice_events(coords, col, e0, e1):
+    """numpy restatement of reference HDF5Dataset.py:238-248 (first row of e0, first row of e1 + 1)."""
+    a = 0 if e0 == 0 else int(np.where(coords[:, col] == e0)[0][0])
+    hit = np.where(coords[:, col] == e1 + 1)[0]
+    return a, (int(hit[0]) if len(hit) else len(coords))
+
+
+@pytest.mark.parametrize("rel,table,layout,cols,is_float", [
+    ("Gamma/a_WaveformPairSim.h5", "WaveformPairs", h5data.WFH5_COMPOUND, 3, False),
+    ("Gamma/a_Waveform3DPairSim.h5", "Waveform3DPairs", h5data.WFH5_COMPOUND, 4, True),
+    ("combined/Combined_0_WaveformPairSim.h5", "WaveformPairs", h5data.WFH5_GROUP, 3, False),
+])
+def test_whole_table_matches_h5py(rel, table, layout, cols, is_float):
+    with h5data.H5Table(os.path.join(H5, rel), table) as t:
+        c_ref, w_ref = EXP[rel + "/coord"], EXP[rel + "/waveform"]
+        assert (t.layout, t.coord_cols, t.feat_is_float) == (layout, cols, is_float)
+        assert (t.n_rows, t.feat_cols) == (len(c_ref), w_ref.shape[1])
+        assert t.n_events == c_ref[:, -1].max() + 1
+        c, f = t.read_rows(0, t.n_rows)
+        assert c.dtype == torch.int32 and f.dtype == torch.float32
+        assert np.array_equal(c.numpy(), c_ref)
+        assert np.array_equal(f.numpy(), w_ref.astype(np.float32))       # int16 -> float32 is exact
+        # a scaled partial read equals the reference's `vals *= MAX_RANGE_INV` on the float32 array
+        c2, f2 = t.read_rows(3, 11, h5data.MAX_RANGE_INV)
+        assert np.array_equal(c2.numpy(), c_ref[3:11])
+        want = w_ref[3:11].astype(np.float32)
+        want *= h5data.MAX_RANGE_INV
+        assert np.array_equal(f2.numpy(), want)
+
+
+def test_event_rows_follow_first_occurrence_rule():
+    rel = "Electron/a_WaveformPairSim.h5"
+    c_ref = EXP[rel + "/coord"]
+    with h5data.H5Table(os.path.join(H5, rel), "WaveformPairs") as t:
+        for e0, e1 in ((0, 0), (0, 4), (3, 7), (5, 11), (11, 11)):
+            assert t.event_rows(e0, e1, 2) == _slice_events(c_ref, 2, e0, e1)
+        with pytest.raises(h5data.H5Error):
+            t.event_rows(40, 41, 2)
+        with pytest.raises(h5data.H5Error):
+            t.read_rows(0, t.n_rows + 1)
+
+
+def test_labels_dataset_is_widened_to_int64():
+    rel = "combined/Combined_0_WaveformPairSim.h5"
+    with h5data.H5Table(os.path.join(H5, rel), "WaveformPairs") as t:
+        assert t.n_labels == 11
+        y = t.read_labels(2, 9)
+        assert y.dtype == torch.int64 and np.array_equal(y.numpy(), EXP[rel + "/labels"][2:9].astype(np.int64))
+    with h5data.H5Table(os.path.join(H5, "Gamma/a_WaveformPairSim.h5"), "WaveformPairs") as t:
+        assert t.n_labels == 0
+        with pytest.raises(h5data.H5Error):
+            t.read_labels(0, 1)
+
+
+def test_open_errors_are_reported_not_crashed():
+    with pytest.raises(h5data.H5Error, match="cannot open"):
+        h5data.H5Table(os.path.join(H5, "nope.h5"), "WaveformPairs")
+    with pytest.raises(h5data.H5Error, match="no object named"):
+        h5data.H5Table(os.path.join(H5, "Gamma/a_WaveformPairSim.h5"), "Waveform3DPairs")
+    with pytest.raises(h5data.H5Error):                       # not an HDF5 file at all
+        h5data.H5Table(os.path.join(H5, "expected.npz"), "WaveformPairs")
+
+
+def test_dataset_orders_files_round_robin_and_applies_the_event_budget():
+    ds = h5data.PulseDataset2D([os.path.join(H5, "Gamma"), os.path.join(H5, "Electron")], 10, normalize=True)
+    got = [(os.path.relpath(d["file_path"], H5), d["event_range"], d["dir_index"], d["n_events"])
+           for d in ds.info["data_info"]]
+    # Gamma/a (9 ev) -> Electron/a (12 ev, cut to 10) -> Gamma/b (5 ev, 1 left of the budget)
+    assert got == [("Gamma/a_WaveformPairSim.h5", [0, 8], 0, 9), ("Electron/a_WaveformPairSim.h5", [0, 9], 1, 12),
+                   ("Gamma/b_WaveformPairSim.h5", [0, 0], 0, 5)]
+    assert ds.n_events == [10, 10] and len(ds) == 3
+    for i, (rel, (e0, e1), dir_index, _) in enumerate(got):
+        (c, f), y = ds[i]
+        c_ref, w_ref = EXP[rel + "/coord"], EXP[rel + "/waveform"]
+        a, b = _slice_events(c_ref, 2, e0, e1)
+        want = w_ref[a:b].astype(np.float32)
+        want *= h5data.MAX_RANGE_INV
+        assert np.array_equal(c.numpy(), c_ref[a:b]) and np.array_equal(f.numpy(), want)
+        assert y.dtype == torch.int64 and y.tolist() == [dir_index] * (e1 + 1 - e0)
+        assert f.max() <= 1.0
+
+
+def test_single_directory_budget_and_excludes():
+    gamma = os.path.join(H5, "Gamma")
+    ds = h5data.PulseDataset2D([gamma], 11)
+    assert [d["event_range"] for d in ds.info["data_info"]] == [[0, 8], [0, 1]]
+    ds = h5data.PulseDataset2D([gamma], 100, file_excludes=[os.path.join(gamma, "a_WaveformPairSim.h5")])
+    assert [os.path.basename(p) for p in ds.ordered_file_set] == ["b_WaveformPairSim.h5"]
+    with pytest.raises(RuntimeError, match="No hdf5 datasets found"):
+        h5data.PulseDataset3D([os.path.join(H5, "Electron")], 10)
+    with pytest.raises(RuntimeError, match="not a valid directory"):
+        h5data.PulseDataset2D([os.path.join(H5, "Proton")], 10)
+
+
+def test_3d_items_slice_on_the_batch_column_and_collate():
+    rel = "Gamma/a_Waveform3DPairSim.h5"
+    c_ref, w_ref = EXP[rel + "/coord"], EXP[rel + "/waveform"]
+    ds = h5data.PulseDataset3D([os.path.join(H5, "Gamma")], 5, use_half=True)
+    (c, f), y = ds[0]
+    a, b = _slice_events(c_ref, 3, 0, 4)
+    assert np.array_equal(c.numpy(), c_ref[a:b]) and f.dtype == torch.float16 and len(y) == 5
+    assert torch.equal(f, torch.from_numpy(w_ref[a:b]).half())
+    # two items through the reference collate: the second item's event ids continue after the first's
+    full = h5data.PulseDataset3D([os.path.join(H5, "Gamma")], 7)
+    (coords, feats), labels = data.collate_fn_3d([full[0], ds[0]])
+    assert coords.shape[0] == len(c_ref) + (b - a) and labels.shape[0] == 12
+    assert coords[len(c_ref):, 3].min() == 7 and coords[:, 3].max() == 11
+    assert torch.equal(feats[:len(c_ref)].float(), torch.from_numpy(w_ref))
+
+
+def test_group_layout_with_labels_dataset_and_label_map():
+    rel = "combined/Combined_0_WaveformPairSim.h5"
+    c_ref, l_ref = EXP[rel + "/coord"], EXP[rel + "/labels"].astype(np.int64)
+    args = ([os.path.join(H5, "combined")], "*WaveformPairSim.h5", "WaveformPairs", "coord", "waveform", 8)
+    ds = h5data.HDF5Dataset(*args, label_name="labels")
+    (c, f), y = ds[0]
+    a, b = _slice_events(c_ref, 2, 0, 7)
+    assert np.array_equal(c.numpy(), c_ref[a:b]) and np.array_equal(y.numpy(), l_ref[:8])
+    ds = h5data.HDF5Dataset(*args, label_name="labels", label_map={"2": 0})
+    assert np.array_equal(ds[0][1].numpy(), np.where(l_ref[:8] == 2, 0, l_ref[:8]))
+
+
+def test_dataloader_workers_read_through_their_own_handles():
+    ds = h5data.PulseDataset2D([os.path.join(H5, "Gamma"), os.path.join(H5, "Electron")], 10)
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, num_workers=2, collate_fn=data.collate_fn)
+    (coords, feats), labels = next(iter(loader))
+    assert labels.tolist() == [0] * 9 + [1] * 10 + [0]
+    assert coords[:, 2].max() == 19 and feats.shape[0] == coords.shape[0]

@@ -1,0 +1,283 @@
+// h5reader.cpp -- libwfh5.so: native HDF5 -> COO reader (include/wfh5.h).  Host-only C++ over the HDF5 C API
+// (libhdf5 1.10 from the image's /opt/conda; gzip chunk decoding is libhdf5's).
+//
+// Replaces the h5py column reads + event slicing of reference src/datasets/HDF5Dataset.py:225-347,430-476 for the
+// group layout written by src/datasets/PulseDataset.py:312-333 and the compound tables of
+// src/datasets/H5CompoundTypes.py:105-120.  Only the members the PSD path consumes (coord, waveform, labels) are
+// materialised: compound records are read through a memory type that names just those members.
+#include <hdf5.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/wfh5.h"
+
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *wfh5_last_error(void) { return g_err; }
+
+struct wfh5_file {
+    hid_t file = -1;
+    int layout = WFH5_GROUP;
+    // group layout
+    hid_t d_coord = -1, d_feat = -1, d_labels = -1;
+    // compound layout
+    hid_t d_table = -1;
+    bool labels_member = false;
+    wfh5_info info{};
+    std::vector<int32_t> event_col_cache;     // the event-id column, loaded once for wfh5_event_rows
+    int cached_event_col = -1;
+};
+
+static int64_t read_nevents(hid_t obj) {
+    if (H5Aexists(obj, "nevents") <= 0) return -1;
+    hid_t a = H5Aopen(obj, "nevents", H5P_DEFAULT);
+    if (a < 0) return -1;
+    int64_t v = -1;
+    hid_t sp = H5Aget_space(a);
+    hssize_t n = H5Sget_simple_extent_npoints(sp);
+    std::vector<int64_t> buf(n > 0 ? n : 1, -1);
+    if (H5Aread(a, H5T_NATIVE_INT64, buf.data()) >= 0) v = buf[0];
+    H5Sclose(sp);
+    H5Aclose(a);
+    return v;
+}
+
+static bool dims2(hid_t dset, hsize_t *d0, hsize_t *d1) {
+    hid_t sp = H5Dget_space(dset);
+    int nd = H5Sget_simple_extent_ndims(sp);
+    hsize_t dims[4] = {0, 1, 1, 1};
+    if (nd >= 1 && nd <= 4) H5Sget_simple_extent_dims(sp, dims, nullptr);
+    H5Sclose(sp);
+    if (nd < 1 || nd > 2) return false;
+    *d0 = dims[0];
+    *d1 = nd == 2 ? dims[1] : 1;
+    return true;
+}
+
+extern "C" void wfh5_close(wfh5_file *f) {
+    if (!f) return;
+    if (f->d_coord >= 0) H5Dclose(f->d_coord);
+    if (f->d_feat >= 0) H5Dclose(f->d_feat);
+    if (f->d_labels >= 0) H5Dclose(f->d_labels);
+    if (f->d_table >= 0) H5Dclose(f->d_table);
+    if (f->file >= 0) H5Fclose(f->file);
+    delete f;
+}
+
+// number of elements of an array-typed (or scalar) compound member
+static hsize_t member_len(hid_t mtype) {
+    if (H5Tget_class(mtype) != H5T_ARRAY) return 1;
+    int nd = H5Tget_array_ndims(mtype);
+    hsize_t dims[8];
+    H5Tget_array_dims2(mtype, dims);
+    hsize_t n = 1;
+    for (int i = 0; i < nd; ++i) n *= dims[i];
+    return n;
+}
+
+extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
+    if (!path || !table || !out) {
+        set_err("NULL argument");
+        return WFH5_EINVAL;
+    }
+    H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);          // errors are reported through return codes
+    wfh5_file *f = new wfh5_file;
+    f->file = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f->file < 0) {
+        set_err("cannot open %s", path);
+        wfh5_close(f);
+        return WFH5_EIO;
+    }
+    H5O_info_t oi;
+    if (H5Lexists(f->file, table, H5P_DEFAULT) <= 0 || H5Oget_info_by_name(f->file, table, &oi, H5P_DEFAULT) < 0) {
+        set_err("%s: no object named %s", path, table);
+        wfh5_close(f);
+        return WFH5_EFORMAT;
+    }
+    if (oi.type == H5O_TYPE_GROUP) {
+        f->layout = WFH5_GROUP;
+        hid_t g = H5Gopen2(f->file, table, H5P_DEFAULT);
+        f->info.n_events = read_nevents(g);
+        f->d_coord = H5Lexists(g, "coord", H5P_DEFAULT) > 0 ? H5Dopen2(g, "coord", H5P_DEFAULT) : -1;
+        f->d_feat = H5Lexists(g, "waveform", H5P_DEFAULT) > 0 ? H5Dopen2(g, "waveform", H5P_DEFAULT) : -1;
+        f->d_labels = H5Lexists(g, "labels", H5P_DEFAULT) > 0 ? H5Dopen2(g, "labels", H5P_DEFAULT) : -1;
+        H5Gclose(g);
+        hsize_t n0, c0, n1, c1;
+        if (f->d_coord < 0 || f->d_feat < 0 || !dims2(f->d_coord, &n0, &c0) || !dims2(f->d_feat, &n1, &c1) || n0 != n1) {
+            set_err("%s:%s is a group without matching coord / waveform datasets", path, table);
+            wfh5_close(f);
+            return WFH5_EFORMAT;
+        }
+        f->info.n_rows = (int64_t)n0;
+        f->info.coord_cols = (int32_t)c0;
+        f->info.feat_cols = (int32_t)c1;
+        hid_t t = H5Dget_type(f->d_feat);
+        f->info.feat_is_float = H5Tget_class(t) == H5T_FLOAT;
+        H5Tclose(t);
+        if (f->d_labels >= 0) {
+            hsize_t nl, cl;
+            f->info.n_labels = dims2(f->d_labels, &nl, &cl) ? (int64_t)nl : 0;
+        }
+    } else if (oi.type == H5O_TYPE_DATASET) {
+        f->layout = WFH5_COMPOUND;
+        f->d_table = H5Dopen2(f->file, table, H5P_DEFAULT);
+        hid_t t = f->d_table >= 0 ? H5Dget_type(f->d_table) : -1;
+        hsize_t n0 = 0, c0 = 0;
+        if (t < 0 || H5Tget_class(t) != H5T_COMPOUND || !dims2(f->d_table, &n0, &c0)) {
+            set_err("%s:%s is not a compound table", path, table);
+            if (t >= 0) H5Tclose(t);
+            wfh5_close(f);
+            return WFH5_EFORMAT;
+        }
+        int ic = H5Tget_member_index(t, "coord"), iw = H5Tget_member_index(t, "waveform");
+        if (ic < 0 || iw < 0) {
+            set_err("%s:%s has no coord / waveform members", path, table);
+            H5Tclose(t);
+            wfh5_close(f);
+            return WFH5_EFORMAT;
+        }
+        hid_t tc = H5Tget_member_type(t, ic), tw = H5Tget_member_type(t, iw);
+        f->info.coord_cols = (int32_t)member_len(tc);
+        f->info.feat_cols = (int32_t)member_len(tw);
+        hid_t twb = H5Tget_class(tw) == H5T_ARRAY ? H5Tget_super(tw) : H5Tcopy(tw);
+        f->info.feat_is_float = H5Tget_class(twb) == H5T_FLOAT;
+        H5Tclose(twb);
+        H5Tclose(tc);
+        H5Tclose(tw);
+        f->labels_member = H5Tget_member_index(t, "labels") >= 0;
+        H5Tclose(t);
+        f->info.n_rows = (int64_t)n0;
+        f->info.n_events = read_nevents(f->d_table);
+        f->info.n_labels = f->labels_member ? (int64_t)n0 : 0;
+    } else {
+        set_err("%s:%s is neither a group nor a dataset", path, table);
+        wfh5_close(f);
+        return WFH5_EFORMAT;
+    }
+    f->info.layout = f->layout;
+    *out = f;
+    return WFH5_OK;
+}
+
+extern "C" int wfh5_get_info(const wfh5_file *f, wfh5_info *info) {
+    if (!f || !info) {
+        set_err("NULL argument");
+        return WFH5_EINVAL;
+    }
+    *info = f->info;
+    return WFH5_OK;
+}
+
+// hyperslab read of rows [r0, r1) x all columns of a 1-D / 2-D dataset into `buf` of memory type `mt`
+static int read_slab(hid_t dset, hsize_t r0, hsize_t r1, hsize_t cols, bool two_d, hid_t mt, void *buf) {
+    hid_t fs = H5Dget_space(dset);
+    hsize_t start[2] = {r0, 0}, count[2] = {r1 - r0, cols};
+    H5Sselect_hyperslab(fs, H5S_SELECT_SET, start, nullptr, count, nullptr);
+    hid_t ms = H5Screate_simple(two_d ? 2 : 1, count, nullptr);
+    herr_t rc = H5Dread(dset, mt, ms, fs, H5P_DEFAULT, buf);
+    H5Sclose(ms);
+    H5Sclose(fs);
+    return rc < 0 ? WFH5_EIO : WFH5_OK;
+}
+
+// read ONE array member of the compound table for rows [r0, r1) as `base` elements (HDF5 converts)
+static int read_member(wfh5_file *f, const char *name, hsize_t len, hid_t base, size_t base_size, hsize_t r0, hsize_t r1,
+                       void *buf) {
+    hid_t arr = len > 1 ? H5Tarray_create2(base, 1, &len) : H5Tcopy(base);
+    hid_t mt = H5Tcreate(H5T_COMPOUND, base_size * len);
+    H5Tinsert(mt, name, 0, arr);
+    int rc = read_slab(f->d_table, r0, r1, 1, false, mt, buf);
+    H5Tclose(mt);
+    H5Tclose(arr);
+    return rc;
+}
+
+extern "C" int wfh5_read_rows(wfh5_file *f, int64_t row0, int64_t row1, int32_t *coords, float *feats, float scale) {
+    if (!f || row0 < 0 || row1 < row0 || row1 > f->info.n_rows) {
+        set_err("bad row range [%lld, %lld) of %lld", (long long)row0, (long long)row1, f ? (long long)f->info.n_rows : -1ll);
+        return WFH5_EINVAL;
+    }
+    if (row1 == row0) return WFH5_OK;
+    int rc = WFH5_OK;
+    const hsize_t r0 = (hsize_t)row0, r1 = (hsize_t)row1;
+    if (f->layout == WFH5_GROUP) {
+        if (coords) rc = read_slab(f->d_coord, r0, r1, f->info.coord_cols, true, H5T_NATIVE_INT32, coords);
+        if (rc == WFH5_OK && feats) rc = read_slab(f->d_feat, r0, r1, f->info.feat_cols, true, H5T_NATIVE_FLOAT, feats);
+    } else {
+        if (coords) rc = read_member(f, "coord", f->info.coord_cols, H5T_NATIVE_INT32, 4, r0, r1, coords);
+        if (rc == WFH5_OK && feats) rc = read_member(f, "waveform", f->info.feat_cols, H5T_NATIVE_FLOAT, 4, r0, r1, feats);
+    }
+    if (rc != WFH5_OK) {
+        set_err("HDF5 read failed for rows [%lld, %lld)", (long long)row0, (long long)row1);
+        return rc;
+    }
+    if (feats && scale != 1.0f) {
+        const size_t n = (size_t)(row1 - row0) * f->info.feat_cols;
+        for (size_t i = 0; i < n; ++i) feats[i] *= scale;
+    }
+    return WFH5_OK;
+}
+
+extern "C" int wfh5_read_labels(wfh5_file *f, int64_t e0, int64_t e1, int64_t *labels) {
+    if (!f || !labels || e0 < 0 || e1 < e0 || e1 > f->info.n_labels) {
+        set_err("bad label range");
+        return WFH5_EINVAL;
+    }
+    if (e1 == e0) return WFH5_OK;
+    int rc;
+    if (f->layout == WFH5_GROUP) {
+        if (f->d_labels < 0) {
+            set_err("no labels dataset");
+            return WFH5_EFORMAT;
+        }
+        rc = read_slab(f->d_labels, (hsize_t)e0, (hsize_t)e1, 1, false, H5T_NATIVE_INT64, labels);
+    } else {
+        if (!f->labels_member) {
+            set_err("no labels member");
+            return WFH5_EFORMAT;
+        }
+        rc = read_member(f, "labels", 1, H5T_NATIVE_INT64, 8, (hsize_t)e0, (hsize_t)e1, labels);
+    }
+    if (rc != WFH5_OK) set_err("HDF5 label read failed");
+    return rc;
+}
+
+extern "C" int wfh5_event_rows(wfh5_file *f, int32_t event_col, int64_t e0, int64_t e1, int64_t *row0, int64_t *row1) {
+    if (!f || !row0 || !row1 || event_col < 0 || event_col >= f->info.coord_cols || e1 < e0) {
+        set_err("bad argument");
+        return WFH5_EINVAL;
+    }
+    const int64_t n = f->info.n_rows;
+    if (f->cached_event_col != event_col) {
+        std::vector<int32_t> all((size_t)n * f->info.coord_cols);
+        int rc = n ? wfh5_read_rows(f, 0, n, all.data(), nullptr, 1.0f) : WFH5_OK;
+        if (rc != WFH5_OK) return rc;
+        f->event_col_cache.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) f->event_col_cache[(size_t)i] = all[(size_t)i * f->info.coord_cols + event_col];
+        f->cached_event_col = event_col;
+    }
+    // first occurrence, scanning like the reference's `where(col == e)[0][0]` (no sortedness assumed)
+    auto first_of = [&](int64_t e, int64_t from) -> int64_t {
+        for (int64_t i = from; i < n; ++i)
+            if (f->event_col_cache[(size_t)i] == e) return i;
+        return -1;
+    };
+    int64_t a = e0 > 0 ? first_of(e0, 0) : 0;
+    if (a < 0) {
+        set_err("event %lld not found", (long long)e0);
+        return WFH5_EINVAL;
+    }
+    int64_t b = first_of(e1 + 1, 0);
+    *row0 = a;
+    *row1 = b < 0 ? n : b;
+    return WFH5_OK;
+}

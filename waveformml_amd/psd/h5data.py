@@ -1,0 +1,270 @@
+"""HDF5 -> sparse-COO items for the PSD path, read natively through libwfh5.so (include/wfh5.h).
+
+Host-side mirror of the reference's dataset interface for this row:
+
+  * ``HDF5Dataset``      reference src/datasets/HDF5Dataset.py:36-217 -- file discovery by pattern, natural sort on the
+                         first ``_<n>`` of the name (:19-24), round-robin ordering across class directories with a
+                         per-directory event budget (:152-183), ONE item = one file's event range ``[0, n-1]``,
+                         ``[[coords, feats], labels]``, labels = directory index unless a ``labels`` dataset / member is
+                         named, features scaled by 1/(2^14 - 1) when ``normalize`` (:14-17, :345-346)
+  * ``PulseDataset2D`` / ``PulseDataset3D``   the table / pattern / batch-column bindings of
+                         reference src/datasets/PulseDataset.py:543-625
+
+What differs from the reference, on purpose:
+  * rows are read with hyperslab selections of just the item's range and of just the ``coord`` / ``waveform`` members
+    of a compound record (the reference loads every member of the whole table into numpy, :430-476, then slices);
+  * the event column of the range search is ``batch_index`` (3 for the 3-D table); the reference searches column 2 for
+    every 2-D coord array (:231-248), which for (x, y, t, evt) rows is the time sample.  Identical results whenever an
+    item is a whole file, which is every file but the last one of a directory's budget;
+  * no data cache: items are decoded straight into (optionally pinned) tensors.
+"""
+import ctypes
+import os
+import re
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libwfh5.so")
+
+WFH5_OK, WFH5_EIO, WFH5_EFORMAT, WFH5_EINVAL = 0, 1, 2, 3
+WFH5_GROUP, WFH5_COMPOUND = 0, 1
+N_CHANNELS = 14
+MAX_RANGE_INV = 1.0 / (2 ** N_CHANNELS - 1)
+
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+class Info(ctypes.Structure):
+    """struct wfh5_info"""
+    _fields_ = [("n_rows", _i64), ("n_events", _i64), ("n_labels", _i64), ("coord_cols", _i32),
+                ("feat_cols", _i32), ("feat_is_float", _i32), ("layout", _i32)]
+
+
+# name -> (restype, argtypes); mirrors include/wfh5.h one to one (tests/test_abi.py checks the export list)
+SIGNATURES = {
+    "wfh5_last_error": (ctypes.c_char_p, []),
+    "wfh5_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    "wfh5_close": (None, [_vp]),
+    "wfh5_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(Info)]),
+    "wfh5_read_rows": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, ctypes.c_float]),
+    "wfh5_read_labels": (ctypes.c_int, [_vp, _i64, _i64, _vp]),
+    "wfh5_event_rows": (ctypes.c_int, [_vp, _i32, _i64, _i64, c_i64p, c_i64p]),
+}
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libwfh5.so is missing at %s -- build it with `make -C waveformml_amd/csrc`" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+class H5Error(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != WFH5_OK:
+        raise H5Error("wfh5 error %d: %s" % (rc, load().wfh5_last_error().decode()))
+
+
+class H5Table:
+    """One open table of one file (a handle is not shared between DataLoader workers: open per use)."""
+
+    def __init__(self, path, table):
+        self._lib = load()
+        self._h = _vp()
+        _check(self._lib.wfh5_open(str(path).encode(), table.encode(), ctypes.byref(self._h)))
+        info = Info()
+        _check(self._lib.wfh5_get_info(self._h, ctypes.byref(info)))
+        self.n_rows, self.n_events, self.n_labels = info.n_rows, info.n_events, info.n_labels
+        self.coord_cols, self.feat_cols = info.coord_cols, info.feat_cols
+        self.feat_is_float, self.layout = bool(info.feat_is_float), info.layout
+
+    def close(self):
+        if self._h and self._lib is not None:
+            close = getattr(self._lib, "wfh5_close", None)
+            if close is not None:          # None during interpreter shutdown
+                close(self._h)
+            self._h = _vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def event_rows(self, e0, e1, event_col):
+        """Row range of events [e0, e1] inclusive (reference HDF5Dataset.py:238-248)."""
+        r0, r1 = _i64(), _i64()
+        _check(self._lib.wfh5_event_rows(self._h, event_col, e0, e1, ctypes.byref(r0), ctypes.byref(r1)))
+        return r0.value, r1.value
+
+    def read_rows(self, row0, row1, scale=1.0, pin_memory=False):
+        n = row1 - row0
+        coords = torch.empty((n, self.coord_cols), dtype=torch.int32, pin_memory=pin_memory)
+        feats = torch.empty((n, self.feat_cols), dtype=torch.float32, pin_memory=pin_memory)
+        _check(self._lib.wfh5_read_rows(self._h, row0, row1, coords.data_ptr(), feats.data_ptr(), scale))
+        return coords, feats
+
+    def read_labels(self, e0, e1):
+        y = torch.empty((e1 - e0,), dtype=torch.int64)
+        _check(self._lib.wfh5_read_labels(self._h, e0, e1, y.data_ptr()))
+        return y
+
+
+_SORT_RE = re.compile(r'_(\d+)')
+
+
+def _sort_key(name):
+    """Natural order on the first ``_<digits>`` of the path; names without one sort after, alphabetically
+    (the reference's key returns int or the path itself, which Python 3 cannot compare when mixed;
+    src/datasets/HDF5Dataset.py:19-24)."""
+    nums = _SORT_RE.findall(str(name))
+    return (0, int(nums[0]), str(name)) if nums else (1, 0, str(name))
+
+
+def _needs_more_data(tally, n, all_files):
+    return any(val < n and len(all_files[i]) > 0 for i, val in enumerate(tally))
+
+
+class HDF5Dataset(Dataset):
+    """See the module docstring.  Constructor arguments follow reference src/datasets/HDF5Dataset.py:86-104
+    (``device`` is kept for signature parity; items are host tensors, moved by the step's own H2D copy)."""
+
+    def __init__(self, file_paths, file_pattern, data_name, coordinate_name, feature_name, events_per_dir,
+                 device=None, recursive=False, load_data=False, file_excludes=None, label_name=None,
+                 label_file_pattern=None, data_cache_size=1, normalize=False, use_half=False, event_based=True,
+                 additional_fields=None, label_map=None, batch_index=2, pin_memory=False):
+        super().__init__()
+        if (coordinate_name, feature_name) != ("coord", "waveform"):
+            raise NotImplementedError("the native reader binds the PSD tables' coord / waveform columns")
+        if label_file_pattern is not None or additional_fields is not None or not event_based:
+            raise NotImplementedError("separate label files / additional fields / length-based ranges are not on "
+                                      "the PSD classification path")
+        if label_name not in (None, "labels"):
+            raise NotImplementedError("labels come from the directory index or a `labels` dataset")
+        self.num_dirs = len(file_paths)
+        self.normalize = normalize
+        self.half_precision = use_half
+        self.device = device
+        self.batch_index = batch_index
+        self.pin_memory = pin_memory
+        self.n_events = [0] * self.num_dirs
+        self.file_paths = [os.path.normpath(os.path.abspath(f)) for f in file_paths]
+        self.info = {"file_paths": self.file_paths, "data_info": [], "data_cache_size": data_cache_size,
+                     "data_name": data_name, "coord_name": coordinate_name, "feat_name": feature_name,
+                     "label_name": label_name, "label_file_pattern": label_file_pattern,
+                     "file_pattern": file_pattern, "events_per_dir": events_per_dir, "event_based": event_based,
+                     "additional_fields": additional_fields, "label_map": label_map}
+        self.ordered_file_set = []
+        all_files = []
+        for file_path in self.file_paths:
+            p = Path(file_path)
+            if not p.is_dir():
+                raise RuntimeError("{0} is not a valid directory.".format(str(p.resolve())))
+            files = sorted(p.glob(('**/' if recursive else '') + file_pattern), key=_sort_key)
+            if file_excludes:
+                files = [f for f in files if str(f.resolve()) not in file_excludes]
+            if len(files) < 1 and file_excludes:
+                raise RuntimeError('No remaining datasets available, lower the number of training and / or '
+                                   'validation data')
+            elif len(files) < 1:
+                raise RuntimeError('No hdf5 datasets found')
+            all_files.append(files)
+        if len(all_files) == 1:
+            ordered = [(f, 0) for f in all_files[0]]
+        else:
+            # round-robin across directories, always topping up the directory that is behind (reference :163-174)
+            tally = [0] * len(all_files)
+            ordered = []
+            while sum(len(fs) for fs in all_files) > 0 and _needs_more_data(tally, events_per_dir, all_files):
+                for i, file_set in enumerate(all_files):
+                    while len(file_set) > 0 and tally[i] < events_per_dir:
+                        f = file_set.pop(0)
+                        ordered.append((f, i))
+                        tally[i] += self._get_event_num(f)
+                        if not tally[i] < max(tally):
+                            break
+        for f, dir_index in ordered:
+            if self.n_events[dir_index] >= events_per_dir:
+                continue
+            self.ordered_file_set.append(str(f.resolve()))
+            self._add_data_infos(str(f.resolve()), dir_index)
+
+    def _get_event_num(self, file_path):
+        with H5Table(file_path, self.info["data_name"]) as t:
+            if t.n_events < 0:
+                raise H5Error("%s:%s has no nevents attribute" % (file_path, self.info["data_name"]))
+            return t.n_events
+
+    def _add_data_infos(self, file_path, dir_index):
+        n_file_events = self._get_event_num(file_path)
+        n = min(n_file_events, self.info["events_per_dir"] - self.n_events[dir_index])
+        self.n_events[dir_index] += n
+        self.info["data_info"].append({"file_path": file_path, "name": self.info["data_name"],
+                                       "modified": os.path.getmtime(file_path), "n_events": int(n_file_events),
+                                       "event_range": [0, int(n) - 1], "dir_index": dir_index})
+
+    def __len__(self):
+        return len(self.info["data_info"])
+
+    def __getitem__(self, index):
+        di = self.info["data_info"][index]
+        e0, e1 = di["event_range"]
+        scale = MAX_RANGE_INV if self.normalize else 1.0
+        with H5Table(di["file_path"], self.info["data_name"]) as t:
+            if e0 == 0 and e1 + 1 >= di["n_events"]:
+                r0, r1 = 0, t.n_rows
+            else:
+                r0, r1 = t.event_rows(e0, e1, min(self.batch_index, t.coord_cols - 1))
+            coords, feats = t.read_rows(r0, r1, scale, self.pin_memory)
+            if self.info["label_name"] is None:
+                y = torch.full((e1 + 1 - e0,), di["dir_index"], dtype=torch.int64)
+            else:
+                y = t.read_labels(e0, e1 + 1)
+                if self.info["label_map"]:
+                    m = {int(k): int(v) for k, v in self.info["label_map"].items()}
+                    y = torch.from_numpy(np.vectorize(lambda v: m.get(int(v), int(v)), otypes=[np.int64])(y.numpy()))
+        if self.half_precision:
+            feats = feats.half()
+        return [coords, feats], y
+
+
+class PulseDataset2D(HDF5Dataset):
+    """``WaveformPairs`` tables of ``*WaveformPairSim.h5`` files: coord (x, y, evt), waveform [2 * nsamples]
+    (reference src/datasets/PulseDataset.py:543-579)."""
+    layout = "2d"
+
+    def __init__(self, file_paths, n_per_dir, device=None, **kw):
+        super().__init__(file_paths, "*WaveformPairSim.h5", "WaveformPairs", "coord", "waveform", n_per_dir,
+                         device, batch_index=2, **kw)
+
+
+class PulseDataset3D(HDF5Dataset):
+    """``Waveform3DPairs`` tables of ``*Waveform3DPairSim.h5`` files: coord (x, y, t, evt), waveform [2]
+    (reference src/datasets/PulseDataset.py:582-621)."""
+    layout = "3d"
+
+    def __init__(self, file_paths, n_per_dir, device=None, **kw):
+        super().__init__(file_paths, "*Waveform3DPairSim.h5", "Waveform3DPairs", "coord", "waveform", n_per_dir,
+                         device, batch_index=3, **kw)
