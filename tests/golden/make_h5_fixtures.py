@@ -96,5 +96,9 @@ c, w, l = write_group_2d(os.path.join(OUT, "combined", "Combined_0_WaveformPairS
 expected["combined/Combined_0_WaveformPairSim.h5/coord"] = c
 expected["combined/Combined_0_WaveformPairSim.h5/waveform"] = w
 expected["combined/Combined_0_WaveformPairSim.h5/labels"] = l
+for cls, name, ne in (("Electron", "a_Waveform3DPairSim.h5", 6), ("Gamma", "b_Waveform3DPairSim.h5", 4)):
+    c, w = write_compound_3d(os.path.join(OUT, cls, name), ne)
+    expected["%s/%s/coord" % (cls, name)] = c
+    expected["%s/%s/waveform" % (cls, name)] = w
 np.savez_compressed(os.path.join(OUT, "expected.npz"), **expected)
 print("wrote", sorted(expected))

@@ -107,7 +107,7 @@ def test_single_directory_budget_and_excludes():
     ds = h5data.PulseDataset2D([gamma], 100, file_excludes=[os.path.join(gamma, "a_WaveformPairSim.h5")])
     assert [os.path.basename(p) for p in ds.ordered_file_set] == ["b_WaveformPairSim.h5"]
     with pytest.raises(RuntimeError, match="No hdf5 datasets found"):
-        h5data.PulseDataset3D([os.path.join(H5, "Electron")], 10)
+        h5data.PulseDataset3D([os.path.join(H5, "combined")], 10)
     with pytest.raises(RuntimeError, match="not a valid directory"):
         h5data.PulseDataset2D([os.path.join(H5, "Proton")], 10)
 

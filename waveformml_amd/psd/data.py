@@ -71,3 +71,46 @@ def to_device(batch, device, feature_dtype=None, non_blocking=True):
     if feature_dtype is not None:
         f = f.to(feature_dtype)
     return [c, f], y.to(device, non_blocking=non_blocking)
+
+
+class DevicePrefetcher(object):
+    """Pinned double-buffering of the loader -> HBM hand-over: while step i computes, batch i+1's
+    host->device copies run on a dedicated copy stream; the consumer's stream waits on the copy's event, never on the
+    host.  Replaces the reference's synchronous ``.to(self.device)`` inside ``_concat_range``
+    (src/datasets/HDF5Dataset.py:250-300), which a forked DataLoader worker cannot do on a HIP device anyway."""
+
+    def __init__(self, loader, device, feature_dtype=None, depth=2):
+        self.loader, self.device, self.feature_dtype, self.depth = loader, torch.device(device), feature_dtype, depth
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        (c, f), y = batch
+        host = [t if t.is_pinned() else t.pin_memory() for t in (c, f, y)]
+        with torch.cuda.stream(self.copy_stream):
+            dev = [t.to(self.device, non_blocking=True) for t in host]
+            if self.feature_dtype is not None:
+                dev[1] = dev[1].to(self.feature_dtype)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        return host, dev, done           # `host` is kept alive until the copy has been waited on
+
+    def __iter__(self):
+        queue = []
+        it = iter(self.loader)
+        while True:
+            while len(queue) < self.depth:
+                try:
+                    queue.append(self._stage(next(it)))
+                except StopIteration:
+                    break
+            if not queue:
+                return
+            host, dev, done = queue.pop(0)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)
+            for t in dev:
+                t.record_stream(cur)      # allocated on the copy stream, consumed on the compute stream
+            yield [dev[0], dev[1]], dev[2]

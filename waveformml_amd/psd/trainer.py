@@ -6,7 +6,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from .data import to_device
+from .data import DevicePrefetcher, to_device
 from .ddp import FlatGradAllReducer, broadcast_parameters
 
 
@@ -36,8 +36,7 @@ class Trainer(object):
         best = float("inf")
         for epoch in range(self.max_epochs):
             module.train()
-            for i, batch in enumerate(train_loader):
-                batch = to_device(batch, self.device, self.feature_dtype)
+            for i, batch in enumerate(DevicePrefetcher(train_loader, self.device, self.feature_dtype)):
                 loss = self.training_step(module, reducer, optimizer, batch, i)
                 if self.log_every and i % self.log_every == 0:
                     print("epoch %d step %d train_loss %.5f" % (epoch, i, loss.item()), flush=True)
