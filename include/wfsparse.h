@@ -145,6 +145,35 @@ int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, i
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
                     int32_t dtype, const int64_t *r_dev, void *stream);
 
+/* The same product when an nn.BatchNorm1d in TRAINING mode directly follows the convolution inside
+ * spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508, SURVEY.md 8a rows a9 + a12): the conv
+ * kernel's epilogue also takes the per-channel batch statistics of the rows it stores, so BatchNorm needs no
+ * reduction pass of its own (wfs_bn_apply_fwd then normalises with save_mean / save_invstd).
+ * On return (stream order): save_mean, save_invstd [Cy] hold the batch mean and 1/sqrt(biased var + eps);
+ * running_mean / running_var (optional) are updated with momentum and the unbiased variance, num_batches_tracked
+ * (optional) is incremented -- exactly what torch.nn.functional.batch_norm(training=True) does.
+ * workspace: wfs_conv_stats_workspace_bytes(R, Cy) bytes (per-block partial statistics, folded by one small launch).
+ * Shapes without a fused epilogue run the convolution followed by the reduction kernels of wfs_bn_relu_fwd: same
+ * results, same interface. */
+typedef struct wfs_bn_stats {
+    float *save_mean;
+    float *save_invstd;
+    float *running_mean;          /* may be NULL (track_running_stats=False) */
+    float *running_var;
+    int64_t *num_batches_tracked; /* may be NULL */
+    float momentum;
+    float eps;
+    void *workspace;
+    size_t workspace_bytes;
+} wfs_bn_stats;
+
+size_t wfs_conv_stats_workspace_bytes(int64_t R, int32_t C);
+
+int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                            int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
+                            int32_t Cw_in, int32_t Cw_out, const float *bias, void *Y, int32_t dtype,
+                            const int64_t *r_dev, const wfs_bn_stats *stats, void *stream);
+
 /* Replaces the dW half of torch.ops.spconv.indice_conv_backward:
  *     dW[k, a, b] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 0)
  *     dW[k, b, a] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 1)
@@ -169,8 +198,8 @@ int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_
 /* BatchNorm1d (+ReLU) over the active rows ------------------------------------------------------
  * What spconv.SparseSequential does with the plain nn.BatchNorm1d / nn.ReLU modules the reference
  * puts after every sparse conv (src/models/SPConvBlocks.py:505-508): applied to .features [N, C],
- * statistics over the N active rows.  Three small launches per direction (column reduction into per-block
- * partials; fold of the partials in a fixed order; elementwise pass): deterministic.
+ * statistics over the N active rows.  Two launches per direction (column reduction into per-block partials;
+ * elementwise pass whose blocks first fold the partials in a fixed order): deterministic, no atomics.
  * training != 0: batch statistics (biased variance), running_mean/var (may be NULL) updated with
  * `momentum` using the unbiased variance and *num_batches_tracked (device int64, may be NULL)
  * incremented, exactly as torch.  training == 0: running statistics.
@@ -190,6 +219,12 @@ int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const f
                     int32_t training, int32_t relu, void *dX, float *dgamma, float *dbeta,
                     void *workspace, size_t workspace_bytes, int32_t dtype, const int64_t *n_dev,
                     void *stream);
+
+/* The elementwise half of wfs_bn_relu_fwd alone, for statistics that are already known (taken by
+ * wfs_gather_conv_bnstats):  Y = [relu] (gamma * (X - mean) * invstd + beta). */
+int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
+                     const float *save_mean, const float *save_invstd, int32_t relu, void *Y, int32_t dtype,
+                     const int64_t *n_dev, void *stream);
 
 /* SparseConvTensor.dense() -------------------------------------------------------------------
  * Y is [B, C, *spatial] (channels first, contiguous) and must be zero-filled by the caller;
@@ -218,6 +253,24 @@ int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W, const floa
 
 int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const float *W, int32_t O,
                  void *dX, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
+                 void *stream);
+
+/* loss ---------------------------------------------------------------------------------------------
+ * torch.nn.CrossEntropyLoss(reduction='mean') as the reference's LitPSD applies it to the [B, n_type] logits
+ * (src/engineering/LitBase.py:38-43, LitPSD.py:102), forward AND d loss / d logits in one launch (torch runs six:
+ * log_softmax, nll_loss, their backwards and two fills).  logits fp32 [B, C], target int64 [B]; rows whose target
+ * equals ignore_index are skipped and do not count in the mean (torch's default is -100).
+ * loss: device float [1]; dlogits [B, C] = (softmax - onehot) / counted rows, or NULL for the forward alone. */
+int wfs_xent_mean_fwd_bwd(const float *logits, const int64_t *target, int64_t B, int32_t C,
+                          int64_t ignore_index, float *loss, float *dlogits, void *stream);
+
+/* optimizer ----------------------------------------------------------------------------------------
+ * torch.optim.SGD's update (the optimizer of the reference's example configs, config/examples/GEP.json:51-69, built
+ * by src/engineering/LitPSD.py:60-76) on one flat fp32 parameter buffer in a single launch; arithmetic and order of
+ * torch/optim/sgd.py.  lr is read from device memory so that a scheduler can change it under a captured graph.
+ * momentum_buf may be NULL when momentum == 0; first_step != 0 initialises it with the gradient, as torch does. */
+int wfs_sgd_step(float *param, const float *grad, float *momentum_buf, int64_t n, const float *lr_dev,
+                 float momentum, float dampening, float weight_decay, int32_t nesterov, int32_t first_step,
                  void *stream);
 
 /* opt-in per-kernel timing (HIP events on the launch stream), used by bench.py's roofline ---- */

@@ -26,6 +26,13 @@ class Geometry(ctypes.Structure):
                 ("padding", _i32 * WFS_MAX_DIM), ("dilation", _i32 * WFS_MAX_DIM)]
 
 
+class BnStats(ctypes.Structure):
+    """struct wfs_bn_stats"""
+    _fields_ = [("save_mean", _vp), ("save_invstd", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("num_batches_tracked", _vp), ("momentum", ctypes.c_float), ("eps", ctypes.c_float),
+                ("workspace", _vp), ("workspace_bytes", _sz)]
+
+
 # name -> (restype, argtypes); mirrors include/wfsparse.h one to one
 SIGNATURES = {
     "wfs_abi_version": (ctypes.c_int, []),
@@ -39,6 +46,10 @@ SIGNATURES = {
     "wfs_indices_check": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _sz, c_i64p, _vp]),
     "wfs_gather_conv": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _i32,
                                        _vp, _vp, _i32, _vp, _vp]),
+    "wfs_conv_stats_workspace_bytes": (_sz, [_i64, _i32]),
+    "wfs_gather_conv_bnstats": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp,
+                                               _i32, _vp, ctypes.POINTER(BnStats), _vp]),
+    "wfs_bn_apply_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "wfs_gather_dw": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
                                      _sz, _vp, _vp]),
@@ -53,6 +64,9 @@ SIGNATURES = {
     "wfs_head_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "wfs_head_fwd": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp]),
     "wfs_head_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "wfs_xent_mean_fwd_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "wfs_sgd_step": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32, _i32,
+                                    _vp]),
     "wfs_timing_enable": (ctypes.c_int, [_i32]),
     "wfs_timing_read": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_double), c_i64p]),
 }

@@ -2,10 +2,10 @@
 //
 // The reference applies plain nn.BatchNorm1d / nn.ReLU modules to SparseConvTensor.features inside
 // spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508): batch
-// statistics over the N ACTIVE voxels only, per rank (no SyncBN).  Same arithmetic here, in three small launches
-// per direction: a column reduction into per-block partials (many blocks, bandwidth), a one-block-per-32-channels
-// fold of the partials in a fixed order (deterministic, no atomics) that also finalises the statistics, and the
-// elementwise pass.
+// statistics over the N ACTIVE voxels only, per rank (no SyncBN).  Same arithmetic here, in two launches per
+// direction: a column reduction into <= 128 per-block partials, and the elementwise pass, whose every block first
+// folds those partials in a fixed order (deterministic, no atomics; at the PSD batch sizes a launch costs ~5 us, more
+// than re-reading 32 KB of L2-resident partials per block) and whose block 0 publishes the statistics.
 //
 //   forward   mean_c, var_c (biased) over rows;  y = max(0, gamma*(x-mean)*invstd + beta)   [ReLU optional]
 //             running_mean/var updated with momentum (unbiased var), as torch does
@@ -203,15 +203,96 @@ __global__ void __launch_bounds__(FOLD_SL * 32) k_bn_fold(const float *__restric
     if (MODE == 0 && batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;
 }
 
+// Sums of the per-block partials [nblk][2][C] in a fixed order, computed by EVERY block of the elementwise kernels in
+// their prologue (the partials are a few KB and L2-resident; a separate fold launch costs more than this):
+// S = TB / Cp slices x Cp columns, Cp = C rounded up to a power of two.  Slice s owns partials s, s + S, ...; the
+// reduce kernel launches at most FOLD_PER * S blocks, so a thread has at most FOLD_PER partials and issues ALL its
+// loads before the first add (one memory round trip); slices are then added in slice order.
+constexpr int FOLD_PER = 16;
+__device__ __forceinline__ int fold_cp(int C) {
+    int Cp = 1;
+    while (Cp < C && Cp < TB) Cp <<= 1;
+    return Cp;
+}
+__device__ __forceinline__ void fold_partials(const float *__restrict__ partial, int nblk, int C, float *sSlice,
+                                              float *sA, float *sB) {
+    const int Cp = fold_cp(C);
+    const int S = TB / Cp;                                  // 1 when C >= TB
+    const int col = threadIdx.x % Cp, sl = threadIdx.x / Cp;
+    const long long st = 2ll * C;
+    for (int cbase = 0; cbase < C; cbase += Cp) {          // one pass unless C > TB
+        const int c = cbase + col;
+        const int cc = c < C ? c : 0;
+        float av[FOLD_PER], bv[FOLD_PER];
+#pragma unroll
+        for (int i = 0; i < FOLD_PER; ++i) {
+            const int p = sl + i * S;
+            const float *q = partial + (long long)(p < nblk ? p : 0) * st + cc;
+            av[i] = q[0];
+            bv[i] = q[C];
+        }
+        float a = 0.f, bb = 0.f;
+#pragma unroll
+        for (int i = 0; i < FOLD_PER; ++i) {
+            const bool ok = (sl + i * S < nblk) & (c < C);
+            a += ok ? av[i] : 0.f;
+            bb += ok ? bv[i] : 0.f;
+        }
+        sSlice[threadIdx.x] = a;
+        sSlice[TB + threadIdx.x] = bb;
+        __syncthreads();
+        if (sl == 0 && c < C) {
+            float ta = 0.f, tb = 0.f;
+            for (int q = 0; q < S; ++q) {
+                ta += sSlice[q * Cp + col];
+                tb += sSlice[TB + q * Cp + col];
+            }
+            sA[c] = ta;
+            sB[c] = tb;
+        }
+        __syncthreads();
+    }
+}
+
+// y = [relu](gamma * (x - mean) * invstd + beta).  Statistics: folded from `partial` (training, the reduce kernel's
+// shifted sums; block 0 also publishes save_mean / save_invstd and updates the running statistics), or given in
+// save_mean / save_invstd (training with known statistics: partial == NULL), or the running ones (eval).
 template <typename T, int VEC>
 __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long long Ncap,
                                                  const long long *__restrict__ n_dev, int C, long long rows_per_block,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                 const float *__restrict__ running_mean,
-                                                 const float *__restrict__ running_var, float eps, int training,
-                                                 int relu, T *__restrict__ Y, float *__restrict__ save_mean,
-                                                 float *__restrict__ save_invstd) {
+                                                 float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                 long long *__restrict__ batches_tracked, float momentum, float eps,
+                                                 int training, int relu, T *__restrict__ Y,
+                                                 float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                 const float *__restrict__ partial, int nblk) {
+    __shared__ float sSlice[2 * TB];
+    __shared__ float sA[MAXC], sB[MAXC];
     const long long N = valid_rows(Ncap, n_dev);
+    if (partial) {
+        fold_partials(partial, nblk, C, sSlice, sA, sB);
+        const float n = N > 0 ? (float)N : 1.f;
+        for (int c = threadIdx.x; c < C; c += TB) {
+            float shift = wfs_ld(X + c);
+            float md = sA[c] / n;                       // mean of (x - shift)
+            float var = sB[c] / n - md * md;            // biased, what torch normalises with
+            var = var > 0.f ? var : 0.f;
+            float mean = shift + md, inv = rsqrtf(var + eps);
+            sA[c] = mean;
+            sB[c] = inv;
+            if (blockIdx.x == 0) {
+                save_mean[c] = mean;
+                save_invstd[c] = inv;
+                if (running_mean) {
+                    float unbiased = N > 1 ? var * (n / (n - 1.f)) : var;
+                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+                }
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && batches_tracked) *batches_tracked += 1;
+        __syncthreads();
+    }
     const int groups = C / VEC, slots = TB / groups;
     const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
     if (slot >= slots) return;
@@ -219,7 +300,10 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
     float m[VEC], is[VEC], ga[VEC], be[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        if (training) {
+        if (partial) {
+            m[i] = sA[c0 + i];
+            is[i] = sB[c0 + i];
+        } else if (training) {
             m[i] = save_mean[c0 + i];
             is[i] = save_invstd[c0 + i];
         } else {
@@ -248,20 +332,25 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
     }
 }
 
+// dx; the sums (sum g, sum g*xhat) are folded from the reduce kernel's partials in the prologue, block 0 publishes
+// them as dbeta / dgamma.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, const T *__restrict__ dY,
                                                      long long Ncap, const long long *__restrict__ n_dev, int C,
-                                                     long long rows_per_block, const float *__restrict__ sum_g,
-                                                     const float *__restrict__ sum_gx,
+                                                     long long rows_per_block, const float *__restrict__ partial,
+                                                     int nblk,
                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                      int training, int relu, T *__restrict__ dX,
                                                      float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float sSlice[2 * TB];
+    __shared__ float sA[MAXC], sB[MAXC];
     const long long N = valid_rows(Ncap, n_dev);
+    fold_partials(partial, nblk, C, sSlice, sA, sB);
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += TB) {
-            if (dbeta) dbeta[c] = sum_g[c];
-            if (dgamma) dgamma[c] = sum_gx[c];
+            if (dbeta) dbeta[c] = sA[c];
+            if (dgamma) dgamma[c] = sB[c];
         }
     }
     const int groups = C / VEC, slots = TB / groups;
@@ -276,8 +365,8 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
         is[i] = invstd[c0 + i];
         ga[i] = gamma ? gamma[c0 + i] : 1.f;
         be[i] = beta ? beta[c0 + i] : 0.f;
-        k1[i] = training ? sum_g[c0 + i] * invN : 0.f;
-        k2[i] = training ? sum_gx[c0 + i] * invN : 0.f;
+        k1[i] = training ? sA[c0 + i] * invN : 0.f;
+        k2[i] = training ? sB[c0 + i] * invN : 0.f;
     }
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     const long long r_end = r_begin + rows_per_block < N ? r_begin + rows_per_block : N;
@@ -297,23 +386,26 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
     }
 }
 
-long long bn_reduce_blocks(long long N) {      // = number of partials the fold kernel sums
+long long bn_reduce_blocks(long long N, int C) {      // = number of partials every elementwise block folds
+    int Cp = 1;
+    while (Cp < C && Cp < TB) Cp <<= 1;
+    const long long cap = (long long)FOLD_PER * (TB / Cp);      // 128 at C = 32, 16 from C = 129 on
     long long b = wfs_cdiv(N, 64);
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > cap) b = cap;
     return b;
 }
 long long bn_apply_blocks(long long N) {
     long long b = wfs_cdiv(N, 64);
     if (b < 1) b = 1;
-    if (b > 2048) b = 2048;
+    if (b > 256) b = 256;                   // one block per CU: each pays the fold prologue once
     return b;
 }
 
 }  // namespace
 
 extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
-    return ((size_t)bn_reduce_blocks(N) + 1) * 2 * C * sizeof(float);     // partials + the folded sums
+    return ((size_t)bn_reduce_blocks(N, C) + 1) * 2 * C * sizeof(float);
 }
 
 extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
@@ -328,24 +420,20 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
     WFS_REQUIRE(training || (running_mean && running_var), WFS_EINVAL, "eval mode needs running statistics");
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(X && Y && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
-    const long long nblk = bn_reduce_blocks(N), nblk_a = bn_apply_blocks(N);
+    const long long nblk = bn_reduce_blocks(N, C), nblk_a = bn_apply_blocks(N);
     WFS_REQUIRE(workspace_bytes >= wfs_bn_workspace_bytes(N, C), WFS_EWORKSPACE, "workspace too small");
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
-    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), grid_f((unsigned)wfs_cdiv(C, 32)), block(TB);
+    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
 #define WFS_BN_FWD(T, VEC)                                                                                          \
     do {                                                                                                            \
-        if (training) {                                                                                             \
+        if (training)                                                                                               \
             k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,    \
                                                                 nullptr, nullptr, nullptr, 0, partial);             \
-            k_bn_fold<T, 0><<<grid_f, dim3(FOLD_SL * 32), 0, stream>>>(partial, (int)nblk, C, (const T *)X, N, n_dev,            \
-                                                           running_mean, running_var,                               \
-                                                           (long long *)num_batches_tracked, momentum, eps,         \
-                                                           save_mean, save_invstd);                                 \
-        }                                                                                                           \
-        k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, rpb_a, gamma, beta,             \
-                                                          running_mean, running_var, eps, training, relu, (T *)Y,   \
-                                                          save_mean, save_invstd);                                  \
+        k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>(                                                           \
+            (const T *)X, N, n_dev, C, rpb_a, gamma, beta, running_mean, running_var,                               \
+            (long long *)num_batches_tracked, momentum, eps, training, relu, (T *)Y, save_mean, save_invstd,        \
+            training ? partial : nullptr, (int)nblk);                                                               \
     } while (0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_FWD(float, 4); else WFS_BN_FWD(float, 1);
@@ -353,6 +441,56 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
         if (C % 4 == 0) WFS_BN_FWD(wfs_bf16, 4); else WFS_BN_FWD(wfs_bf16, 1);
     }
 #undef WFS_BN_FWD
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long long *n_dev, const wfs_bn_stats *st,
+                        hipStream_t stream) {
+    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
+    const long long nblk = bn_reduce_blocks(N, C);
+    const long long rpb = wfs_cdiv(N, nblk);
+    float *partial = (float *)st->workspace;
+    dim3 grid((unsigned)nblk), grid_f((unsigned)wfs_cdiv(C, 32)), block(TB);
+#define WFS_BN_STATS(T, VEC)                                                                                        \
+    do {                                                                                                            \
+        k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,        \
+                                                            nullptr, nullptr, nullptr, 0, partial);                 \
+        k_bn_fold<T, 0><<<grid_f, dim3(FOLD_SL * 32), 0, stream>>>(                                                 \
+            partial, (int)nblk, C, (const T *)X, N, n_dev, st->running_mean, st->running_var,                       \
+            (long long *)st->num_batches_tracked, st->momentum, st->eps, st->save_mean, st->save_invstd);           \
+    } while (0)
+    if (dtype == WFS_F32) {
+        if (C % 4 == 0) WFS_BN_STATS(float, 4); else WFS_BN_STATS(float, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_STATS(wfs_bf16, 4); else WFS_BN_STATS(wfs_bf16, 1);
+    }
+#undef WFS_BN_STATS
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
+                                const float *save_mean, const float *save_invstd, int32_t relu, void *Y, int32_t dtype,
+                                const int64_t *n_dev_, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long *n_dev = (const long long *)n_dev_;
+    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    if (N == 0) return WFS_OK;
+    WFS_REQUIRE(X && Y && save_mean && save_invstd, WFS_EINVAL, "NULL device pointer");
+    const long long nblk_a = bn_apply_blocks(N), rpb_a = wfs_cdiv(N, nblk_a);
+    dim3 grid_a((unsigned)nblk_a), block(TB);
+    float *sm = const_cast<float *>(save_mean), *si = const_cast<float *>(save_invstd);     // only read when training = 1
+#define WFS_BN_APPLY(T, VEC)                                                                                         \
+    k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, rpb_a, gamma, beta, nullptr, nullptr, \
+                                                      nullptr, 0.f, 0.f, 1, relu, (T *)Y, sm, si, nullptr, 0)
+    if (dtype == WFS_F32) {
+        if (C % 4 == 0) WFS_BN_APPLY(float, 4); else WFS_BN_APPLY(float, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_APPLY(wfs_bf16, 4); else WFS_BN_APPLY(wfs_bf16, 1);
+    }
+#undef WFS_BN_APPLY
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
@@ -371,20 +509,17 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
         return WFS_OK;
     }
     WFS_REQUIRE(X && dY && dX && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
-    const long long nblk = bn_reduce_blocks(N), nblk_a = bn_apply_blocks(N);
+    const long long nblk = bn_reduce_blocks(N, C), nblk_a = bn_apply_blocks(N);
     WFS_REQUIRE(workspace_bytes >= wfs_bn_workspace_bytes(N, C), WFS_EWORKSPACE, "workspace too small");
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
-    float *sums = partial + (size_t)nblk * 2 * C;            // [2][C]: sum g, sum g*xhat
-    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), grid_f((unsigned)wfs_cdiv(C, 32)), block(TB);
+    dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
 #define WFS_BN_BWD(T, VEC)                                                                                          \
     do {                                                                                                            \
         k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb, save_mean,  \
                                                             save_invstd, gamma, beta, relu, partial);               \
-        k_bn_fold<T, 1><<<grid_f, dim3(FOLD_SL * 32), 0, stream>>>(partial, (int)nblk, C, nullptr, N, n_dev, nullptr, nullptr,   \
-                                                       nullptr, 0.f, 0.f, sums, sums + C);                          \
-        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb_a, sums,  \
-                                                              sums + C, save_mean, save_invstd, gamma, beta,        \
+        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb_a, partial, \
+                                                              (int)nblk, save_mean, save_invstd, gamma, beta,       \
                                                               training, relu, (T *)dX, dgamma, dbeta);              \
     } while (0)
     if (dtype == WFS_F32) {

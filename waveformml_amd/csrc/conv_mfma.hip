@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "wfs_common.h"
+#include "conv_stats.h"
 
 namespace {
 
@@ -34,14 +35,16 @@ __device__ __forceinline__ long long valid_rows(long long R, const long long *r_
 // ------------------------------------------------------------------------------------------ 32 -> 32
 // LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
 // (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
-template <bool TRANSPOSE_W>
+template <bool TRANSPOSE_W, bool STATS>
 __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                       long long R, const long long *__restrict__ r_dev,
                                                       const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                       float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
-                                                      int dbg) {
+                                                      int dbg, WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
+    __shared__ float sStat[STATS ? 16 * 65 : 1];
+    WfsColStats cst = {0.f, 0.f, 0.f};
     const int nthreads = blockDim.x;
     if (dbg & 4) {
     } else if (!TRANSPOSE_W) {
@@ -156,7 +159,15 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
             long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (orow < Rv) Y[orow * 32 + r] = acc[i];
         }
+        if constexpr (STATS) {
+            float vals[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vals[i] = acc[i];
+            const long long left = Rv - tile * 32;
+            wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
+        }
     }
+    if constexpr (STATS) wfs_stats_finish(cst, sStat, sa);
 }
 
 // ------------------------------------------------------------------------------------------ 32 -> 32, bf16
@@ -181,6 +192,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return (unsigned)a | ((unsigned)b << 16);
 }
 
+__device__ __forceinline__ float bf16_round(float v) {
+    wfs_bf16 t;
+    wfs_st(&t, v);
+    return wfs_ld(&t);
+}
+
 __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-wise: a vector select goes through scratch
     v.x = ok ? v.x : 0u;
     v.y = ok ? v.y : 0u;
@@ -189,36 +206,51 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
     return v;
 }
 
-template <bool TRANSPOSE_W>
+template <bool TRANSPOSE_W, bool STATS>
 __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
                                                        const wfs_bf16 *__restrict__ X,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                        wfs_bf16 *__restrict__ Y, long long ntiles,
-                                                       long long tiles_per_xcd) {
+                                                       long long tiles_per_xcd, WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float sStat[STATS ? 16 * 65 : 1];
+    WfsColStats cst = {0.f, 0.f, 0.f};
     uint4 *sWb = reinterpret_cast<uint4 *>(smem);                           // K * 128 fragments of 16 B
     int *sNb = reinterpret_cast<int *>(smem + (size_t)K * 2048);            // [waves][K][32]
     const int nthreads = blockDim.x;
-    for (int u = threadIdx.x; u < K * 128; u += nthreads) {
-        int k = u >> 7, s = (u >> 6) & 1, h = (u >> 5) & 1, col = u & 31;
-        int c0 = 16 * h + 8 * s;
-        float w[8];
-        if (!TRANSPOSE_W) {
+    // filter staging, WSB fragments per thread at a time: all their loads are issued (unconditionally, clamped)
+    // before the first conversion, so a block pays one memory round trip per batch instead of one per fragment
+    constexpr int WSB = 5;
+    const int nfrag = K * 128;
+    for (int u0 = threadIdx.x; u0 < nfrag; u0 += nthreads * WSB) {
+        float w[WSB][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = W[((long long)k * 32 + c0 + j) * 32 + col];
-        } else {
-            const f32x4 *src = (const f32x4 *)(W + ((long long)k * 32 + col) * 32 + c0);
-            f32x4 lo = src[0], hi = src[1];
-            w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
-            w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+        for (int b = 0; b < WSB; ++b) {
+            int u = u0 + b * nthreads;
+            u = u < nfrag ? u : nfrag - 1;
+            int k = u >> 7, s = (u >> 6) & 1, h = (u >> 5) & 1, col = u & 31;
+            int c0 = 16 * h + 8 * s;
+            if (!TRANSPOSE_W) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[b][j] = W[((long long)k * 32 + c0 + j) * 32 + col];
+            } else {
+                const f32x4 *src = (const f32x4 *)(W + ((long long)k * 32 + col) * 32 + c0);
+                f32x4 lo = src[0], hi = src[1];
+                w[b][0] = lo.x; w[b][1] = lo.y; w[b][2] = lo.z; w[b][3] = lo.w;
+                w[b][4] = hi.x; w[b][5] = hi.y; w[b][6] = hi.z; w[b][7] = hi.w;
+            }
         }
-        uint4 v;
-        v.x = pack_bf16x2(w[0], w[1]);
-        v.y = pack_bf16x2(w[2], w[3]);
-        v.z = pack_bf16x2(w[4], w[5]);
-        v.w = pack_bf16x2(w[6], w[7]);
-        sWb[u] = v;
+#pragma unroll
+        for (int b = 0; b < WSB; ++b) {
+            int u = u0 + b * nthreads;
+            uint4 v;
+            v.x = pack_bf16x2(w[b][0], w[b][1]);
+            v.y = pack_bf16x2(w[b][2], w[b][3]);
+            v.z = pack_bf16x2(w[b][4], w[b][5]);
+            v.w = pack_bf16x2(w[b][6], w[b][7]);
+            if (u < nfrag) sWb[u] = v;
+        }
     }
     __syncthreads();
 
@@ -299,7 +331,15 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
             long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
             if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
         }
+        if constexpr (STATS) {
+            float vals[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vals[i] = bf16_round(acc[i]);      // statistics of the values as stored
+            const long long left = Rv - tile * 32;
+            wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
+        }
     }
+    if constexpr (STATS) wfs_stats_finish(cst, sStat, sa);
 }
 
 // ------------------------------------------------------------------------------------------ 2 -> 32
@@ -445,13 +485,17 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
 // (2 bf16 channels each) of offsets 8s + 4h + {0,1,2,3} of row r -- read straight from global memory, no LDS, no
 // transpose; all 16 table entries of a lane are loaded together, then all 16 gathers.  The filter image
 // sWc[s][h][co][j] = W[k = 8s + 4h + j/2][c = j & 1][co] (zero for k >= K) is 4 KiB.
+template <bool STATS>
 __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict__ table, int mirror, int K,
                                                          int identity_k, long long R,
                                                          const long long *__restrict__ r_dev,
                                                          const wfs_bf16 *__restrict__ X, const float *__restrict__ W,
-                                                         const float *__restrict__ bias, wfs_bf16 *__restrict__ Y) {
+                                                         const float *__restrict__ bias, wfs_bf16 *__restrict__ Y,
+                                                         WfsStatsArgs sa) {
     __shared__ __attribute__((aligned(16))) uint4 sWc[4 * 2 * 32];
-    {
+    __shared__ float sStat[STATS ? 16 * 65 : 1];
+    WfsColStats cst = {0.f, 0.f, 0.f};
+    if (threadIdx.x < 256) {
         const int u = threadIdx.x;                 // 256 threads = 4 steps x 2 halves x 32 output channels
         const int st = u >> 6, hh = (u >> 5) & 1, co = u & 31;
         float w[8];
@@ -474,7 +518,8 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
     const long long ntiles = (Rv + 31) >> 5;
     const float bj = bias ? bias[r] : 0.f;
     const unsigned *Xw = reinterpret_cast<const unsigned *>(X);
-    for (long long tile = (long long)blockIdx.x * 4 + wid; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const int nw = blockDim.x >> 6;
+    for (long long tile = (long long)blockIdx.x * nw + wid; tile < ntiles; tile += (long long)gridDim.x * nw) {
         const long long row = tile * 32 + r;
         const bool live = row < Rv;
         const long long rowc = live ? row : 0;
@@ -515,7 +560,15 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
             long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
             if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
         }
+        if constexpr (STATS) {
+            float vals[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vals[i] = bf16_round(acc[i]);
+            const long long left = Rv - tile * 32;
+            wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
+        }
     }
+    if constexpr (STATS) wfs_stats_finish(cst, sStat, sa);
 }
 
 // ------------------------------------------------------------------------------------------ dW 32 x 32, bf16
@@ -819,74 +872,121 @@ __global__ void __launch_bounds__(256) k_slab_reduce(const float *__restrict__ p
     }
 }
 
-bool g_attr_done[2] = {false, false};
 
 }  // namespace
 
 // ---- launchers used by gather_conv.hip's C entry points -------------------------------------------------
 bool wfs_mfma_gconv32_ok(int K) { return K >= 1 && K <= 32; }       // K * 4 KiB of LDS <= 128 KiB
 
+template <typename KernelT, typename... Args>
+static int launch_big_lds(KernelT kernel, bool *attr_done, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                          Args... args) {
+    if (!*attr_done) {
+        // 160 KiB per CU minus the kernels' static LDS (statistics scratch of the STATS variants)
+        WFS_HIP_CHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        *attr_done = true;
+    }
+    kernel<<<grid, block, lds, stream>>>(args...);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+// grid of the two 32 -> 32 kernels: <= 256 persistent blocks (multiple of 8: one slice of the row range per XCD)
+static void gconv32_grid(long long R, long long *ntiles, int *wpb, long long *nblk, long long *tiles_per_xcd) {
+    *ntiles = (R + 31) >> 5;
+    // waves per block: enough tiles per SIMD without leaving CUs idle on small inputs
+    int w = (int)((*ntiles + 255) / 256);
+    w = w < 4 ? 4 : (w > 16 ? 16 : (w + 3) / 4 * 4);
+    long long nb = (*ntiles + w - 1) / w;
+    if (nb > 256) nb = 256;
+    nb = (nb + 7) / 8 * 8;
+    *wpb = w;
+    *nblk = nb;
+    *tiles_per_xcd = (*ntiles + 7) / 8;
+}
+
+// block partials of the fused BatchNorm statistics: (mean, M2)[32] + count per block
+size_t wfs_conv_stats_fast_workspace(long long R) {
+    long long blocks = ((R + 31) / 32 + 3) / 4;       // the 2 -> 32 kernel launches the most blocks
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 256) blocks = 256;
+    return (size_t)blocks * 65 * sizeof(float);
+}
+
+static int stats_fold(const WfsStatsArgs &sa, long long nblk, hipStream_t stream) {
+    k_stats_fold<<<dim3(1), dim3(1024), 0, stream>>>(sa, (int)nblk);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+static WfsStatsArgs stats_args(const wfs_bn_stats *st, long long nblk) {
+    WfsStatsArgs sa = {};
+    if (st) {
+        sa.part = (float *)st->workspace;
+        sa.partn = sa.part + (size_t)nblk * 64;
+        sa.save_mean = st->save_mean;
+        sa.save_invstd = st->save_invstd;
+        sa.running_mean = st->running_mean;
+        sa.running_var = st->running_var;
+        sa.batches_tracked = (long long *)st->num_batches_tracked;
+        sa.momentum = st->momentum;
+        sa.eps = st->eps;
+    }
+    return sa;
+}
+
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           hipStream_t stream) {
-    const long long ntiles = (R + 31) >> 5;
-    // waves per block: enough tiles per SIMD without leaving CUs idle on small inputs
-    int wpb = (int)((ntiles + 255) / 256);
-    wpb = wpb < 4 ? 4 : (wpb > 16 ? 16 : (wpb + 3) / 4 * 4);
-    long long nblk = (ntiles + wpb - 1) / wpb;
-    if (nblk > 256) nblk = 256;
-    nblk = (nblk + 7) / 8 * 8;
-    const long long tiles_per_xcd = (ntiles + 7) / 8;
+                           const wfs_bn_stats *stats, hipStream_t stream) {
+    long long ntiles, nblk, tiles_per_xcd;
+    int wpb;
+    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
     const size_t lds = (size_t)K * 4096;
     static int dbg = -1;
     if (dbg < 0) dbg = getenv("WFS_DBG") ? atoi(getenv("WFS_DBG")) : 0;
-    const int which = transpose_w ? 1 : 0;
-    if (!g_attr_done[which]) {
-        const void *fn = transpose_w ? (const void *)k_gconv32_f32<true> : (const void *)k_gconv32_f32<false>;
-        WFS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attr_done[which] = true;
-    }
+    static bool attr[3] = {false, false, false};
+    const WfsStatsArgs sa = stats_args(stats, nblk);
+    const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
-        k_gconv32_f32<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
-            table, mirror, K, identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg);
-    else
-        k_gconv32_f32<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
-            table, mirror, K, identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg);
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
+        return launch_big_lds(k_gconv32_f32<true, false>, &attr[0], grid, block, lds, stream, table, mirror, K, identity_k,
+                              R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg, sa);
+    if (stats) {
+        int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
+                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg, sa);
+        return rc != WFS_OK ? rc : stats_fold(sa, nblk, stream);
+    }
+    return launch_big_lds(k_gconv32_f32<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K, identity_k, R,
+                          r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg, sa);
 }
 
 int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                             const void *X, const float *W, int transpose_w, const float *bias, void *Y,
-                            hipStream_t stream) {
-    static bool attr[2] = {false, false};
-    const long long ntiles = (R + 31) >> 5;
-    int wpb = (int)((ntiles + 255) / 256);
-    wpb = wpb < 4 ? 4 : (wpb > 16 ? 16 : (wpb + 3) / 4 * 4);
-    long long nblk = (ntiles + wpb - 1) / wpb;
-    if (nblk > 256) nblk = 256;
-    nblk = (nblk + 7) / 8 * 8;
-    const long long tiles_per_xcd = (ntiles + 7) / 8;
+                            const wfs_bn_stats *stats, hipStream_t stream) {
+    long long ntiles, nblk, tiles_per_xcd;
+    int wpb;
+    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
     const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
-    const int which = transpose_w ? 1 : 0;
-    if (!attr[which]) {
-        const void *fn = transpose_w ? (const void *)k_gconv32_bf16<true> : (const void *)k_gconv32_bf16<false>;
-        WFS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr[which] = true;
-    }
+    static bool attr[3] = {false, false, false};
+    const WfsStatsArgs sa = stats_args(stats, nblk);
+    const dim3 grid((unsigned)nblk), block(wpb * 64);
+    const wfs_bf16 *Xb = (const wfs_bf16 *)X;
+    wfs_bf16 *Yb = (wfs_bf16 *)Y;
     if (transpose_w)
-        k_gconv32_bf16<true><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
-            table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
-    else
-        k_gconv32_bf16<false><<<dim3((unsigned)nblk), dim3(wpb * 64), lds, stream>>>(
-            table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, ntiles, tiles_per_xcd);
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
+        return launch_big_lds(k_gconv32_bf16<true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+    if (stats) {
+        int rc = launch_big_lds(k_gconv32_bf16<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
+                                identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+        return rc != WFS_OK ? rc : stats_fold(sa, nblk, stream);
+    }
+    return launch_big_lds(k_gconv32_bf16<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K, identity_k,
+                          R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
 }
 
+// 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
-                           hipStream_t stream) {
+                           const wfs_bn_stats *stats, bool *stats_done, hipStream_t stream) {
     KMap km;
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K; ++k) {
@@ -894,11 +994,22 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
         is_ident = is_ident && km.v[k] == k;
         is_mirror = is_mirror && km.v[k] == K - 1 - k;
     }
+    if (stats_done) *stats_done = false;
     if (dtype == WFS_BF16 && K <= 32 && (is_ident || is_mirror)) {
         long long nb = ((R + 31) / 32 + 3) / 4;
         if (nb > 4096) nb = 4096;
-        k_gconv_c2c32_bf16<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(table, is_ident ? 0 : 1, K, identity_k, R, r_dev,
-                                                                        (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y);
+        if (stats && nb > 1024) nb = 1024;          // one partial per block for k_stats_fold
+        const WfsStatsArgs sa = stats_args(stats, nb);
+        if (stats) {
+            k_gconv_c2c32_bf16<true><<<dim3((unsigned)nb), dim3(256), 0, stream>>>(
+                table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, sa);
+            WFS_LAUNCH_CHECK();
+            if (stats_done) *stats_done = true;
+            return stats_fold(sa, nb, stream);
+        } else {
+            k_gconv_c2c32_bf16<false><<<dim3((unsigned)nb), dim3(256), 0, stream>>>(
+                table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, sa);
+        }
         WFS_LAUNCH_CHECK();
         return WFS_OK;
     }

@@ -203,11 +203,12 @@ long long dw_chunks(long long R) {
 
 }  // namespace
 
-extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
-                               int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
-                               int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
-                               const int64_t *r_dev_, void *stream_) {
+static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                            int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
+                            int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
+                            const int64_t *r_dev_, const wfs_bn_stats *stats, bool *stats_done, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    *stats_done = false;
     const long long *r_dev = (const long long *)r_dev_;
     (void)X_rows;
     WFS_REQUIRE(K >= 1 && K <= 128, WFS_EINVAL, "kernel volume %d not in [1,128]", K);
@@ -229,14 +230,19 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
         is_ident = is_ident && km.v[k] == k;
         is_mirror = is_mirror && km.v[k] == K - 1 - k;
     }
-    if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror))
+    if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror)) {
+        *stats_done = stats != nullptr;
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
-                                      bias, (float *)Y, stream);
-    if (dtype == WFS_BF16 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror))
+                                      bias, (float *)Y, stats, stream);
+    }
+    if (dtype == WFS_BF16 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror)) {
+        *stats_done = stats != nullptr;
         return wfs_launch_gconv32_bf16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
-                                       stream);
+                                       stats, stream);
+    }
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
-        return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stream);
+        return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stats, stats_done,
+                                      stream);
     dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
 #define WFS_GC(T, TR)                                                                                           \
     k_gather_conv<T, TR><<<grid, block, 0, stream>>>(table, km, K, identity_k, R, r_dev, (const T *)X, Cx, W,  \
@@ -249,6 +255,38 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
 #undef WFS_GC
     WFS_LAUNCH_CHECK();
     return WFS_OK;
+}
+
+extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                               int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
+                               int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
+                               const int64_t *r_dev, void *stream) {
+    bool unused;
+    return gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, transpose_w, bias, Y,
+                            dtype, r_dev, nullptr, &unused, stream);
+}
+
+extern "C" size_t wfs_conv_stats_workspace_bytes(int64_t R, int32_t C) {
+    size_t fused = wfs_conv_stats_fast_workspace(R), plain = wfs_bn_workspace_bytes(R, C);
+    return fused > plain ? fused : plain;
+}
+
+extern "C" int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                                       int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
+                                       int32_t Cw_in, int32_t Cw_out, const float *bias, void *Y, int32_t dtype,
+                                       const int64_t *r_dev, const wfs_bn_stats *stats, void *stream) {
+    WFS_REQUIRE(stats && stats->save_mean && stats->save_invstd && stats->workspace, WFS_EINVAL,
+                "incomplete wfs_bn_stats");
+    WFS_REQUIRE((stats->running_mean == nullptr) == (stats->running_var == nullptr), WFS_EINVAL,
+                "running_mean and running_var come together");
+    WFS_REQUIRE(stats->workspace_bytes >= wfs_conv_stats_workspace_bytes(R, Cw_out), WFS_EWORKSPACE,
+                "statistics workspace %zu < %zu", stats->workspace_bytes, wfs_conv_stats_workspace_bytes(R, Cw_out));
+    WFS_REQUIRE(R > 0, WFS_EINVAL, "batch statistics of zero rows");
+    bool done = false;
+    int rc = gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, 0, bias, Y, dtype, r_dev,
+                              stats, &done, stream);
+    if (rc != WFS_OK || done) return rc;
+    return wfs_launch_bn_stats(Y, R, Cw_out, dtype, (const long long *)r_dev, stats, (hipStream_t)stream);
 }
 
 extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X,

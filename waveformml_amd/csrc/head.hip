@@ -139,6 +139,58 @@ int head_chunks(long long B) {
     long long c = (B + 31) / 32;
     return (int)(c < 1 ? 1 : (c > 16 ? 16 : c));
 }
+// CrossEntropyLoss(reduction='mean'), forward and the gradient w.r.t. the logits in ONE block: pass 1 gives every
+// row's  lse - z[target]  (max-shifted log-sum-exp) and the number of counted rows, a fixed-order tree reduction gives
+// the mean, pass 2 writes (softmax - onehot) / count.  Rows whose target equals ignore_index count for nothing.
+constexpr int XE_TB = 1024;
+__global__ void __launch_bounds__(XE_TB) k_xent_mean(const float *__restrict__ Z, const long long *__restrict__ target,
+                                                     long long B, int C, long long ignore_index,
+                                                     float *__restrict__ loss, float *__restrict__ dZ) {
+    __shared__ float sL[XE_TB];
+    __shared__ float sN[XE_TB];
+    float l = 0.f, n = 0.f;
+    for (long long b = threadIdx.x; b < B; b += XE_TB) {
+        const long long t = target[b];
+        if (t == ignore_index || t < 0 || t >= C) continue;
+        const float *z = Z + b * C;
+        float m = z[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - m);
+        l += (m + logf(se)) - z[t];
+        n += 1.f;
+    }
+    sL[threadIdx.x] = l;
+    sN[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = XE_TB / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sL[threadIdx.x] += sL[threadIdx.x + w];
+            sN[threadIdx.x] += sN[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    const float cnt = sN[0];
+    if (threadIdx.x == 0) *loss = sL[0] / cnt;              // 0/0 = NaN when every row is ignored, as torch
+    if (!dZ) return;
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    for (long long b = threadIdx.x; b < B; b += XE_TB) {
+        const long long t = target[b];
+        const float *z = Z + b * C;
+        float *d = dZ + b * C;
+        if (t == ignore_index || t < 0 || t >= C) {
+            for (int c = 0; c < C; ++c) d[c] = 0.f;
+            continue;
+        }
+        float m = z[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - m);
+        const float r = inv / se;
+        for (int c = 0; c < C; ++c) d[c] = expf(z[c] - m) * r - (c == t ? inv : 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O) {
@@ -210,5 +262,15 @@ extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I,
         k_head_dw_reduce<<<dim3((unsigned)wfs_cdiv(OI, TB)), dim3(TB), 0, stream>>>(part, nchunk, OI, dW);
         WFS_LAUNCH_CHECK();
     }
+    return WFS_OK;
+}
+
+extern "C" int wfs_xent_mean_fwd_bwd(const float *logits, const int64_t *target, int64_t B, int32_t C,
+                                     int64_t ignore_index, float *loss, float *dlogits, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(B >= 1 && C >= 1 && C <= 4096, WFS_EINVAL, "bad logits shape [%lld, %d]", (long long)B, C);
+    WFS_REQUIRE(logits && target && loss, WFS_EINVAL, "NULL device pointer");
+    k_xent_mean<<<dim3(1), dim3(XE_TB), 0, stream>>>(logits, (const long long *)target, B, C, ignore_index, loss, dlogits);
+    WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

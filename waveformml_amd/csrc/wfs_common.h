@@ -56,15 +56,20 @@ struct WfsTimerScope {
 
 // shape-specialised launchers (conv_mfma.hip); r_dev: optional device-side count of valid rows (<= R)
 bool wfs_mfma_gconv32_ok(int K);
+// stats (optional): BatchNorm statistics taken in the epilogue (conv_stats.h); forward products only
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           hipStream_t stream);
+                           const wfs_bn_stats *stats, hipStream_t stream);
 int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                             const void *X, const float *W, int transpose_w, const float *bias, void *Y,
-                            hipStream_t stream);
+                            const wfs_bn_stats *stats, hipStream_t stream);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
-                           hipStream_t stream);
+                           const wfs_bn_stats *stats, bool *stats_done, hipStream_t stream);
+size_t wfs_conv_stats_fast_workspace(long long R);
+// bn.hip: the stand-alone statistics pass (reduce + fold) over X [N, C]
+int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long long *n_dev, const wfs_bn_stats *stats,
+                        hipStream_t stream);
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg);
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
                      const void *G, int swap, float *dW, float *part, int dtype, hipStream_t stream);

@@ -47,6 +47,8 @@ class FlatGradAllReducer(object):
             self.flat_param = torch.nn.Parameter(flat)
             self.flat_param.grad = self.flat_grad
         # contiguous buckets of roughly equal size over that order
+        if self.world <= 1:
+            n_buckets = 1              # nothing to overlap: pack with one concatenation
         n_buckets = max(1, min(n_buckets, len(self.params)))
         target = total / n_buckets
         self.buckets = []          # (start, end, [param indices in flat order])

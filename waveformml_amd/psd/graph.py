@@ -97,6 +97,8 @@ class GraphedTrainStep(object):
         if torch.cuda.current_stream(self.coords.device) == torch.cuda.default_stream(self.coords.device):
             torch.cuda.set_stream(self.stream)         # see "Stream discipline" in __init__
         self._load(batch)
+        if hasattr(self.optimizer, "sync_hyperparameters"):
+            self.optimizer.sync_hyperparameters()      # a scheduler's new lr reaches the captured update
         self.graph.replay()
         if not self.in_graph_optimizer:
             self._after()

@@ -56,8 +56,29 @@ def _masked_column_sum(t, r_dev):
     return torch.where(valid, t.float(), torch.zeros((), device=t.device)).sum(0)
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None):
-    """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w)."""
+class BatchNormRequest(object):
+    """Hand-over between a convolution and the training-mode nn.BatchNorm1d that follows it in a SparseSequential:
+    the conv kernel's epilogue takes the batch statistics (include/wfsparse.h, wfs_gather_conv_bnstats), the
+    BatchNorm step then only normalises.  ``stats`` is filled by the convolution that honoured the request."""
+
+    def __init__(self, bn):
+        self.bn = bn
+        self.stats = None          # (save_mean, save_invstd)
+
+
+def can_take_batch_norm_stats(bn, features):
+    """A conv can take the statistics for ``bn`` when the fused BatchNorm kernels would run it anyway
+    (can_fuse_batch_norm) and it normalises with batch statistics."""
+    return (type(bn) is torch.nn.BatchNorm1d and bn.momentum is not None and features.is_cuda
+            and features.dtype in (torch.float32, torch.bfloat16) and features.shape[0] > 0
+            and (bn.num_features <= 256 or (bn.num_features % 4 == 0 and bn.num_features <= 1024))
+            and (bn.weight is None or bn.weight.dtype == torch.float32)
+            and (bn.training or bn.running_mean is None))
+
+
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None):
+    """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
+    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
     Cy = Cw_in if transpose_w else Cw_out
@@ -66,9 +87,25 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
-    _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
-                                   _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
-                                   _lib.dtype_code(X), _lib.ptr(r_dev), _lib.stream_ptr()))
+    if bn_request is not None and not transpose_w and R > 0 and bn_request.bn.num_features == Cy:
+        bn = bn_request.bn
+        track = bn.track_running_stats and bn.running_mean is not None
+        save_mean = torch.empty((Cy,), dtype=torch.float32, device=X.device)
+        save_invstd = torch.empty((Cy,), dtype=torch.float32, device=X.device)
+        ws = torch.empty((int(lib.wfs_conv_stats_workspace_bytes(R, Cy)),), dtype=torch.uint8, device=X.device)
+        st = _lib.BnStats(_lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(bn.running_mean) if track else None,
+                          _lib.ptr(bn.running_var) if track else None,
+                          _lib.ptr(bn.num_batches_tracked) if (track and bn.training) else None,
+                          float(bn.momentum), float(bn.eps), _lib.ptr(ws), ws.numel())
+        _lib.check(lib.wfs_gather_conv_bnstats(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0],
+                                               X.shape[1], _lib.ptr(W), Cw_in, Cw_out, _lib.ptr(bias), _lib.ptr(Y),
+                                               _lib.dtype_code(X), _lib.ptr(r_dev), ctypes.byref(st),
+                                               _lib.stream_ptr()))
+        bn_request.stats = (save_mean, save_invstd)
+    else:
+        _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
+                                       _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias),
+                                       _lib.ptr(Y), _lib.dtype_code(X), _lib.ptr(r_dev), _lib.stream_ptr()))
     _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
     return Y
 
@@ -141,7 +178,7 @@ class SparseConvFunction(Function):
     """features [n_in, Cin], filters [*k, Cin, Cout] fp32, bias [Cout] or None -> [n_out, Cout]."""
 
     @staticmethod
-    def forward(ctx, features, filters, bias, rulebook, mode):
+    def forward(ctx, features, filters, bias, rulebook, mode, bn_request=None):
         rb = rulebook
         features = _features_ok(features)
         K = rb.K
@@ -150,13 +187,13 @@ class SparseConvFunction(Function):
         ident = rb.centre_k if rb.subm else -1
         if mode == INVERSE:
             assert features.shape[0] == rb.M, "inverse conv input must be the coupled conv's output set"
-            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b, rb.n_dev)
+            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b, rb.n_dev, bn_request)
         elif rb.has_dup:
             out = scatter_conv(rb.nbr_out, K, ident, rb.N, features, W, False, rb.M, b)
         else:
             assert features.shape[0] == rb.N
             table, kmap = rb.table_by_out()
-            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev)
+            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev, bn_request)
         ctx.save_for_backward(features, filters, bias)
         ctx.rb, ctx.mode = rb, mode
         return out
@@ -198,7 +235,7 @@ class SparseConvFunction(Function):
         if bias is not None and ctx.needs_input_grad[2]:
             # dY has one row per OUTPUT of this product: rb.N rows for an inverse conv, rb.M otherwise
             db = _masked_column_sum(dY, rb.n_dev if mode == INVERSE else rb.m_dev).to(bias.dtype)
-        return dX, dW, db, None, None
+        return dX, dW, db, None, None, None
 
 
 class ToDenseFunction(Function):
@@ -246,16 +283,27 @@ class BatchNormReLUFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, n_dev=None,
-                batches_tracked=None):
+                batches_tracked=None, stats=None):
         lib = _lib.load()
         x = _features_ok(x)
         N, C = x.shape
         y = _rows(tuple(x.shape), x, n_dev)
+        for t in (weight, bias, running_mean, running_var):
+            assert t is None or (t.dtype == torch.float32 and t.numel() == C and t.is_contiguous())
+        if stats is not None:
+            # the producing convolution took the statistics (and updated the running ones): normalise only
+            assert training
+            save_mean, save_invstd = stats
+            _lib.check(lib.wfs_bn_apply_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(save_mean),
+                                            _lib.ptr(save_invstd), 1 if relu else 0, _lib.ptr(y), _lib.dtype_code(x),
+                                            _lib.ptr(n_dev), _lib.stream_ptr()))
+            ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
+            ctx.flags = (True, bool(relu))
+            ctx.n_dev = n_dev
+            return y
         save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
-        for t in (weight, bias, running_mean, running_var):
-            assert t is None or (t.dtype == torch.float32 and t.numel() == C and t.is_contiguous())
         _lib.check(lib.wfs_bn_relu_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
                                        _lib.ptr(running_var), _lib.ptr(batches_tracked) if training else None,
                                        float(momentum), float(eps), 1 if training else 0,
@@ -284,17 +332,18 @@ class BatchNormReLUFunction(Function):
                                        _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
                                        1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
                                        ws.numel(), _lib.dtype_code(x), _lib.ptr(ctx.n_dev), _lib.stream_ptr()))
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm_relu(features, bn, relu, n_dev=None):
+def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
     """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features
-    (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts")."""
+    (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts";
+    ``stats``: (save_mean, save_invstd) already taken by the producing convolution)."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # bumped by the kernel
     return BatchNormReLUFunction.apply(features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps,
-                                       training, relu, n_dev, tracked)
+                                       training, relu, n_dev, tracked, stats)
 
 
 def can_fuse_batch_norm(bn, features):
@@ -353,13 +402,46 @@ def skinny_linear(x, linear):
     return SkinnyLinearFunction.apply(x, linear.weight, linear.bias)
 
 
-def indice_conv(features, filters, bias, rulebook):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV)
+class CrossEntropyMeanFunction(Function):
+    """nn.CrossEntropyLoss(reduction='mean') on [B, C] fp32 logits: loss and d loss / d logits from one launch
+    (reference criterion: src/engineering/LitBase.py:38-43, applied at LitPSD.py:102)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        lib = _lib.load()
+        logits = _features_ok(logits)
+        target = target.contiguous()
+        B, C = logits.shape
+        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        _lib.check(lib.wfs_xent_mean_fwd_bwd(_lib.ptr(logits), _lib.ptr(target), B, C, int(ignore_index),
+                                             _lib.ptr(loss), _lib.ptr(dlogits), _lib.stream_ptr()))
+        ctx.dlogits = dlogits
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return ctx.dlogits * grad_output, None, None
 
 
-def indice_subm_conv(features, filters, bias, rulebook):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM)
+def can_fuse_cross_entropy(criterion, logits, target):
+    return (type(criterion) is torch.nn.CrossEntropyLoss and criterion.reduction == "mean" and criterion.weight is None
+            and getattr(criterion, "label_smoothing", 0.0) == 0.0 and logits.is_cuda and logits.dim() == 2
+            and logits.dtype == torch.float32 and target.dtype == torch.int64 and target.dim() == 1
+            and logits.shape[0] >= 1 and logits.shape[1] <= 4096)
 
 
-def indice_inverse_conv(features, filters, bias, rulebook):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE)
+def cross_entropy_mean(logits, target, ignore_index=-100):
+    return CrossEntropyMeanFunction.apply(logits, target, ignore_index)
+
+
+def indice_conv(features, filters, bias, rulebook, bn_request=None):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request)
+
+
+def indice_subm_conv(features, filters, bias, rulebook, bn_request=None):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request)
+
+
+def indice_inverse_conv(features, filters, bias, rulebook, bn_request=None):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE, bn_request)

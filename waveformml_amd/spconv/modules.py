@@ -101,6 +101,12 @@ class SparseSequential(SparseModule):
         while i < len(mods):
             module = mods[i]
             if isinstance(module, SparseModule):
+                if (ops.FUSE_CONV_BN_STATS and _is_sparse_tensor(input) and i + 1 < len(mods)
+                        and isinstance(mods[i + 1], nn.BatchNorm1d)
+                        and getattr(module, "weight", None) is not None
+                        and Fsp.can_take_batch_norm_stats(mods[i + 1], input.features)):
+                    # conv -> BatchNorm1d (training): the conv's epilogue takes the batch statistics
+                    input.bn_request = Fsp.BatchNormRequest(mods[i + 1])
                 input = module(input)
                 if want_prefetch and _is_sparse_tensor(input):
                     # the first layer has built its own rulebook and launched its conv on this stream; the
@@ -112,7 +118,10 @@ class SparseSequential(SparseModule):
                     if isinstance(module, nn.BatchNorm1d) and Fsp.can_fuse_batch_norm(module, input.features):
                         # BatchNorm1d [+ ReLU] over the active rows: one fused pair of HIP launches
                         relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                        input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid)
+                        req = getattr(input, "bn_stats", None)
+                        stats = req.stats if (req is not None and req.bn is module) else None
+                        input.bn_stats = None
+                        input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats)
                         if relu:
                             i += 1
                     else:

@@ -7,6 +7,8 @@ materialises spconv's ``indice_pairs`` encoding only when somebody asks for it.
 """
 import ctypes
 
+import os
+
 import numpy as np
 import torch
 
@@ -30,6 +32,13 @@ ASSUME_VALID_UNIQUE_INDICES = False
 #                       when the backward pass ends).
 PREFETCH_RULEBOOKS = False
 OVERLAP_DW = False
+
+# conv -> nn.BatchNorm1d (training) inside SparseSequential: the conv kernel's epilogue can take the batch statistics
+# (functional.BatchNormRequest; include/wfsparse.h wfs_gather_conv_bnstats), which saves BatchNorm's read of the conv
+# output.  Same results either way.  OFF by default: at the PSD batch sizes (256 events, ~10^5 voxels) the epilogue
+# costs the latency-bound conv kernel more (+4 us) than the 6 us reduction launch it replaces saves once the fold
+# launch is counted (measured: 0.834 vs 0.814 ms/step, profiles/r01_e_*); it pays when the rows no longer fit the L2s.
+FUSE_CONV_BN_STATS = os.environ.get("WFS_FUSE_CONV_BN_STATS", "0") != "0"
 
 _SIDE_STREAMS = {}
 
