@@ -220,22 +220,17 @@ __global__ void __launch_bounds__(TB) k_conv_insert2(Geo g, int batch, const int
     nbr_out[(long long)k * N + j] = slot;
 }
 
-// rowmask[j] bit k = candidate (j, k) holds the first ticket of its site (rowmask zeroed by the caller)
-__global__ void __launch_bounds__(TB) k_conv_first2(int K, long long N, const long long *n_dev,
-                                                    const int *__restrict__ nbr_out,
-                                                    const unsigned *__restrict__ ticket,
-                                                    unsigned *__restrict__ rowmask) {
-    const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    if (k >= K || j >= valid_rows(N, n_dev)) return;
-    int s = nbr_out[(long long)k * N + j];
-    if (s >= 0 && ticket[s] == (unsigned)(j * K + k)) atomicOr(&rowmask[j], 1u << k);
-}
-
 __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const long long *n_dev, long long M_cap,
                                                      const int *__restrict__ nbr_out, const unsigned *__restrict__ rowmask,
                                                      const int *__restrict__ rowbase, Table t, int *__restrict__ slot_id,
-                                                     int *__restrict__ out_indices, long long *info) {
+                                                     int *__restrict__ out_indices, long long *info,
+                                                     int *__restrict__ nbr_in_fill, long long n_fill) {
+    // nbr_in = -1 everywhere, for the atomicMax of k_conv_finalize2 (the NEXT launch): saves a memset launch
+    if (nbr_in_fill) {
+        const long long nthreads = (long long)gridDim.x * gridDim.y * TB;
+        for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * TB + threadIdx.x; i < n_fill; i += nthreads)
+            nbr_in_fill[i] = -1;
+    }
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     if (k >= g.K || j >= valid_rows(N, n_dev)) return;
@@ -451,6 +446,69 @@ __global__ void k_scan_apply(const int *in, long long n, const long long *n_dev,
     }
 }
 
+// ---------------------------------------------------------------- fewer, fatter launches for the K <= 32 path
+// At the PSD batch sizes a launch costs ~5 us whatever it does, and the strided layers' rulebook chain sits on the
+// critical path of the step (their builds run beside the first layers on a side stream and must be done when those
+// are): ten launches per rulebook became six.
+
+// workspace initialisation in one launch: info[0..3] = 0, `ones` region (hash keys, values / tickets) = 0xFF
+__global__ void __launch_bounds__(TB) k_ws_init(long long *__restrict__ info, uint4 *__restrict__ ones, long long n16) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) info[threadIdx.x] = 0;
+    const uint4 v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n16; i += (long long)gridDim.x * TB) ones[i] = v;
+}
+
+// row-parallel: rowmask[j] bit k = candidate (j, k) holds the first ticket of its site; bsum[block] = number of
+// first tickets of the block's TB rows (= output sites they introduce).  No atomics, rowmask needs no clearing.
+__global__ void __launch_bounds__(TB) k_conv_first_bsum(int K, long long N, const long long *n_dev,
+                                                        const int *__restrict__ nbr_out,
+                                                        const unsigned *__restrict__ ticket,
+                                                        unsigned *__restrict__ rowmask, int *__restrict__ bsum) {
+    const long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    const long long nv = valid_rows(N, n_dev);
+    const bool live = j < nv;
+    const long long jc = live ? j : 0;
+    int s[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s[k] = nbr_out[(long long)(k < K ? k : K - 1) * N + jc];
+    unsigned t[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t[k] = ticket[s[k] >= 0 ? s[k] : 0];
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        if (k < K && live && s[k] >= 0 && t[k] == (unsigned)(j * K + k)) m |= 1u << k;
+    if (j < N) rowmask[j] = m;
+    int tot;
+    block_excl_scan(__popc(m), &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// rowbase[j] = number of output sites introduced by rows < j (exclusive scan of popc(rowmask)): every block adds up
+// the block sums in front of it (<= a few hundred ints) instead of waiting for a separate top-level scan launch; the
+// last block publishes the totals: *total = M, *total2 = min(M, cap) = the row count downstream kernels bound by.
+__global__ void __launch_bounds__(TB) k_conv_rowbase(long long N, const unsigned *__restrict__ rowmask,
+                                                     const int *__restrict__ bsum, int *__restrict__ rowbase,
+                                                     long long *total, long long *total2, long long cap) {
+    __shared__ int sPre;
+    int acc = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += TB) acc += bsum[i];
+    int pre;
+    block_excl_scan(acc, &pre);
+    if (threadIdx.x == 0) sPre = pre;
+    __syncthreads();
+    const long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    const int v = j < N ? __popc(rowmask[j]) : 0;           // rows beyond the valid count hold an empty mask
+    int tot;
+    const int ex = block_excl_scan(v, &tot);
+    if (j < N) rowbase[j] = sPre + ex;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const long long M = (long long)sPre + tot;
+        *total = M;
+        if (total2) *total2 = M < cap ? M : cap;
+    }
+}
+
 // ---------------------------------------------------------------- compaction to spconv's encoding
 // tile = TB consecutive input rows.  tcount[k * ntiles + tile] = valid entries of column k in tile.
 __global__ void k_compact_count(int K, long long N, const long long *n_dev, long long ntiles, const int *nbr_out,
@@ -591,7 +649,7 @@ void make_plan(const wfs_geometry *g, long long N, Plan *p) {
         p->ones_bytes = o - p->off_keys;
         p->off_slot_id = take((size_t)p->cap * 4);
         p->off_rowbase = take((size_t)(N + 1) * 4);
-        p->off_bsum = take((size_t)p->nscan * 4);
+        p->off_bsum = take((size_t)p->ntiles * 4);          // one block sum per TB rows (>= nscan)
     }
     p->off_tcount = take((size_t)g->K * p->ntiles * 4);
     p->total = o;
@@ -663,8 +721,18 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
     long long *info = (long long *)(ws + p.off_info);
     p.tbl.keys = (int *)(ws + p.off_keys);
     dim3 grid((unsigned)wfs_cdiv(N, TB)), block(TB);
-    WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_info, 0, p.zero_bytes, stream));        // info (+ first-ticket words)
-    WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_keys, 0xFF, p.ones_bytes, stream));     // keys + values / tickets
+    const int wide = !g->subm && g->K <= 32 && (long long)N * g->K < (1ll << 32);
+    if (g->subm || wide) {
+        // info = 0 and keys / values / tickets = 0xFF in one launch (the row masks of the wide path need no clearing)
+        const long long n16 = (long long)(p.ones_bytes / 16);
+        long long ib = wfs_cdiv(n16 > 0 ? n16 : 1, TB * 4);
+        if (ib > 2048) ib = 2048;
+        k_ws_init<<<dim3((unsigned)ib), block, 0, stream>>>(info, (uint4 *)(ws + p.off_keys), n16);
+        WFS_LAUNCH_CHECK();
+    } else {
+        WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_info, 0, p.zero_bytes, stream));        // info + first-ticket words
+        WFS_HIP_CHECK(hipMemsetAsync(ws + p.off_keys, 0xFF, p.ones_bytes, stream));     // keys + tickets
+    }
     if (g->subm) {
         int *vals = (int *)(ws + p.off_vals);
         k_site_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, info);
@@ -679,31 +747,31 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         int *rowfirst = (int *)(ws + p.off_rowfirst);
         int *rowbase = (int *)(ws + p.off_rowbase);
         int *bsum = (int *)(ws + p.off_bsum);
-        // (row, offset)-parallel kernels; rowfirst[] then holds first-ticket masks, tickets are 32-bit
-        const int wide = g->K <= 32 && (long long)N * g->K < (1ll << 32);
+        // (row, offset)-parallel insert; rowfirst[] then holds first-ticket masks, tickets are 32-bit
         dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
+        const long long mcap = M_cap > 0 ? M_cap : (1ll << 62);
         if (wide) {
             k_conv_insert2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, (unsigned *)ticket,
                                                         nbr_out, info);
             WFS_LAUNCH_CHECK();
-            k_conv_first2<<<grid2, block, 0, stream>>>(g->K, N, nd, nbr_out, (const unsigned *)ticket,
-                                                       (unsigned *)rowfirst);
+            k_conv_first_bsum<<<grid, block, 0, stream>>>(g->K, N, nd, nbr_out, (const unsigned *)ticket,
+                                                          (unsigned *)rowfirst, bsum);
+            WFS_LAUNCH_CHECK();
+            // info[0] = M; m_dev = min(M, M_cap) = the row count every consumer of the outputs is bounded by
+            k_conv_rowbase<<<grid, block, 0, stream>>>(N, (const unsigned *)rowfirst, bsum, rowbase, info,
+                                                       (long long *)m_dev, mcap);
             WFS_LAUNCH_CHECK();
         } else {
             k_conv_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, ticket, nbr_out, info);
             WFS_LAUNCH_CHECK();
             k_conv_rowcount<<<grid, block, 0, stream>>>(g->K, N, nd, nbr_out, ticket, rowfirst);
             WFS_LAUNCH_CHECK();
-        }
-        // info[0] = M; m_dev = min(M, M_cap) = the row count every consumer of the outputs is bounded by
-        const long long mcap = M_cap > 0 ? M_cap : (1ll << 62);
-        {
             dim3 sgrid((unsigned)p.nscan);
-            k_scan_blocksum<<<sgrid, block, 0, stream>>>(rowfirst, N, nd, wide, bsum);
+            k_scan_blocksum<<<sgrid, block, 0, stream>>>(rowfirst, N, nd, 0, bsum);
             WFS_LAUNCH_CHECK();
             k_scan_top<<<dim3(1), block, 0, stream>>>(bsum, p.nscan, info, (long long *)m_dev, mcap);
             WFS_LAUNCH_CHECK();
-            k_scan_apply<<<sgrid, block, 0, stream>>>(rowfirst, N, nd, wide, bsum, rowbase);
+            k_scan_apply<<<sgrid, block, 0, stream>>>(rowfirst, N, nd, 0, bsum, rowbase);
             WFS_LAUNCH_CHECK();
         }
     }
@@ -738,17 +806,19 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
     long long *info = (long long *)(ws + p.off_info);
     p.tbl.keys = (int *)(ws + p.off_keys);
     dim3 grid((unsigned)wfs_cdiv(N, TB)), block(TB);
-    if (nbr_in && M > 0) WFS_HIP_CHECK(hipMemsetAsync(nbr_in, 0xFF, (size_t)g->K * M * 4, stream));
+    const bool wide = !g->subm && g->K <= 32 && (long long)N * g->K < (1ll << 32);
+    if (nbr_in && M > 0 && !wide) WFS_HIP_CHECK(hipMemsetAsync(nbr_in, 0xFF, (size_t)g->K * M * 4, stream));
     if (!g->subm) {
         WFS_REQUIRE(out_indices || M == 0, WFS_EINVAL, "out_indices is NULL");
         unsigned long long *ticket = (unsigned long long *)(ws + p.off_ticket);
         int *slot_id = (int *)(ws + p.off_slot_id);
         int *rowbase = (int *)(ws + p.off_rowbase);
-        if (g->K <= 32 && (long long)N * g->K < (1ll << 32)) {
+        if (wide) {
             int *rowmask = (int *)(ws + p.off_rowfirst);
             dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
             k_conv_assign2<<<grid2, block, 0, stream>>>(p.geo, N, nd, M, nbr_out, (const unsigned *)rowmask, rowbase, p.tbl,
-                                                        slot_id, out_indices, info);
+                                                        slot_id, out_indices, info, M > 0 ? nbr_in : nullptr,
+                                                        (long long)g->K * M);
             WFS_LAUNCH_CHECK();
             k_conv_finalize2<<<grid2, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in, info, overflow_dev);
             WFS_LAUNCH_CHECK();
