@@ -581,6 +581,22 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
 constexpr int DWB_WAVES = 16;
 constexpr int DWB_KG = 4;
 
+// The same fragment with gfx950's transposing LDS read: ds_read_b64_tr_b16 hands each 16-lane group a block of
+// 4 rows x 16 columns column-major (lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column
+// i of the 4 rows), so the lane (c = lane & 31, h = lane >> 5) gets rows row0 .. row0+7 of column c, row0 = 16 s + 8 h,
+// from two reads instead of eight 16-bit reads and their packing.  Conflict-free on plain 64-byte rows (a 32-lane
+// half covers 4 whole rows = 64 banks).  Needs EXEC all ones: call only from wave-uniform control flow.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_column_frag_tr(const unsigned short *tile, int lane, int s) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const unsigned short *a = tile + (16 * s + 8 * (g >> 1) + q) * 32 + 16 * (g & 1) + 4 * p;
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * 32));
+    s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 __device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, int col, int row0) {
     unsigned w[4];
 #pragma unroll
@@ -598,7 +614,6 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
                                                      const wfs_bf16 *__restrict__ S, const wfs_bf16 *__restrict__ G,
                                                      float *__restrict__ part, int ngroups, long long tiles_per_block) {
     __shared__ __attribute__((aligned(16))) unsigned short sTiles[DWB_WAVES][2][32 * 32];   // per wave: S tile, G tile
-    __shared__ float sAcc[DWB_KG * 1024];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;          // fragment coordinates
     const int grow = lane >> 2, gchunk = lane & 3;   // staging coordinates: rows grow and grow+16, 16-B chunk gchunk
@@ -613,7 +628,6 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
     for (int q = 0; q < DWB_KG; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-    for (int e = threadIdx.x; e < DWB_KG * 1024; e += 1024) sAcc[e] = 0.f;
     for (long long tile = t_begin + wid; tile < t_end; tile += DWB_WAVES) {
         const long long row0 = tile * 32;
         const long long ra = row0 + grow, rb = row0 + grow + 16;
@@ -646,38 +660,46 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
         *(uint4 *)(sS + grow * 32 + gchunk * 8) = keep_if(s0, la);
         *(uint4 *)(sS + (grow + 16) * 32 + gchunk * 8) = keep_if(s1, lb);
         __builtin_amdgcn_wave_barrier();
-        const bf16x8 a0 = lds_column_frag(sS, c, 8 * h), a1 = lds_column_frag(sS, c, 16 + 8 * h);
+        // the gathers of ALL the block's offsets are issued together and unconditionally (clamped rows): one memory
+        // round trip per tile; a load under the per-offset branch would cost one per offset (hipcc waits vmcnt(0))
+        uint4 g0[DWB_KG], g1[DWB_KG];
+#pragma unroll
+        for (int q = 0; q < DWB_KG; ++q) {
+            g0[q] = *(const uint4 *)(G + (long long)(ta[q] >= 0 ? ta[q] : 0) * 32 + gchunk * 8);
+            g1[q] = *(const uint4 *)(G + (long long)(tb[q] >= 0 ? tb[q] : 0) * 32 + gchunk * 8);
+        }
+        const bf16x8 a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
 #pragma unroll
         for (int q = 0; q < DWB_KG; ++q) {
             if (act[q] == 0ull) continue;
-            uint4 g0 = *(const uint4 *)(G + (long long)(ta[q] >= 0 ? ta[q] : 0) * 32 + gchunk * 8);
-            uint4 g1 = *(const uint4 *)(G + (long long)(tb[q] >= 0 ? tb[q] : 0) * 32 + gchunk * 8);
             __builtin_amdgcn_wave_barrier();           // the previous offset's fragment reads are done (in order)
-            *(uint4 *)(sG + grow * 32 + gchunk * 8) = keep_if(g0, ta[q] >= 0);
-            *(uint4 *)(sG + (grow + 16) * 32 + gchunk * 8) = keep_if(g1, tb[q] >= 0);
+            *(uint4 *)(sG + grow * 32 + gchunk * 8) = keep_if(g0[q], ta[q] >= 0);
+            *(uint4 *)(sG + (grow + 16) * 32 + gchunk * 8) = keep_if(g1[q], tb[q] >= 0);
             __builtin_amdgcn_wave_barrier();
-            const bf16x8 b0 = lds_column_frag(sG, c, 8 * h), b1 = lds_column_frag(sG, c, 16 + 8 * h);
+            const bf16x8 b0 = lds_column_frag_tr(sG, lane, 0), b1 = lds_column_frag_tr(sG, lane, 1);
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[q], 0, 0, 0);
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[q], 0, 0, 0);
         }
     }
+    // deterministic block reduction, one offset at a time: all 16 waves park that offset's accumulator in LDS (the
+    // tile staging area is free now: 16 x 4 KiB), then every thread adds ONE output element over the waves in wave
+    // order.  (Was: 16 serial read-modify-write passes over a shared 16 KiB accumulator, ~8 us of the kernel.)
     __syncthreads();
-    for (int w = 0; w < DWB_WAVES; ++w) {
-        if (wid == w) {
+    float *sRed = reinterpret_cast<float *>(&sTiles[0][0][0]);          // [DWB_WAVES][1024]
 #pragma unroll
-            for (int q = 0; q < DWB_KG; ++q)
+    for (int q = 0; q < DWB_KG; ++q) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    sAcc[(q * 32 + arow) * 32 + c] += acc[q][i];
-                }
+        for (int i = 0; i < 16; ++i) {
+            int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sRed[wid * 1024 + arow * 32 + c] = acc[q][i];
         }
         __syncthreads();
-    }
-    for (int e = threadIdx.x; e < DWB_KG * 1024; e += 1024) {
-        int q = e >> 10, ab = e & 1023;
-        int k = g + q * ngroups;
-        if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + ab] = sAcc[e];
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < DWB_WAVES; ++w) v += sRed[w * 1024 + threadIdx.x];
+        const int k = g + q * ngroups;
+        if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + threadIdx.x] = v;
+        __syncthreads();
     }
 }
 
