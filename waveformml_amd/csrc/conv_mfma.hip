@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
                                                   const long long *__restrict__ r_dev, const T *__restrict__ S,
                                                   const T *__restrict__ G,
                                                   float *__restrict__ part, int ngroups, long long tiles_per_block) {
-    __shared__ float sAcc[DW_KG * 1024];                              // [DW_KG][32][32], 16 KiB
+    __shared__ float sRed[DW_WAVES * 1024];                           // block reduction staging, 32 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int g = blockIdx.y;
@@ -412,7 +412,6 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
     for (int q = 0; q < DW_KG; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-    for (int e = threadIdx.x; e < DW_KG * 1024; e += 512) sAcc[e] = 0.f;
     for (long long tile = t_begin + wid; tile < t_end; tile += DW_WAVES) {
         const long long row0 = tile * 32;
         // lane j holds the table entries of row (row0 + j) for this wave's offsets.  Loads are unconditional
@@ -458,24 +457,24 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
             for (int s = 0; s < 16; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[q], 0, 0, 0);
         }
     }
-    // deterministic block reduction: waves add their accumulators into LDS one after the other
-    __syncthreads();
-    for (int w = 0; w < DW_WAVES; ++w) {
-        if (wid == w) {
+    // deterministic block reduction, one offset at a time: the 8 waves park that offset's accumulator in LDS, then
+    // every thread adds two output elements over the waves in wave order
 #pragma unroll
-            for (int q = 0; q < DW_KG; ++q)
+    for (int q = 0; q < DW_KG; ++q) {
+        __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    sAcc[(q * 32 + arow) * 32 + j] += acc[q][i];
-                }
+        for (int i = 0; i < 16; ++i) {
+            int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sRed[wid * 1024 + arow * 32 + j] = acc[q][i];
         }
         __syncthreads();
-    }
-    for (int e = threadIdx.x; e < DW_KG * 1024; e += 512) {
-        int q = e >> 10, ab = e & 1023;
-        int k = g + q * ngroups;
-        if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + ab] = sAcc[e];
+        const int k = g + q * ngroups;
+        for (int e = threadIdx.x; e < 1024; e += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < DW_WAVES; ++w) v += sRed[w * 1024 + e];
+            if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + e] = v;
+        }
     }
 }
 
@@ -777,7 +776,6 @@ __global__ void __launch_bounds__(512, 4) k_gdw_c32c2_bf16(const int *__restrict
                                                           float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) unsigned sA[C2_WAVES][32 * 33];
     __shared__ __attribute__((aligned(16))) unsigned short sB[C2_WAVES][32 * 32];
-    __shared__ float sAcc[64 * 32];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int grow = lane >> 2, gchunk = lane & 3;
@@ -788,7 +786,6 @@ __global__ void __launch_bounds__(512, 4) k_gdw_c32c2_bf16(const int *__restrict
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
-    for (int e = threadIdx.x; e < 64 * 32; e += 512) sAcc[e] = 0.f;
     const unsigned *Gw = reinterpret_cast<const unsigned *>(G);          // one dword = the 2 bf16 channels of a row
     for (long long tile = (long long)blockIdx.x * C2_WAVES + wid; tile < ntiles; tile += (long long)gridDim.x * C2_WAVES) {
         const long long row0 = tile * 32;
@@ -851,38 +848,46 @@ __global__ void __launch_bounds__(512, 4) k_gdw_c32c2_bf16(const int *__restrict
                                                            acc1, 0, 0, 0);
         }
     }
+    // deterministic block reduction in two halves (offsets 0..15, 16..31): every wave parks its accumulator in the
+    // free A-staging area (8 x 4 KiB), then each thread adds output elements over the waves in wave order
     __syncthreads();
-    for (int w = 0; w < C2_WAVES; ++w) {
-        if (wid == w) {
+    float *sRed = reinterpret_cast<float *>(&sA[0][0]);                  // [C2_WAVES][1024] <= 8 x 32 x 33 words
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int col = (i & 3) + 8 * (i >> 2) + 4 * h;
-                sAcc[col * 32 + c] += acc0[i];
-                sAcc[(32 + col) * 32 + c] += acc1[i];
-            }
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int col = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sRed[wid * 1024 + col * 32 + c] = half ? acc1[i] : acc0[i];
+        }
+        __syncthreads();
+        // part[block][k][ch][b] = element (k*2 + ch, b) for the first 2K columns
+        for (int e = threadIdx.x; e < 1024; e += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < C2_WAVES; ++w) v += sRed[w * 1024 + e];
+            const int ee = half * 1024 + e;
+            if (ee < K * 64) part[(long long)blockIdx.x * K * 64 + ee] = v;
         }
         __syncthreads();
     }
-    // part[block][k][ch][b] = sAcc[k*2 + ch][b] for the first 2K columns
-    for (int e = threadIdx.x; e < K * 64; e += 512) part[(long long)blockIdx.x * K * 64 + e] = sAcc[e];
 }
 
-// dW[k][a][b] (swap==0) or dW[k][b][a] (swap==1) = sum over slabs of part[slab][k][a][b]; 8 slab slices per
-// output are summed in parallel and folded in slice order (deterministic).
-__global__ void __launch_bounds__(256) k_slab_reduce(const float *__restrict__ part, long long nslabs, long long per,
-                                                     int K, int Cs, int Cg, int swap, float *__restrict__ dW) {
-    __shared__ float sR[8][32];
+// dW[k][a][b] (swap==0) or dW[k][b][a] (swap==1) = sum over slabs of part[slab][k][a][b]; blockDim.x / 32 slab slices
+// per output (8, or 32 when there are many slabs) are summed in parallel and folded in slice order (deterministic).
+__global__ void __launch_bounds__(1024) k_slab_reduce(const float *__restrict__ part, long long nslabs, long long per,
+                                                      int K, int Cs, int Cg, int swap, float *__restrict__ dW) {
+    __shared__ float sR[32][32];
+    const int nsl = blockDim.x >> 5;
     const int sl = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const long long e = (long long)blockIdx.x * 32 + lane;
     float s = 0.f;
     if (e < per)
-        for (long long c = sl; c < nslabs; c += 8) s += part[c * per + e];
+        for (long long c = sl; c < nslabs; c += nsl) s += part[c * per + e];
     sR[sl][lane] = s;
     __syncthreads();
     if (sl == 0 && e < per) {
         s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += sR[q][lane];
+        for (int q = 0; q < nsl; ++q) s += sR[q][lane];
         if (swap) {
             int k = (int)(e / ((long long)Cs * Cg));
             int rem = (int)(e % ((long long)Cs * Cg));
@@ -1082,7 +1087,7 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
             table, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
-    k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
+    k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(nblk > 64 ? 1024 : 256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
@@ -1105,7 +1110,7 @@ int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, lo
     WFS_LAUNCH_CHECK();
     // part is [chunk][k][c (gathered, 2)][b (stationary, 32)] = the "swap" orientation of (S=32, G=2)
     const long long per = (long long)K * 64;
-    k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(256), 0, stream>>>(part, chunks, per, K, 2, 32, swap ? 0 : 1, dW);
+    k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(chunks > 64 ? 1024 : 256), 0, stream>>>(part, chunks, per, K, 2, 32, swap ? 0 : 1, dW);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
