@@ -3,9 +3,9 @@
 // The reference applies plain nn.BatchNorm1d / nn.ReLU modules to SparseConvTensor.features inside
 // spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508): batch
 // statistics over the N ACTIVE voxels only, per rank (no SyncBN).  Same arithmetic here, in two launches per
-// direction: a column reduction into <= 128 per-block partials, and the elementwise pass, whose every block first
+// direction: a column reduction into <= 256 per-block partials, and the elementwise pass, whose every block first
 // folds those partials in a fixed order (deterministic, no atomics; at the PSD batch sizes a launch costs ~5 us, more
-// than re-reading 32 KB of L2-resident partials per block) and whose block 0 publishes the statistics.
+// than re-reading 64 KB of L2-resident partials per block) and whose block 0 publishes the statistics.
 //
 //   forward   mean_c, var_c (biased) over rows;  y = max(0, gamma*(x-mean)*invstd + beta)   [ReLU optional]
 //             running_mean/var updated with momentum (unbiased var), as torch does
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(FOLD_SL * 32) k_bn_fold(const float *__restric
 // S = TB / Cp slices x Cp columns, Cp = C rounded up to a power of two.  Slice s owns partials s, s + S, ...; the
 // reduce kernel launches at most FOLD_PER * S blocks, so a thread has at most FOLD_PER partials and issues ALL its
 // loads before the first add (one memory round trip); slices are then added in slice order.
-constexpr int FOLD_PER = 16;
+constexpr int FOLD_PER = 32;
 __device__ __forceinline__ int fold_cp(int C) {
     int Cp = 1;
     while (Cp < C && Cp < TB) Cp <<= 1;
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
 long long bn_reduce_blocks(long long N, int C) {      // = number of partials every elementwise block folds
     int Cp = 1;
     while (Cp < C && Cp < TB) Cp <<= 1;
-    const long long cap = (long long)FOLD_PER * (TB / Cp);      // 128 at C = 32, 16 from C = 129 on
+    const long long cap = (long long)FOLD_PER * (TB / Cp);      // 256 at C = 32, 32 from C = 129 on
     long long b = wfs_cdiv(N, 64);
     if (b < 1) b = 1;
     if (b > cap) b = cap;
