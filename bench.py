@@ -317,6 +317,8 @@ def main():
     _ops.ASSUME_VALID_UNIQUE_INDICES = True
     _ops.PREFETCH_RULEBOOKS = True        # strided layers' rulebooks build on a side stream beside the first layers
     # _ops.OVERLAP_DW stays off: dW and dX each fill the CUs' LDS; side by side they just take twice as long
+    if os.environ.get("WFS_OVERLAP_DW") == "1":
+        _ops.OVERLAP_DW = True
 
     single = env.world == 1
     f32 = None

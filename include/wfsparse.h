@@ -255,6 +255,23 @@ int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const floa
                  void *dX, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
                  void *stream);
 
+/* hybrid front end -----------------------------------------------------------------------------------
+ * TemporalConvNet(1, [1] * levels, kernel_size = k) as the reference's SPConvNet applies it to the waveform rows
+ * before the sparse stack (src/models/SPConvNet.py:56-61,83-92; src/models/ConvBlocks.py:114-173): per level i two
+ * causal k-tap FIR filters with dilation 2^i, ReLU after each, residual + ReLU.  One launch per direction; a row
+ * [L] stays in LDS through all levels.  X, Y, dY, dX [N, L] fp32 or bf16 (dtype); taps [levels][2][k] and bias
+ * [levels][2] are the EFFECTIVE filter taps (after weight norm) in DEVICE memory, fp32.  levels <= 8, k <= 8,
+ * L <= 4096; the backward needs wfs_tcn_lds_bytes(L, levels, 1) <= 150 KiB (else WFS_EINVAL: use another path).
+ * wfs_tcn_bwd writes per-row partial sums partial[N][levels][2][k + 1] (taps, then the bias); their sum over rows is
+ * d loss / d (taps, bias).  Dropout is not part of these kernels (identity in eval mode / p = 0). */
+size_t wfs_tcn_lds_bytes(int32_t L, int32_t levels, int32_t backward);
+
+int wfs_tcn_fwd(const void *X, int64_t N, int32_t L, const float *taps, const float *bias, int32_t levels,
+                int32_t k, void *Y, int32_t dtype, void *stream);
+
+int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, const float *taps, const float *bias,
+                int32_t levels, int32_t k, void *dX, float *partial, int32_t dtype, void *stream);
+
 /* loss ---------------------------------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(reduction='mean') as the reference's LitPSD applies it to the [B, n_type] logits
  * (src/engineering/LitBase.py:38-43, LitPSD.py:102), forward AND d loss / d logits in one launch (torch runs six:

@@ -742,3 +742,42 @@ def test_flat_sgd_matches_torch_sgd(kw):
         _assert_close(opt.state[pg]["momentum_buffer"].cpu().numpy(), ref.state[pr]["momentum_buffer"].numpy(), 1e-6, "buf")
     sd = opt.state_dict()
     assert "_lr_dev" not in sd["param_groups"][0] and abs(sd["param_groups"][0]["lr"] - 0.01) < 1e-12
+
+
+@pytest.mark.parametrize("levels,k,L,dtype", [(3, 3, 300, torch.float32), (1, 2, 64, torch.float32), (4, 5, 2048, torch.float32),
+                                              (3, 3, 512, torch.bfloat16)],
+                         ids=["l3_k3_L300", "l1_k2_L64", "l4_k5_L2048", "l3_k3_L512_bf16"])
+def test_fused_temporal_conv_net_matches_torch(levels, k, L, dtype):
+    """The hybrid net's waveform front end, TemporalConvNet(1, [1] * n_dil, k) (reference src/models/ConvBlocks.py:
+    114-173 as built at src/models/SPConvNet.py:83-92): one HIP launch per direction (wfs_tcn_fwd / wfs_tcn_bwd) against
+    the torch composition of weight-normed Conv1d / chomp / ReLU / residual on the CPU in fp32 -- output, dX and the
+    gradients of every weight_g, weight_v and bias within 1e-5 (fp32 rows)."""
+    from waveformml_amd.psd.tcn import TemporalConvNet
+    rng = np.random.default_rng(31)
+    N = 37
+    torch.manual_seed(4)
+    ref = TemporalConvNet(1, [1] * levels, kernel_size=k, dropout=0.0)
+    with torch.no_grad():
+        for p in ref.parameters():                  # the reference's N(0, 0.01) taps make every ReLU trivial: spread them
+            p.copy_(torch.randn_like(p) * 0.7)
+    net = TemporalConvNet(1, [1] * levels, kernel_size=k, dropout=0.0).to(DEV)
+    net.load_state_dict(ref.state_dict())
+    x = rng.standard_normal((N, 1, L)).astype(np.float32)
+    g = rng.standard_normal((N, 1, L)).astype(np.float32)
+    xin = torch.from_numpy(x).to(dtype).float()
+    xr = xin.clone().requires_grad_(True)
+    yr = ref.network(xr)                                            # the torch composition
+    yr.backward(torch.from_numpy(g))
+    xg = xin.to(DEV).to(dtype).requires_grad_(True)
+    assert net._can_fuse(xg)
+    yg = net(xg)
+    yg.backward(torch.from_numpy(g).to(DEV).to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    _assert_close(yg.detach().float().cpu().numpy(), yr.detach().numpy(), tol, "y")
+    if dtype == torch.float32:
+        _assert_close(xg.grad.cpu().numpy(), xr.grad.numpy(), 1e-5, "dX")
+        for (name, a), b in zip(net.named_parameters(), ref.parameters()):
+            _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-4, name)
+    # active dropout (training) is torch's business: the module then takes the torch composition
+    drop = TemporalConvNet(1, [1] * levels, kernel_size=k, dropout=0.2).to(DEV)
+    assert not drop._can_fuse(xg) and drop.eval()._can_fuse(xg)

@@ -25,17 +25,25 @@ W = torch.randn(27, 32, 32, device=dev) * 0.1
 W2 = torch.randn(27, 2, 32, device=dev) * 0.1
 
 
-def timeit(name, fn, nbytes=None):
-    for _ in range(5):
+def timeit(name, fn, nbytes=None, reps=10):
+    """`reps` launches captured into a HIP graph and replayed: the number is GPU time per launch including the
+    in-graph launch gap, free of Python / ctypes overhead (which is ~15 us per call here)."""
+    for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        fn()
+        g.replay()
     b.record()
     torch.cuda.synchronize()
-    us = a.elapsed_time(b) / iters * 1e3
+    us = a.elapsed_time(b) / (iters * reps) * 1e3
     extra = "  %.0f GB/s algorithmic" % (nbytes / us / 1e3) if nbytes else ""
     print("%-34s %8.1f us%s" % (name, us, extra), flush=True)
 

@@ -1,0 +1,279 @@
+// tcn.hip -- the hybrid net's waveform front end in one launch per direction.
+//
+// Reference: SPConvNet puts TemporalConvNet(1, [1] * n_dil, kernel_size, dropout) in front of the sparse stack
+// (src/models/SPConvNet.py:56-61,83-92); the TCN (src/models/ConvBlocks.py:114-173, the locuslab design) is, per
+// level i with dilation d = 2^i, two weight-normed Conv1d(1 -> 1, k, dilation d, padding (k-1) d) each chomped on the
+// right (= causal), ReLU after each, and a residual:  x_{i+1} = relu(relu(conv2(relu(conv1(x_i)))) + x_i).
+// With ONE channel a level is two k-tap causal FIR filters per row, and the rows [N, L = 2 T samples] are independent:
+// torch runs ~8 launches per level, each a full pass over [N, L] in HBM; here a block keeps its row in LDS through all
+// levels -- one read and one write of the row per direction (HBM-bound: 2 N L s bytes forward, 3 N L s backward).
+//
+//   forward   h1[t] = relu(b1 + sum_j w1[j] x[t - (k-1-j) d]),  h2 likewise from h1,  x' = relu(h2 + x)
+//   backward  recomputes the activations of all levels into LDS ((3 levels + 1) rows), then walks the levels down;
+//             per-row partial sums of dW / dB are reduced by the caller in a fixed order.
+// Weight norm (w = g v / |v|) and dropout stay with the caller: the kernels take the effective taps (device memory).
+#include "wfs_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int MAXLV = 8, MAXK = 8;
+
+// the effective taps [levels][2][k] and biases [levels][2] are autograd tensors in device memory: every block
+// copies them into LDS first (a few dozen floats, no host round trip, capturable in a HIP graph)
+struct Taps {
+    float w[MAXLV * 2 * MAXK];
+    float b[MAXLV * 2];
+};
+template <int K>
+__device__ __forceinline__ void load_taps(Taps *tp, const float *W, const float *B, int levels) {
+    for (int i = threadIdx.x; i < levels * 2 * K; i += TB) tp->w[i] = W[i];
+    for (int i = threadIdx.x; i < levels * 2; i += TB) tp->b[i] = B[i];
+}
+
+template <typename T>
+__device__ __forceinline__ float ldv(const T *p) {
+    return wfs_ld(p);
+}
+
+// out[t] = bias + sum_j w[j] in[t - (K-1-j) d]   (zero to the left of the row)
+template <int K>
+__device__ __forceinline__ float fir(const float *in, int t, const float *w, float bias, int d) {
+    float a = bias;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        int s = t - (K - 1 - j) * d;
+        a = fmaf(w[j], s >= 0 ? in[s] : 0.f, a);
+    }
+    return a;
+}
+
+template <typename T, int K>
+__global__ void __launch_bounds__(TB) k_tcn_fwd(const T *__restrict__ X, long long N, int L, const float *__restrict__ Wd,
+                                                const float *__restrict__ Bd, int levels, T *__restrict__ Y) {
+    extern __shared__ float lds[];
+    __shared__ Taps tp;
+    float *A = lds, *B = lds + L;
+    const long long row = blockIdx.x;
+    const T *x = X + row * L;
+    load_taps<K>(&tp, Wd, Bd, levels);
+    for (int t = threadIdx.x; t < L; t += TB) A[t] = ldv(x + t);
+    __syncthreads();
+    for (int lv = 0; lv < levels; ++lv) {
+        const int d = 1 << lv;
+        for (int t = threadIdx.x; t < L; t += TB) {
+            float v = fir<K>(A, t, tp.w + (lv * 2 + 0) * K, tp.b[lv * 2 + 0], d);
+            B[t] = v > 0.f ? v : 0.f;
+        }
+        __syncthreads();
+        // x' overwrites A in place: A[t] is read only at index t by the thread that rewrites it
+        for (int t = threadIdx.x; t < L; t += TB) {
+            float v = fir<K>(B, t, tp.w + (lv * 2 + 1) * K, tp.b[lv * 2 + 1], d);
+            v = (v > 0.f ? v : 0.f) + A[t];
+            A[t] = v > 0.f ? v : 0.f;
+        }
+        __syncthreads();
+    }
+    T *y = Y + row * L;
+    for (int t = threadIdx.x; t < L; t += TB) wfs_st(y + t, A[t]);
+}
+
+// LDS: Xs[levels + 1][L], H1[levels][L], H2[levels][L], G[L], G2[L], G3[L]
+template <typename T, int K>
+__global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T *__restrict__ dY, long long N, int L,
+                                                const float *__restrict__ Wd, const float *__restrict__ Bd, int levels,
+                                                T *__restrict__ dX, float *__restrict__ partial) {
+    constexpr int k = K;
+    extern __shared__ float lds[];
+    __shared__ Taps tp;
+    float *Xs = lds;
+    float *H1 = Xs + (size_t)(levels + 1) * L;
+    float *H2 = H1 + (size_t)levels * L;
+    float *G = H2 + (size_t)levels * L;
+    float *G2 = G + L;
+    float *G3 = G2 + L;
+    __shared__ float sred[TB];
+    const long long row = blockIdx.x;
+    const T *x = X + row * L;
+    load_taps<K>(&tp, Wd, Bd, levels);
+    for (int t = threadIdx.x; t < L; t += TB) {
+        Xs[t] = ldv(x + t);
+        G[t] = ldv(dY + row * L + t);
+    }
+    __syncthreads();
+    // ---- forward recompute, everything kept
+    for (int lv = 0; lv < levels; ++lv) {
+        const int d = 1 << lv;
+        const float *A = Xs + (size_t)lv * L;
+        float *h1 = H1 + (size_t)lv * L, *h2 = H2 + (size_t)lv * L, *An = Xs + (size_t)(lv + 1) * L;
+        for (int t = threadIdx.x; t < L; t += TB) {
+            float v = fir<K>(A, t, tp.w + (lv * 2 + 0) * K, tp.b[lv * 2 + 0], d);
+            h1[t] = v > 0.f ? v : 0.f;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < L; t += TB) {
+            float v = fir<K>(h1, t, tp.w + (lv * 2 + 1) * K, tp.b[lv * 2 + 1], d);
+            v = v > 0.f ? v : 0.f;
+            h2[t] = v;
+            float o = v + A[t];
+            An[t] = o > 0.f ? o : 0.f;
+        }
+        __syncthreads();
+    }
+    // ---- backward walk; acc[(lv*2 + c) * (k+1) + j]: dW taps j < k, dB at j == k (per thread, then block-reduced)
+    const int per = 2 * (k + 1);
+    for (int lv = levels - 1; lv >= 0; --lv) {
+        const int d = 1 << lv;
+        const float *A = Xs + (size_t)lv * L, *An = Xs + (size_t)(lv + 1) * L;
+        const float *h1 = H1 + (size_t)lv * L, *h2 = H2 + (size_t)lv * L;
+        float a2[K + 1], a1[K + 1];
+#pragma unroll
+        for (int j = 0; j <= k; ++j) a2[j] = a1[j] = 0.f;
+        // G  <- g_out = G * [x_{lv+1} > 0];   G2 <- g_h2 = g_out * [h2 > 0]
+        for (int t = threadIdx.x; t < L; t += TB) {
+            float go = An[t] > 0.f ? G[t] : 0.f;
+            float gh = h2[t] > 0.f ? go : 0.f;
+            G[t] = go;
+            G2[t] = gh;
+            a2[k] += gh;
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                int s = t - (k - 1 - j) * d;
+                a2[j] = fmaf(gh, s >= 0 ? h1[s] : 0.f, a2[j]);
+            }
+        }
+        __syncthreads();
+        // g_h1[s] = [h1 > 0] * sum_j w2[j] g_h2[s + (k-1-j) d]  -> G3;  its dW1 / dB1 sums in the same pass
+        for (int s = threadIdx.x; s < L; s += TB) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                int t = s + (k - 1 - j) * d;
+                v = fmaf(tp.w[(lv * 2 + 1) * K + j], t < L ? G2[t] : 0.f, v);
+            }
+            v = h1[s] > 0.f ? v : 0.f;
+            G3[s] = v;
+            a1[k] += v;
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                int u = s - (k - 1 - j) * d;
+                a1[j] = fmaf(v, u >= 0 ? A[u] : 0.f, a1[j]);
+            }
+        }
+        __syncthreads();
+        // dX_lv[s] = g_out[s] (residual) + sum_j w1[j] g_h1[s + (k-1-j) d]   (G[s] is read only at index s)
+        for (int s = threadIdx.x; s < L; s += TB) {
+            float v = G[s];
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                int t = s + (k - 1 - j) * d;
+                v = fmaf(tp.w[(lv * 2 + 0) * K + j], t < L ? G3[t] : 0.f, v);
+            }
+            G[s] = v;
+        }
+        // block reduction of this level's 2 (k + 1) sums, fixed tree order
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j <= k; ++j) {
+                __syncthreads();
+                sred[threadIdx.x] = c ? a2[j] : a1[j];
+                __syncthreads();
+                for (int w = TB / 2; w > 0; w >>= 1) {
+                    if ((int)threadIdx.x < w) sred[threadIdx.x] += sred[threadIdx.x + w];
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) partial[row * ((long long)levels * per) + (lv * 2 + c) * (k + 1) + j] = sred[0];
+            }
+        __syncthreads();
+    }
+    T *dx = dX + row * L;
+    for (int t = threadIdx.x; t < L; t += TB) wfs_st(dx + t, G[t]);
+}
+
+}  // namespace
+
+extern "C" size_t wfs_tcn_lds_bytes(int32_t L, int32_t levels, int32_t backward) {
+    return (size_t)L * sizeof(float) * (backward ? (3 * levels + 4) : 2);
+}
+
+#define WFS_TCN_DISPATCH_K(KERNEL, T, ...)                                  \
+    switch (k) {                                                            \
+        case 1: KERNEL<T, 1><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+        case 2: KERNEL<T, 2><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+        case 3: KERNEL<T, 3><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+        case 4: KERNEL<T, 4><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+        case 5: KERNEL<T, 5><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+        case 6: KERNEL<T, 6><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+        case 7: KERNEL<T, 7><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+        default: KERNEL<T, 8><<<grid, block, lds, stream>>>(__VA_ARGS__); break; \
+    }
+
+extern "C" int wfs_tcn_fwd(const void *X, int64_t N, int32_t L, const float *taps, const float *bias, int32_t levels,
+                           int32_t k, void *Y, int32_t dtype, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(levels >= 1 && levels <= MAXLV && k >= 1 && k <= MAXK, WFS_EINVAL, "unsupported TCN shape: %d levels, k = %d",
+                levels, k);
+    WFS_REQUIRE(L >= 1 && L <= 16 * TB, WFS_EINVAL, "row length %d not in [1, %d]", L, 16 * TB);
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    if (N == 0) return WFS_OK;
+    WFS_REQUIRE(X && Y && taps && bias, WFS_EINVAL, "NULL device pointer");
+    const size_t lds = wfs_tcn_lds_bytes(L, levels, 0);
+    const dim3 grid((unsigned)N), block(TB);
+    if (dtype == WFS_F32) {
+        WFS_TCN_DISPATCH_K(k_tcn_fwd, float, (const float *)X, N, L, taps, bias, levels, (float *)Y)
+    } else {
+        WFS_TCN_DISPATCH_K(k_tcn_fwd, wfs_bf16, (const wfs_bf16 *)X, N, L, taps, bias, levels, (wfs_bf16 *)Y)
+    }
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+template <typename T, int K>
+static int tcn_bwd_attr() {
+    static bool done = false;
+    if (!done) {
+        WFS_HIP_CHECK(hipFuncSetAttribute((const void *)k_tcn_bwd<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        done = true;
+    }
+    return WFS_OK;
+}
+template <typename T>
+static int tcn_bwd_attr_k(int k) {
+    switch (k) {
+        case 1: return tcn_bwd_attr<T, 1>();
+        case 2: return tcn_bwd_attr<T, 2>();
+        case 3: return tcn_bwd_attr<T, 3>();
+        case 4: return tcn_bwd_attr<T, 4>();
+        case 5: return tcn_bwd_attr<T, 5>();
+        case 6: return tcn_bwd_attr<T, 6>();
+        case 7: return tcn_bwd_attr<T, 7>();
+        default: return tcn_bwd_attr<T, 8>();
+    }
+}
+
+extern "C" int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, const float *taps, const float *bias,
+                           int32_t levels, int32_t k, void *dX, float *partial, int32_t dtype, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(levels >= 1 && levels <= MAXLV && k >= 1 && k <= MAXK, WFS_EINVAL, "unsupported TCN shape: %d levels, k = %d",
+                levels, k);
+    WFS_REQUIRE(L >= 1 && L <= 16 * TB, WFS_EINVAL, "row length %d not in [1, %d]", L, 16 * TB);
+    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    const size_t lds = wfs_tcn_lds_bytes(L, levels, 1);
+    WFS_REQUIRE(lds <= 150 * 1024, WFS_EINVAL, "row of %d samples x %d levels needs %zu B of LDS", L, levels, lds);
+    if (N == 0) return WFS_OK;
+    WFS_REQUIRE(X && dY && dX && partial && taps && bias, WFS_EINVAL, "NULL device pointer");
+    const dim3 grid((unsigned)N), block(TB);
+    if (dtype == WFS_F32) {
+        int rc = tcn_bwd_attr_k<float>(k);
+        if (rc != WFS_OK) return rc;
+        WFS_TCN_DISPATCH_K(k_tcn_bwd, float, (const float *)X, (const float *)dY, N, L, taps, bias, levels, (float *)dX, partial)
+    } else {
+        int rc = tcn_bwd_attr_k<wfs_bf16>(k);
+        if (rc != WFS_OK) return rc;
+        WFS_TCN_DISPATCH_K(k_tcn_bwd, wfs_bf16, (const wfs_bf16 *)X, (const wfs_bf16 *)dY, N, L, taps, bias, levels,
+                           (wfs_bf16 *)dX, partial)
+    }
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}

@@ -1,9 +1,19 @@
 """Causal dilated 1-D conv front end (hybrid config C5): mirror of the reference's TemporalConvNet
 (src/models/ConvBlocks.py:105-173, itself the locuslab TCN): per level two weight-normed Conv1d with
 left padding (k-1)*d chomped on the right, ReLU, dropout, residual; dilation doubles per level.
-Dense torch ops (MIOpen) -- not part of the hand-written path yet."""
+
+The reference only ever builds it with ONE channel (``TemporalConvNet(1, [1] * n_dil, ...)``,
+src/models/SPConvNet.py:83-92).  In that shape every level is two k-tap causal FIR filters per waveform row, and the
+whole net runs as one HIP launch per direction with the row resident in LDS (include/wfsparse.h, wfs_tcn_fwd /
+wfs_tcn_bwd; csrc/tcn.hip).  Same modules, parameters and state_dict as the torch composition below, which remains
+the path for everything else (more channels, active dropout, CPU tensors, rows too long for the LDS-resident backward).
+"""
+import torch
 from torch import nn
+from torch.autograd import Function
 from torch.nn.utils import weight_norm
+
+from .. import _lib
 
 
 class _Chomp(nn.Module):
@@ -19,9 +29,11 @@ class TemporalBlock(nn.Module):
     def __init__(self, n_in, n_out, kernel_size, stride, dilation, padding, dropout=0.2):
         super().__init__()
         layers = []
+        self.convs = []
         for cin in (n_in, n_out):
             conv = weight_norm(nn.Conv1d(cin, n_out, kernel_size, stride=stride, padding=padding, dilation=dilation))
             conv.weight.data.normal_(0, 0.01)
+            self.convs.append(conv)
             layers += [conv, _Chomp(padding), nn.ReLU()]
             if dropout != 0:
                 layers.append(nn.Dropout(dropout))
@@ -30,10 +42,44 @@ class TemporalBlock(nn.Module):
         if self.downsample is not None:
             self.downsample.weight.data.normal_(0, 0.01)
         self.relu = nn.ReLU()
+        self.shape = (n_in, n_out, kernel_size, stride, dilation, padding, dropout)
 
     def forward(self, x):
         res = x if self.downsample is None else self.downsample(x)
         return self.relu(self.net(x) + res)
+
+
+class FusedTCNFunction(Function):
+    """rows [N, L], effective taps [levels, 2, k] and biases [levels, 2] (fp32, on the GPU) -> rows [N, L]."""
+
+    @staticmethod
+    def forward(ctx, x, taps, bias):
+        lib = _lib.load()
+        x = x.contiguous()
+        taps, bias = taps.contiguous(), bias.contiguous()
+        N, L = x.shape
+        levels, _, k = taps.shape
+        y = torch.empty_like(x)
+        _lib.check(lib.wfs_tcn_fwd(_lib.ptr(x), N, L, _lib.ptr(taps), _lib.ptr(bias), levels, k, _lib.ptr(y),
+                                   _lib.dtype_code(x), _lib.stream_ptr()))
+        ctx.save_for_backward(x, taps, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        x, taps, bias = ctx.saved_tensors
+        N, L = x.shape
+        levels, _, k = taps.shape
+        dy = grad_output.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        partial = torch.empty((N, levels, 2, k + 1), dtype=torch.float32, device=x.device)
+        _lib.check(lib.wfs_tcn_bwd(_lib.ptr(x), _lib.ptr(dy), N, L, _lib.ptr(taps), _lib.ptr(bias), levels, k, _lib.ptr(dx),
+                                   _lib.ptr(partial), _lib.dtype_code(x), _lib.stream_ptr()))
+        sums = partial.sum(0)
+        return dx, sums[:, :, :k].contiguous(), sums[:, :, k].contiguous()
 
 
 class TemporalConvNet(nn.Module):
@@ -45,6 +91,34 @@ class TemporalConvNet(nn.Module):
             n_in = num_inputs if i == 0 else num_channels[i - 1]
             blocks.append(TemporalBlock(n_in, n_out, kernel_size, 1, d, (kernel_size - 1) * d, dropout))
         self.network = nn.Sequential(*blocks)
+        self.kernel_size, self.dropout = kernel_size, dropout
+        self.single_channel = num_inputs == 1 and all(c == 1 for c in num_channels)
+
+    def _can_fuse(self, x):
+        levels, k = len(self.network), self.kernel_size
+        if not (self.single_channel and x.is_cuda and x.dim() == 3 and x.shape[1] == 1
+                and x.dtype in (torch.float32, torch.bfloat16) and 1 <= levels <= 8 and 1 <= k <= 8
+                and 1 <= x.shape[2] <= 4096 and x.shape[0] > 0):
+            return False
+        if self.dropout != 0 and self.training:
+            return False                                  # dropout masks come from torch's generator
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if _lib.load().wfs_tcn_lds_bytes(int(x.shape[2]), levels, 1) > 150 * 1024:
+                return False                              # the backward keeps (3 levels + 4) rows in LDS
+        return True
+
+    def effective_taps(self):
+        """[levels, 2, k] taps after weight norm (w = g v / |v|, differentiable) and [levels, 2] biases."""
+        taps, bias = [], []
+        for blk in self.network:
+            for conv in blk.convs:
+                taps.append(torch._weight_norm(conv.weight_v, conv.weight_g, 0).reshape(-1))
+                bias.append(conv.bias.reshape(()) if conv.bias is not None else conv.weight_v.new_zeros(()))
+        levels = len(self.network)
+        return torch.stack(taps).reshape(levels, 2, -1).float(), torch.stack(bias).reshape(levels, 2).float()
 
     def forward(self, x):
+        if self._can_fuse(x):
+            taps, bias = self.effective_taps()
+            return FusedTCNFunction.apply(x.reshape(x.shape[0], x.shape[2]), taps, bias).reshape(x.shape)
         return self.network(x)
