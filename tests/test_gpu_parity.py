@@ -781,3 +781,40 @@ def test_fused_temporal_conv_net_matches_torch(levels, k, L, dtype):
     # active dropout (training) is torch's business: the module then takes the torch composition
     drop = TemporalConvNet(1, [1] * levels, kernel_size=k, dropout=0.2).to(DEV)
     assert not drop._can_fuse(xg) and drop.eval()._can_fuse(xg)
+
+
+def test_hybrid_2d_net_with_waveform_front_end_matches_the_cpu_path():
+    """The reference's hybrid configuration (GEP.json hparams with n_dil > 0, src/models/SPConvNet.py:71-109): the
+    fused TemporalConvNet over the [N, 2T] waveform rows feeding the 2-D SparseConv2d stack (300 -> 252 -> 158 -> 64
+    channels: the shape-generic conv kernels) and the LinearBlock, against the CPU restatement with the same weights:
+    logits, loss and every gradient within 1e-5 / 1e-4."""
+    import copy
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.lit import LitPSD
+    cfg = json.load(open(os.path.join(HERE, "golden", "gep_config.json")))
+    cfg["net_config"]["hparams"]["n_dil"] = 2
+    cfg["net_config"]["hparams"]["wf_params"]["dropout"] = 0.0
+    torch.manual_seed(21)
+    gpu = LitPSD(load_config(copy.deepcopy(cfg)))
+    with torch.no_grad():
+        for p in gpu.model.waveformLayer.parameters():        # N(0, 0.01) taps would leave the front end almost linear
+            p.copy_(torch.randn_like(p) * 0.5)
+    cpu_cfg = copy.deepcopy(cfg)
+    cpu_cfg["net_config"]["imports"] = ["oracle.spconv" if m == "waveformml_amd.spconv" else m
+                                        for m in cpu_cfg["net_config"]["imports"]]
+    cpu = LitPSD(load_config(cpu_cfg))
+    cpu.load_state_dict(gpu.state_dict())
+    gpu = gpu.to(DEV)
+    c, f, y = synthetic.generate(8, 150, 3, seed=3, layout="2d")
+    assert f.shape[1] == 300
+    lc = cpu.training_step(([torch.from_numpy(c), torch.from_numpy(f)], torch.from_numpy(y)), 0)
+    lg = gpu.training_step(([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV)), 0)
+    lc.backward()
+    lg.backward()
+    assert abs(lg.item() - lc.item()) <= 1e-5 * abs(lc.item()), (lg.item(), lc.item())
+    for (name, a), b in zip(gpu.model.named_parameters(), cpu.model.parameters()):
+        if b.grad is None:
+            assert a.grad is None, name
+            continue
+        _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-4, name)
