@@ -171,20 +171,34 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
             }
             G[s] = v;
         }
-        // block reduction of this level's 2 (k + 1) sums, fixed tree order
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
+        // block reduction of this level's 2 (k + 1) sums in a fixed order: butterfly inside each wave, then the four
+        // waves' sums added in wave order -- one barrier per level
+        {
+            constexpr int P = 2 * (K + 1);
+            float vals[P];
 #pragma unroll
             for (int j = 0; j <= k; ++j) {
-                __syncthreads();
-                sred[threadIdx.x] = c ? a2[j] : a1[j];
-                __syncthreads();
-                for (int w = TB / 2; w > 0; w >>= 1) {
-                    if ((int)threadIdx.x < w) sred[threadIdx.x] += sred[threadIdx.x + w];
-                    __syncthreads();
-                }
-                if (threadIdx.x == 0) partial[row * ((long long)levels * per) + (lv * 2 + c) * (k + 1) + j] = sred[0];
+                vals[j] = a1[j];
+                vals[(K + 1) + j] = a2[j];
             }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) vals[i] += __shfl_xor(vals[i], o, 64);
+            }
+            __syncthreads();                        // sred is free (previous level's readers are done)
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) sred[(threadIdx.x >> 6) * P + i] = vals[i];
+            }
+            __syncthreads();
+            if (threadIdx.x < P) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < TB / 64; ++w) v += sred[w * P + threadIdx.x];
+                partial[row * ((long long)levels * per) + lv * per + threadIdx.x] = v;
+            }
+        }
         __syncthreads();
     }
     T *dx = dX + row * L;
