@@ -818,3 +818,43 @@ def test_hybrid_2d_net_with_waveform_front_end_matches_the_cpu_path():
             assert a.grad is None, name
             continue
         _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-4, name)
+
+
+def test_occlusion_sweep_reuses_rulebooks_and_matches_separate_evaluations():
+    """Inference path (reference Evaluate.py --occlude / scripts/RunOcclusionStudy.py): one batch evaluated for several
+    occluded feature columns.  With rulebook reuse the sweep builds each layer geometry's rulebook ONCE; its results
+    are identical (same kernels, same inputs) to evaluating every index from scratch, and equal the CPU path's."""
+    import copy
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.evaluate import occlusion_sweep
+    from waveformml_amd.psd.lit import LitPSD
+    sp = _sp()
+    cfg = json.load(open(os.path.join(HERE, "golden", "gep_config.json")))
+    torch.manual_seed(8)
+    gpu = LitPSD(load_config(copy.deepcopy(cfg)))
+    cpu_cfg = copy.deepcopy(cfg)
+    cpu_cfg["net_config"]["imports"] = ["oracle.spconv" if m == "waveformml_amd.spconv" else m
+                                        for m in cpu_cfg["net_config"]["imports"]]
+    cpu = LitPSD(load_config(cpu_cfg))
+    cpu.load_state_dict(gpu.state_dict())
+    gpu = gpu.to(DEV)
+    c, f, y = synthetic.generate(12, 150, 3, seed=4, layout="2d")
+    batch = ([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV))
+    indices = [None, 0, 17, 150, 299]
+    n0 = sp.ops.BUILD_COUNT
+    sweep = occlusion_sweep(gpu, batch, indices)
+    built = sp.ops.BUILD_COUNT - n0
+    assert built == 2, built           # GEP's two 3x3 layers (the 1x1 layer needs no rulebook), once for all five passes
+    cpu.eval()
+    for idx in indices:
+        gpu.occlude_index = idx
+        cpu.occlude_index = idx
+        with torch.no_grad():
+            alone = gpu.eval().test_step(([batch[0][0], batch[0][1].clone()], batch[1]), 0)
+            want = cpu.test_step(([torch.from_numpy(c), torch.from_numpy(f.copy())], torch.from_numpy(y)), 0)
+        assert float(alone["test_loss"]) == sweep[idx]["test_loss"] and float(alone["test_acc"]) == sweep[idx]["test_acc"]
+        assert abs(sweep[idx]["test_loss"] - float(want["test_loss"])) <= 1e-5 * abs(float(want["test_loss"]))
+    assert sweep[None] == sweep[0]                               # the reference's falsy index 0
+    assert sweep[17]["test_loss"] != sweep[None]["test_loss"]
+    assert sp.ops.BUILD_COUNT - n0 == 2 + 2 * len(indices)      # the from-scratch evaluations rebuilt them each time

@@ -49,7 +49,10 @@ class SPConvNet(nn.Module):
             batch_size = getattr(self, "batch_size_hint", None)
         if batch_size is None:
             batch_size = int(coords[-1, -1]) + 1          # one device->host read, as the reference's
-        st = self.spconv.SparseConvTensor(feats, coords[:, self.permute_tensor].contiguous(), self.spatial_size,
+        make = lambda: coords[:, self.permute_tensor].contiguous()          # noqa: E731
+        reused = getattr(getattr(self.spconv, "ops", None), "reused", None)
+        indices = reused("batch_first", coords, make) if reused is not None else make()
+        st = self.spconv.SparseConvTensor(feats, indices, self.spatial_size,
                                           batch_size)
         if len(x) > 2 and x[2] is not None:       # [coords, feats, n_valid]: rows beyond n_valid[0] are padding
             st.n_valid = x[2]

@@ -65,3 +65,8 @@ class Trainer(object):
             acc += float(res["val_acc"]) * b
             n += b
         return {"val_loss": tot / max(n, 1), "val_acc": acc / max(n, 1)}
+
+    def test(self, module, loader):
+        """``pl.Trainer.test`` for the PSD module (reference Evaluate.py:84): see psd/evaluate.test_loop."""
+        from .evaluate import test_loop
+        return test_loop(module, loader, self.device, self.feature_dtype)

@@ -160,8 +160,69 @@ def default_out_capacity(n_cap, K, cells):
     return int(min(n_cap * K, cells))
 
 
+_REUSE = None          # {key: Rulebook} while a reuse_rulebooks() context is open
+BUILD_COUNT = 0        # rulebooks actually built (tests / diagnostics)
+
+
+class reuse_rulebooks(object):
+    """Context manager: rulebooks depend on the index rows and the layer geometry only, so while it is open a build for
+    the same index tensor (same storage, same shape) and the same geometry returns the rulebook built the first time --
+    across forward calls and across layers that have no ``indice_key``.  Made for evaluation sweeps that run ONE batch
+    through the net many times with different features (the reference's occlusion study zeroes one feature column per
+    pass, scripts/RunOcclusionStudy.py -> Evaluate.py --occlude, src/engineering/LitPSD.py:133-135).
+    Contract: index tensors are not modified in place while the context is open (the cache keeps them alive)."""
+
+    def __enter__(self):
+        global _REUSE
+        self._outer = _REUSE
+        if _REUSE is None:
+            _REUSE = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _REUSE
+        _REUSE = self._outer
+        return False
+
+
+def reused(tag, source, make):
+    """``make()`` -- or, inside a reuse_rulebooks() context, the tensor it returned the first time for the same
+    ``source`` storage.  For index tensors DERIVED from the batch (the reference permutes the coordinate columns on
+    every forward, src/models/SPConvNet.py:64), so that the derived tensor -- the rulebook cache's key -- is stable."""
+    if _REUSE is None:
+        return make()
+    key = (tag, source.data_ptr(), tuple(source.shape), tuple(source.stride()))
+    hit = _REUSE.get(key)
+    if hit is None:
+        hit = _REUSE[key] = (make(), source)
+    return hit[0]
+
+
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
                    known_unique=None, n_dev=None, out_capacity=None):
+    """Cached front of :func:`_build_rulebook` (see :class:`reuse_rulebooks`)."""
+    global BUILD_COUNT
+    if _REUSE is None:
+        BUILD_COUNT += 1
+        return _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
+                               known_unique, n_dev, out_capacity)
+    ndim = indices.shape[1] - 1
+    key = (indices.data_ptr(), tuple(indices.shape), tuple(indices.stride()), int(batch_size),
+           tuple(int(s) for s in spatial_shape), tuple(_listify(ksize, ndim)), tuple(_listify(stride, ndim)),
+           tuple(_listify(padding, ndim)), tuple(_listify(dilation, ndim)), bool(subm),
+           None if n_dev is None else n_dev.data_ptr(), out_capacity)
+    rb = _REUSE.get(key)
+    if rb is None:
+        BUILD_COUNT += 1
+        rb = _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
+                             known_unique, n_dev, out_capacity)
+        rb._keepalive = indices          # the key holds a data_ptr: keep the storage from being recycled
+        _REUSE[key] = rb
+    return rb
+
+
+def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
+                    known_unique=None, n_dev=None, out_capacity=None):
     """Builds the device rulebook.  ``known_unique``: True if the caller knows the index rows are
     distinct sites (skips the duplicate check a regular conv would otherwise run once).
 
