@@ -858,3 +858,41 @@ def test_occlusion_sweep_reuses_rulebooks_and_matches_separate_evaluations():
     assert sweep[None] == sweep[0]                               # the reference's falsy index 0
     assert sweep[17]["test_loss"] != sweep[None]["test_loss"]
     assert sp.ops.BUILD_COUNT - n0 == 2 + 2 * len(indices)      # the from-scratch evaluations rebuilt them each time
+
+
+@pytest.mark.parametrize("algorithm", ["conv", "point"])
+def test_litz_per_segment_regression_matches_the_cpu_path(algorithm):
+    """The sibling task on the same surface: LitZ / SingleEndedZConv -- regular SparseConv2d
+    layers with "same" padding, BatchNorm, ReLU, ToDense, and the segment loss built from SparseConvTensor.dense() --
+    on the GPU against the CPU restatement with the same weights: loss 1e-5, gradients 1e-4."""
+    import copy
+    from test_host_mirror import _z_config
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.litz import LitZ
+    cfg = _z_config(["waveformml_amd.spconv"])
+    cfg["net_config"]["algorithm"] = algorithm
+    torch.manual_seed(13)
+    gpu = LitZ(load_config(copy.deepcopy(cfg)))
+    cpu_cfg = copy.deepcopy(cfg)
+    cpu_cfg["net_config"]["imports"] = ["torch.nn", "oracle.spconv"]
+    cpu = LitZ(load_config(cpu_cfg))
+    cpu.load_state_dict(gpu.state_dict())
+    gpu = gpu.to(DEV)
+    rng = np.random.default_rng(6)
+    B = 9
+    rows = sorted({(int(rng.integers(0, 14)), int(rng.integers(0, 11)), e) for e in range(B) for _ in range(4)},
+                  key=lambda r: r[2])
+    c = torch.tensor(rows, dtype=torch.int32)
+    f = torch.from_numpy(rng.random((len(rows), 40)).astype(np.float32))
+    z = torch.from_numpy(rng.standard_normal(len(rows)).astype(np.float32))
+    lc = cpu.training_step(([c, f], z), 0)
+    lg = gpu.training_step(([c.to(DEV), f.to(DEV)], z.to(DEV)), 0)
+    lc.backward()
+    lg.backward()
+    assert abs(lg.item() - lc.item()) <= 1e-5 * abs(lc.item()), (lg.item(), lc.item())
+    for (name, a), b in zip(gpu.model.named_parameters(), cpu.model.parameters()):
+        if float(b.grad.abs().max()) < 1e-6:
+            # a conv bias in front of BatchNorm: its gradient is identically zero up to rounding noise on both sides
+            assert float(a.grad.abs().max()) < 1e-6, name
+            continue
+        _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-4, name)

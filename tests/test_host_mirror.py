@@ -147,3 +147,62 @@ def test_synthetic_generator_is_seeded_and_well_formed():
     assert c1[:, 0].max() < 14 and c1[:, 1].max() < 11 and c1[:, 2].max() < 64 and set(c1[:, 3]) == set(range(16))
     assert len({tuple(r) for r in c1.tolist()}) == len(c1)            # distinct sites
     assert 0 < f1.max() <= 1.0 and (f1.max(1) >= 8 / (2 ** 14 - 1) - 1e-9).all()   # zero-suppression threshold
+
+
+def test_per_segment_block_schedules_match_the_reference_builders():
+    """zblocks.{z,point,ez}_schedule against the layer lists the REFERENCE's SparseConv2DForZ / Pointwise2DForZ /
+    SparseConv2DForEZ (v0) constructors produced (tests/golden/z_schedules.json, made by make_z_goldens.py)."""
+    from waveformml_amd.psd import zblocks
+    gold = json.load(open(os.path.join(HERE, "golden", "z_schedules.json")))
+
+    def as_layers(plan, todense=True):
+        out = []
+        for cin, cout, k, pad, bn in plan:
+            out.append(["SparseConv2d", cin, cout, k, 1, pad])
+            if bn:
+                out.append(["BatchNorm1d", cout])
+            out.append(["ReLU"])
+        return out + ([["ToDense"]] if todense else [])
+
+    for case in gold["z"]:
+        assert as_layers(zblocks.z_schedule(**case["args"])) == case["layers"], case["args"]
+    for case in gold["point"]:
+        assert as_layers(zblocks.point_schedule(**case["args"])) == case["layers"], case["args"]
+    for case in gold["ez"]:
+        assert as_layers(zblocks.ez_schedule(**case["args"])) == case["layers"], case["args"]
+    assert len(gold["z"]) == 90 and len(gold["ez"]) == 15
+
+
+def _z_config(imports):
+    return {
+        "system_config": {"model_name": "SingleEndedZConv", "n_samples": 20, "gpu_enabled": False, "half_precision": 0},
+        "net_config": {"criterion_class": "L1Loss", "criterion_params": [], "imports": ["torch.nn"] + imports,
+                       "net_type": "2DConvolution", "algorithm": "conv",
+                       "hparams": {"conv": {"kernel_size": 3, "n_layers": 3}, "point": {"pointwise_layers": 2}}},
+        "optimize_config": {"imports": ["torch.optim"], "lr": 0.01, "optimizer_class": "optim.SGD",
+                            "optimizer_params": {"momentum": 0.9}},
+        "dataset_config": {"imports": []},
+    }
+
+
+def test_litz_segment_loss_on_the_cpu_restatement():
+    """LitZ (reference src/engineering/LitZ.py, LitBase._calc_segment_loss) over the CPU restatement of spconv: the
+    loss equals sum |prediction - target| over the ACTIVE segments / rows, computed independently from the dense map."""
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.litz import LitZ
+    torch.manual_seed(0)
+    m = LitZ(load_config(_z_config(["oracle.spconv"])))
+    assert [p[:3] for p in m.model.model.plan] == [(40, 27, 3), (27, 14, 1), (14, 1, 1)]
+    rng = np.random.default_rng(2)
+    B = 5
+    rows = sorted({(int(rng.integers(0, 14)), int(rng.integers(0, 11)), e) for e in range(B) for _ in range(3)},
+                  key=lambda r: r[2])
+    c = torch.tensor(rows, dtype=torch.int32)
+    f = torch.from_numpy(rng.random((len(rows), 40)).astype(np.float32))
+    z = torch.from_numpy(rng.standard_normal(len(rows)).astype(np.float32))
+    loss = m.training_step(([c, f], z), 0)
+    dense = m.model([c, f]).detach()
+    want = sum(abs(float(dense[e, 0, x, y]) - float(z[i])) for i, (x, y, e) in enumerate(rows)) / len(rows)
+    assert abs(loss.item() - want) <= 1e-5 * abs(want)
+    loss.backward()
+    assert all(p.grad is not None for p in m.model.parameters())
