@@ -50,7 +50,7 @@ def timeit(name, fn, nbytes=None, reps=10):
 
 P = int((rb.nbr_out >= 0).sum())
 P1 = int((rb1.nbr_out >= 0).sum())
-print("N %d  P %d  M1 %d  P1 %d  dbg=%s" % (N, P, M1, P1, os.environ.get("WFS_DBG", "0")))
+print("N %d  P %d  M1 %d  P1 %d" % (N, P, M1, P1))
 t, km = rb.table_by_out()
 by = N * 32 * ES * 2 + P * 8 + 27 * 4096
 timeit("subm fwd 32->32", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None), by)

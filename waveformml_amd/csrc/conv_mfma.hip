@@ -41,13 +41,12 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
                                                       const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                       float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
-                                                      int dbg, WfsStatsArgs sa) {
+                                                      WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
     WfsColStats cst = {0.f, 0.f, 0.f};
     const int nthreads = blockDim.x;
-    if (dbg & 4) {
-    } else if (!TRANSPOSE_W) {
+    if (!TRANSPOSE_W) {
         for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
             int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;
             const float *src = W + ((long long)k * 32 + c4 * 4) * 32 + j4 * 4;
@@ -119,7 +118,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
             int k_next = mask ? __builtin_ctz(mask) : k_cur;
             int nb_next = entry(k_next);
             while (true) {
-                const f32x4 *xn = (const f32x4 *)(X + (long long)(nb_next >= 0 && !(dbg & 2) ? nb_next : 0) * 32 + h * 16);
+                const f32x4 *xn = (const f32x4 *)(X + (long long)(nb_next >= 0 ? nb_next : 0) * 32 + h * 16);
                 f32x4 n0 = xn[0], n1 = xn[1], n2 = xn[2], n3 = xn[3];
                 unsigned m2 = mask & (mask - 1);
                 int k_nn = m2 ? __builtin_ctz(m2) : k_next;
@@ -132,14 +131,10 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-                if (dbg & 1) {
-                    acc[0] += a0.x * b0.x + a1.y * b1.y + a2.z * b2.z + a3.w * b3.w;
-                } else {
-                    WFS_MFMA4(a0, b0)
-                    WFS_MFMA4(a1, b1)
-                    WFS_MFMA4(a2, b2)
-                    WFS_MFMA4(a3, b3)
-                }
+                WFS_MFMA4(a0, b0)
+                WFS_MFMA4(a1, b1)
+                WFS_MFMA4(a2, b2)
+                WFS_MFMA4(a3, b3)
 #undef WFS_MFMA4
                 if (mask == 0) break;
                 mask &= mask - 1;
@@ -969,21 +964,19 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     int wpb;
     gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
     const size_t lds = (size_t)K * 4096;
-    static int dbg = -1;
-    if (dbg < 0) dbg = getenv("WFS_DBG") ? atoi(getenv("WFS_DBG")) : 0;
     static bool attr[3] = {false, false, false};
     const WfsStatsArgs sa = stats_args(stats, nblk);
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
         return launch_big_lds(k_gconv32_f32<true, false>, &attr[0], grid, block, lds, stream, table, mirror, K, identity_k,
-                              R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg, sa);
+                              R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
     if (stats) {
         int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg, sa);
+                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, stream);
     }
     return launch_big_lds(k_gconv32_f32<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K, identity_k, R,
-                          r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, dbg, sa);
+                          r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
 }
 
 int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
