@@ -896,3 +896,29 @@ def test_litz_per_segment_regression_matches_the_cpu_path(algorithm):
             assert float(a.grad.abs().max()) < 1e-6, name
             continue
         _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-4, name)
+
+
+@pytest.mark.parametrize("cols,perm,C,dtype", [(4, [3, 0, 1, 2], 2, torch.float32), (3, [2, 0, 1], 301, torch.bfloat16)])
+def test_batch_hand_over_kernel_copies_and_permutes(cols, perm, C, dtype):
+    """wfs_load_batch: the one-launch hand-over of a batch into a captured step's fixed buffers (coordinates as they are
+    and in the reference's batch-first order, features incl. a byte tail, labels, row count) against torch copies."""
+    from waveformml_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    n, B, cap = 1237, 19, 1500
+    coords = torch.from_numpy(rng.integers(0, 200, (n, cols)).astype(np.int32)).to(DEV)
+    feats = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(DEV).to(dtype)
+    labels = torch.from_numpy(rng.integers(0, 3, B)).to(DEV)
+    cdst = torch.full((cap, cols), -7, dtype=torch.int32, device=DEV)
+    idst = torch.full((cap, cols), -7, dtype=torch.int32, device=DEV)
+    fdst = torch.zeros((cap, C), dtype=dtype, device=DEV)
+    ldst = torch.zeros_like(labels)
+    nv = torch.zeros((1,), dtype=torch.int64, device=DEV)
+    _lib.check(lib.wfs_load_batch(_lib.ptr(coords), n, cols, _lib.i32_array(perm), _lib.ptr(cdst), _lib.ptr(idst),
+                                  _lib.ptr(feats), _lib.ptr(fdst), feats.numel() * feats.element_size(), _lib.ptr(labels),
+                                  _lib.ptr(ldst), B, _lib.ptr(nv), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(cdst[:n], coords) and bool((cdst[n:] == -7).all())
+    assert torch.equal(idst[:n], coords[:, perm]) and bool((idst[n:] == -7).all())
+    assert torch.equal(fdst.reshape(-1)[:n * C], feats.reshape(-1)) and float(fdst.reshape(-1)[n * C:].abs().sum()) == 0.0
+    assert torch.equal(ldst, labels) and int(nv) == n

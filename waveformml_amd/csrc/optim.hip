@@ -48,3 +48,65 @@ extern "C" int wfs_sgd_step(float *param, const float *grad, float *momentum_buf
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hand-over of a batch to a captured step in ONE launch: a replayed HIP graph reads its inputs from fixed buffers, so
+// every step starts by copying the batch there -- coordinates, features, labels, the row count -- and the reference's
+// forward then permutes the coordinate columns to batch-first (src/models/SPConvNet.py:64).  Five launches (three
+// copies, a fill, an index kernel) at ~5 us each become one.
+namespace {
+
+struct Perm {
+    int v[8];
+};
+
+__global__ void __launch_bounds__(256) k_load_batch(const int *__restrict__ coords, long long n, int cols, Perm perm,
+                                                    int *__restrict__ coords_dst, int *__restrict__ indices_dst,
+                                                    const uint4 *__restrict__ feats, uint4 *__restrict__ feats_dst,
+                                                    long long feat_words, const unsigned char *__restrict__ feats_tail,
+                                                    unsigned char *__restrict__ feats_tail_dst, int tail_bytes,
+                                                    const long long *__restrict__ labels, long long *__restrict__ labels_dst,
+                                                    long long B, long long *__restrict__ n_valid_dst) {
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
+    if (tid == 0 && n_valid_dst) *n_valid_dst = n;
+    for (long long i = tid; i < n * cols; i += nth) {
+        const long long row = i / cols;
+        const int col = (int)(i - row * cols);
+        if (coords_dst) coords_dst[i] = coords[i];
+        if (indices_dst) indices_dst[i] = coords[row * cols + perm.v[col]];
+    }
+    for (long long i = tid; i < feat_words; i += nth) feats_dst[i] = feats[i];
+    for (long long i = tid; i < tail_bytes; i += nth) feats_tail_dst[i] = feats_tail[i];
+    for (long long i = tid; i < B; i += nth) labels_dst[i] = labels[i];
+}
+
+}  // namespace
+
+extern "C" int wfs_load_batch(const int32_t *coords, int64_t n, int32_t cols, const int32_t *perm_host,
+                              int32_t *coords_dst, int32_t *indices_dst, const void *feats, void *feats_dst,
+                              int64_t feat_bytes, const int64_t *labels, int64_t *labels_dst, int64_t B,
+                              int64_t *n_valid_dst, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(cols >= 1 && cols <= 8, WFS_EINVAL, "bad coordinate width %d", cols);
+    WFS_REQUIRE(n >= 0 && B >= 0 && feat_bytes >= 0, WFS_EINVAL, "negative size");
+    WFS_REQUIRE((n == 0 || coords) && (feat_bytes == 0 || (feats && feats_dst)) && (B == 0 || (labels && labels_dst)),
+                WFS_EINVAL, "NULL device pointer");
+    Perm pm;
+    for (int c = 0; c < 8; ++c) {
+        pm.v[c] = (perm_host && c < cols) ? perm_host[c] : c;
+        WFS_REQUIRE(pm.v[c] >= 0 && pm.v[c] < (c < cols ? cols : 8), WFS_EINVAL, "bad column permutation");
+    }
+    const bool aligned = ((uintptr_t)feats % 16 == 0) && ((uintptr_t)feats_dst % 16 == 0);
+    const long long words = aligned ? feat_bytes / 16 : 0;
+    const int tail = (int)(feat_bytes - words * 16 > (1 << 30) ? 0 : feat_bytes - words * 16);
+    WFS_REQUIRE(aligned || feat_bytes < (1 << 30), WFS_EINVAL, "unaligned feature buffers");
+    long long work = n * cols > words ? n * cols : words;
+    long long blocks = wfs_cdiv(work > 0 ? work : 1, 256);
+    if (blocks > 1024) blocks = 1024;
+    k_load_batch<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(
+        coords, n, cols, pm, coords_dst, indices_dst, (const uint4 *)feats, (uint4 *)feats_dst, words,
+        (const unsigned char *)feats + words * 16, (unsigned char *)feats_dst + words * 16, tail, (const long long *)labels,
+        (long long *)labels_dst, B, (long long *)n_valid_dst);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}

@@ -30,6 +30,12 @@ class GraphedTrainStep(object):
         self.feats = torch.zeros((self.n_cap, feats.shape[1]), dtype=feats.dtype, device=dev)
         self.labels = torch.zeros_like(labels)
         self.n_valid = torch.zeros((1,), dtype=torch.int64, device=dev)
+        # the coordinates in the reference's batch-first column order, written by the same hand-over launch; the net
+        # takes them instead of permuting when it is given exactly self.coords (psd/net.py)
+        net = getattr(module, "model", None)
+        perm = getattr(net, "permute_tensor", None)
+        self._perm = [int(v) for v in perm.tolist()] if perm is not None else None
+        self.indices = torch.zeros_like(self.coords) if self._perm is not None else None
         self.world = reducer.world
         self.in_graph_optimizer = self.world == 1
         self._convs = [m for m in module.modules()
@@ -56,6 +62,8 @@ class GraphedTrainStep(object):
         if self.world > 1:
             reducer.remove()              # no collectives inside the graph: gradients are exchanged after the replay
         # ---- warm-up in device-count mode, then capture
+        if self.indices is not None:
+            net.batch_first_indices = (self.coords, self.indices)
         self._load(example_batch)
         for _ in range(warmup):
             self._body()
@@ -88,10 +96,24 @@ class GraphedTrainStep(object):
         n = coords.shape[0]
         if n > self.n_cap:
             raise RuntimeError("batch has %d voxels, the captured step holds %d" % (n, self.n_cap))
+        if (coords.is_cuda and coords.dtype == torch.int32 and coords.is_contiguous() and feats.is_cuda
+                and feats.is_contiguous() and feats.dtype == self.feats.dtype and labels.is_cuda
+                and labels.dtype == torch.int64 and labels.is_contiguous() and labels.shape == self.labels.shape):
+            # one launch: coordinates (as they are and batch-first), features, labels, row count
+            from .. import _lib
+            lib = _lib.load()
+            perm = _lib.i32_array(self._perm) if self._perm is not None else None
+            _lib.check(lib.wfs_load_batch(_lib.ptr(coords), n, coords.shape[1], perm, _lib.ptr(self.coords),
+                                          _lib.ptr(self.indices), _lib.ptr(feats), _lib.ptr(self.feats),
+                                          feats.numel() * feats.element_size(), _lib.ptr(labels), _lib.ptr(self.labels),
+                                          labels.numel(), _lib.ptr(self.n_valid), _lib.stream_ptr()))
+            return
         self.coords[:n].copy_(coords, non_blocking=True)
         self.feats[:n].copy_(feats, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         self.n_valid.fill_(n)
+        if self.indices is not None:
+            self.indices[:n].copy_(coords[:, self._perm], non_blocking=True)
 
     def __call__(self, batch):
         if torch.cuda.current_stream(self.coords.device) == torch.cuda.default_stream(self.coords.device):

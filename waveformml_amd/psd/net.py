@@ -49,9 +49,13 @@ class SPConvNet(nn.Module):
             batch_size = getattr(self, "batch_size_hint", None)
         if batch_size is None:
             batch_size = int(coords[-1, -1]) + 1          # one device->host read, as the reference's
-        make = lambda: coords[:, self.permute_tensor].contiguous()          # noqa: E731
-        reused = getattr(getattr(self.spconv, "ops", None), "reused", None)
-        indices = reused("batch_first", coords, make) if reused is not None else make()
+        handed = getattr(self, "batch_first_indices", None)
+        if handed is not None and handed[0] is coords:
+            indices = handed[1]            # psd/graph.py's hand-over kernel already wrote the batch-first columns
+        else:
+            make = lambda: coords[:, self.permute_tensor].contiguous()          # noqa: E731
+            reused = getattr(getattr(self.spconv, "ops", None), "reused", None)
+            indices = reused("batch_first", coords, make) if reused is not None else make()
         st = self.spconv.SparseConvTensor(feats, indices, self.spatial_size,
                                           batch_size)
         if len(x) > 2 and x[2] is not None:       # [coords, feats, n_valid]: rows beyond n_valid[0] are padding
