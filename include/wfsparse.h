@@ -255,6 +255,21 @@ int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const floa
                  void *dX, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
                  void *stream);
 
+/* ToDense + flatten + Linear without the dense tensor ---------------------------------------------------
+ * What the reference computes at src/models/SPConvNet.py:65-68 for the last sparse layer's rows X [M, C] (dtype) with
+ * DISTINCT sites indices [M, ndim+1] (batch first, rows of one event contiguous and events in increasing order, as
+ * every conv of this library emits them): Y [batch, O] = bias + flatten(dense(X)) . W^T with W [O, C * V] fp32
+ * (nn.Linear.weight over the [C, *spatial] flattening), V = prod(spatial) <= 16384, C % 8 == 0, O <= 8.
+ * forward also fills grid [batch, V] int32 (row of each cell or -1; may be NULL when no dW will be asked for).
+ * backward: G [batch, O] fp32 -> dX [M, C] (dtype), dW [O, C * V], dB [O] (each may be NULL).  No atomics. */
+int wfs_sparse_head_fwd(const void *X, const int32_t *indices, int64_t M, int32_t ndim, const int32_t *spatial,
+                        int32_t batch, int32_t C, const float *W, const float *bias, int32_t O, float *Y,
+                        int32_t *grid, int32_t dtype, const int64_t *m_dev, void *stream);
+
+int wfs_sparse_head_bwd(const void *X, const int32_t *indices, int64_t M, int32_t ndim, const int32_t *spatial,
+                        int32_t batch, int32_t C, const float *W, int32_t O, const float *G, void *dX, float *dW,
+                        float *dB, const int32_t *grid, int32_t dtype, const int64_t *m_dev, void *stream);
+
 /* hybrid front end -----------------------------------------------------------------------------------
  * TemporalConvNet(1, [1] * levels, kernel_size = k) as the reference's SPConvNet applies it to the waveform rows
  * before the sparse stack (src/models/SPConvNet.py:56-61,83-92; src/models/ConvBlocks.py:114-173): per level i two

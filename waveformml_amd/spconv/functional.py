@@ -402,6 +402,73 @@ def skinny_linear(x, linear):
     return SkinnyLinearFunction.apply(x, linear.weight, linear.bias)
 
 
+class SparseHeadFunction(Function):
+    """ToDense + flatten + nn.Linear on the sparse rows themselves (reference src/models/SPConvNet.py:65-68):
+    features [M, C] at distinct sites -> logits [B, O]; the dense [B, C, *spatial] tensor is never built."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, indices, spatial_shape, batch_size, m_dev):
+        lib = _lib.load()
+        features = _features_ok(features)
+        indices = indices.contiguous()
+        M, C = features.shape
+        O = weight.shape[0]
+        spatial = [int(s) for s in spatial_shape]
+        V = 1
+        for s_ in spatial:
+            V *= s_
+        B = int(batch_size)
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty((B, O), dtype=torch.float32, device=features.device)
+        grid = torch.empty((B, V), dtype=torch.int32, device=features.device) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.wfs_sparse_head_fwd(_lib.ptr(features), _lib.ptr(indices), M, len(spatial), _lib.i32_array(spatial),
+                                           B, C, _lib.ptr(w), _lib.ptr(b), O, _lib.ptr(y), _lib.ptr(grid),
+                                           _lib.dtype_code(features), _lib.ptr(m_dev), _lib.stream_ptr()))
+        ctx.save_for_backward(features, weight, bias, indices)
+        ctx.meta = (spatial, B, grid, m_dev)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        features, weight, bias, indices = ctx.saved_tensors
+        spatial, B, grid, m_dev = ctx.meta
+        M, C = features.shape
+        O = weight.shape[0]
+        g = grad_output.float().contiguous()
+        w = weight.detach().float().contiguous()
+        dx = _rows(tuple(features.shape), features, m_dev) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=features.device) if ctx.needs_input_grad[1] else None
+        db = (torch.empty((O,), dtype=torch.float32, device=features.device)
+              if (bias is not None and ctx.needs_input_grad[2] and dw is not None) else None)
+        _lib.check(lib.wfs_sparse_head_bwd(_lib.ptr(features), _lib.ptr(indices), M, len(spatial), _lib.i32_array(spatial),
+                                           B, C, _lib.ptr(w), O, _lib.ptr(g), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                           _lib.ptr(grid), _lib.dtype_code(features), _lib.ptr(m_dev), _lib.stream_ptr()))
+        if bias is not None and ctx.needs_input_grad[2] and db is None:
+            db = g.sum(0)
+        return (dx, dw.to(weight.dtype) if dw is not None else None, db.to(bias.dtype) if db is not None else None,
+                None, None, None, None)
+
+
+def can_use_sparse_head(linear, st):
+    """``st``: the SparseConvTensor that would go into ToDense.  Needs distinct sites (then dense() has no "last row
+    wins" to reproduce) and the shapes the kernels cover."""
+    f = st.features
+    v = 1
+    for s_ in st.spatial_shape:
+        v *= int(s_)
+    return (type(linear) is torch.nn.Linear and linear.out_features <= 8 and linear.weight.dtype == torch.float32
+            and f.is_cuda and f.dim() == 2 and f.dtype in (torch.float32, torch.bfloat16) and f.shape[1] % 8 == 0
+            and f.shape[1] // 8 <= 256 and v <= 16384 and linear.in_features == f.shape[1] * v
+            and getattr(st, "unique", None) is True and len(st.spatial_shape) <= 4 and int(st.batch_size) >= 1)
+
+
+def sparse_head(st, linear):
+    return SparseHeadFunction.apply(st.features, linear.weight, linear.bias, st.indices, st.spatial_shape,
+                                    st.batch_size, st.n_valid)
+
+
 class CrossEntropyMeanFunction(Function):
     """nn.CrossEntropyLoss(reduction='mean') on [B, C] fp32 logits: loss and d loss / d logits from one launch
     (reference criterion: src/engineering/LitBase.py:38-43, applied at LitPSD.py:102)."""

@@ -92,9 +92,13 @@ class SparseSequential(SparseModule):
         x.prefetched = plan
 
     def forward(self, input):
+        return self.run(input, list(self._modules.values()))
+
+    def run(self, input, mods):
+        """``forward`` over an explicit module list (a prefix of this container's modules: psd/net.py stops before a
+        trailing ToDense when the head can consume the sparse rows directly)."""
         from . import functional as Fsp
         from . import ops
-        mods = list(self._modules.values())
         want_prefetch = (ops.PREFETCH_RULEBOOKS and _is_sparse_tensor(input) and input.n_valid is not None
                          and getattr(input, "prefetched", None) is None and input.features.is_cuda)
         i = 0
