@@ -998,3 +998,45 @@ def test_net_with_sparse_head_matches_dense_route():
         if float(pa.grad.abs().max()) < 1e-6:
             continue
         _assert_close(pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), 1e-4, name)
+
+
+def _random_geometry(rng):
+    ndim = int(rng.integers(1, 5))
+    shape = [int(rng.integers(3, 10 if ndim > 2 else 24)) for _ in range(ndim)]
+    subm = bool(rng.integers(0, 2))
+    if subm:
+        k = [int(rng.choice([1, 3, 3, 5])) for _ in range(ndim)]
+        if ndim == 4:
+            k = [min(v, 3) for v in k]
+        s, p, d = [1] * ndim, [0] * ndim, [int(rng.choice([1, 1, 2])) for _ in range(ndim)]
+    else:
+        k = [int(rng.integers(1, 4 if ndim > 2 else 6)) for _ in range(ndim)]
+        s = [int(rng.integers(1, 4)) for _ in range(ndim)]
+        d = [1 if s[i] > 1 else int(rng.choice([1, 1, 2])) for i in range(ndim)]
+        p = [int(rng.integers(0, k[i])) for i in range(ndim)]
+        for i in range(ndim):                       # keep the output extent positive
+            while (shape[i] + 2 * p[i] - d[i] * (k[i] - 1) - 1) // s[i] + 1 < 1:
+                shape[i] += 1
+    return ndim, shape, k, s, p, d, subm
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_rulebook_random_geometries_bitexact(seed):
+    """Seeded random geometries (1-D .. 4-D, mixed kernel extents incl. kernel volumes > 32 that take the legacy kernels,
+    strides, paddings, dilations, sparse and nearly full occupancy, hash and direct-grid site tables): out_indices,
+    indice_pairs and indice_pair_num must equal the sequential CPU algorithm's bit for bit; every fourth case also
+    feeds duplicate coordinates to the SubM build ("last row wins")."""
+    rng = np.random.default_rng(9000 + seed)
+    ndim, shape, k, s, p, d, subm = _random_geometry(rng)
+    B = int(rng.integers(1, 6))
+    vol = int(np.prod(shape))
+    n = max(1, int(B * vol * rng.choice([0.02, 0.2, 0.9])))
+    n = min(n, B * vol, 4000)
+    idx = rand_coords(rng, B, shape, n)
+    if subm and seed % 4 == 0 and n > 4:
+        idx = np.concatenate([idx, idx[rng.integers(0, n, size=max(1, n // 10))]])
+        idx = idx[np.argsort(idx[:, 0], kind="stable")]
+    got, want = _rulebook_both(idx, B, shape, k, s, p, d, subm)
+    for g, w, name in zip(got, want, ("out_indices", "indice_pairs", "indice_pair_num")):
+        assert g.shape == w.shape, (name, ndim, shape, k, s, p, d, subm)
+        assert np.array_equal(g, w), (name, ndim, shape, k, s, p, d, subm)
