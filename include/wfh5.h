@@ -58,12 +58,17 @@ int wfh5_get_info(const wfh5_file *f, wfh5_info *info);
  * Either output pointer may be NULL.                                                              */
 int wfh5_read_rows(wfh5_file *f, int64_t row0, int64_t row1, int32_t *coords, float *feats, float scale);
 
+/* Worker threads for bulk reads of gzip-chunked tables (raw chunks are fetched serially, inflated and converted in
+ * parallel; libhdf5's own filter pipeline is single-threaded).  Default: $WFH5_THREADS or 4.  Per process. */
+int wfh5_set_threads(int n);
+
 /* labels [e0, e1) widened to int64 (reference :319-327) */
 int wfh5_read_labels(wfh5_file *f, int64_t e0, int64_t e1, int64_t *labels);
 
 /* Row range of the events [e0, e1] (inclusive, as the reference's event_range): first row whose event id
  * (column event_col of coord) equals e0, and first row whose event id equals e1 + 1 (n_rows if e1 is the
- * last event) -- what `where(coords[:, c] == e)[0][0]` returns at reference :241-248.              */
+ * last event) -- what `where(coords[:, c] == e)[0][0]` returns at reference :241-248.  Sorted files are searched by
+ * bisection (a few chunk decodes) and the answer verified; unsorted ones fall back to a scan of the column.       */
 int wfh5_event_rows(wfh5_file *f, int32_t event_col, int64_t e0, int64_t e1, int64_t *row0, int64_t *row1);
 
 #ifdef __cplusplus

@@ -100,5 +100,36 @@ for cls, name, ne in (("Electron", "a_Waveform3DPairSim.h5", 6), ("Gamma", "b_Wa
     c, w = write_compound_3d(os.path.join(OUT, cls, name), ne)
     expected["%s/%s/coord" % (cls, name)] = c
     expected["%s/%s/waveform" % (cls, name)] = w
+
+
+def write_compound_3d_gzip(path, n_events, shuffle_events=False):
+    """the same compound table, chunked (64 records) + gzip-6: what libwfh5's chunk-parallel path reads"""
+    coords, feats = [], []
+    order = list(range(n_events))
+    if shuffle_events:
+        order = order[::2] + order[1::2]                 # event ids NOT ascending: the search must fall back to a scan
+    for e in order:
+        for _ in range(int(rng.integers(1, 3))):
+            x, y, t0 = int(rng.integers(0, 14)), int(rng.integers(0, 11)), int(rng.integers(0, 20))
+            for t in range(t0, t0 + int(rng.integers(5, 30))):
+                coords.append([x, y, t, e])
+                feats.append(rng.random(2))
+    coords, feats = np.asarray(coords, np.int32), np.asarray(feats, np.float32)
+    dt = np.dtype([("evt", "<i8"), ("coord", "<i4", (4,)), ("waveform", "<f4", (2,)), ("PID", "<i4")])
+    rec = np.zeros(len(coords), dt)
+    rec["evt"] = coords[:, 3]
+    rec["coord"] = coords
+    rec["waveform"] = feats
+    with h5py.File(path, "w") as f:
+        d = f.create_dataset("Waveform3DPairs", data=rec, chunks=(64,), compression="gzip", compression_opts=6)
+        d.attrs.create("nevents", np.array([n_events]))
+    return coords, feats
+
+
+os.makedirs(os.path.join(OUT, "gz"), exist_ok=True)
+for name, ne, shuf in (("sorted_Waveform3DPairSim.h5", 23, False), ("unsorted_Waveform3DPairSim.h5", 10, True)):
+    c, w = write_compound_3d_gzip(os.path.join(OUT, "gz", name), ne, shuf)
+    expected["gz/%s/coord" % name] = c
+    expected["gz/%s/waveform" % name] = w
 np.savez_compressed(os.path.join(OUT, "expected.npz"), **expected)
 print("wrote", sorted(expected))

@@ -146,3 +146,31 @@ def test_dataloader_workers_read_through_their_own_handles():
     (coords, feats), labels = next(iter(loader))
     assert labels.tolist() == [0] * 9 + [1] * 10 + [0]
     assert coords[:, 2].max() == 19 and feats.shape[0] == coords.shape[0]
+
+
+def test_gzip_chunked_compound_table_takes_the_parallel_path_and_bisects_events():
+    """Chunked + gzip compound table (64-record chunks): bulk reads inflate the raw chunks on worker threads, the event
+    search bisects a sorted file; both must give exactly what h5py read."""
+    rel = "gz/sorted_Waveform3DPairSim.h5"
+    c_ref, w_ref = EXP[rel + "/coord"], EXP[rel + "/waveform"]
+    for threads in (1, 3):
+        h5data.set_threads(threads)
+        with h5data.H5Table(os.path.join(H5, rel), "Waveform3DPairs") as t:
+            assert (t.n_rows, t.n_events, t.coord_cols, t.feat_cols) == (len(c_ref), 23, 4, 2)
+            for r0, r1 in ((0, t.n_rows), (1, 65), (63, 129), (100, 500), (t.n_rows - 70, t.n_rows), (5, 6)):
+                c, f = t.read_rows(r0, r1, 0.5)
+                assert np.array_equal(c.numpy(), c_ref[r0:r1]) and np.array_equal(f.numpy(), w_ref[r0:r1] * np.float32(0.5))
+            for e0, e1 in ((0, 22), (0, 0), (4, 9), (22, 22), (11, 21)):
+                assert t.event_rows(e0, e1, 3) == _slice_events(c_ref, 3, e0, e1)
+            with pytest.raises(h5data.H5Error):
+                t.event_rows(23, 25, 3)
+    h5data.set_threads(4)
+
+
+def test_unsorted_event_ids_fall_back_to_the_first_occurrence_scan():
+    rel = "gz/unsorted_Waveform3DPairSim.h5"
+    c_ref = EXP[rel + "/coord"]
+    assert not np.all(np.diff(c_ref[:, 3]) >= 0)
+    with h5data.H5Table(os.path.join(H5, rel), "Waveform3DPairs") as t:
+        for e0, e1 in ((2, 3), (4, 7), (1, 2)):                # e0 and e1 + 1 both occur: the reference's rule applies
+            assert t.event_rows(e0, e1, 3) == _slice_events(c_ref, 3, e0, e1)

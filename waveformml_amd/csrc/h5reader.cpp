@@ -8,9 +8,16 @@
 #include <hdf5.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wfh5.h"
@@ -26,6 +33,7 @@ extern "C" const char *wfh5_last_error(void) { return g_err; }
 
 struct wfh5_file {
     hid_t file = -1;
+    int fd = -1;                  // the same file through POSIX, for parallel reads of raw chunks at known addresses
     int layout = WFH5_GROUP;
     // group layout
     hid_t d_coord = -1, d_feat = -1, d_labels = -1;
@@ -33,9 +41,66 @@ struct wfh5_file {
     hid_t d_table = -1;
     bool labels_member = false;
     wfh5_info info{};
-    std::vector<int32_t> event_col_cache;     // the event-id column, loaded once for wfh5_event_rows
+    std::vector<int32_t> event_col_cache;     // the event-id column, loaded once for the linear event search
     int cached_event_col = -1;
+    // chunk-parallel fast path (gzip-only chunked storage whose chunks span whole rows): raw chunks are fetched with
+    // H5Dread_chunk (serial, cheap) and inflated + converted on worker threads -- libhdf5's own filter pipeline is
+    // single-threaded and is what bounds a plain H5Dread of these files.
+    struct Fast {
+        bool ok = false;
+        hid_t dset = -1;
+        hsize_t chunk_rows = 0;
+        size_t row_bytes = 0;          // bytes of one row / record as stored
+        size_t off = 0;                // byte offset of the member inside the record (compound) or 0
+        size_t elem = 0;               // stored element size
+        bool is_float = false;
+        int cols = 0;
+        bool two_d = false;
+    };
+    Fast fast_coord, fast_feat;
 };
+
+static int g_threads = -1;
+static int reader_threads() {
+    if (g_threads < 0) {
+        const char *e = getenv("WFH5_THREADS");
+        g_threads = e ? atoi(e) : 4;
+        if (g_threads < 1) g_threads = 1;
+    }
+    return g_threads;
+}
+extern "C" int wfh5_set_threads(int n) {
+    g_threads = n < 1 ? 1 : n;
+    return WFH5_OK;
+}
+
+static bool little_endian_native(hid_t t) { return H5Tget_size(t) == 1 || H5Tget_order(t) == H5T_ORDER_LE; }
+
+// is `dset` stored in gzip-only chunks of whole rows?  (1-D compound table, or 2-D [n, cols] with chunk (r, cols))
+static bool chunked_gzip_rows(hid_t dset, hsize_t *chunk_rows) {
+    hid_t pl = H5Dget_create_plist(dset);
+    bool ok = false;
+    if (pl >= 0 && H5Pget_layout(pl) == H5D_CHUNKED && H5Pget_nfilters(pl) == 1) {
+        unsigned flags = 0, cfg = 0;
+        size_t nelm = 0;
+        char name[16];
+        if (H5Pget_filter2(pl, 0, &flags, &nelm, nullptr, sizeof(name), name, &cfg) == H5Z_FILTER_DEFLATE) {
+            hid_t sp = H5Dget_space(dset);
+            int nd = H5Sget_simple_extent_ndims(sp);
+            hsize_t dims[2] = {0, 1}, cd[2] = {0, 1};
+            if (nd >= 1 && nd <= 2) {
+                H5Sget_simple_extent_dims(sp, dims, nullptr);
+                H5Pget_chunk(pl, nd, cd);
+                ok = cd[0] >= 1 && (nd == 1 || cd[1] == dims[1]);
+                *chunk_rows = cd[0];
+            }
+            H5Sclose(sp);
+        }
+    }
+    if (pl >= 0) H5Pclose(pl);
+    return ok;
+}
+
 
 static int64_t read_nevents(hid_t obj) {
     if (H5Aexists(obj, "nevents") <= 0) return -1;
@@ -70,6 +135,7 @@ extern "C" void wfh5_close(wfh5_file *f) {
     if (f->d_labels >= 0) H5Dclose(f->d_labels);
     if (f->d_table >= 0) H5Dclose(f->d_table);
     if (f->file >= 0) H5Fclose(f->file);
+    if (f->fd >= 0) close(f->fd);
     delete f;
 }
 
@@ -97,6 +163,7 @@ extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
         wfh5_close(f);
         return WFH5_EIO;
     }
+    f->fd = open(path, O_RDONLY);
     H5O_info_t oi;
     if (H5Lexists(f->file, table, H5P_DEFAULT) <= 0 || H5Oget_info_by_name(f->file, table, &oi, H5P_DEFAULT) < 0) {
         set_err("%s: no object named %s", path, table);
@@ -122,6 +189,34 @@ extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
         f->info.feat_cols = (int32_t)c1;
         hid_t t = H5Dget_type(f->d_feat);
         f->info.feat_is_float = H5Tget_class(t) == H5T_FLOAT;
+        {
+            hid_t tcd = H5Dget_type(f->d_coord);
+            hsize_t cr = 0;
+            if (H5Tget_class(tcd) == H5T_INTEGER && H5Tget_size(tcd) == 4 && little_endian_native(tcd) &&
+                chunked_gzip_rows(f->d_coord, &cr)) {
+                f->fast_coord.ok = true;
+                f->fast_coord.dset = f->d_coord;
+                f->fast_coord.chunk_rows = cr;
+                f->fast_coord.row_bytes = (size_t)c0 * 4;
+                f->fast_coord.elem = 4;
+                f->fast_coord.cols = (int)c0;
+                f->fast_coord.two_d = true;
+            }
+            H5Tclose(tcd);
+            const size_t es = H5Tget_size(t);
+            const bool flt = H5Tget_class(t) == H5T_FLOAT;
+            if (((flt && es == 4) || (!flt && es == 2 && H5Tget_sign(t) == H5T_SGN_2)) && little_endian_native(t) &&
+                chunked_gzip_rows(f->d_feat, &cr)) {
+                f->fast_feat.ok = true;
+                f->fast_feat.dset = f->d_feat;
+                f->fast_feat.chunk_rows = cr;
+                f->fast_feat.row_bytes = (size_t)c1 * es;
+                f->fast_feat.elem = es;
+                f->fast_feat.is_float = flt;
+                f->fast_feat.cols = (int)c1;
+                f->fast_feat.two_d = true;
+            }
+        }
         H5Tclose(t);
         if (f->d_labels >= 0) {
             hsize_t nl, cl;
@@ -150,6 +245,35 @@ extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
         f->info.feat_cols = (int32_t)member_len(tw);
         hid_t twb = H5Tget_class(tw) == H5T_ARRAY ? H5Tget_super(tw) : H5Tcopy(tw);
         f->info.feat_is_float = H5Tget_class(twb) == H5T_FLOAT;
+        {
+            hid_t tcb = H5Tget_class(tc) == H5T_ARRAY ? H5Tget_super(tc) : H5Tcopy(tc);
+            hsize_t cr = 0;
+            const bool chunked = chunked_gzip_rows(f->d_table, &cr);
+            const size_t rec = H5Tget_size(t);
+            if (chunked && H5Tget_class(tcb) == H5T_INTEGER && H5Tget_size(tcb) == 4 && little_endian_native(tcb)) {
+                f->fast_coord.ok = true;
+                f->fast_coord.dset = f->d_table;
+                f->fast_coord.chunk_rows = cr;
+                f->fast_coord.row_bytes = rec;
+                f->fast_coord.off = H5Tget_member_offset(t, (unsigned)ic);
+                f->fast_coord.elem = 4;
+                f->fast_coord.cols = f->info.coord_cols;
+            }
+            const size_t es = H5Tget_size(twb);
+            const bool flt = H5Tget_class(twb) == H5T_FLOAT;
+            if (chunked && ((flt && es == 4) || (!flt && es == 2 && H5Tget_sign(twb) == H5T_SGN_2)) &&
+                little_endian_native(twb)) {
+                f->fast_feat.ok = true;
+                f->fast_feat.dset = f->d_table;
+                f->fast_feat.chunk_rows = cr;
+                f->fast_feat.row_bytes = rec;
+                f->fast_feat.off = H5Tget_member_offset(t, (unsigned)iw);
+                f->fast_feat.elem = es;
+                f->fast_feat.is_float = flt;
+                f->fast_feat.cols = f->info.feat_cols;
+            }
+            H5Tclose(tcb);
+        }
         H5Tclose(twb);
         H5Tclose(tc);
         H5Tclose(tw);
@@ -201,6 +325,75 @@ static int read_member(wfh5_file *f, const char *name, hsize_t len, hid_t base, 
     return rc;
 }
 
+// rows [r0, r1) of one or two members that live in the same chunked dataset (compound) or of one 2-D dataset:
+// chunk addresses from libhdf5 (serial), then pread + inflate + convert on worker threads.  Returns false if anything is unexpected (the caller then
+// uses H5Dread).
+static bool read_rows_chunked(int fd, const wfh5_file::Fast *fc, int32_t *coords, const wfh5_file::Fast *ff,
+                              float *feats, float scale, hsize_t r0, hsize_t r1) {
+    const wfh5_file::Fast *any = fc ? fc : ff;
+    const hsize_t cr = any->chunk_rows;
+    const hsize_t c_first = r0 / cr, c_last = (r1 - 1) / cr;
+    const size_t nchunks = (size_t)(c_last - c_first + 1);
+    // where the raw chunks are (libhdf5's chunk index, serial); their bytes are then read with pread() on the worker
+    // threads -- H5Dread_chunk costs ~0.5 ms per call and would serialise the whole read
+    std::vector<haddr_t> addr(nchunks);
+    std::vector<hsize_t> size(nchunks);
+    for (size_t i = 0; i < nchunks; ++i) {
+        hsize_t off[2] = {(c_first + i) * cr, 0};
+        unsigned mask = 0;
+        if (H5Dget_chunk_info_by_coord(any->dset, off, &mask, &addr[i], &size[i]) < 0 || size[i] == 0 || mask != 0 ||
+            addr[i] == HADDR_UNDEF)
+            return false;
+    }
+    if (fd < 0) return false;
+    std::atomic<size_t> next(0);
+    std::atomic<bool> failed(false);
+    auto work = [&]() {
+        std::vector<unsigned char> rows((size_t)cr * any->row_bytes), raw;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= nchunks || failed.load()) return;
+            raw.resize((size_t)size[i]);
+            size_t done = 0;
+            while (done < raw.size()) {
+                ssize_t n = pread(fd, raw.data() + done, raw.size() - done, (off_t)(addr[i] + done));
+                if (n <= 0) {
+                    failed.store(true);
+                    return;
+                }
+                done += (size_t)n;
+            }
+            uLongf got = (uLongf)rows.size();
+            if (uncompress(rows.data(), &got, raw.data(), (uLong)raw.size()) != Z_OK || got != rows.size()) {
+                failed.store(true);
+                return;
+            }
+            const hsize_t base = (c_first + i) * cr;
+            const hsize_t a = std::max(base, r0), b = std::min(base + cr, r1);
+            for (hsize_t r = a; r < b; ++r) {
+                const unsigned char *rec = rows.data() + (size_t)(r - base) * any->row_bytes;
+                if (fc && coords) memcpy(coords + (size_t)(r - r0) * fc->cols, rec + fc->off, (size_t)fc->cols * 4);
+                if (ff && feats) {
+                    float *o = feats + (size_t)(r - r0) * ff->cols;
+                    if (ff->is_float) {
+                        const float *src = (const float *)(rec + ff->off);
+                        for (int c = 0; c < ff->cols; ++c) o[c] = src[c] * scale;
+                    } else {
+                        const int16_t *src = (const int16_t *)(rec + ff->off);
+                        for (int c = 0; c < ff->cols; ++c) o[c] = (float)src[c] * scale;
+                    }
+                }
+            }
+        }
+    };
+    const int nt = (int)std::min<size_t>((size_t)reader_threads(), nchunks);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    return !failed.load();
+}
+
 extern "C" int wfh5_read_rows(wfh5_file *f, int64_t row0, int64_t row1, int32_t *coords, float *feats, float scale) {
     if (!f || row0 < 0 || row1 < row0 || row1 > f->info.n_rows) {
         set_err("bad row range [%lld, %lld) of %lld", (long long)row0, (long long)row1, f ? (long long)f->info.n_rows : -1ll);
@@ -209,6 +402,22 @@ extern "C" int wfh5_read_rows(wfh5_file *f, int64_t row0, int64_t row1, int32_t 
     if (row1 == row0) return WFH5_OK;
     int rc = WFH5_OK;
     const hsize_t r0 = (hsize_t)row0, r1 = (hsize_t)row1;
+    // chunk-parallel path first (bulk reads only: single rows -- the event search's probes -- go through H5Dread, whose
+    // chunk cache keeps the probed chunk); it scales the features itself, so the generic scaling below is skipped
+    const bool bulk = row1 - row0 >= 64;
+    if (!bulk) {
+    } else if (f->layout == WFH5_COMPOUND && (!coords || f->fast_coord.ok) && (!feats || f->fast_feat.ok) && (coords || feats)) {
+        if (read_rows_chunked(f->fd, coords ? &f->fast_coord : nullptr, coords, feats ? &f->fast_feat : nullptr, feats, scale, r0,
+                              r1))
+            return WFH5_OK;
+    } else if (f->layout == WFH5_GROUP) {
+        bool done_c = !coords, done_f = !feats;
+        if (coords && f->fast_coord.ok) done_c = read_rows_chunked(f->fd, &f->fast_coord, coords, nullptr, nullptr, 1.0f, r0, r1);
+        if (feats && f->fast_feat.ok) done_f = read_rows_chunked(f->fd, nullptr, nullptr, &f->fast_feat, feats, scale, r0, r1);
+        if (done_c && done_f) return WFH5_OK;
+        if (done_c) coords = nullptr;                 // the rest goes through H5Dread
+        if (done_f) feats = nullptr;
+    }
     if (f->layout == WFH5_GROUP) {
         if (coords) rc = read_slab(f->d_coord, r0, r1, f->info.coord_cols, true, H5T_NATIVE_INT32, coords);
         if (rc == WFH5_OK && feats) rc = read_slab(f->d_feat, r0, r1, f->info.feat_cols, true, H5T_NATIVE_FLOAT, feats);
@@ -257,6 +466,37 @@ extern "C" int wfh5_event_rows(wfh5_file *f, int32_t event_col, int64_t e0, int6
         return WFH5_EINVAL;
     }
     const int64_t n = f->info.n_rows;
+    // Sorted files (what the simulation chain writes, and what collate_fn's event re-numbering needs): two binary
+    // searches with single-row reads -- a handful of chunk decodes instead of the whole column.  The result is checked
+    // against the first-occurrence rule at both ends; anything inconsistent falls back to the linear scan below.
+    if (f->cached_event_col != event_col && n > 0) {
+        std::vector<int32_t> one((size_t)f->info.coord_cols);
+        bool io_ok = true;
+        auto ev = [&](int64_t r) -> int64_t {
+            if (wfh5_read_rows(f, r, r + 1, one.data(), nullptr, 1.0f) != WFH5_OK) {
+                io_ok = false;
+                return 0;
+            }
+            return one[(size_t)event_col];
+        };
+        auto lower = [&](int64_t e) {
+            int64_t lo = 0, hi = n;
+            while (lo < hi && io_ok) {
+                int64_t mid = lo + (hi - lo) / 2;
+                if (ev(mid) < e) lo = mid + 1; else hi = mid;
+            }
+            return lo;
+        };
+        const int64_t a = e0 > 0 ? lower(e0) : 0, b = lower(e1 + 1);
+        bool good = io_ok && a < n && ev(a) == e0 && (a == 0 || ev(a - 1) < e0) && a < b && ev(b - 1) <= e1 &&
+                    (b == n || ev(b) == e1 + 1);
+        if (e0 == 0) good = good && ev(0) >= 0;
+        if (good && io_ok) {
+            *row0 = a;
+            *row1 = b;
+            return WFH5_OK;
+        }
+    }
     if (f->cached_event_col != event_col) {
         std::vector<int32_t> all((size_t)n * f->info.coord_cols);
         int rc = n ? wfh5_read_rows(f, 0, n, all.data(), nullptr, 1.0f) : WFH5_OK;

@@ -54,7 +54,13 @@ SIGNATURES = {
     "wfh5_read_rows": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, ctypes.c_float]),
     "wfh5_read_labels": (ctypes.c_int, [_vp, _i64, _i64, _vp]),
     "wfh5_event_rows": (ctypes.c_int, [_vp, _i32, _i64, _i64, c_i64p, c_i64p]),
+    "wfh5_set_threads": (ctypes.c_int, [ctypes.c_int]),
 }
+
+
+def set_threads(n):
+    """Worker threads libwfh5 uses to inflate the chunks of a bulk read (default $WFH5_THREADS or 4)."""
+    load().wfh5_set_threads(int(n))
 
 _LIB = None
 
