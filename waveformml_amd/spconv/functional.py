@@ -76,6 +76,45 @@ def can_take_batch_norm_stats(bn, features):
             and (bn.training or bn.running_mean is None))
 
 
+# Wide-channel layers on few rows (the reference's 2-D nets: 300 -> 252 -> 158 -> 64 channels on a few hundred rows,
+# config/examples/GEP.json) are small dense GEMMs per kernel offset.  They go to the library GEMM (rocBLAS / hipBLASLt
+# batched fp32, i.e. MFMA) on rows gathered through the SAME tables -- still output-stationary, no atomics, deterministic.
+# The hand-written kernels keep the shapes they are built for (32- and 2-channel rows) and everything else that does
+# not fit this route (device-side row counts, huge K * R * C).  Measured on GEP at batch 32: 741 us -> ~40 us per layer.
+GEMM_ROUTE_MIN_CHANNELS = 48
+GEMM_ROUTE_MAX_ELEMENTS = 1 << 27
+
+
+def _gemm_route(Cx, Cy, K, R, r_dev, table):
+    fast = (Cx == 32 and Cy == 32) or (Cx == 2 and Cy == 32) or (Cx == 32 and Cy == 2)
+    return (not fast and table is not None and R > 0 and max(Cx, Cy) >= GEMM_ROUTE_MIN_CHANNELS
+            and K * R * max(Cx, Cy) <= GEMM_ROUTE_MAX_ELEMENTS and ACCOUNT is None)
+
+
+def _row_ok(R, r_dev, device):
+    """[R] bool: rows below the device-side valid count (rows beyond it hold uninitialised table entries / features)."""
+    return None if r_dev is None else torch.arange(R, device=device) < r_dev
+
+
+def _gathered(table, kmap, K, identity_k, R, X, r_dev=None):
+    """[K, R, C] rows of X gathered through table[kmap[k]] (zeros where the entry is -1 or the row is beyond the valid
+    count; the row itself at identity_k)."""
+    idx = table.long()
+    if kmap is not None:
+        idx = idx[torch.as_tensor(list(kmap), dtype=torch.long, device=table.device)]
+    if identity_k is not None and identity_k >= 0:
+        idx = idx.clone()
+        idx[identity_k] = torch.arange(R, device=table.device)
+    n = X.shape[0]
+    bad = idx < 0
+    ok = _row_ok(R, r_dev, table.device)
+    if ok is not None:
+        bad = bad | ~ok.unsqueeze(0) | (idx >= n)
+    idx = torch.where(bad, torch.full_like(idx, n), idx)
+    Xp = torch.cat([X, X.new_zeros((1, X.shape[1]))])
+    return Xp[idx.reshape(-1)].reshape(K, R, X.shape[1])
+
+
 def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
     With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only)."""
@@ -87,6 +126,13 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
+    if _gemm_route(X.shape[1], Cy, K, R, r_dev, table) and bn_request is None:
+        G = _gathered(table, kmap, K, identity_k, R, X, r_dev).float()
+        Wk = W.transpose(1, 2) if transpose_w else W
+        out = torch.bmm(G, Wk).sum(0)
+        if bias is not None:
+            out = out + bias
+        return out.to(X.dtype)
     if bn_request is not None and not transpose_w and R > 0 and bn_request.bn.num_features == Cy:
         bn = bn_request.bn
         track = bn.track_running_stats and bn.running_mean is not None
@@ -147,6 +193,12 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
     dW = torch.empty((K, Cg, Cs) if swap else (K, Cs, Cg), dtype=torch.float32, device=S.device)
     assert S.dtype == G.dtype and S.shape[0] == R
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
+    if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap:
+        Gk = _gathered(table, kmap, K, identity_k, R, G, r_dev).float()             # [K, R, Cg]
+        ok = _row_ok(R, r_dev, S.device)
+        Sf = S.float() if ok is None else torch.where(ok.unsqueeze(1), S.float(), S.new_zeros((), dtype=torch.float32))
+        dWk = torch.matmul(Sf.t().unsqueeze(0), Gk)                                   # [K, Cs, Cg]
+        return dWk.transpose(1, 2).contiguous() if swap else dWk.contiguous()
     nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
 
