@@ -1040,3 +1040,36 @@ def test_rulebook_random_geometries_bitexact(seed):
     for g, w, name in zip(got, want, ("out_indices", "indice_pairs", "indice_pair_num")):
         assert g.shape == w.shape, (name, ndim, shape, k, s, p, d, subm)
         assert np.array_equal(g, w), (name, ndim, shape, k, s, p, d, subm)
+
+
+def test_fp16_storage_runs_on_the_fp32_kernels():
+    """The reference's ``half_precision`` feeds float16 features (src/datasets/HDF5Dataset.py:228).  Here fp16 rows are
+    widened on entry and rounded on exit of every operator (fp16 storage, fp32 arithmetic).  A C2-shaped stack with
+    fp16 features against the CPU restatement in fp32 fed the same fp16-rounded input: activations stay fp16 between
+    layers, logits within 5e-3 (ten mantissa bits through five layers), gradients flow in fp16."""
+    from oracle import spconv as osp
+    sp = _sp()
+    rng = np.random.default_rng(404)
+    B, T = 6, 32
+    idx = _waveform_like(rng, B, T)
+    feat = rng.random((len(idx), 2)).astype(np.float32)
+
+    def build(m):
+        return m.SparseSequential(
+            m.SubMConv3d(2, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            m.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            m.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False), torch.nn.BatchNorm1d(32), torch.nn.ReLU(), m.ToDense())
+
+    torch.manual_seed(7)
+    ref_net = build(osp)
+    net = build(sp).to(DEV)
+    net.load_state_dict(ref_net.state_dict())
+    fin = torch.from_numpy(feat).half()
+    fg = fin.to(DEV).requires_grad_(True)
+    yg = net(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), [14, 11, T], B))
+    assert yg.dtype == torch.float16
+    yr = ref_net(osp.SparseConvTensor(fin.float(), torch.from_numpy(idx), [14, 11, T], B))
+    _assert_close(yg.detach().float().cpu().numpy(), yr.detach().numpy(), 5e-3, "dense output")
+    yg.float().square().mean().backward()
+    assert fg.grad is not None and fg.grad.dtype == torch.float16 and bool(torch.isfinite(fg.grad).all())
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())

@@ -97,7 +97,7 @@ class TemporalConvNet(nn.Module):
     def _can_fuse(self, x):
         levels, k = len(self.network), self.kernel_size
         if not (self.single_channel and x.is_cuda and x.dim() == 3 and x.shape[1] == 1
-                and x.dtype in (torch.float32, torch.bfloat16) and 1 <= levels <= 8 and 1 <= k <= 8
+                and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and 1 <= levels <= 8 and 1 <= k <= 8
                 and 1 <= x.shape[2] <= 4096 and x.shape[0] > 0):
             return False
         if self.dropout != 0 and self.training:
@@ -120,5 +120,8 @@ class TemporalConvNet(nn.Module):
     def forward(self, x):
         if self._can_fuse(x):
             taps, bias = self.effective_taps()
-            return FusedTCNFunction.apply(x.reshape(x.shape[0], x.shape[2]), taps, bias).reshape(x.shape)
+            rows = x.reshape(x.shape[0], x.shape[2])
+            if rows.dtype == torch.float16:            # fp16 rows: fp32 kernels, rounded back to fp16 (as spconv/functional)
+                return FusedTCNFunction.apply(rows.float(), taps, bias).half().reshape(x.shape)
+            return FusedTCNFunction.apply(rows, taps, bias).reshape(x.shape)
         return self.network(x)

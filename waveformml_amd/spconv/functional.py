@@ -70,7 +70,7 @@ def can_take_batch_norm_stats(bn, features):
     """A conv can take the statistics for ``bn`` when the fused BatchNorm kernels would run it anyway
     (can_fuse_batch_norm) and it normalises with batch statistics."""
     return (type(bn) is torch.nn.BatchNorm1d and bn.momentum is not None and features.is_cuda
-            and features.dtype in (torch.float32, torch.bfloat16) and features.shape[0] > 0
+            and features.dtype in (torch.float32, torch.bfloat16, torch.float16) and features.shape[0] > 0
             and (bn.num_features <= 256 or (bn.num_features % 4 == 0 and bn.num_features <= 1024))
             and (bn.weight is None or bn.weight.dtype == torch.float32)
             and (bn.training or bn.running_mean is None))
@@ -393,9 +393,10 @@ def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
     ``stats``: (save_mean, save_invstd) already taken by the producing convolution)."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # bumped by the kernel
-    return BatchNormReLUFunction.apply(features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                                       bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps,
-                                       training, relu, n_dev, tracked, stats)
+    return _half_io(lambda f: BatchNormReLUFunction.apply(
+        f, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats),
+        features)
 
 
 def can_fuse_batch_norm(bn, features):
@@ -403,7 +404,7 @@ def can_fuse_batch_norm(bn, features):
     fp32/bf16 features on the GPU, C <= 1024."""
     c = bn.num_features
     return (type(bn) is torch.nn.BatchNorm1d and bn.momentum is not None and features.is_cuda and features.dim() == 2
-            and features.dtype in (torch.float32, torch.bfloat16) and features.shape[0] > 0
+            and features.dtype in (torch.float32, torch.bfloat16, torch.float16) and features.shape[0] > 0
             and (c <= 256 or (c % 4 == 0 and c <= 1024))
             and (bn.weight is None or bn.weight.dtype == torch.float32)
             and (bn.training or bn.running_mean is not None))
@@ -446,12 +447,12 @@ class SkinnyLinearFunction(Function):
 
 def can_use_skinny_linear(linear, x):
     return (type(linear) is torch.nn.Linear and x.is_cuda and x.dim() == 2 and linear.out_features <= 8
-            and x.shape[1] % 8 == 0 and x.shape[1] >= 1024 and x.dtype in (torch.float32, torch.bfloat16)
+            and x.shape[1] % 8 == 0 and x.shape[1] >= 1024 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
             and linear.weight.dtype == torch.float32)
 
 
 def skinny_linear(x, linear):
-    return SkinnyLinearFunction.apply(x, linear.weight, linear.bias)
+    return SkinnyLinearFunction.apply(x.float() if x.dtype == torch.float16 else x, linear.weight, linear.bias)
 
 
 class SparseHeadFunction(Function):
@@ -511,14 +512,14 @@ def can_use_sparse_head(linear, st):
     for s_ in st.spatial_shape:
         v *= int(s_)
     return (type(linear) is torch.nn.Linear and linear.out_features <= 8 and linear.weight.dtype == torch.float32
-            and f.is_cuda and f.dim() == 2 and f.dtype in (torch.float32, torch.bfloat16) and f.shape[1] % 8 == 0
+            and f.is_cuda and f.dim() == 2 and f.dtype in (torch.float32, torch.bfloat16, torch.float16) and f.shape[1] % 8 == 0
             and f.shape[1] // 8 <= 256 and v <= 16384 and linear.in_features == f.shape[1] * v
             and getattr(st, "unique", None) is True and len(st.spatial_shape) <= 4 and int(st.batch_size) >= 1)
 
 
 def sparse_head(st, linear):
-    return SparseHeadFunction.apply(st.features, linear.weight, linear.bias, st.indices, st.spatial_shape,
-                                    st.batch_size, st.n_valid)
+    f = st.features.float() if st.features.dtype == torch.float16 else st.features
+    return SparseHeadFunction.apply(f, linear.weight, linear.bias, st.indices, st.spatial_shape, st.batch_size, st.n_valid)
 
 
 class CrossEntropyMeanFunction(Function):
@@ -554,13 +555,26 @@ def cross_entropy_mean(logits, target, ignore_index=-100):
     return CrossEntropyMeanFunction.apply(logits, target, ignore_index)
 
 
+# fp16 storage (the reference's ``half_precision`` / ``use_half``: float16 features, src/datasets/HDF5Dataset.py:228) is
+# served by the fp32 kernels: rows are widened on entry and rounded to fp16 on exit of every operator, i.e. fp16
+# storage with fp32 arithmetic, through autograd's own casts.  bf16 is the 16-bit format with native kernels on gfx950.
+def _half_io(fn, x, *args):
+    if x.dtype == torch.float16:
+        return fn(x.float(), *args).half()
+    return fn(x, *args)
+
+
 def indice_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request)
+    return _half_io(lambda f: SparseConvFunction.apply(f, filters, bias, rulebook, CONV, bn_request), features)
 
 
 def indice_subm_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request)
+    return _half_io(lambda f: SparseConvFunction.apply(f, filters, bias, rulebook, SUBM, bn_request), features)
 
 
 def indice_inverse_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE, bn_request)
+    return _half_io(lambda f: SparseConvFunction.apply(f, filters, bias, rulebook, INVERSE, bn_request), features)
+
+
+def to_dense(features, indices, spatial_shape, batch_size, unique, m_dev=None):
+    return _half_io(lambda f: ToDenseFunction.apply(f, indices, spatial_shape, batch_size, unique, m_dev), features)

@@ -78,8 +78,8 @@ class SparseConvTensor(object):
         return None
 
     def dense(self, channels_first=True):
-        out = Fsp.ToDenseFunction.apply(self.features, self.indices, self.spatial_shape, self.batch_size,
-                                        self.unique is True or self.n_valid is not None, self.n_valid)
+        out = Fsp.to_dense(self.features, self.indices, self.spatial_shape, self.batch_size,
+                           self.unique is True or self.n_valid is not None, self.n_valid)
         if channels_first:
             return out
         ndim = len(self.spatial_shape)
