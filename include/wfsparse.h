@@ -245,14 +245,14 @@ int wfs_to_dense_bwd(const void *dY, const int32_t *indices, int64_t M, int32_t 
  * thousands of inputs, a streaming problem rather than a GEMM.  X [B, I] fp32 or bf16 (dtype),
  * W [O, I] fp32 (nn.Linear.weight), Y / G [B, O] fp32, 1 <= O <= 8, I % 8 == 0.
  *     Y = X W^T + bias;   dX = G W (X's dtype);   dW = G^T X (deterministic chunked reduction).
- * dX or dW may be NULL to skip that product.                                                     */
+ * dX or dW may be NULL to skip that product; dB [O] (optional, computed with dW) = sum_b G[b][:].      */
 size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O);
 
 int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W, const float *bias, int32_t O,
                  float *Y, int32_t dtype, void *stream);
 
 int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const float *W, int32_t O,
-                 void *dX, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
+                 void *dX, float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes,
                  void *stream);
 
 /* ToDense + flatten + Linear without the dense tensor ---------------------------------------------------

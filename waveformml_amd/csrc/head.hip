@@ -127,7 +127,14 @@ __global__ void __launch_bounds__(TB) k_head_dw(const float *__restrict__ G, con
     for (int o = 0; o < O; ++o) store8<float>(part + ((long long)blockIdx.y * O + o) * I + i, acc[o]);
 }
 
-__global__ void k_head_dw_reduce(const float *__restrict__ part, int nchunk, long long OI, float *__restrict__ dW) {
+// also the bias gradient dB[o] = sum_b G[b][o] (block 0; saves the caller a reduction launch)
+__global__ void k_head_dw_reduce(const float *__restrict__ part, int nchunk, long long OI, float *__restrict__ dW,
+                                 const float *__restrict__ G, long long B, int O, float *__restrict__ dB) {
+    if (dB && blockIdx.x == 0 && (int)threadIdx.x < O) {
+        float v = 0.f;
+        for (long long b = 0; b < B; ++b) v += G[b * O + threadIdx.x];
+        dB[threadIdx.x] = v;
+    }
     long long e = (long long)blockIdx.x * TB + threadIdx.x;
     if (e >= OI) return;
     float s = 0.f;
@@ -440,7 +447,7 @@ extern "C" int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W,
 }
 
 extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const float *W, int32_t O, void *dX,
-                            float *dW, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
+                            float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
     WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
@@ -472,7 +479,7 @@ extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I,
         }
         WFS_LAUNCH_CHECK();
         const long long OI = (long long)O * I;
-        k_head_dw_reduce<<<dim3((unsigned)wfs_cdiv(OI, TB)), dim3(TB), 0, stream>>>(part, nchunk, OI, dW);
+        k_head_dw_reduce<<<dim3((unsigned)wfs_cdiv(OI, TB)), dim3(TB), 0, stream>>>(part, nchunk, OI, dW, G, B, O, dB);
         WFS_LAUNCH_CHECK();
     }
     return WFS_OK;

@@ -439,10 +439,13 @@ class SkinnyLinearFunction(Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty((O, I), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
         ws = torch.empty((max(int(lib.wfs_head_workspace_bytes(B, I, O)), 1),), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.wfs_head_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw),
+        want_db = bias is not None and ctx.needs_input_grad[2]
+        db = torch.empty((O,), dtype=torch.float32, device=x.device) if (want_db and dw is not None) else None
+        _lib.check(lib.wfs_head_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
                                     _lib.dtype_code(x), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
-        db = g.sum(0).to(bias.dtype) if (bias is not None and ctx.needs_input_grad[2]) else None
-        return dx, (dw.to(weight.dtype) if dw is not None else None), db
+        if want_db and db is None:
+            db = g.sum(0)
+        return dx, (dw.to(weight.dtype) if dw is not None else None), (db.to(bias.dtype) if db is not None else None)
 
 
 def can_use_skinny_linear(linear, x):
