@@ -130,10 +130,21 @@ __global__ void __launch_bounds__(TB) k_head_dw(const float *__restrict__ G, con
 // also the bias gradient dB[o] = sum_b G[b][o] (block 0; saves the caller a reduction launch)
 __global__ void k_head_dw_reduce(const float *__restrict__ part, int nchunk, long long OI, float *__restrict__ dW,
                                  const float *__restrict__ G, long long B, int O, float *__restrict__ dB) {
-    if (dB && blockIdx.x == 0 && (int)threadIdx.x < O) {
-        float v = 0.f;
-        for (long long b = 0; b < B; ++b) v += G[b * O + threadIdx.x];
-        dB[threadIdx.x] = v;
+    if (dB && blockIdx.x == 0) {                    // all TB threads: strided rows, butterfly, waves in wave order
+        __shared__ float sdb[TB / 64][MAXO];
+        for (int o = 0; o < O; ++o) {
+            float v = 0.f;
+            for (long long b = threadIdx.x; b < B; b += TB) v += G[b * O + o];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((threadIdx.x & 63) == 0) sdb[threadIdx.x >> 6][o] = v;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < O) {
+            float v = 0.f;
+            for (int w = 0; w < TB / 64; ++w) v += sdb[w][threadIdx.x];
+            dB[threadIdx.x] = v;
+        }
     }
     long long e = (long long)blockIdx.x * TB + threadIdx.x;
     if (e >= OI) return;
