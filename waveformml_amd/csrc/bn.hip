@@ -386,6 +386,271 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Register-resident variants for batches whose rows fit the chip's register files (the PSD sizes: ~10^5 x 32).
+// A kernel node of a replayed graph costs ~1.7 us empty and ~2.8 us for a 5.5 MB elementwise pass
+// (tools/exp/launch_floor.hip); what made the loop kernels above take 6-10 us is DEPENDENT memory round trips at ~1 us
+// each: valid count -> loop bound -> row loads -> statistics -> ...  Here every thread owns PER rows
+// (first + i * stride) and issues ALL its loads -- rows (bounded by the capacity, not by the count), count, shift,
+// partials, affine parameters -- back to back at the top: one round trip, then arithmetic and stores.
+constexpr int RR_BLOCKS = 256;
+
+template <typename T>
+struct Raw4;
+template <>
+struct Raw4<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const float4 *>(p); }
+    __device__ __forceinline__ void get(float *o) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+template <>
+struct Raw4<wfs_bf16> {
+    uint2 v;
+    __device__ __forceinline__ void load(const wfs_bf16 *p) { v = *reinterpret_cast<const uint2 *>(p); }
+    __device__ __forceinline__ void get(float *o) const {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    }
+};
+
+template <typename T, int PER, int MODE>
+__global__ void __launch_bounds__(TB) k_bn_reduce_rr(const T *__restrict__ X, const T *__restrict__ dY, long long Ncap,
+                                                     const long long *__restrict__ n_dev, int C,
+                                                     const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     int relu, float *__restrict__ partial) {
+    constexpr int VEC = 4;
+    __shared__ float red[2][TB][VEC];
+    const int groups = C / VEC, slots = TB / groups;
+    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
+    const bool active = slot < slots;
+    const int c0 = grp * VEC;
+    const long long stride = (long long)gridDim.x * slots, first = (long long)blockIdx.x * slots + slot;
+    Raw4<T> x[PER], g[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long long r = first + i * stride;
+        const long long rc = (active && r < Ncap) ? r : 0;
+        x[i].load(X + rc * C + c0);
+        if (MODE == 1) g[i].load(dY + rc * C + c0);
+    }
+    const long long N = valid_rows(Ncap, n_dev);                 // in flight together with the rows
+    float m[VEC], is[VEC], ga[VEC], be[VEC], sa[VEC], sb[VEC];
+    if (MODE == 0) {
+        load_vec<T, VEC>(X + c0, m);                             // the shift: row 0
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        sa[i] = sb[i] = 0.f;
+        if (MODE == 1) {
+            m[i] = mean[c0 + i];
+            is[i] = invstd[c0 + i];
+            ga[i] = gamma ? gamma[c0 + i] : 1.f;
+            be[i] = beta ? beta[c0 + i] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long long r = first + i * stride;
+        if (active && r < N) {
+            float xv[VEC], gv[VEC];
+            x[i].get(xv);
+            if (MODE == 1) g[i].get(gv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                if (MODE == 0) {
+                    float d = xv[q] - m[q];
+                    sa[q] += d;
+                    sb[q] = fmaf(d, d, sb[q]);
+                } else {
+                    float xh = (xv[q] - m[q]) * is[q];
+                    float gi = gv[q];
+                    if (relu && !(fmaf(ga[q], xh, be[q]) > 0.f)) gi = 0.f;
+                    sa[q] += gi;
+                    sb[q] = fmaf(gi, xh, sb[q]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        red[0][threadIdx.x][i] = sa[i];
+        red[1][threadIdx.x][i] = sb[i];
+    }
+    __syncthreads();
+    if (active && slot == 0) {
+        for (int q = 1; q < slots; ++q)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sa[i] += red[0][q * groups + grp][i];
+                sb[i] += red[1][q * groups + grp][i];
+            }
+        float *p = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            p[c0 + i] = sa[i];
+            p[C + c0 + i] = sb[i];
+        }
+    }
+}
+
+template <typename T, int PER>
+__global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, long long Ncap,
+                                                    const long long *__restrict__ n_dev, int C,
+                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                    float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                    long long *__restrict__ batches_tracked, float momentum, float eps,
+                                                    int relu, T *__restrict__ Y, float *__restrict__ save_mean,
+                                                    float *__restrict__ save_invstd, const float *__restrict__ partial,
+                                                    int nblk) {
+    constexpr int VEC = 4;
+    __shared__ float sSlice[2 * TB];
+    __shared__ float sA[MAXC], sB[MAXC];
+    const int groups = C / VEC, slots = TB / groups;
+    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
+    const bool active = slot < slots;
+    const int c0 = grp * VEC;
+    const long long stride = (long long)gridDim.x * slots, first = (long long)blockIdx.x * slots + slot;
+    Raw4<T> x[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long long r = first + i * stride;
+        x[i].load(X + ((active && r < Ncap) ? r : 0) * C + c0);
+    }
+    const long long N = valid_rows(Ncap, n_dev);
+    float ga[VEC], be[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        ga[i] = (gamma && active) ? gamma[c0 + i] : 1.f;
+        be[i] = (beta && active) ? beta[c0 + i] : 0.f;
+    }
+    fold_partials(partial, nblk, C, sSlice, sA, sB);             // its loads join the ones above
+    const float n = N > 0 ? (float)N : 1.f;
+    for (int c = threadIdx.x; c < C; c += TB) {
+        float shift = wfs_ld(X + c);
+        float md = sA[c] / n;
+        float var = sB[c] / n - md * md;
+        var = var > 0.f ? var : 0.f;
+        float mean = shift + md, inv = rsqrtf(var + eps);
+        sA[c] = mean;
+        sB[c] = inv;
+        if (blockIdx.x == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = inv;
+            if (running_mean) {
+                float unbiased = N > 1 ? var * (n / (n - 1.f)) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && batches_tracked) *batches_tracked += 1;
+    __syncthreads();
+    if (!active) return;
+    float m[VEC], is[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        m[i] = sA[c0 + i];
+        is[i] = sB[c0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long long r = first + i * stride;
+        if (r < N) {
+            float v[VEC], y[VEC];
+            x[i].get(v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                float t = fmaf(ga[q], (v[q] - m[q]) * is[q], be[q]);
+                y[q] = (relu && !(t > 0.f)) ? 0.f : t;
+            }
+            store_vec<T, VEC>(Y + r * C + c0, y);
+        }
+    }
+}
+
+template <typename T, int PER>
+__global__ void __launch_bounds__(TB) k_bn_bwd_apply_rr(const T *__restrict__ X, const T *__restrict__ dY,
+                                                        long long Ncap, const long long *__restrict__ n_dev, int C,
+                                                        const float *__restrict__ partial, int nblk,
+                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        int training, int relu, T *__restrict__ dX,
+                                                        float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    constexpr int VEC = 4;
+    __shared__ float sSlice[2 * TB];
+    __shared__ float sA[MAXC], sB[MAXC];
+    const int groups = C / VEC, slots = TB / groups;
+    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
+    const bool active = slot < slots;
+    const int c0 = grp * VEC;
+    const long long stride = (long long)gridDim.x * slots, first = (long long)blockIdx.x * slots + slot;
+    Raw4<T> x[PER], g[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long long r = first + i * stride;
+        const long long rc = (active && r < Ncap) ? r : 0;
+        x[i].load(X + rc * C + c0);
+        g[i].load(dY + rc * C + c0);
+    }
+    const long long N = valid_rows(Ncap, n_dev);
+    float m[VEC], is[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        m[i] = active ? mean[c0 + i] : 0.f;
+        is[i] = active ? invstd[c0 + i] : 0.f;
+        ga[i] = (gamma && active) ? gamma[c0 + i] : 1.f;
+        be[i] = (beta && active) ? beta[c0 + i] : 0.f;
+    }
+    fold_partials(partial, nblk, C, sSlice, sA, sB);
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += TB) {
+            if (dbeta) dbeta[c] = sA[c];
+            if (dgamma) dgamma[c] = sB[c];
+        }
+    }
+    if (!active) return;
+    const float invN = N > 0 ? 1.f / (float)N : 0.f;
+    float k1[VEC], k2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        k1[i] = training ? sA[c0 + i] * invN : 0.f;
+        k2[i] = training ? sB[c0 + i] * invN : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long long r = first + i * stride;
+        if (r < N) {
+            float xv[VEC], gv[VEC], o[VEC];
+            x[i].get(xv);
+            g[i].get(gv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                float xh = (xv[q] - m[q]) * is[q];
+                float gi = gv[q];
+                if (relu && !(fmaf(ga[q], xh, be[q]) > 0.f)) gi = 0.f;
+                o[q] = ga[q] * is[q] * (gi - k1[q] - xh * k2[q]);
+            }
+            store_vec<T, VEC>(dX + r * C + c0, o);
+        }
+    }
+}
+
+// blocks and rows per thread of the register-resident kernels; 0 = the batch does not fit (use the loop kernels)
+int rr_plan(long long N, int C, int max_per, long long *blocks) {
+    if (C % 4 != 0 || C / 4 > TB) return 0;
+    int Cp = 1;
+    while (Cp < C && Cp < TB) Cp <<= 1;
+    long long nb = (long long)FOLD_PER * (TB / Cp);
+    if (nb > RR_BLOCKS) nb = RR_BLOCKS;
+    const long long slots = TB / (C / 4);
+    const long long need = wfs_cdiv(N, nb * slots);
+    *blocks = nb;
+    for (int per : {2, 4, 8, 16})
+        if (need <= per && per <= max_per) return per;
+    return 0;
+}
+
 long long bn_reduce_blocks(long long N, int C) {      // = number of partials every elementwise block folds
     int Cp = 1;
     while (Cp < C && Cp < TB) Cp <<= 1;
@@ -405,7 +670,9 @@ long long bn_apply_blocks(long long N) {
 }  // namespace
 
 extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
-    return ((size_t)bn_reduce_blocks(N, C) + 1) * 2 * C * sizeof(float);
+    size_t nb = (size_t)bn_reduce_blocks(N, C);
+    if (nb < (size_t)RR_BLOCKS) nb = RR_BLOCKS;
+    return (nb + 1) * 2 * C * sizeof(float);
 }
 
 extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
@@ -425,6 +692,29 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
     dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
+    if (training) {
+        long long rb = 0;
+        const int per = rr_plan(N, C, 16, &rb);
+        if (per) {
+            const dim3 g2((unsigned)rb);
+#define WFS_BN_FWD_RR(T, PER)                                                                                          \
+    do {                                                                                                               \
+        k_bn_reduce_rr<T, PER, 0><<<g2, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, nullptr, nullptr,      \
+                                                             nullptr, nullptr, 0, partial);                            \
+        k_bn_apply_rr<T, PER><<<g2, block, 0, stream>>>((const T *)X, N, n_dev, C, gamma, beta, running_mean,           \
+                                                        running_var, (long long *)num_batches_tracked, momentum, eps,  \
+                                                        relu, (T *)Y, save_mean, save_invstd, partial, (int)rb);       \
+    } while (0)
+#define WFS_BN_FWD_RR_T(T)                                                                                             \
+    if (per == 2) WFS_BN_FWD_RR(T, 2); else if (per == 4) WFS_BN_FWD_RR(T, 4); else if (per == 8) WFS_BN_FWD_RR(T, 8);   \
+    else WFS_BN_FWD_RR(T, 16)
+            if (dtype == WFS_F32) { WFS_BN_FWD_RR_T(float); } else { WFS_BN_FWD_RR_T(wfs_bf16); }
+#undef WFS_BN_FWD_RR_T
+#undef WFS_BN_FWD_RR
+            WFS_LAUNCH_CHECK();
+            return WFS_OK;
+        }
+    }
 #define WFS_BN_FWD(T, VEC)                                                                                          \
     do {                                                                                                            \
         if (training)                                                                                               \
@@ -514,6 +804,29 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
     dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
+    {
+        long long rb = 0;
+        const int per = rr_plan(N, C, dtype == WFS_F32 ? 8 : 16, &rb);
+        if (per) {
+            const dim3 g2((unsigned)rb);
+#define WFS_BN_BWD_RR(T, PER)                                                                                          \
+    do {                                                                                                               \
+        k_bn_reduce_rr<T, PER, 1><<<g2, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, save_mean,       \
+                                                             save_invstd, gamma, beta, relu, partial);                 \
+        k_bn_bwd_apply_rr<T, PER><<<g2, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, partial, (int)rb, \
+                                                            save_mean, save_invstd, gamma, beta, training, relu,       \
+                                                            (T *)dX, dgamma, dbeta);                                   \
+    } while (0)
+#define WFS_BN_BWD_RR_T(T)                                                                                             \
+    if (per == 2) WFS_BN_BWD_RR(T, 2); else if (per == 4) WFS_BN_BWD_RR(T, 4); else if (per == 8) WFS_BN_BWD_RR(T, 8);   \
+    else WFS_BN_BWD_RR(T, 16)
+            if (dtype == WFS_F32) { WFS_BN_BWD_RR_T(float); } else { WFS_BN_BWD_RR_T(wfs_bf16); }
+#undef WFS_BN_BWD_RR_T
+#undef WFS_BN_BWD_RR
+            WFS_LAUNCH_CHECK();
+            return WFS_OK;
+        }
+    }
 #define WFS_BN_BWD(T, VEC)                                                                                          \
     do {                                                                                                            \
         k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb, save_mean,  \
