@@ -6,7 +6,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwfsparse.so")
+# WFS_LIB: another build of the same library (A/B timing of kernel variants, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("WFS_LIB") or os.path.join(_HERE, "lib", "libwfsparse.so")
 
 WFS_OK, WFS_EINVAL, WFS_EOVERFLOW, WFS_EHIP, WFS_EWORKSPACE = 0, 1, 2, 3, 4
 WFS_F32, WFS_BF16 = 0, 1
