@@ -27,8 +27,10 @@
  *     (SURVEY.md 8b "Error conventions").
  *   - index tensors are int32, batch-first [N, ndim+1] exactly as spconv's (the reference
  *     permutes its (x,y[,t],evt) columns to batch-first at src/models/SPConvNet.py:47-52,64).
- *   - feature dtype codes: WFS_F32 (fp32 storage, fp32 accumulate) and WFS_BF16 (bf16 storage,
- *     fp32 accumulate).  Filters [K, Cin, Cout] are fp32 in both cases (master weights).
+ *   - feature dtype codes: WFS_F32 (fp32 storage, fp32 accumulate), WFS_BF16 and WFS_F16 (16-bit
+ *     storage, fp32 accumulate; the reference's `half_precision` rows are fp16,
+ *     src/datasets/HDF5Dataset.py:227).  Filters [K, Cin, Cout] are fp32 in every case (master
+ *     weights, rounded to the storage type while they are staged for the matrix cores).
  *   - device-side row counts: every row-dimensioned call takes its row count BY VALUE (array
  *     strides, grid size, = the capacity) and an optional `const int64_t *..._dev` that, when not
  *     NULL, holds the number of VALID rows (<= the capacity) in device memory.  Rows beyond it are
@@ -53,6 +55,7 @@ extern "C" {
 
 #define WFS_F32 0
 #define WFS_BF16 1
+#define WFS_F16 2
 
 #define WFS_MAX_DIM 4
 

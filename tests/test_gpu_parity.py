@@ -154,14 +154,16 @@ def test_conv_forward_backward_fp32(case, chan):
     _assert_close(layer.bias.grad.cpu().numpy(), ref_layer.bias.grad.numpy(), 1e-5, "dbias")
 
 
-def test_conv_bf16_storage_against_fp32_oracle():
-    """bf16 rows in HBM, fp32 accumulate: 8 mantissa bits -> tolerance 2e-2 of the tensor scale."""
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)], ids=["bf16", "f16"])
+def test_conv_bf16_storage_against_fp32_oracle(dtype, tol):
+    """16-bit rows in HBM, fp32 accumulate: bf16 has 8 mantissa bits -> tolerance 2e-2 of the tensor scale; fp16 (the
+    reference's half_precision rows) 11 bits -> 3e-3."""
     case = (3, (14, 11, 24), 3, 1, 0, 1, True)
-    layer, ref_layer, xg, xr, rng = _conv_pair(case, 32, 32, 600, 3, 404, dtype=torch.bfloat16)
-    xr.features = xr.features.detach().to(torch.bfloat16).float()     # same rounded inputs
+    layer, ref_layer, xg, xr, rng = _conv_pair(case, 32, 32, 600, 3, 404, dtype=dtype)
+    xr.features = xr.features.detach().to(dtype).float()     # same rounded inputs
     yg, yr = layer(xg), ref_layer(xr)
-    assert yg.features.dtype == torch.bfloat16
-    _assert_close(yg.features.detach().float().cpu().numpy(), yr.features.detach().numpy(), 2e-2, "bf16 forward")
+    assert yg.features.dtype == dtype
+    _assert_close(yg.features.detach().float().cpu().numpy(), yr.features.detach().numpy(), tol, "16-bit forward")
 
 
 def test_inverse_conv_and_rulebook_reuse():
@@ -308,8 +310,9 @@ def test_layers_at_bench_geometry_fp32(layer_kind):
 
 
 @pytest.mark.parametrize("C,relu,dtype", [(32, True, torch.float32), (32, False, torch.float32), (7, True, torch.float32),
-                                          (252, True, torch.float32), (32, True, torch.bfloat16)],
-                         ids=["c32_relu", "c32", "c7_relu", "c252_relu", "c32_relu_bf16"])
+                                          (252, True, torch.float32), (32, True, torch.bfloat16),
+                                          (32, True, torch.float16), (7, False, torch.float16)],
+                         ids=["c32_relu", "c32", "c7_relu", "c252_relu", "c32_relu_bf16", "c32_relu_f16", "c7_f16"])
 def test_fused_batchnorm_relu_matches_torch(C, relu, dtype):
     """The fused BatchNorm1d(+ReLU) kernels against torch's own modules on the CPU in fp32 (what the
     reference's SparseSequential runs), training mode: output, running stats, dX, dgamma, dbeta."""
@@ -335,7 +338,7 @@ def test_fused_batchnorm_relu_matches_torch(C, relu, dtype):
     assert Fsp.can_fuse_batch_norm(bn, xg)
     yg = Fsp.batch_norm_relu(xg, bn, relu)
     yg.backward(torch.from_numpy(g).to(DEV).to(dtype))
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    tol = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 2e-3}[dtype]
     _assert_close(yg.detach().float().cpu().numpy(), yr.detach().numpy(), tol, "y")
     _assert_close(bn.running_mean.cpu().numpy(), ref.running_mean.numpy(), 1e-5, "running_mean")
     _assert_close(bn.running_var.cpu().numpy(), ref.running_var.numpy(), 1e-5, "running_var")
@@ -354,11 +357,13 @@ def test_fused_batchnorm_relu_matches_torch(C, relu, dtype):
     _assert_close(ye.detach().float().cpu().numpy(), yre.detach().numpy(), tol, "eval y")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("layer_kind", ["subm32", "conv32_s4", "subm2"])
-def test_layers_at_bench_geometry_bf16(layer_kind):
-    """bf16 storage / bf16 MFMA with fp32 accumulate against the fp32 oracle fed the same bf16-rounded
-    inputs and bf16-rounded filters: what is left is accumulation order and the bf16 rounding of the
-    outputs (2^-9 relative) -> 1e-2 of the tensor scale."""
+def test_layers_at_bench_geometry_bf16(layer_kind, dtype):
+    """16-bit storage / 16-bit MFMA with fp32 accumulate against the fp32 oracle fed the same rounded
+    inputs and rounded filters: what is left is accumulation order and the rounding of the
+    outputs (bf16: 2^-9 relative -> 1e-2 of the tensor scale; fp16: 2^-12 -> 2e-3)."""
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
     from oracle import spconv as osp
     from waveformml_amd.psd import synthetic
     sp = _sp()
@@ -368,7 +373,7 @@ def test_layers_at_bench_geometry_bf16(layer_kind):
     rng = np.random.default_rng(910)
     cin = 2 if layer_kind == "subm2" else 32
     feat = f if cin == 2 else rng.standard_normal((len(idx), 32)).astype(np.float32)
-    feat = torch.from_numpy(feat).to(torch.bfloat16)
+    feat = torch.from_numpy(feat).to(dtype)
     torch.manual_seed(6)
     if layer_kind == "conv32_s4":
         mk = lambda m: m.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, True)
@@ -377,20 +382,19 @@ def test_layers_at_bench_geometry_bf16(layer_kind):
     ref_layer = mk(osp)
     layer = mk(sp).to(DEV)
     layer.load_state_dict(ref_layer.state_dict())
-    if cin == 32:                      # the MFMA kernels round the filters to bf16
-        with torch.no_grad():
-            ref_layer.weight.copy_(ref_layer.weight.to(torch.bfloat16).float())
+    with torch.no_grad():              # the MFMA kernels round the filters to the storage type
+        ref_layer.weight.copy_(ref_layer.weight.to(dtype).float())
     fr = feat.float().requires_grad_(True)
     fg = feat.to(DEV).requires_grad_(True)
     yr = ref_layer(osp.SparseConvTensor(fr, torch.from_numpy(idx), [14, 11, T], B))
     yg = layer(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), [14, 11, T], B))
-    assert yg.features.dtype == torch.bfloat16
-    _assert_close(yg.features.detach().float().cpu().numpy(), yr.features.detach().numpy(), 1e-2, "forward")
-    g = torch.from_numpy(rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)).to(torch.bfloat16)
+    assert yg.features.dtype == dtype
+    _assert_close(yg.features.detach().float().cpu().numpy(), yr.features.detach().numpy(), tol, "forward")
+    g = torch.from_numpy(rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)).to(dtype)
     yr.features.backward(g.float())
     yg.features.backward(g.to(DEV))
-    _assert_close(fg.grad.float().cpu().numpy(), fr.grad.numpy(), 1e-2, "dX")
-    _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-2, "dW")
+    _assert_close(fg.grad.float().cpu().numpy(), fr.grad.numpy(), tol, "dX")
+    _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), tol, "dW")
 
 
 def _c2_module(T, n_lin, dtype_seed=0):
@@ -480,8 +484,9 @@ def test_graph_captured_step_matches_eager_steps():
         _assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 1e-5, "parameters after 6 steps")
 
 
-@pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.bfloat16, 3), (torch.float32, 8), (torch.float32, 1)],
-                         ids=["f32_o3", "bf16_o3", "f32_o8", "f32_o1"])
+@pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.bfloat16, 3), (torch.float32, 8), (torch.float32, 1),
+                                     (torch.float16, 3)],
+                         ids=["f32_o3", "bf16_o3", "f32_o8", "f32_o1", "f16_o3"])
 def test_skinny_linear_head_matches_torch(dtype, O):
     from waveformml_amd.spconv import functional as Fsp
     torch.manual_seed(4)
@@ -609,8 +614,10 @@ def test_training_from_hdf5_files_matches_the_cpu_path():
 @pytest.mark.parametrize("cin,cout,dtype,kind", [
     (32, 32, torch.float32, "subm"), (32, 32, torch.bfloat16, "subm"), (2, 32, torch.bfloat16, "subm"),
     (32, 32, torch.bfloat16, "conv"), (32, 32, torch.float32, "conv"),
-    (2, 32, torch.float32, "subm"), (16, 24, torch.float32, "subm")],
-    ids=["f32_subm32", "bf16_subm32", "bf16_subm2", "bf16_conv32", "f32_conv32", "f32_subm2_unfused", "f32_generic_unfused"])
+    (2, 32, torch.float32, "subm"), (16, 24, torch.float32, "subm"),
+    (32, 32, torch.float16, "subm"), (2, 32, torch.float16, "subm")],
+    ids=["f32_subm32", "bf16_subm32", "bf16_subm2", "bf16_conv32", "f32_conv32", "f32_subm2_unfused", "f32_generic_unfused",
+         "f16_subm32", "f16_subm2"])
 def test_conv_epilogue_takes_the_batchnorm_statistics(cin, cout, dtype, kind, monkeypatch):
     """conv -> BatchNorm1d(training) -> ReLU inside SparseSequential: the conv kernel's epilogue takes the batch
     statistics (wfs_gather_conv_bnstats; shapes without a fused epilogue run conv + reduction behind the same entry
@@ -634,11 +641,11 @@ def test_conv_epilogue_takes_the_batchnorm_statistics(cin, cout, dtype, kind, mo
     with torch.no_grad():
         ref_net[1].weight.uniform_(0.5, 1.5)
         ref_net[1].bias.uniform_(-0.3, 0.3)
-        if dtype == torch.bfloat16:                     # both sides multiply the same bf16-representable filters
-            ref_net[0].weight.copy_(ref_net[0].weight.bfloat16().float())
+        if dtype != torch.float32:                      # both sides multiply the same representable filters
+            ref_net[0].weight.copy_(ref_net[0].weight.to(dtype).float())
     net = build(sp).to(DEV)
     net.load_state_dict(ref_net.state_dict())
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    tol = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
     for step in range(2):
         feat = (rng.standard_normal((len(idx), cin)) + 0.5).astype(np.float32)
         fin = torch.from_numpy(feat).to(dtype).float()
@@ -745,8 +752,8 @@ def test_flat_sgd_matches_torch_sgd(kw):
 
 
 @pytest.mark.parametrize("levels,k,L,dtype", [(3, 3, 300, torch.float32), (1, 2, 64, torch.float32), (4, 5, 2048, torch.float32),
-                                              (3, 3, 512, torch.bfloat16)],
-                         ids=["l3_k3_L300", "l1_k2_L64", "l4_k5_L2048", "l3_k3_L512_bf16"])
+                                              (3, 3, 512, torch.bfloat16), (3, 3, 2048, torch.float16)],
+                         ids=["l3_k3_L300", "l1_k2_L64", "l4_k5_L2048", "l3_k3_L512_bf16", "l3_k3_L2048_f16"])
 def test_fused_temporal_conv_net_matches_torch(levels, k, L, dtype):
     """The hybrid net's waveform front end, TemporalConvNet(1, [1] * n_dil, k) (reference src/models/ConvBlocks.py:
     114-173 as built at src/models/SPConvNet.py:83-92): one HIP launch per direction (wfs_tcn_fwd / wfs_tcn_bwd) against
@@ -772,8 +779,10 @@ def test_fused_temporal_conv_net_matches_torch(levels, k, L, dtype):
     assert net._can_fuse(xg)
     yg = net(xg)
     yg.backward(torch.from_numpy(g).to(DEV).to(dtype))
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    tol = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
     _assert_close(yg.detach().float().cpu().numpy(), yr.detach().numpy(), tol, "y")
+    if dtype == torch.float16:
+        _assert_close(xg.grad.float().cpu().numpy(), xr.grad.numpy(), tol, "dX")
     if dtype == torch.float32:
         _assert_close(xg.grad.cpu().numpy(), xr.grad.numpy(), 1e-5, "dX")
         for (name, a), b in zip(net.named_parameters(), ref.parameters()):
@@ -924,7 +933,8 @@ def test_batch_hand_over_kernel_copies_and_permutes(cols, perm, C, dtype):
     assert torch.equal(ldst, labels) and int(nv) == n
 
 
-@pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.float32, 8), (torch.bfloat16, 2)], ids=["f32_o3", "f32_o8", "bf16_o2"])
+@pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.float32, 8), (torch.bfloat16, 2), (torch.float16, 3)],
+                         ids=["f32_o3", "f32_o8", "bf16_o2", "f16_o3"])
 def test_sparse_head_equals_todense_view_linear(dtype, O):
     """wfs_sparse_head_fwd / _bwd (ToDense + view + nn.Linear on the sparse rows, no dense tensor) against the literal
     composition the reference runs (src/models/SPConvNet.py:65-68) on the CPU in fp32: logits, dX, dW, db.  Events with
@@ -962,7 +972,7 @@ def test_sparse_head_equals_todense_view_linear(dtype, O):
     assert Fsp.can_use_sparse_head(lin, st)
     yg = Fsp.sparse_head(st, lin)
     yg.backward(torch.from_numpy(g).to(DEV))
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    tol = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
     _assert_close(yg.detach().cpu().numpy(), yr.detach().numpy(), tol, "logits")
     _assert_close(feat_cap.grad[:M].float().cpu().numpy(), fr.grad.numpy(), tol, "dX")
     _assert_close(lin.weight.grad.cpu().numpy(), lin_ref.weight.grad.numpy(), tol, "dW")
@@ -1042,11 +1052,12 @@ def test_rulebook_random_geometries_bitexact(seed):
         assert np.array_equal(g, w), (name, ndim, shape, k, s, p, d, subm)
 
 
-def test_fp16_storage_runs_on_the_fp32_kernels():
-    """The reference's ``half_precision`` feeds float16 features (src/datasets/HDF5Dataset.py:228).  Here fp16 rows are
-    widened on entry and rounded on exit of every operator (fp16 storage, fp32 arithmetic).  A C2-shaped stack with
+def test_fp16_storage_native_kernels():
+    """The reference's ``half_precision`` feeds float16 features (src/datasets/HDF5Dataset.py:227-228).  fp16 rows have
+    native kernels (fp16 storage and MFMA operands, fp32 accumulate, fp32 master weights).  A C2-shaped stack with
     fp16 features against the CPU restatement in fp32 fed the same fp16-rounded input: activations stay fp16 between
-    layers, logits within 5e-3 (ten mantissa bits through five layers), gradients flow in fp16."""
+    layers, dense output within 5e-3 (eleven mantissa bits through three conv + BatchNorm layers), gradients flow in
+    fp16 and the parameter gradients agree with the fp32 path's within 2e-2 of each tensor's scale."""
     from oracle import spconv as osp
     sp = _sp()
     rng = np.random.default_rng(404)
@@ -1070,6 +1081,9 @@ def test_fp16_storage_runs_on_the_fp32_kernels():
     assert yg.dtype == torch.float16
     yr = ref_net(osp.SparseConvTensor(fin.float(), torch.from_numpy(idx), [14, 11, T], B))
     _assert_close(yg.detach().float().cpu().numpy(), yr.detach().numpy(), 5e-3, "dense output")
-    yg.float().square().mean().backward()
+    yg.float().square().sum().backward()
+    yr.square().sum().backward()
     assert fg.grad is not None and fg.grad.dtype == torch.float16 and bool(torch.isfinite(fg.grad).all())
-    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    for (name, a), b_ in zip(net.named_parameters(), ref_net.parameters()):
+        assert a.grad is not None and bool(torch.isfinite(a.grad).all()), name
+        _assert_close(a.grad.float().cpu().numpy(), b_.grad.numpy(), 2e-2, name)

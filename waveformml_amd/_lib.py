@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WFS_LIB") or os.path.join(_HERE, "lib", "libwfsparse.so")
 
 WFS_OK, WFS_EINVAL, WFS_EOVERFLOW, WFS_EHIP, WFS_EWORKSPACE = 0, 1, 2, 3, 4
-WFS_F32, WFS_BF16 = 0, 1
+WFS_F32, WFS_BF16, WFS_F16 = 0, 1, 2
 WFS_MAX_DIM = 4
 TIMER_GATHER_CONV, TIMER_GATHER_DW, TIMER_RULEBOOK = 0, 1, 2
 
@@ -130,7 +130,9 @@ def dtype_code(t):
         return WFS_F32
     if t.dtype == torch.bfloat16:
         return WFS_BF16
-    raise RuntimeError("waveformml_amd: features must be float32 or bfloat16, got %s" % t.dtype)
+    if t.dtype == torch.float16:
+        return WFS_F16
+    raise RuntimeError("waveformml_amd: features must be float32, bfloat16 or float16, got %s" % t.dtype)
 
 
 def i32_array(values):

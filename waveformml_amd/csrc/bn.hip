@@ -33,8 +33,8 @@ __device__ __forceinline__ void load_vec(const T *p, float *out) {
         out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
     } else if constexpr (VEC == 4) {
         uint2 v = *reinterpret_cast<const uint2 *>(p);
-        out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xFFFF0000u);
-        out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xFFFF0000u);
+        wfs_unpack2<T>(v.x, out[0], out[1]);
+        wfs_unpack2<T>(v.y, out[2], out[3]);
     } else {
         out[0] = wfs_ld(p);
     }
@@ -44,12 +44,9 @@ __device__ __forceinline__ void store_vec(T *p, const float *in) {
     if constexpr (VEC == 4 && sizeof(T) == 4) {
         *reinterpret_cast<float4 *>(p) = make_float4(in[0], in[1], in[2], in[3]);
     } else if constexpr (VEC == 4) {
-        wfs_bf16 h[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wfs_st(&h[i], in[i]);
         uint2 v;
-        v.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-        v.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+        v.x = wfs_pack2<T>(in[0], in[1]);
+        v.y = wfs_pack2<T>(in[2], in[3]);
         *reinterpret_cast<uint2 *>(p) = v;
     } else {
 #pragma unroll
@@ -396,21 +393,19 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
 constexpr int RR_BLOCKS = 256;
 
 template <typename T>
-struct Raw4;
+struct Raw4 {                                     // four 16-bit channels (bf16 / fp16) as loaded
+    uint2 v;
+    __device__ __forceinline__ void load(const T *p) { v = *reinterpret_cast<const uint2 *>(p); }
+    __device__ __forceinline__ void get(float *o) const {
+        wfs_unpack2<T>(v.x, o[0], o[1]);
+        wfs_unpack2<T>(v.y, o[2], o[3]);
+    }
+};
 template <>
 struct Raw4<float> {
     float4 v;
     __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const float4 *>(p); }
     __device__ __forceinline__ void get(float *o) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-};
-template <>
-struct Raw4<wfs_bf16> {
-    uint2 v;
-    __device__ __forceinline__ void load(const wfs_bf16 *p) { v = *reinterpret_cast<const uint2 *>(p); }
-    __device__ __forceinline__ void get(float *o) const {
-        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
-        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
-    }
 };
 
 template <typename T, int PER, int MODE>
@@ -683,7 +678,7 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
     hipStream_t stream = (hipStream_t)stream_;
     const long long *n_dev = (const long long *)n_dev_;
     WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(training || (running_mean && running_var), WFS_EINVAL, "eval mode needs running statistics");
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(X && Y && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
@@ -708,7 +703,7 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
 #define WFS_BN_FWD_RR_T(T)                                                                                             \
     if (per == 2) WFS_BN_FWD_RR(T, 2); else if (per == 4) WFS_BN_FWD_RR(T, 4); else if (per == 8) WFS_BN_FWD_RR(T, 8);   \
     else WFS_BN_FWD_RR(T, 16)
-            if (dtype == WFS_F32) { WFS_BN_FWD_RR_T(float); } else { WFS_BN_FWD_RR_T(wfs_bf16); }
+            if (dtype == WFS_F32) { WFS_BN_FWD_RR_T(float); } else if (dtype == WFS_BF16) { WFS_BN_FWD_RR_T(wfs_bf16); } else { WFS_BN_FWD_RR_T(wfs_f16); }
 #undef WFS_BN_FWD_RR_T
 #undef WFS_BN_FWD_RR
             WFS_LAUNCH_CHECK();
@@ -727,8 +722,10 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
     } while (0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_FWD(float, 4); else WFS_BN_FWD(float, 1);
-    } else {
+    } else if (dtype == WFS_BF16) {
         if (C % 4 == 0) WFS_BN_FWD(wfs_bf16, 4); else WFS_BN_FWD(wfs_bf16, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_FWD(wfs_f16, 4); else WFS_BN_FWD(wfs_f16, 1);
     }
 #undef WFS_BN_FWD
     WFS_LAUNCH_CHECK();
@@ -752,8 +749,10 @@ int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long
     } while (0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_STATS(float, 4); else WFS_BN_STATS(float, 1);
-    } else {
+    } else if (dtype == WFS_BF16) {
         if (C % 4 == 0) WFS_BN_STATS(wfs_bf16, 4); else WFS_BN_STATS(wfs_bf16, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_STATS(wfs_f16, 4); else WFS_BN_STATS(wfs_f16, 1);
     }
 #undef WFS_BN_STATS
     WFS_LAUNCH_CHECK();
@@ -766,7 +765,7 @@ extern "C" int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float
     hipStream_t stream = (hipStream_t)stream_;
     const long long *n_dev = (const long long *)n_dev_;
     WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(X && Y && save_mean && save_invstd, WFS_EINVAL, "NULL device pointer");
     const long long nblk_a = bn_apply_blocks(N), rpb_a = wfs_cdiv(N, nblk_a);
@@ -777,8 +776,10 @@ extern "C" int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float
                                                       nullptr, 0.f, 0.f, 1, relu, (T *)Y, sm, si, nullptr, 0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_APPLY(float, 4); else WFS_BN_APPLY(float, 1);
-    } else {
+    } else if (dtype == WFS_BF16) {
         if (C % 4 == 0) WFS_BN_APPLY(wfs_bf16, 4); else WFS_BN_APPLY(wfs_bf16, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_APPLY(wfs_f16, 4); else WFS_BN_APPLY(wfs_f16, 1);
     }
 #undef WFS_BN_APPLY
     WFS_LAUNCH_CHECK();
@@ -792,7 +793,7 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     hipStream_t stream = (hipStream_t)stream_;
     const long long *n_dev = (const long long *)n_dev_;
     WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (N == 0) {
         if (dgamma) WFS_HIP_CHECK(hipMemsetAsync(dgamma, 0, C * sizeof(float), stream));
         if (dbeta) WFS_HIP_CHECK(hipMemsetAsync(dbeta, 0, C * sizeof(float), stream));
@@ -820,7 +821,7 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
 #define WFS_BN_BWD_RR_T(T)                                                                                             \
     if (per == 2) WFS_BN_BWD_RR(T, 2); else if (per == 4) WFS_BN_BWD_RR(T, 4); else if (per == 8) WFS_BN_BWD_RR(T, 8);   \
     else WFS_BN_BWD_RR(T, 16)
-            if (dtype == WFS_F32) { WFS_BN_BWD_RR_T(float); } else { WFS_BN_BWD_RR_T(wfs_bf16); }
+            if (dtype == WFS_F32) { WFS_BN_BWD_RR_T(float); } else if (dtype == WFS_BF16) { WFS_BN_BWD_RR_T(wfs_bf16); } else { WFS_BN_BWD_RR_T(wfs_f16); }
 #undef WFS_BN_BWD_RR_T
 #undef WFS_BN_BWD_RR
             WFS_LAUNCH_CHECK();
@@ -837,8 +838,10 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     } while (0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_BWD(float, 4); else WFS_BN_BWD(float, 1);
-    } else {
+    } else if (dtype == WFS_BF16) {
         if (C % 4 == 0) WFS_BN_BWD(wfs_bf16, 4); else WFS_BN_BWD(wfs_bf16, 1);
+    } else {
+        if (C % 4 == 0) WFS_BN_BWD(wfs_f16, 4); else WFS_BN_BWD(wfs_f16, 1);
     }
 #undef WFS_BN_BWD
     WFS_LAUNCH_CHECK();

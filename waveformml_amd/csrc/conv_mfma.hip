@@ -180,17 +180,19 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BF_GROUP = 6;
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    wfs_bf16 a, b;
-    wfs_st(&a, lo);
-    wfs_st(&b, hi);
-    return (unsigned)a | ((unsigned)b << 16);
-}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float bf16_round(float v) {
-    wfs_bf16 t;
-    wfs_st(&t, v);
-    return wfs_ld(&t);
+// the kernels below are written once for both 16-bit row types H (wfs_bf16 / wfs_f16): rows travel as raw dwords,
+// only the float <-> H conversions (wfs_pack2<H>, wfs_round_to<H>) and the MFMA opcode differ
+template <typename H, typename V>
+__device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 acc) {
+    static_assert(sizeof(V) == 16, "8 x 16-bit operands");
+    if constexpr (sizeof(H) == 2 && __is_same(H, wfs_f16))
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0,
+                                                      0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                       0, 0, 0);
 }
 
 __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-wise: a vector select goes through scratch
@@ -201,12 +203,12 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
     return v;
 }
 
-template <bool TRANSPOSE_W, bool STATS>
+template <typename H, bool TRANSPOSE_W, bool STATS>
 __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
-                                                       const wfs_bf16 *__restrict__ X,
+                                                       const H *__restrict__ X,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
-                                                       wfs_bf16 *__restrict__ Y, long long ntiles,
+                                                       H *__restrict__ Y, long long ntiles,
                                                        long long tiles_per_xcd, WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
@@ -240,10 +242,10 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
         for (int b = 0; b < WSB; ++b) {
             int u = u0 + b * nthreads;
             uint4 v;
-            v.x = pack_bf16x2(w[b][0], w[b][1]);
-            v.y = pack_bf16x2(w[b][2], w[b][3]);
-            v.z = pack_bf16x2(w[b][4], w[b][5]);
-            v.w = pack_bf16x2(w[b][6], w[b][7]);
+            v.x = wfs_pack2<H>(w[b][0], w[b][1]);
+            v.y = wfs_pack2<H>(w[b][2], w[b][3]);
+            v.z = wfs_pack2<H>(w[b][4], w[b][5]);
+            v.w = wfs_pack2<H>(w[b][6], w[b][7]);
             if (u < nfrag) sWb[u] = v;
         }
     }
@@ -307,10 +309,8 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
                     hi = keep_if(hi, nbs[g] >= 0);
                     const uint4 *bp = sWb + (size_t)ks[g] * 128 + h * 32 + r;
                     uint4 b0 = bp[0], b1 = bp[64];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, lo),
-                                                                  __builtin_bit_cast(bf16x8, b0), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hi),
-                                                                  __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+                    acc = mfma16<H>(lo, b0, acc);
+                    acc = mfma16<H>(hi, b1, acc);
                 }
         }
         // ---- epilogue: reg i holds (row (i&3) + 8(i>>2) + 4h, col r).  Neighbouring columns are paired with one
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
             float mine0 = acc[i], mine1 = acc[i + 1];
             float send = (lane & 1) ? mine0 : mine1;
             float got = __shfl_xor(send, 1, 64);
-            unsigned packed = (lane & 1) ? pack_bf16x2(got, mine1) : pack_bf16x2(mine0, got);
+            unsigned packed = (lane & 1) ? wfs_pack2<H>(got, mine1) : wfs_pack2<H>(mine0, got);
             int ri = (lane & 1) ? i + 1 : i;
             long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
             if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
         if constexpr (STATS) {
             float vals[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) vals[i] = bf16_round(acc[i]);      // statistics of the values as stored
+            for (int i = 0; i < 16; ++i) vals[i] = wfs_round_to<H>(acc[i]);      // statistics of the values as stored
             const long long left = Rv - tile * 32;
             wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
@@ -373,8 +373,8 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
             *reinterpret_cast<f32x4 *>(y) = acc;
         } else {
             uint2 pk;
-            pk.x = pack_bf16x2(acc.x, acc.y);
-            pk.y = pack_bf16x2(acc.z, acc.w);
+            pk.x = wfs_pack2<T>(acc.x, acc.y);
+            pk.y = wfs_pack2<T>(acc.z, acc.w);
             *reinterpret_cast<uint2 *>(y) = pk;
         }
     }
@@ -479,12 +479,12 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
 // (2 bf16 channels each) of offsets 8s + 4h + {0,1,2,3} of row r -- read straight from global memory, no LDS, no
 // transpose; all 16 table entries of a lane are loaded together, then all 16 gathers.  The filter image
 // sWc[s][h][co][j] = W[k = 8s + 4h + j/2][c = j & 1][co] (zero for k >= K) is 4 KiB.
-template <bool STATS>
+template <typename H, bool STATS>
 __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict__ table, int mirror, int K,
                                                          int identity_k, long long R,
                                                          const long long *__restrict__ r_dev,
-                                                         const wfs_bf16 *__restrict__ X, const float *__restrict__ W,
-                                                         const float *__restrict__ bias, wfs_bf16 *__restrict__ Y,
+                                                         const H *__restrict__ X, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, H *__restrict__ Y,
                                                          WfsStatsArgs sa) {
     __shared__ __attribute__((aligned(16))) uint4 sWc[4 * 2 * 32];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
@@ -499,10 +499,10 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
             w[j] = k < K ? W[((long long)k * 2 + (j & 1)) * 32 + co] : 0.f;
         }
         uint4 v;
-        v.x = pack_bf16x2(w[0], w[1]);
-        v.y = pack_bf16x2(w[2], w[3]);
-        v.z = pack_bf16x2(w[4], w[5]);
-        v.w = pack_bf16x2(w[6], w[7]);
+        v.x = wfs_pack2<H>(w[0], w[1]);
+        v.y = wfs_pack2<H>(w[2], w[3]);
+        v.z = wfs_pack2<H>(w[4], w[5]);
+        v.w = wfs_pack2<H>(w[6], w[7]);
         sWc[u] = v;
     }
     __syncthreads();
@@ -540,8 +540,7 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
         for (int st = 0; st < 4; ++st) {
             uint4 a = {xv[4 * st], xv[4 * st + 1], xv[4 * st + 2], xv[4 * st + 3]};
             uint4 b = sWc[(st * 2 + h) * 32 + r];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
-                                                          0, 0, 0);
+            acc = mfma16<H>(a, b, acc);
         }
         unsigned *Yw = reinterpret_cast<unsigned *>(Y);
 #pragma unroll
@@ -549,7 +548,7 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
             float mine0 = acc[i], mine1 = acc[i + 1];
             float send = (lane & 1) ? mine0 : mine1;
             float got = __shfl_xor(send, 1, 64);
-            unsigned packed = (lane & 1) ? pack_bf16x2(got, mine1) : pack_bf16x2(mine0, got);
+            unsigned packed = (lane & 1) ? wfs_pack2<H>(got, mine1) : wfs_pack2<H>(mine0, got);
             int ri = (lane & 1) ? i + 1 : i;
             long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
             if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
@@ -557,7 +556,7 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
         if constexpr (STATS) {
             float vals[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) vals[i] = bf16_round(acc[i]);
+            for (int i = 0; i < 16; ++i) vals[i] = wfs_round_to<H>(acc[i]);
             const long long left = Rv - tile * 32;
             wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
@@ -603,9 +602,10 @@ __device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <typename H>
 __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int K, int identity_k,
                                                      long long Rcap, const long long *__restrict__ r_dev,
-                                                     const wfs_bf16 *__restrict__ S, const wfs_bf16 *__restrict__ G,
+                                                     const H *__restrict__ S, const H *__restrict__ G,
                                                      float *__restrict__ part, int ngroups, long long tiles_per_block) {
     __shared__ __attribute__((aligned(16))) unsigned short sTiles[DWB_WAVES][2][32 * 32];   // per wave: S tile, G tile
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -671,8 +671,8 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
             *(uint4 *)(sG + (grow + 16) * 32 + gchunk * 8) = keep_if(g1[q], tb[q] >= 0);
             __builtin_amdgcn_wave_barrier();
             const bf16x8 b0 = lds_column_frag_tr(sG, lane, 0), b1 = lds_column_frag_tr(sG, lane, 1);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[q], 0, 0, 0);
+            acc[q] = mfma16<H>(a0, b0, acc[q]);
+            acc[q] = mfma16<H>(a1, b1, acc[q]);
         }
     }
     // deterministic block reduction, one offset at a time: all 16 waves park that offset's accumulator in LDS (the
@@ -764,10 +764,11 @@ __global__ void __launch_bounds__(256) k_gdw_c32c2(const int *__restrict__ table
 // table reads are issued together, then all gathers: two memory latencies per tile, one tile per wave in flight.
 constexpr int C2_WAVES = 8;
 
+template <typename H>
 __global__ void __launch_bounds__(512, 4) k_gdw_c32c2_bf16(const int *__restrict__ table, int mirror, int K,
                                                           int identity_k, long long Rcap,
                                                           const long long *__restrict__ r_dev,
-                                                          const wfs_bf16 *__restrict__ S, const wfs_bf16 *__restrict__ G,
+                                                          const H *__restrict__ S, const H *__restrict__ G,
                                                           float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) unsigned sA[C2_WAVES][32 * 33];
     __shared__ __attribute__((aligned(16))) unsigned short sB[C2_WAVES][32 * 32];
@@ -837,10 +838,8 @@ __global__ void __launch_bounds__(512, 4) k_gdw_c32c2_bf16(const int *__restrict
             uint4 a_lo = {wa[0][st][0], wa[0][st][1], wa[0][st][2], wa[0][st][3]};
             uint4 a_hi = {wa[1][st][0], wa[1][st][1], wa[1][st][2], wa[1][st][3]};
             uint4 bb = {wb[st][0], wb[st][1], wb[st][2], wb[st][3]};
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo), __builtin_bit_cast(bf16x8, bb),
-                                                           acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bb),
-                                                           acc1, 0, 0, 0);
+            acc0 = mfma16<H>(a_lo, bb, acc0);
+            acc1 = mfma16<H>(a_hi, bb, acc1);
         }
     }
     // deterministic block reduction in two halves (offsets 0..15, 16..31): every wave parks its accumulator in the
@@ -979,28 +978,37 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
                           r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
 }
 
-int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
-                            const void *X, const float *W, int transpose_w, const float *bias, void *Y,
-                            const wfs_bn_stats *stats, hipStream_t stream) {
+template <typename H>
+static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                              const H *Xb, const float *W, int transpose_w, const float *bias, H *Yb,
+                              const wfs_bn_stats *stats, hipStream_t stream) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
     gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
     const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
-    static bool attr[3] = {false, false, false};
+    static bool attr[3] = {false, false, false};          // per instantiation of this template, i.e. per H
     const WfsStatsArgs sa = stats_args(stats, nblk);
     const dim3 grid((unsigned)nblk), block(wpb * 64);
-    const wfs_bf16 *Xb = (const wfs_bf16 *)X;
-    wfs_bf16 *Yb = (wfs_bf16 *)Y;
     if (transpose_w)
-        return launch_big_lds(k_gconv32_bf16<true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
+        return launch_big_lds(k_gconv32_bf16<H, true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
                               identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
     if (stats) {
-        int rc = launch_big_lds(k_gconv32_bf16<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
+        int rc = launch_big_lds(k_gconv32_bf16<H, false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
                                 identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, stream);
     }
-    return launch_big_lds(k_gconv32_bf16<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K, identity_k,
-                          R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+    return launch_big_lds(k_gconv32_bf16<H, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
+                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+}
+
+int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                           const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
+                           const wfs_bn_stats *stats, hipStream_t stream) {
+    if (dtype == WFS_F16)
+        return launch_gconv32_h16<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, transpose_w,
+                                           bias, (wfs_f16 *)Y, stats, stream);
+    return launch_gconv32_h16<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, transpose_w, bias,
+                                        (wfs_bf16 *)Y, stats, stream);
 }
 
 // 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.
@@ -1015,21 +1023,24 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
         is_mirror = is_mirror && km.v[k] == K - 1 - k;
     }
     if (stats_done) *stats_done = false;
-    if (dtype == WFS_BF16 && K <= 32 && (is_ident || is_mirror)) {
+    if (dtype != WFS_F32 && K <= 32 && (is_ident || is_mirror)) {
         long long nb = ((R + 31) / 32 + 3) / 4;
         if (nb > 4096) nb = 4096;
         if (stats && nb > 1024) nb = 1024;          // one partial per block for k_stats_fold
         const WfsStatsArgs sa = stats_args(stats, nb);
+        const dim3 grid((unsigned)nb), block(256);
+        const int mir = is_ident ? 0 : 1;
+#define WFS_C2(H, ST)                                                                                                \
+    k_gconv_c2c32_bf16<H, ST><<<grid, block, 0, stream>>>(table, mir, K, identity_k, R, r_dev, (const H *)X, W, bias,  \
+                                                          (H *)Y, sa)
         if (stats) {
-            k_gconv_c2c32_bf16<true><<<dim3((unsigned)nb), dim3(256), 0, stream>>>(
-                table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, sa);
+            if (dtype == WFS_F16) WFS_C2(wfs_f16, true); else WFS_C2(wfs_bf16, true);
             WFS_LAUNCH_CHECK();
             if (stats_done) *stats_done = true;
             return stats_fold(sa, nb, stream);
-        } else {
-            k_gconv_c2c32_bf16<false><<<dim3((unsigned)nb), dim3(256), 0, stream>>>(
-                table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y, sa);
         }
+        if (dtype == WFS_F16) WFS_C2(wfs_f16, false); else WFS_C2(wfs_bf16, false);
+#undef WFS_C2
         WFS_LAUNCH_CHECK();
         return WFS_OK;
     }
@@ -1038,9 +1049,12 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
     if (dtype == WFS_F32)
         k_gconv_c2c32<float><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(table, km, K, identity_k, R, r_dev,
                                                                             (const float *)X, W, bias, (float *)Y);
-    else
+    else if (dtype == WFS_BF16)
         k_gconv_c2c32<wfs_bf16><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(
             table, km, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, bias, (wfs_bf16 *)Y);
+    else
+        k_gconv_c2c32<wfs_f16><<<dim3((unsigned)nblk), dim3(256), 0, stream>>>(
+            table, km, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, bias, (wfs_f16 *)Y);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
@@ -1075,9 +1089,12 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
     if (dtype == WFS_F32)
         k_gdw32<float><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(
             table, K, identity_k, R, r_dev, (const float *)S, (const float *)G, part, ngroups, tiles_per_block);
-    else
-        k_gdw32_bf16<<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(1024), 0, stream>>>(
+    else if (dtype == WFS_BF16)
+        k_gdw32_bf16<wfs_bf16><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(1024), 0, stream>>>(
             table, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
+    else
+        k_gdw32_bf16<wfs_f16><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(1024), 0, stream>>>(
+            table, K, identity_k, R, r_dev, (const wfs_f16 *)S, (const wfs_f16 *)G, part, ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
     k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(nblk > 64 ? 1024 : 256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
@@ -1097,8 +1114,12 @@ int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, lo
         const long long ntiles = (R + 31) >> 5;
         chunks = (ntiles + C2_WAVES - 1) / C2_WAVES;          // one tile per wave, at most 512 blocks (= slabs)
         if (chunks > 512) chunks = 512;
-        k_gdw_c32c2_bf16<<<dim3((unsigned)chunks), dim3(512), 0, stream>>>(
-            table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
+        if (dtype == WFS_BF16)
+            k_gdw_c32c2_bf16<wfs_bf16><<<dim3((unsigned)chunks), dim3(512), 0, stream>>>(
+                table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part);
+        else
+            k_gdw_c32c2_bf16<wfs_f16><<<dim3((unsigned)chunks), dim3(512), 0, stream>>>(
+                table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)S, (const wfs_f16 *)G, part);
     }
     WFS_LAUNCH_CHECK();
     // part is [chunk][k][c (gathered, 2)][b (stationary, 32)] = the "swap" orientation of (S=32, G=2)

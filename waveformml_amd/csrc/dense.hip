@@ -89,7 +89,7 @@ extern "C" int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, in
     Shape s;
     int rc = make_shape(&s, ndim, spatial_host);
     if (rc) return rc;
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (M == 0 || C == 0) return WFS_OK;
     WFS_REQUIRE(X && indices && Y, WFS_EINVAL, "NULL device pointer");
     if (winner_ws) {
@@ -100,7 +100,7 @@ extern "C" int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, in
     dim3 grid((unsigned)wfs_cdiv(M * C, TB)), block(TB);
     if (dtype == WFS_F32)
         k_to_dense<float><<<grid, block, 0, stream>>>(s, (const float *)X, indices, M, m_dev, C, winner_ws, (float *)Y);
-    else
+    else                                          // bf16 and fp16 alike: 2-byte elements, copied as they are
         k_to_dense<wfs_bf16><<<grid, block, 0, stream>>>(s, (const wfs_bf16 *)X, indices, M, m_dev, C, winner_ws,
                                                          (wfs_bf16 *)Y);
     WFS_LAUNCH_CHECK();
@@ -116,7 +116,7 @@ extern "C" int wfs_to_dense_bwd(const void *dY, const int32_t *indices, int64_t 
     Shape s;
     int rc = make_shape(&s, ndim, spatial_host);
     if (rc) return rc;
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (M == 0 || C == 0) return WFS_OK;
     WFS_REQUIRE(dY && indices && dX, WFS_EINVAL, "NULL device pointer");
     dim3 grid((unsigned)wfs_cdiv(M * C, TB)), block(TB);

@@ -212,7 +212,7 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
     const long long *r_dev = (const long long *)r_dev_;
     (void)X_rows;
     WFS_REQUIRE(K >= 1 && K <= 128, WFS_EINVAL, "kernel volume %d not in [1,128]", K);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     const int Cy = transpose_w ? Cw_in : Cw_out;
     WFS_REQUIRE(Cx == (transpose_w ? Cw_out : Cw_in), WFS_EINVAL, "channel mismatch: X has %d, filter wants %d", Cx,
                 transpose_w ? Cw_out : Cw_in);
@@ -235,10 +235,10 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
                                       bias, (float *)Y, stats, stream);
     }
-    if (dtype == WFS_BF16 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror)) {
+    if (dtype != WFS_F32 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror)) {
         *stats_done = stats != nullptr;
-        return wfs_launch_gconv32_bf16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
-                                       stats, stream);
+        return wfs_launch_gconv32_h16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
+                                      dtype, stats, stream);
     }
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
         return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stats, stats_done,
@@ -249,8 +249,10 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
                                                       Cw_in, Cw_out, bias, (T *)Y, Cy)
     if (dtype == WFS_F32) {
         if (transpose_w) WFS_GC(float, true); else WFS_GC(float, false);
-    } else {
+    } else if (dtype == WFS_BF16) {
         if (transpose_w) WFS_GC(wfs_bf16, true); else WFS_GC(wfs_bf16, false);
+    } else {
+        if (transpose_w) WFS_GC(wfs_f16, true); else WFS_GC(wfs_f16, false);
     }
 #undef WFS_GC
     WFS_LAUNCH_CHECK();
@@ -294,7 +296,7 @@ extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identit
                                 float *Y_accum, int32_t dtype, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(K >= 1, WFS_EINVAL, "bad K");
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     const int Cy = transpose_w ? Cw_in : Cw_out;
     WFS_REQUIRE(Cx == (transpose_w ? Cw_out : Cw_in), WFS_EINVAL, "channel mismatch");
     if (R == 0) return WFS_OK;
@@ -305,8 +307,10 @@ extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identit
                                                        Y_accum, Cy)
     if (dtype == WFS_F32) {
         if (transpose_w) WFS_SC(float, true); else WFS_SC(float, false);
-    } else {
+    } else if (dtype == WFS_BF16) {
         if (transpose_w) WFS_SC(wfs_bf16, true); else WFS_SC(wfs_bf16, false);
+    } else {
+        if (transpose_w) WFS_SC(wfs_f16, true); else WFS_SC(wfs_f16, false);
     }
 #undef WFS_SC
     WFS_LAUNCH_CHECK();
@@ -327,7 +331,7 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     const long long *r_dev = (const long long *)r_dev_;
     (void)G_rows;
     WFS_REQUIRE(K >= 1 && K <= 65535, WFS_EINVAL, "bad K");
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(dW, WFS_EINVAL, "NULL dW");
     if (R == 0) {
         WFS_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)K * Cs * Cg * sizeof(float), stream));
@@ -358,10 +362,14 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     if (dtype == WFS_F32)
         k_gather_dw<float><<<grid, block, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk, (const float *)S,
                                                        Cs, (const float *)G, Cg, part, tiles_a, tiles_b);
-    else
+    else if (dtype == WFS_BF16)
         k_gather_dw<wfs_bf16><<<grid, block, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk,
                                                           (const wfs_bf16 *)S, Cs, (const wfs_bf16 *)G, Cg, part,
                                                           tiles_a, tiles_b);
+    else
+        k_gather_dw<wfs_f16><<<grid, block, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk,
+                                                         (const wfs_f16 *)S, Cs, (const wfs_f16 *)G, Cg, part, tiles_a,
+                                                         tiles_b);
     WFS_LAUNCH_CHECK();
     long long per = (long long)K * Cs * Cg;
     k_dw_reduce<<<dim3((unsigned)wfs_cdiv(per, TB)), block, 0, stream>>>(part, chunks, K, Cs, Cg, swap, dW);

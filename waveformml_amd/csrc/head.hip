@@ -19,10 +19,10 @@ __device__ __forceinline__ void load8(const T *p, float *v) {
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
         uint4 u = *reinterpret_cast<const uint4 *>(p);
-        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
-        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
-        v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xFFFF0000u);
-        v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
+        wfs_unpack2<T>(u.x, v[0], v[1]);
+        wfs_unpack2<T>(u.y, v[2], v[3]);
+        wfs_unpack2<T>(u.z, v[4], v[5]);
+        wfs_unpack2<T>(u.w, v[6], v[7]);
     }
 }
 template <typename T>
@@ -31,14 +31,11 @@ __device__ __forceinline__ void store8(T *p, const float *v) {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        wfs_bf16 h[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wfs_st(&h[i], v[i]);
         uint4 u;
-        u.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-        u.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-        u.z = (unsigned)h[4] | ((unsigned)h[5] << 16);
-        u.w = (unsigned)h[6] | ((unsigned)h[7] << 16);
+        u.x = wfs_pack2<T>(v[0], v[1]);
+        u.y = wfs_pack2<T>(v[2], v[3]);
+        u.z = wfs_pack2<T>(v[4], v[5]);
+        u.w = wfs_pack2<T>(v[6], v[7]);
         *reinterpret_cast<uint4 *>(p) = u;
     }
 }
@@ -444,14 +441,16 @@ extern "C" int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W,
                             float *Y, int32_t dtype, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (B == 0) return WFS_OK;
     WFS_REQUIRE(X && W && Y, WFS_EINVAL, "NULL device pointer");
     dim3 grid((unsigned)B), block(TB);
     if (dtype == WFS_F32) {
         WFS_HEAD_DISPATCH(O, (k_head_fwd<float, OO><<<grid, block, 0, stream>>>((const float *)X, W, bias, Y, I)));
-    } else {
+    } else if (dtype == WFS_BF16) {
         WFS_HEAD_DISPATCH(O, (k_head_fwd<wfs_bf16, OO><<<grid, block, 0, stream>>>((const wfs_bf16 *)X, W, bias, Y, I)));
+    } else {
+        WFS_HEAD_DISPATCH(O, (k_head_fwd<wfs_f16, OO><<<grid, block, 0, stream>>>((const wfs_f16 *)X, W, bias, Y, I)));
     }
     WFS_LAUNCH_CHECK();
     return WFS_OK;
@@ -461,7 +460,7 @@ extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I,
                             float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (B == 0) {
         if (dW) WFS_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)O * I * sizeof(float), stream));
         return WFS_OK;
@@ -472,8 +471,10 @@ extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I,
         dim3 grid(gx, (unsigned)B), block(TB);
         if (dtype == WFS_F32) {
             WFS_HEAD_DISPATCH(O, (k_head_dx<float, OO><<<grid, block, 0, stream>>>(G, W, (float *)dX, I)));
-        } else {
+        } else if (dtype == WFS_BF16) {
             WFS_HEAD_DISPATCH(O, (k_head_dx<wfs_bf16, OO><<<grid, block, 0, stream>>>(G, W, (wfs_bf16 *)dX, I)));
+        } else {
+            WFS_HEAD_DISPATCH(O, (k_head_dx<wfs_f16, OO><<<grid, block, 0, stream>>>(G, W, (wfs_f16 *)dX, I)));
         }
         WFS_LAUNCH_CHECK();
     }
@@ -485,8 +486,10 @@ extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I,
         float *part = (float *)workspace;
         if (dtype == WFS_F32) {
             WFS_HEAD_DISPATCH(O, (k_head_dw<float, OO><<<grid, block, 0, stream>>>(G, (const float *)X, part, B, I, rpc)));
-        } else {
+        } else if (dtype == WFS_BF16) {
             WFS_HEAD_DISPATCH(O, (k_head_dw<wfs_bf16, OO><<<grid, block, 0, stream>>>(G, (const wfs_bf16 *)X, part, B, I, rpc)));
+        } else {
+            WFS_HEAD_DISPATCH(O, (k_head_dw<wfs_f16, OO><<<grid, block, 0, stream>>>(G, (const wfs_f16 *)X, part, B, I, rpc)));
         }
         WFS_LAUNCH_CHECK();
         const long long OI = (long long)O * I;
@@ -541,7 +544,7 @@ extern "C" int wfs_sparse_head_fwd(const void *X, const int32_t *indices, int64_
     if (rc != WFS_OK) return rc;
     WFS_REQUIRE(O >= 1 && O <= MAXO && C >= 8 && C % 8 == 0 && C / 8 <= TB, WFS_EINVAL, "unsupported head shape C=%d O=%d", C, O);
     WFS_REQUIRE(V >= 1 && V * 4 <= 64 * 1024, WFS_EINVAL, "%lld cells per event do not fit the LDS grid", V);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (batch == 0) return WFS_OK;
     WFS_REQUIRE((M == 0 || (X && indices)) && W && Y, WFS_EINVAL, "NULL device pointer");
     const dim3 grd((unsigned)batch), block(TB);
@@ -550,8 +553,11 @@ extern "C" int wfs_sparse_head_fwd(const void *X, const int32_t *indices, int64_
     if (dtype == WFS_F32)                                                                                              \
         k_sparse_head_fwd<float, OO><<<grd, block, lds, stream>>>((const float *)X, indices, M, m_dev, sh, (int)V, C, W, \
                                                                    bias, Y, grid);                                     \
-    else                                                                                                               \
+    else if (dtype == WFS_BF16) \
         k_sparse_head_fwd<wfs_bf16, OO><<<grd, block, lds, stream>>>((const wfs_bf16 *)X, indices, M, m_dev, sh, (int)V, \
+                                                                      C, W, bias, Y, grid); \
+    else \
+        k_sparse_head_fwd<wfs_f16, OO><<<grd, block, lds, stream>>>((const wfs_f16 *)X, indices, M, m_dev, sh, (int)V, \
                                                                       C, W, bias, Y, grid)
     WFS_HEAD_O(WFS_CALL)
 #undef WFS_CALL
@@ -570,7 +576,7 @@ extern "C" int wfs_sparse_head_bwd(const void *X, const int32_t *indices, int64_
     int rc = make_hshape(&sh, ndim, spatial, &V);
     if (rc != WFS_OK) return rc;
     WFS_REQUIRE(O >= 1 && O <= MAXO && C >= 8 && C % 8 == 0, WFS_EINVAL, "unsupported head shape C=%d O=%d", C, O);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(W && G, WFS_EINVAL, "NULL device pointer");
     if (dX && M > 0) {
         WFS_REQUIRE(indices, WFS_EINVAL, "NULL indices");
@@ -580,8 +586,10 @@ extern "C" int wfs_sparse_head_bwd(const void *X, const int32_t *indices, int64_
 #define WFS_CALL(OO)                                                                                                  \
     if (dtype == WFS_F32)                                                                                             \
         k_sparse_head_dx<float, OO><<<grd, block, 0, stream>>>(indices, M, m_dev, sh, (int)V, C, W, G, (float *)dX);   \
+    else if (dtype == WFS_BF16)                                                                                       \
+        k_sparse_head_dx<wfs_bf16, OO><<<grd, block, 0, stream>>>(indices, M, m_dev, sh, (int)V, C, W, G, (wfs_bf16 *)dX); \
     else                                                                                                              \
-        k_sparse_head_dx<wfs_bf16, OO><<<grd, block, 0, stream>>>(indices, M, m_dev, sh, (int)V, C, W, G, (wfs_bf16 *)dX)
+        k_sparse_head_dx<wfs_f16, OO><<<grd, block, 0, stream>>>(indices, M, m_dev, sh, (int)V, C, W, G, (wfs_f16 *)dX)
         WFS_HEAD_O(WFS_CALL)
 #undef WFS_CALL
         WFS_LAUNCH_CHECK();
@@ -592,8 +600,10 @@ extern "C" int wfs_sparse_head_bwd(const void *X, const int32_t *indices, int64_
 #define WFS_CALL(OO)                                                                                                  \
     if (dtype == WFS_F32)                                                                                             \
         k_sparse_head_dw<float, OO><<<grd, block, 0, stream>>>((const float *)X, grid, batch, (int)V, C, G, dW, dB);   \
+    else if (dtype == WFS_BF16)                                                                                       \
+        k_sparse_head_dw<wfs_bf16, OO><<<grd, block, 0, stream>>>((const wfs_bf16 *)X, grid, batch, (int)V, C, G, dW, dB); \
     else                                                                                                              \
-        k_sparse_head_dw<wfs_bf16, OO><<<grd, block, 0, stream>>>((const wfs_bf16 *)X, grid, batch, (int)V, C, G, dW, dB)
+        k_sparse_head_dw<wfs_f16, OO><<<grd, block, 0, stream>>>((const wfs_f16 *)X, grid, batch, (int)V, C, G, dW, dB)
         WFS_HEAD_O(WFS_CALL)
 #undef WFS_CALL
         WFS_LAUNCH_CHECK();

@@ -229,15 +229,17 @@ extern "C" int wfs_tcn_fwd(const void *X, int64_t N, int32_t L, const float *tap
     WFS_REQUIRE(levels >= 1 && levels <= MAXLV && k >= 1 && k <= MAXK, WFS_EINVAL, "unsupported TCN shape: %d levels, k = %d",
                 levels, k);
     WFS_REQUIRE(L >= 1 && L <= 16 * TB, WFS_EINVAL, "row length %d not in [1, %d]", L, 16 * TB);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(X && Y && taps && bias, WFS_EINVAL, "NULL device pointer");
     const size_t lds = wfs_tcn_lds_bytes(L, levels, 0);
     const dim3 grid((unsigned)N), block(TB);
     if (dtype == WFS_F32) {
         WFS_TCN_DISPATCH_K(k_tcn_fwd, float, (const float *)X, N, L, taps, bias, levels, (float *)Y)
-    } else {
+    } else if (dtype == WFS_BF16) {
         WFS_TCN_DISPATCH_K(k_tcn_fwd, wfs_bf16, (const wfs_bf16 *)X, N, L, taps, bias, levels, (wfs_bf16 *)Y)
+    } else {
+        WFS_TCN_DISPATCH_K(k_tcn_fwd, wfs_f16, (const wfs_f16 *)X, N, L, taps, bias, levels, (wfs_f16 *)Y)
     }
     WFS_LAUNCH_CHECK();
     return WFS_OK;
@@ -272,7 +274,7 @@ extern "C" int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, 
     WFS_REQUIRE(levels >= 1 && levels <= MAXLV && k >= 1 && k <= MAXK, WFS_EINVAL, "unsupported TCN shape: %d levels, k = %d",
                 levels, k);
     WFS_REQUIRE(L >= 1 && L <= 16 * TB, WFS_EINVAL, "row length %d not in [1, %d]", L, 16 * TB);
-    WFS_REQUIRE(dtype == WFS_F32 || dtype == WFS_BF16, WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     const size_t lds = wfs_tcn_lds_bytes(L, levels, 1);
     WFS_REQUIRE(lds <= 150 * 1024, WFS_EINVAL, "row of %d samples x %d levels needs %zu B of LDS", L, levels, lds);
     if (N == 0) return WFS_OK;
@@ -282,11 +284,16 @@ extern "C" int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, 
         int rc = tcn_bwd_attr_k<float>(k);
         if (rc != WFS_OK) return rc;
         WFS_TCN_DISPATCH_K(k_tcn_bwd, float, (const float *)X, (const float *)dY, N, L, taps, bias, levels, (float *)dX, partial)
-    } else {
+    } else if (dtype == WFS_BF16) {
         int rc = tcn_bwd_attr_k<wfs_bf16>(k);
         if (rc != WFS_OK) return rc;
         WFS_TCN_DISPATCH_K(k_tcn_bwd, wfs_bf16, (const wfs_bf16 *)X, (const wfs_bf16 *)dY, N, L, taps, bias, levels,
                            (wfs_bf16 *)dX, partial)
+    } else {
+        int rc = tcn_bwd_attr_k<wfs_f16>(k);
+        if (rc != WFS_OK) return rc;
+        WFS_TCN_DISPATCH_K(k_tcn_bwd, wfs_f16, (const wfs_f16 *)X, (const wfs_f16 *)dY, N, L, taps, bias, levels,
+                           (wfs_f16 *)dX, partial)
     }
     WFS_LAUNCH_CHECK();
     return WFS_OK;

@@ -33,17 +33,65 @@ void wfs_set_error(const char *fmt, ...);
 static inline size_t wfs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int64_t wfs_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// bf16 storage helpers (round-to-nearest-even through the hardware cvt; NaN stays NaN)
+// 16-bit storage helpers (round-to-nearest-even through the hardware cvt; NaN stays NaN).  bf16 rows are plain
+// unsigned shorts; fp16 rows get a distinct type so that overloads and templates can tell the two apart.
 typedef unsigned short wfs_bf16;
+struct wfs_f16 {
+    unsigned short bits;
+};
 __device__ __forceinline__ float wfs_ld(const float *p) { return *p; }
 __device__ __forceinline__ float wfs_ld(const wfs_bf16 *p) {
     return __uint_as_float(((unsigned)*p) << 16);
+}
+__device__ __forceinline__ float wfs_ld(const wfs_f16 *p) {
+    return (float)__builtin_bit_cast(_Float16, p->bits);
 }
 __device__ __forceinline__ void wfs_st(float *p, float v) { *p = v; }
 __device__ __forceinline__ void wfs_st(wfs_bf16 *p, float v) {
     __bf16 b = (__bf16)v;
     *p = *reinterpret_cast<unsigned short *>(&b);
 }
+__device__ __forceinline__ void wfs_st(wfs_f16 *p, float v) {
+    p->bits = __builtin_bit_cast(unsigned short, (_Float16)v);
+}
+// one dword = two neighbouring 16-bit elements (low half first)
+template <typename H>
+__device__ __forceinline__ void wfs_unpack2(unsigned w, float &lo, float &hi);
+template <>
+__device__ __forceinline__ void wfs_unpack2<wfs_bf16>(unsigned w, float &lo, float &hi) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xFFFF0000u);
+}
+template <>
+__device__ __forceinline__ void wfs_unpack2<wfs_f16>(unsigned w, float &lo, float &hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v = __builtin_bit_cast(h2, w);
+    lo = (float)v.x;
+    hi = (float)v.y;
+}
+template <typename H>
+__device__ __forceinline__ unsigned wfs_pack2(float lo, float hi);
+template <>
+__device__ __forceinline__ unsigned wfs_pack2<wfs_bf16>(float lo, float hi) {
+    wfs_bf16 a, b;
+    wfs_st(&a, lo);
+    wfs_st(&b, hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+template <>
+__device__ __forceinline__ unsigned wfs_pack2<wfs_f16>(float lo, float hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+// the value a float takes when it is stored in H and read back
+template <typename H>
+__device__ __forceinline__ float wfs_round_to(float v) {
+    H t;
+    wfs_st(&t, v);
+    return wfs_ld(&t);
+}
+static inline bool wfs_dtype_ok(int dtype) { return dtype == WFS_F32 || dtype == WFS_BF16 || dtype == WFS_F16; }
 
 // event timing (opt-in; see wfs_timing_enable)
 struct WfsTimerScope {
@@ -60,9 +108,10 @@ bool wfs_mfma_gconv32_ok(int K);
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
                            const wfs_bn_stats *stats, hipStream_t stream);
-int wfs_launch_gconv32_bf16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
-                            const void *X, const float *W, int transpose_w, const float *bias, void *Y,
-                            const wfs_bn_stats *stats, hipStream_t stream);
+// 16-bit rows (dtype WFS_BF16 or WFS_F16)
+int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                           const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
+                           const wfs_bn_stats *stats, hipStream_t stream);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
                            const wfs_bn_stats *stats, bool *stats_done, hipStream_t stream);

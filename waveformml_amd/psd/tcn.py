@@ -121,7 +121,5 @@ class TemporalConvNet(nn.Module):
         if self._can_fuse(x):
             taps, bias = self.effective_taps()
             rows = x.reshape(x.shape[0], x.shape[2])
-            if rows.dtype == torch.float16:            # fp16 rows: fp32 kernels, rounded back to fp16 (as spconv/functional)
-                return FusedTCNFunction.apply(rows.float(), taps, bias).half().reshape(x.shape)
             return FusedTCNFunction.apply(rows, taps, bias).reshape(x.shape)
         return self.network(x)

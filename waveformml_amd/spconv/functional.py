@@ -393,10 +393,9 @@ def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
     ``stats``: (save_mean, save_invstd) already taken by the producing convolution)."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # bumped by the kernel
-    return _half_io(lambda f: BatchNormReLUFunction.apply(
-        f, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats),
-        features)
+    return BatchNormReLUFunction.apply(
+        features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats)
 
 
 def can_fuse_batch_norm(bn, features):
@@ -455,7 +454,7 @@ def can_use_skinny_linear(linear, x):
 
 
 def skinny_linear(x, linear):
-    return SkinnyLinearFunction.apply(x.float() if x.dtype == torch.float16 else x, linear.weight, linear.bias)
+    return SkinnyLinearFunction.apply(x, linear.weight, linear.bias)
 
 
 class SparseHeadFunction(Function):
@@ -521,8 +520,7 @@ def can_use_sparse_head(linear, st):
 
 
 def sparse_head(st, linear):
-    f = st.features.float() if st.features.dtype == torch.float16 else st.features
-    return SparseHeadFunction.apply(f, linear.weight, linear.bias, st.indices, st.spatial_shape, st.batch_size, st.n_valid)
+    return SparseHeadFunction.apply(st.features, linear.weight, linear.bias, st.indices, st.spatial_shape, st.batch_size, st.n_valid)
 
 
 class CrossEntropyMeanFunction(Function):
@@ -558,26 +556,19 @@ def cross_entropy_mean(logits, target, ignore_index=-100):
     return CrossEntropyMeanFunction.apply(logits, target, ignore_index)
 
 
-# fp16 storage (the reference's ``half_precision`` / ``use_half``: float16 features, src/datasets/HDF5Dataset.py:228) is
-# served by the fp32 kernels: rows are widened on entry and rounded to fp16 on exit of every operator, i.e. fp16
-# storage with fp32 arithmetic, through autograd's own casts.  bf16 is the 16-bit format with native kernels on gfx950.
-def _half_io(fn, x, *args):
-    if x.dtype == torch.float16:
-        return fn(x.float(), *args).half()
-    return fn(x, *args)
-
-
+# 16-bit storage: bf16, and fp16 for the reference's ``half_precision`` / ``use_half`` (float16 features,
+# src/datasets/HDF5Dataset.py:227-228).  Both have native kernels (fp32 accumulate, fp32 master filters).
 def indice_conv(features, filters, bias, rulebook, bn_request=None):
-    return _half_io(lambda f: SparseConvFunction.apply(f, filters, bias, rulebook, CONV, bn_request), features)
+    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request)
 
 
 def indice_subm_conv(features, filters, bias, rulebook, bn_request=None):
-    return _half_io(lambda f: SparseConvFunction.apply(f, filters, bias, rulebook, SUBM, bn_request), features)
+    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request)
 
 
 def indice_inverse_conv(features, filters, bias, rulebook, bn_request=None):
-    return _half_io(lambda f: SparseConvFunction.apply(f, filters, bias, rulebook, INVERSE, bn_request), features)
+    return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE, bn_request)
 
 
 def to_dense(features, indices, spatial_shape, batch_size, unique, m_dev=None):
-    return _half_io(lambda f: ToDenseFunction.apply(f, indices, spatial_shape, batch_size, unique, m_dev), features)
+    return ToDenseFunction.apply(features, indices, spatial_shape, batch_size, unique, m_dev)
