@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="events per rank per step")
     ap.add_argument("--samples", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"], help="storage type of the feature rows")
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "f16"], help="storage type of the feature rows")
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "psd_c2_3d.json"))
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed CPU-baseline steps (0 = skip the CPU leg)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -73,6 +73,12 @@ def load_cfg(path, samples):
         cfg = json.load(f)
     cfg["system_config"]["n_samples"] = samples
     return cfg
+
+
+def workload_name(config_path):
+    """The default config is BASELINE.json configs[1]; any other config is named by its file."""
+    base = os.path.basename(config_path)
+    return "SubMConv3d PSD net" if base == "psd_c2_3d.json" else "SubMConv3d PSD net (%s)" % base
 
 
 class Env(object):
@@ -100,7 +106,7 @@ def measure(env, args, dtype, steps, warmup, roofline):
 
     # synthetic batch, resident in HBM before the timed region (weak scaling: fixed events per rank)
     c, f, y = synthetic.generate(args.batch, args.samples, env.cfg["system_config"]["n_type"], seed=1234, rank=rank)
-    fdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+    fdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
     coords = torch.from_numpy(c).to(dev)
     feats = torch.from_numpy(f).to(dev).to(fdtype)
     labels = torch.from_numpy(y).to(dev)
@@ -332,8 +338,8 @@ def main():
             "metric": "waveforms/sec (LitPSD sparse-conv training step)", "value": main_out["value"], "unit": "events/s",
             "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_out["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "SubMConv3d PSD net, 14x11 PMT grid x %d samples, Cin=2 Cout=32, %d events/rank/step, "
-                                   "rulebook rebuilt every step" % (args.samples, args.batch),
+            "config": {"workload": "%s, 14x11 PMT grid x %d samples, Cin=2 Cout=32, %d events/rank/step, "
+                                   "rulebook rebuilt every step" % (workload_name(args.config), args.samples, args.batch),
                        "active_voxels_per_rank": main_out["active_voxels_per_rank"],
                        "global_batch": args.batch * env.world, "parallelism": "dp%d" % env.world,
                        "final_loss": main_out["final_loss"], "execution": main_out["execution"]},
