@@ -174,3 +174,60 @@ def test_unsorted_event_ids_fall_back_to_the_first_occurrence_scan():
     with h5data.H5Table(os.path.join(H5, rel), "Waveform3DPairs") as t:
         for e0, e1 in ((2, 3), (4, 7), (1, 2)):                # e0 and e1 + 1 both occur: the reference's rule applies
             assert t.event_rows(e0, e1, 3) == _slice_events(c_ref, 3, e0, e1)
+
+
+def _dm_config(dataset_class, **extra):
+    from waveformml_amd.psd.config import DictionaryUtility
+    cfg = {"system_config": {"half_precision": 0},
+           "dataset_config": {"imports": ["waveformml_amd.psd.PulseDataset"], "dataset_class": dataset_class,
+                              "base_path": H5, "paths": ["Gamma", "Electron"], "n_train": 9, "n_validate": 3, "n_test": 3,
+                              "dataset_params": {"data_cache_size": 1},
+                              "dataloader_params": {"batch_size": 2, "num_workers": 0}}}
+    cfg["dataset_config"].update(extra.pop("dataset_config", {}))
+    cfg["system_config"].update(extra.pop("system_config", {}))
+    return DictionaryUtility.to_object(cfg)
+
+
+def test_data_module_builds_splits_from_the_config_like_the_reference():
+    """PSDDataModule(config, device) as main.py uses it (reference src/engineering/PSDDataModule.py:22-151): the dataset
+    class comes from dataset_config.{imports, dataset_class} and is called (config, split, n, device, **dataset_params);
+    directories = base_path + paths (label = directory index), features normalised; validation excludes the training
+    files, test excludes both; loaders batch ITEMS (one item = one file's event range) through the reference's collate."""
+    from waveformml_amd.psd.PSDDataModule import PSDDataModule
+    dm = PSDDataModule(_dm_config("PulseDataset.PulseDataset2D"), "cpu")
+    assert dm.ntype == 2 and dm.total_train == 18 and dm.half_precision == 0
+    dm.setup("fit")
+    train_files = [os.path.relpath(p, H5) for p in dm.train_dataset.get_file_list()]
+    assert train_files == ["Gamma/a_WaveformPairSim.h5", "Electron/a_WaveformPairSim.h5"]
+    assert dm.train_dataset.n_events == [9, 9] and dm.train_dataset.n_categories == 2
+    assert [os.path.relpath(p, H5) for p in dm.train_excludes] == train_files
+    # validation: Gamma/b is left, but the Electron directory has no file the training set did not take -> the
+    # reference's error (src/datasets/HDF5Dataset.py:150-152)
+    with pytest.raises(RuntimeError, match="No remaining datasets available"):
+        dm.setup("test")
+    loader = dm.train_dataloader()
+    batches = list(loader)
+    assert len(batches) == 1
+    (coords, feats), labels = batches[0]
+    assert coords.shape[1] == 3 and feats.dtype == torch.float32 and float(feats.max()) <= 1.0
+    assert labels.shape[0] == 18 and sorted(labels.tolist()) == [0] * 9 + [1] * 9
+    assert int(coords[:, 2].max()) == 17 and coords[:, 2].unique().numel() <= 18     # event ids continue across items
+
+
+def test_data_module_split_excludes_and_half_precision():
+    from waveformml_amd.psd.PSDDataModule import PSDDataModule
+    # one directory with two files: train takes a (7 events), validation must come from b, nothing is left for test
+    cfg = _dm_config("PulseDataset.PulseDataset3D", dataset_config={"paths": ["Gamma"], "n_train": 7, "n_validate": 5},
+                     system_config={"half_precision": 1})
+    dm = PSDDataModule(cfg, "cpu")
+    assert cfg.dataset_config.dataset_params.use_half is True          # propagated as the reference does (:29-33)
+    with pytest.raises(RuntimeError, match="No remaining datasets available"):
+        dm.setup("test")
+    assert [os.path.basename(p) for p in dm.val_dataset.get_file_list()] == ["b_Waveform3DPairSim.h5"]
+    (coords, feats), labels = next(iter(dm.val_dataloader()))
+    assert coords.shape[1] == 4 and feats.dtype == torch.float16 and labels.tolist() == [0] * 4
+    assert int(coords[:, 3].max()) == 3          # b holds 4 events, fewer than the budget of 5
+    for key in ("train_config", "data_prep"):
+        bad = _dm_config("PulseDataset.PulseDataset2D", dataset_config={key: "shuffle"})
+        with pytest.raises(NotImplementedError):
+            PSDDataModule(bad, "cpu")
