@@ -281,14 +281,20 @@ int wfs_sparse_head_bwd(const void *X, const int32_t *indices, int64_t M, int32_
  * [levels][2] are the EFFECTIVE filter taps (after weight norm) in DEVICE memory, fp32.  levels <= 8, k <= 8,
  * L <= 4096; the backward needs wfs_tcn_lds_bytes(L, levels, 1) <= 150 KiB (else WFS_EINVAL: use another path).
  * wfs_tcn_bwd writes per-row partial sums partial[N][levels][2][k + 1] (taps, then the bias); their sum over rows is
- * d loss / d (taps, bias).  Dropout is not part of these kernels (identity in eval mode / p = 0). */
+ * d loss / d (taps, bias).
+ * Dropout (the nn.Dropout(p) after each of a level's two ReLUs, ConvBlocks.py:125-134): dropout_p in [0, 1) and
+ * seed_dev = one int64 in DEVICE memory (drawn by the caller, e.g. torch.randint, so that a captured graph gets a
+ * fresh seed per replay).  Kept elements are scaled by 1 / (1 - p); the decision for element (row, level, conv, t)
+ * is a counter-based hash of the seed, so the backward pass reproduces the forward's masks from the same seed and
+ * nothing is stored.  dropout_p == 0 (seed_dev may be NULL) is the eval-mode identity. */
 size_t wfs_tcn_lds_bytes(int32_t L, int32_t levels, int32_t backward);
 
 int wfs_tcn_fwd(const void *X, int64_t N, int32_t L, const float *taps, const float *bias, int32_t levels,
-                int32_t k, void *Y, int32_t dtype, void *stream);
+                int32_t k, void *Y, int32_t dtype, float dropout_p, const int64_t *seed_dev, void *stream);
 
 int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, const float *taps, const float *bias,
-                int32_t levels, int32_t k, void *dX, float *partial, int32_t dtype, void *stream);
+                int32_t levels, int32_t k, void *dX, float *partial, int32_t dtype, float dropout_p,
+                const int64_t *seed_dev, void *stream);
 
 /* loss ---------------------------------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(reduction='mean') as the reference's LitPSD applies it to the [B, n_type] logits

@@ -311,14 +311,17 @@ def test_layers_at_bench_geometry_fp32(layer_kind):
 
 @pytest.mark.parametrize("C,relu,dtype", [(32, True, torch.float32), (32, False, torch.float32), (7, True, torch.float32),
                                           (252, True, torch.float32), (32, True, torch.bfloat16),
-                                          (32, True, torch.float16), (7, False, torch.float16)],
-                         ids=["c32_relu", "c32", "c7_relu", "c252_relu", "c32_relu_bf16", "c32_relu_f16", "c7_f16"])
+                                          (32, True, torch.float16), (7, False, torch.float16),
+                                          (2048, True, torch.float32), (1300, True, torch.bfloat16),
+                                          (1777, True, torch.float32), (355, False, torch.float16)],
+                         ids=["c32_relu", "c32", "c7_relu", "c252_relu", "c32_relu_bf16", "c32_relu_f16", "c7_f16",
+                              "c2048_relu_sliced", "c1300_relu_bf16_sliced", "c1777_relu_odd_sliced", "c355_f16_odd_sliced"])
 def test_fused_batchnorm_relu_matches_torch(C, relu, dtype):
     """The fused BatchNorm1d(+ReLU) kernels against torch's own modules on the CPU in fp32 (what the
     reference's SparseSequential runs), training mode: output, running stats, dX, dgamma, dbeta."""
     from waveformml_amd.spconv import functional as Fsp
     rng = np.random.default_rng(1001)
-    N = 5000
+    N = 5000 if C <= 256 else 777
     x = (rng.standard_normal((N, C)) * rng.uniform(0.5, 3.0, C) + rng.uniform(-20, 20, C)).astype(np.float32)
     g = rng.standard_normal((N, C)).astype(np.float32)
     torch.manual_seed(3)
@@ -787,9 +790,75 @@ def test_fused_temporal_conv_net_matches_torch(levels, k, L, dtype):
         _assert_close(xg.grad.cpu().numpy(), xr.grad.numpy(), 1e-5, "dX")
         for (name, a), b in zip(net.named_parameters(), ref.parameters()):
             _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), 1e-4, name)
-    # active dropout (training) is torch's business: the module then takes the torch composition
+    # active dropout (training) is fused too (test_fused_temporal_conv_net_dropout); in eval mode it is the identity
     drop = TemporalConvNet(1, [1] * levels, kernel_size=k, dropout=0.2).to(DEV)
-    assert not drop._can_fuse(xg) and drop.eval()._can_fuse(xg)
+    with torch.no_grad():                       # (the Dropout modules shift the Sequential's keys: copy by position)
+        for a, b in zip(drop.parameters(), net.parameters()):
+            a.copy_(b)
+    assert drop._can_fuse(xg) and drop.eval()._can_fuse(xg)
+    assert torch.equal(drop(xg.detach()), net(xg.detach()))
+
+
+def test_fused_temporal_conv_net_dropout():
+    """Dropout inside the fused TCN kernels (training mode of the reference's hybrid front end, ConvBlocks.py:125-134:
+    nn.Dropout(p) after each ReLU).  The masks are a counter-based hash of a device-side seed, so they cannot be compared
+    bit for bit with torch's; checked instead: (1) the drop rate and the 1 / (1 - p) scale on a net whose convs are the
+    identity, (2) determinism for a fixed seed and new masks for a new seed, (3) backward = adjoint of forward for the
+    SAME masks (<g, J v> = <J^T g, v>; with fixed masks the net is piecewise linear in x, so a central difference gives
+    J v exactly away from the ReLU kinks), (4) tap / bias gradients against central differences."""
+    from waveformml_amd.psd.tcn import FusedTCNFunction, TemporalConvNet
+    rng = np.random.default_rng(5)
+    p = 0.3
+    # (1) one level, k = 1, taps 1, biases 0 on positive rows: h1 = x m1, h2 = h1 m2, y = h2 + x
+    N, L = 64, 2048
+    x = torch.from_numpy(rng.uniform(0.5, 1.5, (N, L)).astype(np.float32)).to(DEV)
+    taps = torch.ones((1, 2, 1), device=DEV)
+    bias = torch.zeros((1, 2), device=DEV)
+    seed = torch.tensor([1234567], dtype=torch.int64, device=DEV)
+    y = FusedTCNFunction.apply(x, taps, bias, p, seed)
+    ratio = ((y - x) / x).cpu().numpy()                       # m1 m2 in {0, 1 / (1 - p)^2}
+    kept = ratio > 0
+    assert abs(kept.mean() - (1 - p) ** 2) < 0.01, kept.mean()
+    assert np.allclose(ratio[kept], 1.0 / (1 - p) ** 2, rtol=1e-5)
+    assert abs(kept.mean(axis=1) - (1 - p) ** 2).max() < 0.06 and abs(kept.mean(axis=0) - (1 - p) ** 2).max() < 0.25
+    # (2)
+    assert torch.equal(FusedTCNFunction.apply(x, taps, bias, p, seed), y)
+    y2 = FusedTCNFunction.apply(x, taps, bias, p, seed + 1)
+    assert 0.3 < float(((y2 - x > 0) == (y - x > 0)).float().mean()) < 0.7      # independent masks agree ~58 % of the time
+    # (3) + (4) on a 3-level net with spread-out taps
+    levels, k, N, L = 3, 3, 9, 300
+    taps = torch.from_numpy(rng.standard_normal((levels, 2, k)).astype(np.float32) * 0.6).to(DEV).requires_grad_(True)
+    bias = torch.from_numpy(rng.standard_normal((levels, 2)).astype(np.float32) * 0.3).to(DEV).requires_grad_(True)
+    x = torch.from_numpy(rng.standard_normal((N, L)).astype(np.float32)).to(DEV).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((N, L)).astype(np.float32)).to(DEV)
+    f = lambda xx, tt, bb: FusedTCNFunction.apply(xx, tt, bb, p, seed)          # noqa: E731
+    y = f(x, taps, bias)
+    y.backward(g)
+    eps = 1e-3
+    v = torch.from_numpy(rng.standard_normal((N, L)).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        jv = (f(x + eps * v, taps, bias).double() - f(x - eps * v, taps, bias).double()) / (2 * eps)
+        lhs, rhs = float((g.double() * jv).sum()), float((x.grad.double() * v.double()).sum())
+        assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+        for name, par in (("taps", taps), ("bias", bias)):
+            flat = par.detach().reshape(-1)
+            for i in range(flat.numel()):
+                dpar = torch.zeros_like(flat)
+                dpar[i] = 2e-4                   # (2e-3 is already visibly nonlinear in the taps)
+                dpar = dpar.reshape(par.shape)
+                args_p = (taps + dpar, bias) if name == "taps" else (taps, bias + dpar)
+                args_m = (taps - dpar, bias) if name == "taps" else (taps, bias - dpar)
+                fd = float((g.double() * (f(x, *args_p).double() - f(x, *args_m).double())).sum() / 4e-4)
+                got = float(par.grad.reshape(-1)[i])
+                assert abs(fd - got) <= 2e-2 * max(abs(fd), abs(got), 1.0), (name, i, fd, got)
+    # the module draws a fresh seed per call in training mode
+    net = TemporalConvNet(1, [1] * 2, kernel_size=3, dropout=p).to(DEV)
+    xin = torch.randn(5, 1, 128, device=DEV)
+    assert net._can_fuse(xin) and not torch.equal(net(xin), net(xin))
+    torch.manual_seed(3)
+    a = net(xin)
+    torch.manual_seed(3)
+    assert torch.equal(net(xin), a)
 
 
 def test_hybrid_2d_net_with_waveform_front_end_matches_the_cpu_path():

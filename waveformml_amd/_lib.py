@@ -70,8 +70,9 @@ SIGNATURES = {
     "wfs_sparse_head_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _i32, _vp, _vp]),
     "wfs_tcn_lds_bytes": (_sz, [_i32, _i32, _i32]),
-    "wfs_tcn_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
-    "wfs_tcn_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "wfs_tcn_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _i32, ctypes.c_float, _vp, _vp]),
+    "wfs_tcn_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, ctypes.c_float, _vp,
+                                    _vp]),
     "wfs_xent_mean_fwd_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "wfs_sgd_step": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32, _i32,
                                     _vp]),

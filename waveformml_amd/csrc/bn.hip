@@ -59,7 +59,7 @@ __device__ __forceinline__ void store_vec(T *p, const float *in) {
 //   MODE 1 (backward):       a = g, b = g*xhat with g = dy*[gamma*xhat+beta > 0] (relu), xhat = (x-mean)*invstd
 template <typename T, int VEC, int MODE>
 __global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const T *__restrict__ dY, long long Ncap,
-                                                  const long long *__restrict__ n_dev, int C, long long rows_per_block, const float *__restrict__ mean,
+                                                  const long long *__restrict__ n_dev, int C, long long ld, long long rows_per_block, const float *__restrict__ mean,
                                                   const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                   const float *__restrict__ beta, int relu,
                                                   float *__restrict__ partial) {
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const
 #pragma unroll 4
         for (long long r = r_begin + slot; r < r_end; r += slots) {
             float x[VEC], g[VEC];
-            load_vec<T, VEC>(X + r * C + c0, x);
+            load_vec<T, VEC>(X + r * ld + c0, x);
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const
                     sb[i] = fmaf(d, d, sb[i]);
                 }
             } else {
-                load_vec<T, VEC>(dY + r * C + c0, g);
+                load_vec<T, VEC>(dY + r * ld + c0, g);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     float xh = (x[i] - m[i]) * is[i];
@@ -256,7 +256,7 @@ __device__ __forceinline__ void fold_partials(const float *__restrict__ partial,
 // save_mean / save_invstd (training with known statistics: partial == NULL), or the running ones (eval).
 template <typename T, int VEC>
 __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long long Ncap,
-                                                 const long long *__restrict__ n_dev, int C, long long rows_per_block,
+                                                 const long long *__restrict__ n_dev, int C, long long ld, long long rows_per_block,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                  float *__restrict__ running_mean, float *__restrict__ running_var,
                                                  long long *__restrict__ batches_tracked, float momentum, float eps,
@@ -319,13 +319,13 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
 #pragma unroll 4
     for (long long r = r_begin + slot; r < r_end; r += slots) {
         float x[VEC], y[VEC];
-        load_vec<T, VEC>(X + r * C + c0, x);
+        load_vec<T, VEC>(X + r * ld + c0, x);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float v = fmaf(ga[i], (x[i] - m[i]) * is[i], be[i]);      // same expression as the backward's mask
             y[i] = (relu && !(v > 0.f)) ? 0.f : v;
         }
-        store_vec<T, VEC>(Y + r * C + c0, y);
+        store_vec<T, VEC>(Y + r * ld + c0, y);
     }
 }
 
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply(const T *__restrict__ X, long l
 // them as dbeta / dgamma.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, const T *__restrict__ dY,
-                                                     long long Ncap, const long long *__restrict__ n_dev, int C,
+                                                     long long Ncap, const long long *__restrict__ n_dev, int C, long long ld,
                                                      long long rows_per_block, const float *__restrict__ partial,
                                                      int nblk,
                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -370,8 +370,8 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
 #pragma unroll 4
     for (long long r = r_begin + slot; r < r_end; r += slots) {
         float x[VEC], g[VEC], o[VEC];
-        load_vec<T, VEC>(X + r * C + c0, x);
-        load_vec<T, VEC>(dY + r * C + c0, g);
+        load_vec<T, VEC>(X + r * ld + c0, x);
+        load_vec<T, VEC>(dY + r * ld + c0, g);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float xh = (x[i] - m[i]) * is[i];
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
             if (relu && !(fmaf(ga[i], xh, be[i]) > 0.f)) gi = 0.f;
             o[i] = ga[i] * is[i] * (gi - k1[i] - xh * k2[i]);
         }
-        store_vec<T, VEC>(dX + r * C + c0, o);
+        store_vec<T, VEC>(dX + r * ld + c0, o);
     }
 }
 
@@ -670,14 +670,14 @@ extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
     return (nb + 1) * 2 * C * sizeof(float);
 }
 
-extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
-                               float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
-                               float eps, int32_t training, int32_t relu, void *Y, float *save_mean,
-                               float *save_invstd, void *workspace, size_t workspace_bytes, int32_t dtype,
-                               const int64_t *n_dev_, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long *n_dev = (const long long *)n_dev_;
-    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
+// C channels starting at X / Y (row stride ld elements): one slice of a wide layer, or the whole layer (ld == C)
+static int bn_fwd_slice(const void *X, int64_t N, int32_t C, long long ld, const float *gamma, const float *beta,
+                        float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
+                        float eps, int32_t training, int32_t relu, void *Y, float *save_mean, float *save_invstd,
+                        void *workspace, size_t workspace_bytes, int32_t dtype, const long long *n_dev,
+                        hipStream_t stream) {
+    const bool vec4 = C % 4 == 0 && ld % 4 == 0;       // vector loads need 4-element aligned rows
+    WFS_REQUIRE(C >= 1 && C <= MAXC && (vec4 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(training || (running_mean && running_var), WFS_EINVAL, "eval mode needs running statistics");
     if (N == 0) return WFS_OK;
@@ -687,7 +687,7 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
     dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
-    if (training) {
+    if (training && ld == C) {
         long long rb = 0;
         const int per = rr_plan(N, C, 16, &rb);
         if (per) {
@@ -713,22 +713,51 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
 #define WFS_BN_FWD(T, VEC)                                                                                          \
     do {                                                                                                            \
         if (training)                                                                                               \
-            k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,    \
+            k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, ld, rpb, nullptr, \
                                                                 nullptr, nullptr, nullptr, 0, partial);             \
         k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>(                                                           \
-            (const T *)X, N, n_dev, C, rpb_a, gamma, beta, running_mean, running_var,                               \
+            (const T *)X, N, n_dev, C, ld, rpb_a, gamma, beta, running_mean, running_var,                           \
             (long long *)num_batches_tracked, momentum, eps, training, relu, (T *)Y, save_mean, save_invstd,        \
             training ? partial : nullptr, (int)nblk);                                                               \
     } while (0)
     if (dtype == WFS_F32) {
-        if (C % 4 == 0) WFS_BN_FWD(float, 4); else WFS_BN_FWD(float, 1);
+        if (vec4) WFS_BN_FWD(float, 4); else WFS_BN_FWD(float, 1);
     } else if (dtype == WFS_BF16) {
-        if (C % 4 == 0) WFS_BN_FWD(wfs_bf16, 4); else WFS_BN_FWD(wfs_bf16, 1);
+        if (vec4) WFS_BN_FWD(wfs_bf16, 4); else WFS_BN_FWD(wfs_bf16, 1);
     } else {
-        if (C % 4 == 0) WFS_BN_FWD(wfs_f16, 4); else WFS_BN_FWD(wfs_f16, 1);
+        if (vec4) WFS_BN_FWD(wfs_f16, 4); else WFS_BN_FWD(wfs_f16, 1);
     }
 #undef WFS_BN_FWD
     WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+// layers wider than one block's reach (MAXC channels; the hybrid net's first layers have 2 T = 2048) run slice by slice
+static inline size_t elem_bytes(int dtype) { return dtype == WFS_F32 ? 4 : 2; }
+
+extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
+                               float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum,
+                               float eps, int32_t training, int32_t relu, void *Y, float *save_mean,
+                               float *save_invstd, void *workspace, size_t workspace_bytes, int32_t dtype,
+                               const int64_t *n_dev_, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long *n_dev = (const long long *)n_dev_;
+    if (C <= (C % 4 == 0 ? MAXC : TB))
+        return bn_fwd_slice(X, N, C, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                            training, relu, Y, save_mean, save_invstd, workspace, workspace_bytes, dtype, n_dev, stream);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    const int width = C % 4 == 0 ? MAXC : TB;          // odd widths: scalar path, one channel per thread
+    for (int c0 = 0; c0 < C; c0 += width) {
+        const int cs = C - c0 < width ? C - c0 : width;
+        const size_t off = (size_t)c0 * elem_bytes(dtype);
+        int rc = bn_fwd_slice(X ? (const char *)X + off : nullptr, N, cs, C, gamma ? gamma + c0 : nullptr,
+                              beta ? beta + c0 : nullptr, running_mean ? running_mean + c0 : nullptr,
+                              running_var ? running_var + c0 : nullptr, c0 == 0 ? num_batches_tracked : nullptr,
+                              momentum, eps, training, relu, Y ? (char *)Y + off : nullptr,
+                              save_mean ? save_mean + c0 : nullptr, save_invstd ? save_invstd + c0 : nullptr, workspace,
+                              workspace_bytes, dtype, n_dev, stream);
+        if (rc != WFS_OK) return rc;
+    }
     return WFS_OK;
 }
 
@@ -741,7 +770,7 @@ int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long
     dim3 grid((unsigned)nblk), grid_f((unsigned)wfs_cdiv(C, 32)), block(TB);
 #define WFS_BN_STATS(T, VEC)                                                                                        \
     do {                                                                                                            \
-        k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpb, nullptr,        \
+        k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, C, rpb, nullptr,     \
                                                             nullptr, nullptr, nullptr, 0, partial);                 \
         k_bn_fold<T, 0><<<grid_f, dim3(FOLD_SL * 32), 0, stream>>>(                                                 \
             partial, (int)nblk, C, (const T *)X, N, n_dev, st->running_mean, st->running_var,                       \
@@ -772,7 +801,7 @@ extern "C" int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float
     dim3 grid_a((unsigned)nblk_a), block(TB);
     float *sm = const_cast<float *>(save_mean), *si = const_cast<float *>(save_invstd);     // only read when training = 1
 #define WFS_BN_APPLY(T, VEC)                                                                                         \
-    k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, rpb_a, gamma, beta, nullptr, nullptr, \
+    k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, C, rpb_a, gamma, beta, nullptr, nullptr, \
                                                       nullptr, 0.f, 0.f, 1, relu, (T *)Y, sm, si, nullptr, 0)
     if (dtype == WFS_F32) {
         if (C % 4 == 0) WFS_BN_APPLY(float, 4); else WFS_BN_APPLY(float, 1);
@@ -786,13 +815,12 @@ extern "C" int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float
     return WFS_OK;
 }
 
-extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
-                               const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
-                               int32_t relu, void *dX, float *dgamma, float *dbeta, void *workspace,
-                               size_t workspace_bytes, int32_t dtype, const int64_t *n_dev_, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long *n_dev = (const long long *)n_dev_;
-    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
+static int bn_bwd_slice(const void *X, const void *dY, int64_t N, int32_t C, long long ld, const float *gamma,
+                        const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
+                        int32_t relu, void *dX, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                        int32_t dtype, const long long *n_dev, hipStream_t stream) {
+    const bool vec4 = C % 4 == 0 && ld % 4 == 0;       // vector loads need 4-element aligned rows
+    WFS_REQUIRE(C >= 1 && C <= MAXC && (vec4 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (N == 0) {
         if (dgamma) WFS_HIP_CHECK(hipMemsetAsync(dgamma, 0, C * sizeof(float), stream));
@@ -805,7 +833,7 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     const long long rpb = wfs_cdiv(N, nblk), rpb_a = wfs_cdiv(N, nblk_a);
     float *partial = (float *)workspace;
     dim3 grid((unsigned)nblk), grid_a((unsigned)nblk_a), block(TB);
-    {
+    if (ld == C) {
         long long rb = 0;
         const int per = rr_plan(N, C, dtype == WFS_F32 ? 8 : 16, &rb);
         if (per) {
@@ -830,20 +858,44 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     }
 #define WFS_BN_BWD(T, VEC)                                                                                          \
     do {                                                                                                            \
-        k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb, save_mean,  \
+        k_bn_reduce<T, VEC, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, ld, rpb, save_mean, \
                                                             save_invstd, gamma, beta, relu, partial);               \
-        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpb_a, partial, \
+        k_bn_bwd_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, ld, rpb_a, partial, \
                                                               (int)nblk, save_mean, save_invstd, gamma, beta,       \
                                                               training, relu, (T *)dX, dgamma, dbeta);              \
     } while (0)
     if (dtype == WFS_F32) {
-        if (C % 4 == 0) WFS_BN_BWD(float, 4); else WFS_BN_BWD(float, 1);
+        if (vec4) WFS_BN_BWD(float, 4); else WFS_BN_BWD(float, 1);
     } else if (dtype == WFS_BF16) {
-        if (C % 4 == 0) WFS_BN_BWD(wfs_bf16, 4); else WFS_BN_BWD(wfs_bf16, 1);
+        if (vec4) WFS_BN_BWD(wfs_bf16, 4); else WFS_BN_BWD(wfs_bf16, 1);
     } else {
-        if (C % 4 == 0) WFS_BN_BWD(wfs_f16, 4); else WFS_BN_BWD(wfs_f16, 1);
+        if (vec4) WFS_BN_BWD(wfs_f16, 4); else WFS_BN_BWD(wfs_f16, 1);
     }
 #undef WFS_BN_BWD
     WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
+                               const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
+                               int32_t relu, void *dX, float *dgamma, float *dbeta, void *workspace,
+                               size_t workspace_bytes, int32_t dtype, const int64_t *n_dev_, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long *n_dev = (const long long *)n_dev_;
+    if (C <= (C % 4 == 0 ? MAXC : TB))
+        return bn_bwd_slice(X, dY, N, C, C, gamma, beta, save_mean, save_invstd, training, relu, dX, dgamma, dbeta,
+                            workspace, workspace_bytes, dtype, n_dev, stream);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    const int width = C % 4 == 0 ? MAXC : TB;          // odd widths: scalar path, one channel per thread
+    for (int c0 = 0; c0 < C; c0 += width) {
+        const int cs = C - c0 < width ? C - c0 : width;
+        const size_t off = (size_t)c0 * elem_bytes(dtype);
+        int rc = bn_bwd_slice(X ? (const char *)X + off : nullptr, dY ? (const char *)dY + off : nullptr, N, cs, C,
+                              gamma ? gamma + c0 : nullptr, beta ? beta + c0 : nullptr,
+                              save_mean ? save_mean + c0 : nullptr, save_invstd ? save_invstd + c0 : nullptr, training,
+                              relu, dX ? (char *)dX + off : nullptr, dgamma ? dgamma + c0 : nullptr,
+                              dbeta ? dbeta + c0 : nullptr, workspace, workspace_bytes, dtype, n_dev, stream);
+        if (rc != WFS_OK) return rc;
+    }
     return WFS_OK;
 }

@@ -11,7 +11,11 @@
 //   forward   h1[t] = relu(b1 + sum_j w1[j] x[t - (k-1-j) d]),  h2 likewise from h1,  x' = relu(h2 + x)
 //   backward  recomputes the activations of all levels into LDS ((3 levels + 1) rows), then walks the levels down;
 //             per-row partial sums of dW / dB are reduced by the caller in a fixed order.
-// Weight norm (w = g v / |v|) and dropout stay with the caller: the kernels take the effective taps (device memory).
+// Weight norm (w = g v / |v|) stays with the caller: the kernels take the effective taps (device memory).
+// Dropout (nn.Dropout(p) after each of the two ReLUs of a level, ConvBlocks.py:125-134, active in training) is applied
+// in place: the keep/drop decision of element (row, level, conv, t) is a counter-based hash of a 64-bit seed that the
+// caller draws from torch's generator into device memory -- nothing is stored, the backward's recompute sees the same
+// masks.  (The masks are this library's own stream of random numbers, not torch's: same distribution, other bits.)
 #include "wfs_common.h"
 
 namespace {
@@ -29,6 +33,33 @@ template <int K>
 __device__ __forceinline__ void load_taps(Taps *tp, const float *W, const float *B, int levels) {
     for (int i = threadIdx.x; i < levels * 2 * K; i += TB) tp->w[i] = W[i];
     for (int i = threadIdx.x; i < levels * 2; i += TB) tp->b[i] = B[i];
+}
+
+// dropout multiplier of element t of conv `ci` (= 2 * level + {0, 1}) of `row`: 0 with probability p, else 1 / (1 - p).
+// splitmix64 finaliser over a counter that is unique per element (t < 2^12, ci < 2^4).
+struct Drop {
+    unsigned long long seed;
+    unsigned threshold;      // drop when the hash's high 32 bits are below p * 2^32
+    float scale;             // 1 / (1 - p); 1 when dropout is off
+    bool on;
+};
+__device__ __forceinline__ Drop make_drop(float p, const long long *seed_dev) {
+    Drop d;
+    d.on = p > 0.f && seed_dev != nullptr;
+    d.seed = d.on ? (unsigned long long)*seed_dev : 0ull;
+    double th = (double)p * 4294967296.0;
+    d.threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)th;
+    d.scale = d.on ? 1.f / (1.f - p) : 1.f;
+    return d;
+}
+__device__ __forceinline__ float drop_mult(const Drop &d, long long row, int ci, int t) {
+    if (!d.on) return 1.f;
+    unsigned long long z = d.seed + (((unsigned long long)row << 16) | ((unsigned long long)ci << 12) | (unsigned)t) *
+                                        0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) < d.threshold ? 0.f : d.scale;
 }
 
 template <typename T>
@@ -50,11 +81,13 @@ __device__ __forceinline__ float fir(const float *in, int t, const float *w, flo
 
 template <typename T, int K>
 __global__ void __launch_bounds__(TB) k_tcn_fwd(const T *__restrict__ X, long long N, int L, const float *__restrict__ Wd,
-                                                const float *__restrict__ Bd, int levels, T *__restrict__ Y) {
+                                                const float *__restrict__ Bd, int levels, T *__restrict__ Y,
+                                                float drop_p, const long long *__restrict__ seed_dev) {
     extern __shared__ float lds[];
     __shared__ Taps tp;
     float *A = lds, *B = lds + L;
     const long long row = blockIdx.x;
+    const Drop dr = make_drop(drop_p, seed_dev);
     const T *x = X + row * L;
     load_taps<K>(&tp, Wd, Bd, levels);
     for (int t = threadIdx.x; t < L; t += TB) A[t] = ldv(x + t);
@@ -63,13 +96,13 @@ __global__ void __launch_bounds__(TB) k_tcn_fwd(const T *__restrict__ X, long lo
         const int d = 1 << lv;
         for (int t = threadIdx.x; t < L; t += TB) {
             float v = fir<K>(A, t, tp.w + (lv * 2 + 0) * K, tp.b[lv * 2 + 0], d);
-            B[t] = v > 0.f ? v : 0.f;
+            B[t] = (v > 0.f ? v : 0.f) * drop_mult(dr, row, lv * 2 + 0, t);
         }
         __syncthreads();
         // x' overwrites A in place: A[t] is read only at index t by the thread that rewrites it
         for (int t = threadIdx.x; t < L; t += TB) {
             float v = fir<K>(B, t, tp.w + (lv * 2 + 1) * K, tp.b[lv * 2 + 1], d);
-            v = (v > 0.f ? v : 0.f) + A[t];
+            v = (v > 0.f ? v : 0.f) * drop_mult(dr, row, lv * 2 + 1, t) + A[t];
             A[t] = v > 0.f ? v : 0.f;
         }
         __syncthreads();
@@ -82,7 +115,8 @@ __global__ void __launch_bounds__(TB) k_tcn_fwd(const T *__restrict__ X, long lo
 template <typename T, int K>
 __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T *__restrict__ dY, long long N, int L,
                                                 const float *__restrict__ Wd, const float *__restrict__ Bd, int levels,
-                                                T *__restrict__ dX, float *__restrict__ partial) {
+                                                T *__restrict__ dX, float *__restrict__ partial, float drop_p,
+                                                const long long *__restrict__ seed_dev) {
     constexpr int k = K;
     extern __shared__ float lds[];
     __shared__ Taps tp;
@@ -95,6 +129,7 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
     __shared__ float sred[TB];
     const long long row = blockIdx.x;
     const T *x = X + row * L;
+    const Drop dr = make_drop(drop_p, seed_dev);
     load_taps<K>(&tp, Wd, Bd, levels);
     for (int t = threadIdx.x; t < L; t += TB) {
         Xs[t] = ldv(x + t);
@@ -108,12 +143,12 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
         float *h1 = H1 + (size_t)lv * L, *h2 = H2 + (size_t)lv * L, *An = Xs + (size_t)(lv + 1) * L;
         for (int t = threadIdx.x; t < L; t += TB) {
             float v = fir<K>(A, t, tp.w + (lv * 2 + 0) * K, tp.b[lv * 2 + 0], d);
-            h1[t] = v > 0.f ? v : 0.f;
+            h1[t] = (v > 0.f ? v : 0.f) * drop_mult(dr, row, lv * 2 + 0, t);     // the value conv2 sees
         }
         __syncthreads();
         for (int t = threadIdx.x; t < L; t += TB) {
             float v = fir<K>(h1, t, tp.w + (lv * 2 + 1) * K, tp.b[lv * 2 + 1], d);
-            v = v > 0.f ? v : 0.f;
+            v = (v > 0.f ? v : 0.f) * drop_mult(dr, row, lv * 2 + 1, t);
             h2[t] = v;
             float o = v + A[t];
             An[t] = o > 0.f ? o : 0.f;
@@ -132,7 +167,7 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
         // G  <- g_out = G * [x_{lv+1} > 0];   G2 <- g_h2 = g_out * [h2 > 0]
         for (int t = threadIdx.x; t < L; t += TB) {
             float go = An[t] > 0.f ? G[t] : 0.f;
-            float gh = h2[t] > 0.f ? go : 0.f;
+            float gh = h2[t] > 0.f ? go * dr.scale : 0.f;     // h2 = relu(.) * mult > 0 <=> positive AND kept
             G[t] = go;
             G2[t] = gh;
             a2[k] += gh;
@@ -151,7 +186,7 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
                 int t = s + (k - 1 - j) * d;
                 v = fmaf(tp.w[(lv * 2 + 1) * K + j], t < L ? G2[t] : 0.f, v);
             }
-            v = h1[s] > 0.f ? v : 0.f;
+            v = h1[s] > 0.f ? v * dr.scale : 0.f;
             G3[s] = v;
             a1[k] += v;
 #pragma unroll
@@ -224,22 +259,26 @@ extern "C" size_t wfs_tcn_lds_bytes(int32_t L, int32_t levels, int32_t backward)
     }
 
 extern "C" int wfs_tcn_fwd(const void *X, int64_t N, int32_t L, const float *taps, const float *bias, int32_t levels,
-                           int32_t k, void *Y, int32_t dtype, void *stream_) {
+                           int32_t k, void *Y, int32_t dtype, float dropout_p, const int64_t *seed_dev_,
+                           void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(levels >= 1 && levels <= MAXLV && k >= 1 && k <= MAXK, WFS_EINVAL, "unsupported TCN shape: %d levels, k = %d",
                 levels, k);
     WFS_REQUIRE(L >= 1 && L <= 16 * TB, WFS_EINVAL, "row length %d not in [1, %d]", L, 16 * TB);
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || seed_dev_), WFS_EINVAL,
+                "dropout %g needs 0 <= p < 1 and a seed", (double)dropout_p);
+    const long long *seed_dev = (const long long *)seed_dev_;
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(X && Y && taps && bias, WFS_EINVAL, "NULL device pointer");
     const size_t lds = wfs_tcn_lds_bytes(L, levels, 0);
     const dim3 grid((unsigned)N), block(TB);
     if (dtype == WFS_F32) {
-        WFS_TCN_DISPATCH_K(k_tcn_fwd, float, (const float *)X, N, L, taps, bias, levels, (float *)Y)
+        WFS_TCN_DISPATCH_K(k_tcn_fwd, float, (const float *)X, N, L, taps, bias, levels, (float *)Y, dropout_p, seed_dev)
     } else if (dtype == WFS_BF16) {
-        WFS_TCN_DISPATCH_K(k_tcn_fwd, wfs_bf16, (const wfs_bf16 *)X, N, L, taps, bias, levels, (wfs_bf16 *)Y)
+        WFS_TCN_DISPATCH_K(k_tcn_fwd, wfs_bf16, (const wfs_bf16 *)X, N, L, taps, bias, levels, (wfs_bf16 *)Y, dropout_p, seed_dev)
     } else {
-        WFS_TCN_DISPATCH_K(k_tcn_fwd, wfs_f16, (const wfs_f16 *)X, N, L, taps, bias, levels, (wfs_f16 *)Y)
+        WFS_TCN_DISPATCH_K(k_tcn_fwd, wfs_f16, (const wfs_f16 *)X, N, L, taps, bias, levels, (wfs_f16 *)Y, dropout_p, seed_dev)
     }
     WFS_LAUNCH_CHECK();
     return WFS_OK;
@@ -269,12 +308,16 @@ static int tcn_bwd_attr_k(int k) {
 }
 
 extern "C" int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, const float *taps, const float *bias,
-                           int32_t levels, int32_t k, void *dX, float *partial, int32_t dtype, void *stream_) {
+                           int32_t levels, int32_t k, void *dX, float *partial, int32_t dtype, float dropout_p,
+                           const int64_t *seed_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(levels >= 1 && levels <= MAXLV && k >= 1 && k <= MAXK, WFS_EINVAL, "unsupported TCN shape: %d levels, k = %d",
                 levels, k);
     WFS_REQUIRE(L >= 1 && L <= 16 * TB, WFS_EINVAL, "row length %d not in [1, %d]", L, 16 * TB);
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || seed_dev_), WFS_EINVAL,
+                "dropout %g needs 0 <= p < 1 and a seed", (double)dropout_p);
+    const long long *seed_dev = (const long long *)seed_dev_;
     const size_t lds = wfs_tcn_lds_bytes(L, levels, 1);
     WFS_REQUIRE(lds <= 150 * 1024, WFS_EINVAL, "row of %d samples x %d levels needs %zu B of LDS", L, levels, lds);
     if (N == 0) return WFS_OK;
@@ -283,17 +326,18 @@ extern "C" int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, 
     if (dtype == WFS_F32) {
         int rc = tcn_bwd_attr_k<float>(k);
         if (rc != WFS_OK) return rc;
-        WFS_TCN_DISPATCH_K(k_tcn_bwd, float, (const float *)X, (const float *)dY, N, L, taps, bias, levels, (float *)dX, partial)
+        WFS_TCN_DISPATCH_K(k_tcn_bwd, float, (const float *)X, (const float *)dY, N, L, taps, bias, levels, (float *)dX, partial,
+                           dropout_p, seed_dev)
     } else if (dtype == WFS_BF16) {
         int rc = tcn_bwd_attr_k<wfs_bf16>(k);
         if (rc != WFS_OK) return rc;
         WFS_TCN_DISPATCH_K(k_tcn_bwd, wfs_bf16, (const wfs_bf16 *)X, (const wfs_bf16 *)dY, N, L, taps, bias, levels,
-                           (wfs_bf16 *)dX, partial)
+                           (wfs_bf16 *)dX, partial, dropout_p, seed_dev)
     } else {
         int rc = tcn_bwd_attr_k<wfs_f16>(k);
         if (rc != WFS_OK) return rc;
         WFS_TCN_DISPATCH_K(k_tcn_bwd, wfs_f16, (const wfs_f16 *)X, (const wfs_f16 *)dY, N, L, taps, bias, levels,
-                           (wfs_f16 *)dX, partial)
+                           (wfs_f16 *)dX, partial, dropout_p, seed_dev)
     }
     WFS_LAUNCH_CHECK();
     return WFS_OK;

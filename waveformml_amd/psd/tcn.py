@@ -5,8 +5,10 @@ left padding (k-1)*d chomped on the right, ReLU, dropout, residual; dilation dou
 The reference only ever builds it with ONE channel (``TemporalConvNet(1, [1] * n_dil, ...)``,
 src/models/SPConvNet.py:83-92).  In that shape every level is two k-tap causal FIR filters per waveform row, and the
 whole net runs as one HIP launch per direction with the row resident in LDS (include/wfsparse.h, wfs_tcn_fwd /
-wfs_tcn_bwd; csrc/tcn.hip).  Same modules, parameters and state_dict as the torch composition below, which remains
-the path for everything else (more channels, active dropout, CPU tensors, rows too long for the LDS-resident backward).
+wfs_tcn_bwd; csrc/tcn.hip), dropout included (training mode: masks from a counter-based hash of a seed drawn from torch's
+generator -- the same distribution as nn.Dropout, not the same bits).  Same modules, parameters and state_dict as the
+torch composition below, which remains the path for everything else (more channels, CPU tensors, rows too long for the
+LDS-resident backward).
 """
 import torch
 from torch import nn
@@ -50,10 +52,11 @@ class TemporalBlock(nn.Module):
 
 
 class FusedTCNFunction(Function):
-    """rows [N, L], effective taps [levels, 2, k] and biases [levels, 2] (fp32, on the GPU) -> rows [N, L]."""
+    """rows [N, L], effective taps [levels, 2, k] and biases [levels, 2] (fp32, on the GPU) -> rows [N, L].
+    ``dropout`` > 0 with ``seed`` (int64 [1] on the GPU) applies the levels' dropout inside the kernels."""
 
     @staticmethod
-    def forward(ctx, x, taps, bias):
+    def forward(ctx, x, taps, bias, dropout=0.0, seed=None):
         lib = _lib.load()
         x = x.contiguous()
         taps, bias = taps.contiguous(), bias.contiguous()
@@ -61,8 +64,9 @@ class FusedTCNFunction(Function):
         levels, _, k = taps.shape
         y = torch.empty_like(x)
         _lib.check(lib.wfs_tcn_fwd(_lib.ptr(x), N, L, _lib.ptr(taps), _lib.ptr(bias), levels, k, _lib.ptr(y),
-                                   _lib.dtype_code(x), _lib.stream_ptr()))
+                                   _lib.dtype_code(x), float(dropout), _lib.ptr(seed), _lib.stream_ptr()))
         ctx.save_for_backward(x, taps, bias)
+        ctx.dropout, ctx.seed = float(dropout), seed
         return y
 
     @staticmethod
@@ -77,9 +81,10 @@ class FusedTCNFunction(Function):
         dx = torch.empty_like(x)
         partial = torch.empty((N, levels, 2, k + 1), dtype=torch.float32, device=x.device)
         _lib.check(lib.wfs_tcn_bwd(_lib.ptr(x), _lib.ptr(dy), N, L, _lib.ptr(taps), _lib.ptr(bias), levels, k, _lib.ptr(dx),
-                                   _lib.ptr(partial), _lib.dtype_code(x), _lib.stream_ptr()))
+                                   _lib.ptr(partial), _lib.dtype_code(x), ctx.dropout, _lib.ptr(ctx.seed),
+                                   _lib.stream_ptr()))
         sums = partial.sum(0)
-        return dx, sums[:, :, :k].contiguous(), sums[:, :, k].contiguous()
+        return dx, sums[:, :, :k].contiguous(), sums[:, :, k].contiguous(), None, None
 
 
 class TemporalConvNet(nn.Module):
@@ -100,8 +105,8 @@ class TemporalConvNet(nn.Module):
                 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and 1 <= levels <= 8 and 1 <= k <= 8
                 and 1 <= x.shape[2] <= 4096 and x.shape[0] > 0):
             return False
-        if self.dropout != 0 and self.training:
-            return False                                  # dropout masks come from torch's generator
+        if self.training and not 0.0 <= self.dropout < 1.0:
+            return False                                  # p = 1 (everything dropped) is torch's business
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             if _lib.load().wfs_tcn_lds_bytes(int(x.shape[2]), levels, 1) > 150 * 1024:
                 return False                              # the backward keeps (3 levels + 4) rows in LDS
@@ -121,5 +126,10 @@ class TemporalConvNet(nn.Module):
         if self._can_fuse(x):
             taps, bias = self.effective_taps()
             rows = x.reshape(x.shape[0], x.shape[2])
+            if self.training and self.dropout > 0:
+                # a fresh 64-bit seed per call from torch's CUDA generator (reproducible under torch.manual_seed, and a
+                # captured graph draws a new one per replay); the kernels derive every mask from it
+                seed = torch.randint(-2 ** 62, 2 ** 62, (1,), dtype=torch.int64, device=x.device)
+                return FusedTCNFunction.apply(rows, taps, bias, self.dropout, seed).reshape(x.shape)
             return FusedTCNFunction.apply(rows, taps, bias).reshape(x.shape)
         return self.network(x)

@@ -97,8 +97,10 @@ def _row_ok(R, r_dev, device):
 
 
 def _gathered(table, kmap, K, identity_k, R, X, r_dev=None):
-    """[K, R, C] rows of X gathered through table[kmap[k]] (zeros where the entry is -1 or the row is beyond the valid
-    count; the row itself at identity_k)."""
+    """[R, K * C]: for every output row the K gathered rows of X side by side (X[table[kmap[k], r]] at columns
+    k C .. (k+1) C; zeros where the entry is -1 or the row is beyond the valid count; the row itself at identity_k).
+    With the filters reshaped to [K * Cin, Cout] a whole layer is ONE library GEMM whose contraction runs over
+    (offset, channel) -- the sum over offsets happens inside the GEMM's fp32 accumulator."""
     idx = table.long()
     if kmap is not None:
         idx = idx[torch.as_tensor(list(kmap), dtype=torch.long, device=table.device)]
@@ -112,7 +114,26 @@ def _gathered(table, kmap, K, identity_k, R, X, r_dev=None):
         bad = bad | ~ok.unsqueeze(0) | (idx >= n)
     idx = torch.where(bad, torch.full_like(idx, n), idx)
     Xp = torch.cat([X, X.new_zeros((1, X.shape[1]))])
-    return Xp[idx.reshape(-1)].reshape(K, R, X.shape[1])
+    return Xp[idx.t().reshape(-1)].reshape(R, K * X.shape[1])
+
+
+_MM_OUT_DTYPE = [None]          # does torch.mm take out_dtype= (fp32 results from 16-bit operands)?  probed once
+
+
+def _mm_f32(a, b):
+    """a @ b with fp32 accumulation and an fp32 result.  16-bit operands (bf16 / fp16 rows) stay 16-bit -- the library
+    GEMM then runs on the 16-bit matrix cores -- and the result is taken in fp32 where torch.mm offers ``out_dtype``."""
+    if a.dtype == torch.float32:
+        return torch.mm(a, b)
+    if _MM_OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a[:1], b, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+        except (TypeError, RuntimeError):
+            _MM_OUT_DTYPE[0] = False
+    if _MM_OUT_DTYPE[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
 
 
 def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None):
@@ -127,9 +148,9 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
     if _gemm_route(X.shape[1], Cy, K, R, r_dev, table) and bn_request is None:
-        G = _gathered(table, kmap, K, identity_k, R, X, r_dev).float()
-        Wk = W.transpose(1, 2) if transpose_w else W
-        out = torch.bmm(G, Wk).sum(0)
+        G = _gathered(table, kmap, K, identity_k, R, X, r_dev)                       # [R, K * Cx]
+        Wk = (W.transpose(1, 2) if transpose_w else W).reshape(K * X.shape[1], Cy)   # [K * Cx, Cy]
+        out = _mm_f32(G, Wk.to(X.dtype))
         if bias is not None:
             out = out + bias
         return out.to(X.dtype)
@@ -194,10 +215,10 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
     assert S.dtype == G.dtype and S.shape[0] == R
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
     if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap:
-        Gk = _gathered(table, kmap, K, identity_k, R, G, r_dev).float()             # [K, R, Cg]
+        Gk = _gathered(table, kmap, K, identity_k, R, G, r_dev)                      # [R, K * Cg]
         ok = _row_ok(R, r_dev, S.device)
-        Sf = S.float() if ok is None else torch.where(ok.unsqueeze(1), S.float(), S.new_zeros((), dtype=torch.float32))
-        dWk = torch.matmul(Sf.t().unsqueeze(0), Gk)                                   # [K, Cs, Cg]
+        Sv = S if ok is None else torch.where(ok.unsqueeze(1), S, S.new_zeros(()))
+        dWk = _mm_f32(Sv.t(), Gk).reshape(Cs, K, Cg).permute(1, 0, 2)                 # [K, Cs, Cg]
         return dWk.transpose(1, 2).contiguous() if swap else dWk.contiguous()
     nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
@@ -400,11 +421,12 @@ def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
 
 def can_fuse_batch_norm(bn, features):
     """The fused kernels cover what the reference's nets use: float32 parameters, a fixed momentum,
-    fp32/bf16 features on the GPU, C <= 1024."""
+    fp32 / bf16 / fp16 features on the GPU, any channel count (beyond what one block covers -- 1024 channels, or 256
+    when C is not a multiple of 4; the hybrid net starts at 2 T = 2048 -- the library runs channel slices)."""
     c = bn.num_features
     return (type(bn) is torch.nn.BatchNorm1d and bn.momentum is not None and features.is_cuda and features.dim() == 2
             and features.dtype in (torch.float32, torch.bfloat16, torch.float16) and features.shape[0] > 0
-            and (c <= 256 or (c % 4 == 0 and c <= 1024))
+            and 1 <= c <= 65536
             and (bn.weight is None or bn.weight.dtype == torch.float32)
             and (bn.training or bn.running_mean is not None))
 
