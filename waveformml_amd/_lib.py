@@ -49,8 +49,10 @@ SIGNATURES = {
                                        _vp, _vp, _i32, _vp, _vp]),
     "wfs_conv_stats_workspace_bytes": (_sz, [_i64, _i32]),
     "wfs_gather_conv_bnstats": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp,
-                                               _i32, _vp, ctypes.POINTER(BnStats), _vp]),
+                                               _i32, _vp, ctypes.POINTER(BnStats), c_i32p, _vp]),
     "wfs_bn_apply_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "wfs_bn_apply_fwd_fold": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, ctypes.POINTER(BnStats), _i32, _i32, _vp, _i32,
+                                             _vp, _vp]),
     "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "wfs_gather_dw": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
                                      _sz, _vp, _vp]),

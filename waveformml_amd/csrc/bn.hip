@@ -13,6 +13,7 @@
 //             dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)              (training)
 //             dx = gamma*invstd*g                                           (eval: running statistics)
 #include "wfs_common.h"
+#include "conv_stats.h"
 
 namespace {
 
@@ -489,7 +490,9 @@ __global__ void __launch_bounds__(TB) k_bn_reduce_rr(const T *__restrict__ X, co
     }
 }
 
-template <typename T, int PER>
+// CHAN: `partial` holds the conv epilogue's per-block (mean, M2) [nblk][2][32] and `partn` the block row counts
+// (conv_stats.h) instead of shifted sums; they are merged with Chan's update, C == 32.
+template <typename T, int PER, bool CHAN>
 __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, long long Ncap,
                                                     const long long *__restrict__ n_dev, int C,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -497,7 +500,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
                                                     long long *__restrict__ batches_tracked, float momentum, float eps,
                                                     int relu, T *__restrict__ Y, float *__restrict__ save_mean,
                                                     float *__restrict__ save_invstd, const float *__restrict__ partial,
-                                                    int nblk) {
+                                                    int nblk, const float *__restrict__ partn) {
     constexpr int VEC = 4;
     __shared__ float sSlice[2 * TB];
     __shared__ float sA[MAXC], sB[MAXC];
@@ -519,14 +522,58 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
         ga[i] = (gamma && active) ? gamma[c0 + i] : 1.f;
         be[i] = (beta && active) ? beta[c0 + i] : 0.f;
     }
-    fold_partials(partial, nblk, C, sSlice, sA, sB);             // its loads join the ones above
+    if constexpr (CHAN) {
+        // Block partials (n_b, mean_b, M2_b) become shifted sums about ONE common shift, block 0's mean m0 (within a
+        // few sigma / sqrt(rows of a block) of the batch mean, so nothing cancels):
+        //     sum_b d = n_b (mean_b - m0),      sum_b d^2 = M2_b + n_b (mean_b - m0)^2
+        // -- independent per partial (no chain of Chan merges, no divisions), then plain sums in a fixed order: thread
+        // (column c, slice sl of 8) takes partials sl, sl + 8, ..., 16 at a time; slices are added in slice order.
+        const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const float m0 = partial[c];
+        float a = 0.f, bb = 0.f;
+        for (int b0 = sl; b0 < nblk; b0 += 16 * 8) {
+            float n16[16], m16[16], q16[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = b0 + u * 8, bc = b < nblk ? b : nblk - 1;
+                const float nn = partn[bc];
+                m16[u] = partial[((long long)bc * 2) * 32 + c];
+                q16[u] = partial[((long long)bc * 2 + 1) * 32 + c];
+                n16[u] = b < nblk ? nn : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float dl = m16[u] - m0, nd = n16[u] * dl;
+                a += nd;
+                bb += n16[u] > 0.f ? fmaf(nd, dl, q16[u]) : 0.f;
+            }
+        }
+        sSlice[threadIdx.x] = a;
+        sSlice[TB + threadIdx.x] = bb;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float ta = 0.f, tb = 0.f;
+#pragma unroll
+            for (int q = 0; q < TB / 32; ++q) {
+                ta += sSlice[q * 32 + c];
+                tb += sSlice[TB + q * 32 + c];
+            }
+            sA[c] = ta;                     // sum of (x - m0)
+            sB[c] = tb;                     // sum of (x - m0)^2
+        }
+        __syncthreads();
+    } else {
+        fold_partials(partial, nblk, C, sSlice, sA, sB);             // its loads join the ones above
+    }
     const float n = N > 0 ? (float)N : 1.f;
     for (int c = threadIdx.x; c < C; c += TB) {
-        float shift = wfs_ld(X + c);
-        float md = sA[c] / n;
-        float var = sB[c] / n - md * md;
+        float mean, var;
+        const float shift = CHAN ? partial[c] : wfs_ld(X + c);      // CHAN: block 0's mean, see above
+        const float md = sA[c] / n;
+        var = sB[c] / n - md * md;
+        mean = shift + md;
         var = var > 0.f ? var : 0.f;
-        float mean = shift + md, inv = rsqrtf(var + eps);
+        float inv = rsqrtf(var + eps);
         sA[c] = mean;
         sB[c] = inv;
         if (blockIdx.x == 0) {
@@ -696,9 +743,9 @@ static int bn_fwd_slice(const void *X, int64_t N, int32_t C, long long ld, const
     do {                                                                                                               \
         k_bn_reduce_rr<T, PER, 0><<<g2, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, nullptr, nullptr,      \
                                                              nullptr, nullptr, 0, partial);                            \
-        k_bn_apply_rr<T, PER><<<g2, block, 0, stream>>>((const T *)X, N, n_dev, C, gamma, beta, running_mean,           \
-                                                        running_var, (long long *)num_batches_tracked, momentum, eps,  \
-                                                        relu, (T *)Y, save_mean, save_invstd, partial, (int)rb);       \
+        k_bn_apply_rr<T, PER, false><<<g2, block, 0, stream>>>(                                                        \
+            (const T *)X, N, n_dev, C, gamma, beta, running_mean, running_var, (long long *)num_batches_tracked,       \
+            momentum, eps, relu, (T *)Y, save_mean, save_invstd, partial, (int)rb, nullptr);                           \
     } while (0)
 #define WFS_BN_FWD_RR_T(T)                                                                                             \
     if (per == 2) WFS_BN_FWD_RR(T, 2); else if (per == 4) WFS_BN_FWD_RR(T, 4); else if (per == 8) WFS_BN_FWD_RR(T, 8);   \
@@ -897,5 +944,39 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
                               dbeta ? dbeta + c0 : nullptr, workspace, workspace_bytes, dtype, n_dev, stream);
         if (rc != WFS_OK) return rc;
     }
+    return WFS_OK;
+}
+
+bool wfs_bn_fold_ok(long long N, int C) {
+    long long rb = 0;
+    return C == 32 && N > 0 && rr_plan(N, C, 16, &rb) != 0;
+}
+
+extern "C" int wfs_bn_apply_fwd_fold(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
+                                     const wfs_bn_stats *st, int32_t pending_blocks, int32_t relu, void *Y,
+                                     int32_t dtype, const int64_t *n_dev_, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long *n_dev = (const long long *)n_dev_;
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(st && st->save_mean && st->save_invstd && st->workspace, WFS_EINVAL, "incomplete wfs_bn_stats");
+    WFS_REQUIRE(pending_blocks >= 1 && pending_blocks <= 256, WFS_EINVAL, "%d pending partials (1 .. 256)", pending_blocks);
+    WFS_REQUIRE(X && Y, WFS_EINVAL, "NULL device pointer");
+    long long rb = 0;
+    const int per = C == 32 && N > 0 ? rr_plan(N, C, 16, &rb) : 0;
+    WFS_REQUIRE(per != 0, WFS_EINVAL, "folding apply covers C == 32 and batches that fit the register files (N = %lld)",
+                (long long)N);
+    const float *part = (const float *)st->workspace, *partn = part + (size_t)pending_blocks * 64;   // stats_args()
+    const dim3 g2((unsigned)rb), block(TB);
+#define WFS_BN_FOLD(T, PER)                                                                                            \
+    k_bn_apply_rr<T, PER, true><<<g2, block, 0, stream>>>(                                                             \
+        (const T *)X, N, n_dev, C, gamma, beta, st->running_mean, st->running_var, (long long *)st->num_batches_tracked, \
+        st->momentum, st->eps, relu, (T *)Y, st->save_mean, st->save_invstd, part, pending_blocks, partn)
+#define WFS_BN_FOLD_T(T)                                                                                               \
+    if (per == 2) WFS_BN_FOLD(T, 2); else if (per == 4) WFS_BN_FOLD(T, 4); else if (per == 8) WFS_BN_FOLD(T, 8);         \
+    else WFS_BN_FOLD(T, 16)
+    if (dtype == WFS_F32) { WFS_BN_FOLD_T(float); } else if (dtype == WFS_BF16) { WFS_BN_FOLD_T(wfs_bf16); } else { WFS_BN_FOLD_T(wfs_f16); }
+#undef WFS_BN_FOLD_T
+#undef WFS_BN_FOLD
+    WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

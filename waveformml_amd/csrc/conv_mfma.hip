@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
                                                       WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
-    WfsColStats cst = {0.f, 0.f, 0.f};
+    WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     const int nthreads = blockDim.x;
     if (!TRANSPOSE_W) {
         for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
@@ -159,10 +159,10 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
 #pragma unroll
             for (int i = 0; i < 16; ++i) vals[i] = acc[i];
             const long long left = Rv - tile * 32;
-            wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
+            wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
     }
-    if constexpr (STATS) wfs_stats_finish(cst, sStat, sa);
+    if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
 }
 
 // ------------------------------------------------------------------------------------------ 32 -> 32, bf16
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
                                                        long long tiles_per_xcd, WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
-    WfsColStats cst = {0.f, 0.f, 0.f};
+    WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     uint4 *sWb = reinterpret_cast<uint4 *>(smem);                           // K * 128 fragments of 16 B
     int *sNb = reinterpret_cast<int *>(smem + (size_t)K * 2048);            // [waves][K][32]
     const int nthreads = blockDim.x;
@@ -331,10 +331,10 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
 #pragma unroll
             for (int i = 0; i < 16; ++i) vals[i] = wfs_round_to<H>(acc[i]);      // statistics of the values as stored
             const long long left = Rv - tile * 32;
-            wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
+            wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
     }
-    if constexpr (STATS) wfs_stats_finish(cst, sStat, sa);
+    if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
 }
 
 // ------------------------------------------------------------------------------------------ 2 -> 32
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
 // transpose; all 16 table entries of a lane are loaded together, then all 16 gathers.  The filter image
 // sWc[s][h][co][j] = W[k = 8s + 4h + j/2][c = j & 1][co] (zero for k >= K) is 4 KiB.
 template <typename H, bool STATS>
-__global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict__ table, int mirror, int K,
+__global__ void __launch_bounds__(STATS ? 1024 : 256) k_gconv_c2c32_bf16(const int *__restrict__ table, int mirror, int K,
                                                          int identity_k, long long R,
                                                          const long long *__restrict__ r_dev,
                                                          const H *__restrict__ X, const float *__restrict__ W,
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
                                                          WfsStatsArgs sa) {
     __shared__ __attribute__((aligned(16))) uint4 sWc[4 * 2 * 32];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
-    WfsColStats cst = {0.f, 0.f, 0.f};
+    WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     if (threadIdx.x < 256) {
         const int u = threadIdx.x;                 // 256 threads = 4 steps x 2 halves x 32 output channels
         const int st = u >> 6, hh = (u >> 5) & 1, co = u & 31;
@@ -558,10 +558,10 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict_
 #pragma unroll
             for (int i = 0; i < 16; ++i) vals[i] = wfs_round_to<H>(acc[i]);
             const long long left = Rv - tile * 32;
-            wfs_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
+            wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
     }
-    if constexpr (STATS) wfs_stats_finish(cst, sStat, sa);
+    if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
 }
 
 // ------------------------------------------------------------------------------------------ dW 32 x 32, bf16
@@ -934,7 +934,14 @@ size_t wfs_conv_stats_fast_workspace(long long R) {
     return (size_t)blocks * 65 * sizeof(float);
 }
 
-static int stats_fold(const WfsStatsArgs &sa, long long nblk, hipStream_t stream) {
+// pending == NULL: fold the block partials now (one small launch).  Otherwise the partials stay in the workspace and
+// *pending = their number: the BatchNorm apply kernel folds them in its prologue (wfs_bn_apply_fwd_fold), which saves
+// the launch.
+static int stats_fold(const WfsStatsArgs &sa, long long nblk, int *pending, hipStream_t stream) {
+    if (pending) {
+        *pending = (int)nblk;
+        return WFS_OK;
+    }
     k_stats_fold<<<dim3(1), dim3(1024), 0, stream>>>(sa, (int)nblk);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
@@ -958,7 +965,7 @@ static WfsStatsArgs stats_args(const wfs_bn_stats *st, long long nblk) {
 
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
     gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
@@ -972,7 +979,7 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     if (stats) {
         int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
                                 identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
-        return rc != WFS_OK ? rc : stats_fold(sa, nblk, stream);
+        return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
     return launch_big_lds(k_gconv32_f32<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K, identity_k, R,
                           r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
@@ -981,7 +988,7 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
 template <typename H>
 static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                               const H *Xb, const float *W, int transpose_w, const float *bias, H *Yb,
-                              const wfs_bn_stats *stats, hipStream_t stream) {
+                              const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
     gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
@@ -995,7 +1002,7 @@ static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_
     if (stats) {
         int rc = launch_big_lds(k_gconv32_bf16<H, false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
                                 identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
-        return rc != WFS_OK ? rc : stats_fold(sa, nblk, stream);
+        return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
     return launch_big_lds(k_gconv32_bf16<H, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
                           identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
@@ -1003,18 +1010,18 @@ static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_
 
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
     if (dtype == WFS_F16)
         return launch_gconv32_h16<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, transpose_w,
-                                           bias, (wfs_f16 *)Y, stats, stream);
+                                           bias, (wfs_f16 *)Y, stats, pending, stream);
     return launch_gconv32_h16<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, transpose_w, bias,
-                                        (wfs_bf16 *)Y, stats, stream);
+                                        (wfs_bf16 *)Y, stats, pending, stream);
 }
 
 // 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, bool *stats_done, hipStream_t stream) {
+                           const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream) {
     KMap km;
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K; ++k) {
@@ -1027,8 +1034,11 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
         long long nb = ((R + 31) / 32 + 3) / 4;
         if (nb > 4096) nb = 4096;
         if (stats && nb > 1024) nb = 1024;          // one partial per block for k_stats_fold
+        if (stats && pending && nb > 256) nb = 256; // ... every block of the BatchNorm apply kernel folds them all
         const WfsStatsArgs sa = stats_args(stats, nb);
-        const dim3 grid((unsigned)nb), block(256);
+        // with the partials left to the BatchNorm kernel (<= 256 of them) the blocks get 12 waves instead of 4, so
+        // that the launch still holds about one 32-row tile per wave
+        const dim3 grid((unsigned)nb), block((stats && pending) ? 768 : 256);
         const int mir = is_ident ? 0 : 1;
 #define WFS_C2(H, ST)                                                                                                \
     k_gconv_c2c32_bf16<H, ST><<<grid, block, 0, stream>>>(table, mir, K, identity_k, R, r_dev, (const H *)X, W, bias,  \
@@ -1037,7 +1047,7 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
             if (dtype == WFS_F16) WFS_C2(wfs_f16, true); else WFS_C2(wfs_bf16, true);
             WFS_LAUNCH_CHECK();
             if (stats_done) *stats_done = true;
-            return stats_fold(sa, nb, stream);
+            return stats_fold(sa, nb, pending, stream);
         }
         if (dtype == WFS_F16) WFS_C2(wfs_f16, false); else WFS_C2(wfs_bf16, false);
 #undef WFS_C2

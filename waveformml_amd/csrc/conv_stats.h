@@ -34,7 +34,7 @@ __device__ __forceinline__ void wfs_chan_merge(WfsColStats &a, float nb, float m
     if (nb > 0.f) {
         float n = a.n + nb;
         float d = mb - a.mean;
-        float f = nb / n;
+        float f = nb * __builtin_amdgcn_rcpf(n);          // 1 ulp; an IEEE division is ~10 instructions per merge
         a.mean = fmaf(d, f, a.mean);
         a.m2 = a.m2 + m2b + d * d * (a.n * f);
         a.n = n;
@@ -64,6 +64,48 @@ __device__ __forceinline__ void wfs_stats_tile(WfsColStats &st, const float (&v)
     wfs_chan_merge(st, nt, mt, q);
 }
 
+// Cheaper per-tile bookkeeping (what the kernels use): every lane keeps SHIFTED sums of its own 16 rows per tile --
+// d = v - shift with shift = the first value the lane ever produced (any value near the column's mean keeps
+// sum d^2 - (sum d)^2 / n free of cancellation) -- i.e. two FMAs per value, no shuffles, no divisions inside the tile
+// loop.  At the end of the kernel the lane's (n, shift, s1, s2) becomes (n, mean, M2), the two lanes of a column are
+// merged (Chan), then the waves (wfs_stats_finish).
+struct WfsLaneStats {
+    float n, shift, s1, s2;
+};
+
+__device__ __forceinline__ void wfs_lane_stats_tile(WfsLaneStats &st, const float (&v)[16], int nlive, int h) {
+    if (st.n == 0.f) st.shift = v[0];                 // (a dead row's value is still a finite number near the bias)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const bool live = row < nlive;
+        const float d = v[i] - st.shift;
+        st.s1 += live ? d : 0.f;
+        st.s2 = live ? fmaf(d, d, st.s2) : st.s2;
+        st.n += live ? 1.f : 0.f;
+    }
+}
+
+__device__ __forceinline__ WfsColStats wfs_lane_stats_close(const WfsLaneStats &st) {
+    WfsColStats c = {0.f, 0.f, 0.f};
+    if (st.n > 0.f) {
+        const float md = st.s1 / st.n;
+        c.n = st.n;
+        c.mean = st.shift + md;
+        const float m2 = st.s2 - st.s1 * md;
+        c.m2 = m2 > 0.f ? m2 : 0.f;
+    }
+    // the column's other lane (h ^ 1) holds the other 16 rows of every tile
+    const float on = __shfl_xor(c.n, 32, 64), om = __shfl_xor(c.mean, 32, 64), oq = __shfl_xor(c.m2, 32, 64);
+    WfsColStats lo = c, hi = {on, om, oq};
+    if ((threadIdx.x & 63) >= 32) {                   // merge in (h = 0, h = 1) order on both lanes: identical results
+        lo = hi;
+        hi = c;
+    }
+    wfs_chan_merge(lo, hi.n, hi.mean, hi.m2);
+    return lo;
+}
+
 // End of the conv kernel, called by EVERY thread of the block (blockDim.x = 64 * nw, nw <= 16): the waves' statistics
 // are merged in wave order and stored as this block's partial.  sStat: >= 16 * 65 floats of LDS nobody else touches
 // any more.  No atomics, no fences: the partials are consumed by the next launch (k_stats_fold).
@@ -87,7 +129,7 @@ __device__ __forceinline__ void wfs_stats_finish(const WfsColStats &st, float *s
 // One block of 1024 threads = 32 slices x 32 columns: slice sl merges the block partials sl, sl + 32, ... in order
 // (four at a time, so the independent loads are in flight together), slices are merged in slice order; then mean,
 // invstd and the running statistics exactly as torch updates them (unbiased variance, momentum).
-__global__ void __launch_bounds__(1024) k_stats_fold(WfsStatsArgs sa, int nb) {
+static __global__ void __launch_bounds__(1024) k_stats_fold(WfsStatsArgs sa, int nb) {
     __shared__ float sStat[32 * 65];
     const int t = threadIdx.x, c = t & 31, sl = t >> 5;
     WfsColStats f = {0.f, 0.f, 0.f};

@@ -206,7 +206,8 @@ long long dw_chunks(long long R) {
 static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                             int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
                             int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
-                            const int64_t *r_dev_, const wfs_bn_stats *stats, bool *stats_done, void *stream_) {
+                            const int64_t *r_dev_, const wfs_bn_stats *stats, bool *stats_done, int *pending,
+                            void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     *stats_done = false;
     const long long *r_dev = (const long long *)r_dev_;
@@ -233,16 +234,16 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
     if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
-                                      bias, (float *)Y, stats, stream);
+                                      bias, (float *)Y, stats, pending, stream);
     }
     if (dtype != WFS_F32 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_h16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
-                                      dtype, stats, stream);
+                                      dtype, stats, pending, stream);
     }
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
         return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stats, stats_done,
-                                      stream);
+                                      pending, stream);
     dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
 #define WFS_GC(T, TR)                                                                                           \
     k_gather_conv<T, TR><<<grid, block, 0, stream>>>(table, km, K, identity_k, R, r_dev, (const T *)X, Cx, W,  \
@@ -265,7 +266,7 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
                                const int64_t *r_dev, void *stream) {
     bool unused;
     return gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, transpose_w, bias, Y,
-                            dtype, r_dev, nullptr, &unused, stream);
+                            dtype, r_dev, nullptr, &unused, nullptr, stream);
 }
 
 extern "C" size_t wfs_conv_stats_workspace_bytes(int64_t R, int32_t C) {
@@ -276,7 +277,8 @@ extern "C" size_t wfs_conv_stats_workspace_bytes(int64_t R, int32_t C) {
 extern "C" int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                                        int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
                                        int32_t Cw_in, int32_t Cw_out, const float *bias, void *Y, int32_t dtype,
-                                       const int64_t *r_dev, const wfs_bn_stats *stats, void *stream) {
+                                       const int64_t *r_dev, const wfs_bn_stats *stats, int32_t *pending_blocks,
+                                       void *stream) {
     WFS_REQUIRE(stats && stats->save_mean && stats->save_invstd && stats->workspace, WFS_EINVAL,
                 "incomplete wfs_bn_stats");
     WFS_REQUIRE((stats->running_mean == nullptr) == (stats->running_var == nullptr), WFS_EINVAL,
@@ -285,8 +287,14 @@ extern "C" int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap
                 "statistics workspace %zu < %zu", stats->workspace_bytes, wfs_conv_stats_workspace_bytes(R, Cw_out));
     WFS_REQUIRE(R > 0, WFS_EINVAL, "batch statistics of zero rows");
     bool done = false;
+    int pending = 0;
+    // the partials may stay unfolded when the caller can take them (pending_blocks) and the BatchNorm apply kernel
+    // that folds them covers this batch (32 channels, rows fit its register-resident form)
+    const bool defer = pending_blocks && Cw_out == 32 && wfs_bn_fold_ok(R, Cw_out);
+    if (pending_blocks) *pending_blocks = 0;
     int rc = gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, 0, bias, Y, dtype, r_dev,
-                              stats, &done, stream);
+                              stats, &done, defer ? &pending : nullptr, stream);
+    if (rc == WFS_OK && done && pending_blocks) *pending_blocks = pending;
     if (rc != WFS_OK || done) return rc;
     return wfs_launch_bn_stats(Y, R, Cw_out, dtype, (const long long *)r_dev, stats, (hipStream_t)stream);
 }

@@ -104,17 +104,19 @@ struct WfsTimerScope {
 
 // shape-specialised launchers (conv_mfma.hip); r_dev: optional device-side count of valid rows (<= R)
 bool wfs_mfma_gconv32_ok(int K);
-// stats (optional): BatchNorm statistics taken in the epilogue (conv_stats.h); forward products only
+// stats (optional): BatchNorm statistics taken in the epilogue (conv_stats.h); forward products only.
+// pending (optional): leave the per-block partials unfolded and return their number (see stats_fold, conv_mfma.hip)
+bool wfs_bn_fold_ok(long long N, int C);          // bn.hip: can the apply kernel fold conv partials for this batch?
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, hipStream_t stream);
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream);
 // 16-bit rows (dtype WFS_BF16 or WFS_F16)
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, hipStream_t stream);
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, bool *stats_done, hipStream_t stream);
+                           const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream);
 size_t wfs_conv_stats_fast_workspace(long long R);
 // bn.hip: the stand-alone statistics pass (reduce + fold) over X [N, C]
 int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long long *n_dev, const wfs_bn_stats *stats,

@@ -164,11 +164,14 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
                           _lib.ptr(bn.running_var) if track else None,
                           _lib.ptr(bn.num_batches_tracked) if (track and bn.training) else None,
                           float(bn.momentum), float(bn.eps), _lib.ptr(ws), ws.numel())
+        pending = ctypes.c_int32(0)
         _lib.check(lib.wfs_gather_conv_bnstats(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0],
                                                X.shape[1], _lib.ptr(W), Cw_in, Cw_out, _lib.ptr(bias), _lib.ptr(Y),
                                                _lib.dtype_code(X), _lib.ptr(r_dev), ctypes.byref(st),
-                                               _lib.stream_ptr()))
-        bn_request.stats = (save_mean, save_invstd)
+                                               ctypes.byref(pending), _lib.stream_ptr()))
+        # pending > 0: the per-block partial statistics are still in `ws`; the BatchNorm step's own kernel folds them
+        # (one launch less than folding here)
+        bn_request.stats = (save_mean, save_invstd, (int(pending.value), ws) if pending.value > 0 else None)
     else:
         _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
                                        _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias),
@@ -366,10 +369,19 @@ class BatchNormReLUFunction(Function):
         if stats is not None:
             # the producing convolution took the statistics (and updated the running ones): normalise only
             assert training
-            save_mean, save_invstd = stats
-            _lib.check(lib.wfs_bn_apply_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(save_mean),
-                                            _lib.ptr(save_invstd), 1 if relu else 0, _lib.ptr(y), _lib.dtype_code(x),
-                                            _lib.ptr(n_dev), _lib.stream_ptr()))
+            save_mean, save_invstd, pending = stats
+            if pending is not None:
+                nblk, ws = pending
+                st = _lib.BnStats(_lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(running_mean),
+                                  _lib.ptr(running_var), _lib.ptr(batches_tracked), float(momentum), float(eps),
+                                  _lib.ptr(ws), ws.numel())
+                _lib.check(lib.wfs_bn_apply_fwd_fold(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), ctypes.byref(st),
+                                                     nblk, 1 if relu else 0, _lib.ptr(y), _lib.dtype_code(x),
+                                                     _lib.ptr(n_dev), _lib.stream_ptr()))
+            else:
+                _lib.check(lib.wfs_bn_apply_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias),
+                                                _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if relu else 0, _lib.ptr(y),
+                                                _lib.dtype_code(x), _lib.ptr(n_dev), _lib.stream_ptr()))
             ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
             ctx.flags = (True, bool(relu))
             ctx.n_dev = n_dev
