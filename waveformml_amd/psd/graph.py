@@ -86,7 +86,11 @@ class GraphedTrainStep(object):
     def _body(self):
         self.reducer.reset()
         loss = self.module.training_step(self._static_batch(), 0)
-        loss.backward()
+        if loss.dtype == torch.float32 and loss.dim() == 0:
+            from ..spconv import functional as Fsp
+            torch.autograd.backward(loss, grad_tensors=Fsp.unit_loss_grad(loss.device))   # no ones-fill, no multiply
+        else:
+            loss.backward()
         self.reducer.pack_all()
         if self.in_graph_optimizer:
             self.optimizer.step()

@@ -576,7 +576,26 @@ class CrossEntropyMeanFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
+        unit = _UNIT_LOSS_GRAD.get(grad_output.device)
+        if unit is not None and grad_output.data_ptr() == unit.data_ptr():
+            return ctx.dlogits, None, None            # d loss / d loss = 1, handed in by unit_loss_grad(): no multiply
         return ctx.dlogits * grad_output, None, None
+
+
+# ``loss.backward()`` makes autograd fill a fresh ones tensor for d loss / d loss (a launch) and the loss node multiply
+# by it (another).  A runner that owns the backward call passes this persistent tensor instead:
+#     torch.autograd.backward(loss, grad_tensors=unit_loss_grad(loss.device))
+# and the fused cross-entropy recognises it (by address) and returns its gradient unscaled.
+_UNIT_LOSS_GRAD = {}
+
+
+def unit_loss_grad(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device not in _UNIT_LOSS_GRAD:
+        _UNIT_LOSS_GRAD[device] = torch.ones((), dtype=torch.float32, device=device)
+    return _UNIT_LOSS_GRAD[device]
 
 
 def can_fuse_cross_entropy(criterion, logits, target):
