@@ -190,10 +190,27 @@ int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap_host, int3
  * `workspace` (wfs_gather_dw_workspace_bytes).                                                 */
 size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg);
 
+/* A pending second stage of wfs_gather_dw: dW = sum over `nslabs` partial results in `part` (the workspace).
+ * With `defer` given, wfs_gather_dw runs only its first stage when the shape has a two-stage kernel and describes
+ * the rest here (nslabs > 0; dW is NOT written yet, the workspace must stay alive); the caller later reduces the jobs
+ * of a whole backward pass in ONE launch with wfs_dw_reduce_jobs -- at the PSD batch sizes every launch costs more
+ * than the few hundred KB it reduces.  nslabs == 0 on return: nothing pending, dW is final. */
+typedef struct wfs_dw_job {
+    const float *part;
+    int64_t nslabs;
+    int64_t per;          /* elements of one slab = K * Cs * Cg */
+    int32_t K, A, B;      /* slab layout [K][A][B] */
+    int32_t transpose;    /* dW[k][b][a] = sum part[.][k][a][b] instead of dW[k][a][b] */
+    float *dW;
+} wfs_dw_job;
+
 int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                   int64_t R, const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg,
                   int32_t swap, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
-                  const int64_t *r_dev, void *stream);
+                  const int64_t *r_dev, wfs_dw_job *defer, void *stream);
+
+/* Second stage of up to 16 deferred wfs_gather_dw calls in one launch (deterministic: fixed summation order). */
+int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream);
 
 /* Scatter form with fp32 atomics, used ONLY when the input holds duplicate coordinates (then
  * the inverse of a gather table is not a function):

@@ -34,6 +34,12 @@ class BnStats(ctypes.Structure):
                 ("workspace", _vp), ("workspace_bytes", _sz)]
 
 
+class DwJob(ctypes.Structure):
+    """struct wfs_dw_job"""
+    _fields_ = [("part", _vp), ("nslabs", _i64), ("per", _i64), ("K", _i32), ("A", _i32), ("B", _i32),
+                ("transpose", _i32), ("dW", _vp)]
+
+
 # name -> (restype, argtypes); mirrors include/wfsparse.h one to one
 SIGNATURES = {
     "wfs_abi_version": (ctypes.c_int, []),
@@ -55,7 +61,8 @@ SIGNATURES = {
                                              _vp, _vp]),
     "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "wfs_gather_dw": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
-                                     _sz, _vp, _vp]),
+                                     _sz, _vp, ctypes.POINTER(DwJob), _vp]),
+    "wfs_dw_reduce_jobs": (ctypes.c_int, [ctypes.POINTER(DwJob), _i32, _vp]),
     "wfs_scatter_conv": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "wfs_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "wfs_bn_relu_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32,

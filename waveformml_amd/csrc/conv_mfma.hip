@@ -893,8 +893,58 @@ __global__ void __launch_bounds__(1024) k_slab_reduce(const float *__restrict__ 
     }
 }
 
+// The same for several pending reductions in one launch (wfs_dw_reduce_jobs): block b serves job j with
+// first[j] <= b < first[j + 1], 32 outputs per block; bitwise the results of k_slab_reduce (same slices, same order).
+constexpr int MAX_DW_JOBS = 16;
+struct DwJobs {
+    wfs_dw_job j[MAX_DW_JOBS];
+    int first[MAX_DW_JOBS + 1];
+    int n;
+};
+__global__ void __launch_bounds__(1024) k_slab_reduce_multi(DwJobs jobs) {
+    __shared__ float sR[32][32];
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first[ji + 1]) ++ji;
+    const wfs_dw_job &jb = jobs.j[ji];
+    const int sl = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int nsl = jb.nslabs > 64 ? 32 : 8;          // the slicing (= summation order) of the single-job launches
+    const long long e = (long long)((int)blockIdx.x - jobs.first[ji]) * 32 + lane;
+    float s = 0.f;
+    if (e < jb.per && sl < nsl)
+        for (long long c = sl; c < jb.nslabs; c += nsl) s += jb.part[c * jb.per + e];
+    sR[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && e < jb.per) {
+        s = 0.f;
+        for (int q = 0; q < nsl; ++q) s += sR[q][lane];
+        if (jb.transpose) {
+            const long long ab = (long long)jb.A * jb.B;
+            const int k = (int)(e / ab), rem = (int)(e % ab);
+            const int a = rem / jb.B, b = rem % jb.B;
+            jb.dW[((long long)k * jb.B + b) * jb.A + a] = s;
+        } else {
+            jb.dW[e] = s;
+        }
+    }
+}
 
 }  // namespace
+
+int wfs_launch_dw_jobs(const wfs_dw_job *jobs, int n, hipStream_t stream) {
+    DwJobs dj;
+    dj.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        dj.j[i] = jobs[i];
+        dj.first[i] = blocks;
+        blocks += (int)((jobs[i].per + 31) / 32);
+    }
+    dj.first[n] = blocks;
+    if (blocks == 0) return WFS_OK;
+    k_slab_reduce_multi<<<dim3((unsigned)blocks), dim3(1024), 0, stream>>>(dj);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
 
 // ---- launchers used by gather_conv.hip's C entry points -------------------------------------------------
 bool wfs_mfma_gconv32_ok(int K) { return K >= 1 && K <= 32; }       // K * 4 KiB of LDS <= 128 KiB
@@ -1091,7 +1141,7 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
 }
 
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
-                     const void *G, int swap, float *dW, float *part, int dtype, hipStream_t stream) {
+                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream) {
     const long long nblk = dw32_blocks(R);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
@@ -1107,6 +1157,10 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
             table, K, identity_k, R, r_dev, (const wfs_f16 *)S, (const wfs_f16 *)G, part, ngroups, tiles_per_block);
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
+    if (defer) {
+        *defer = wfs_dw_job{part, nblk, per, K, 32, 32, swap, dW};
+        return WFS_OK;
+    }
     k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(nblk > 64 ? 1024 : 256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
@@ -1114,7 +1168,7 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
 
 int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                          const void *S, const void *G, int swap, float *dW, float *part, int dtype,
-                         hipStream_t stream) {
+                         wfs_dw_job *defer, hipStream_t stream) {
     long long chunks = dwc2_chunks(R);
     const long long rows_per_chunk = (R + chunks - 1) / chunks;
     if (dtype == WFS_F32) {
@@ -1134,6 +1188,10 @@ int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, lo
     WFS_LAUNCH_CHECK();
     // part is [chunk][k][c (gathered, 2)][b (stationary, 32)] = the "swap" orientation of (S=32, G=2)
     const long long per = (long long)K * 64;
+    if (defer) {
+        *defer = wfs_dw_job{part, chunks, per, K, 2, 32, swap ? 0 : 1, dW};
+        return WFS_OK;
+    }
     k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(chunks > 64 ? 1024 : 256), 0, stream>>>(part, chunks, per, K, 2, 32, swap ? 0 : 1, dW);
     WFS_LAUNCH_CHECK();
     return WFS_OK;

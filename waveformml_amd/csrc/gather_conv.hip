@@ -334,13 +334,14 @@ extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs
 extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R, const void *S,
                              int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
                              int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev_,
-                             void *stream_) {
+                             wfs_dw_job *defer, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long *r_dev = (const long long *)r_dev_;
     (void)G_rows;
     WFS_REQUIRE(K >= 1 && K <= 65535, WFS_EINVAL, "bad K");
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(dW, WFS_EINVAL, "NULL dW");
+    if (defer) *defer = wfs_dw_job{nullptr, 0, 0, 0, 0, 0, 0, nullptr};        // nothing pending unless a fast path says so
     if (R == 0) {
         WFS_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)K * Cs * Cg * sizeof(float), stream));
         return WFS_OK;
@@ -350,7 +351,7 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
     if (Cs == 32 && Cg == 32 && table && !kmap_host)
-        return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, stream);
+        return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, defer, stream);
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K && kmap_host; ++k) {
         is_ident = is_ident && kmap_host[k] == k;
@@ -359,7 +360,7 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     if (!kmap_host) is_mirror = false;
     if (Cs == 32 && Cg == 2 && K <= 27 && table && (is_ident || is_mirror))
         return wfs_launch_gdw_c32c2(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace,
-                                    dtype, stream);
+                                    dtype, defer, stream);
     WFS_REQUIRE(is_ident, WFS_EINVAL, "a column map is only supported by the 32 x 2 dW kernel");
     long long chunks = dw_chunks(R);
     long long rows_per_chunk = wfs_cdiv(wfs_cdiv(R, chunks), DW_ROWS) * DW_ROWS;
@@ -383,4 +384,18 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
     k_dw_reduce<<<dim3((unsigned)wfs_cdiv(per, TB)), block, 0, stream>>>(part, chunks, K, Cs, Cg, swap, dW);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
+}
+
+extern "C" int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream) {
+    WFS_REQUIRE(n >= 0 && n <= 16 && (n == 0 || jobs), WFS_EINVAL, "%d jobs (0 .. 16)", n);
+    wfs_dw_job live[16];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (jobs[i].nslabs <= 0) continue;
+        WFS_REQUIRE(jobs[i].part && jobs[i].dW && jobs[i].per > 0 && jobs[i].A > 0 && jobs[i].B > 0, WFS_EINVAL,
+                    "job %d is incomplete", i);
+        live[m++] = jobs[i];
+    }
+    WfsTimerScope timer(WFS_TIMER_GATHER_DW, (hipStream_t)stream);
+    return wfs_launch_dw_jobs(live, m, (hipStream_t)stream);
 }

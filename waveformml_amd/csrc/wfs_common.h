@@ -123,7 +123,8 @@ int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long
                         hipStream_t stream);
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg);
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
-                     const void *G, int swap, float *dW, float *part, int dtype, hipStream_t stream);
+                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream);
 int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                          const void *S, const void *G, int swap, float *dW, float *part, int dtype,
-                         hipStream_t stream);
+                         wfs_dw_job *defer, hipStream_t stream);
+int wfs_launch_dw_jobs(const wfs_dw_job *jobs, int n, hipStream_t stream);

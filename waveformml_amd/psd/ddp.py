@@ -46,6 +46,11 @@ class FlatGradAllReducer(object):
                     p.data = flat[o:o + n].view_as(p)
             self.flat_param = torch.nn.Parameter(flat)
             self.flat_param.grad = self.flat_grad
+            if dev.type == "cuda":
+                # backward passes of the HIP operators write parameter gradients straight into their slots of
+                # flat_grad (spconv/functional.grad_like): _pack then finds them in place and copies nothing
+                from ..spconv import functional as _fsp
+                _fsp.register_grad_slots(self.flat_param, self.flat_grad)
         # contiguous buckets of roughly equal size over that order
         if self.world <= 1:
             n_buckets = 1              # nothing to overlap: pack with one concatenation
@@ -83,12 +88,33 @@ class FlatGradAllReducer(object):
     def _pack(self, b):
         from ..spconv import functional as _fsp
         _fsp.join_side_streams()          # weight gradients may still be in flight on the dW side stream
+        _fsp.flush_deferred_dw()          # ... or wait for their (deferred) second stage
         s, e, idxs = self.buckets[b]
-        grads = []
+        base = self.flat_grad.data_ptr()
+        placed = []                       # gradients that already sit in their slot (written there by the kernels)
         for i in idxs:
             g = self.params[i].grad
-            grads.append(g.reshape(-1) if g is not None else self.flat_grad.new_zeros(self.slices[i][1]))
-        torch.cat(grads, out=self.flat_grad[s:e])
+            slot = base + 4 * self.slices[i][0]
+            placed.append(_fsp.was_deferred(slot) or (g is not None and g.is_contiguous() and g.data_ptr() == slot
+                                                      and g.dtype == self.flat_grad.dtype))
+        if all(placed):
+            return
+        if not any(placed):
+            grads = []
+            for i in idxs:
+                g = self.params[i].grad
+                grads.append(g.reshape(-1) if g is not None else self.flat_grad.new_zeros(self.slices[i][1]))
+            torch.cat(grads, out=self.flat_grad[s:e])
+            return
+        for i, ok in zip(idxs, placed):   # mixed: move only what is elsewhere
+            if ok:
+                continue
+            o, n = self.slices[i]
+            g = self.params[i].grad
+            if g is None:
+                self.flat_grad[o:o + n].zero_()
+            else:
+                self.flat_grad[o:o + n].copy_(g.reshape(-1))
 
     def _make_hook(self, i):
         def hook(param):

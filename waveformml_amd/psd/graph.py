@@ -85,13 +85,18 @@ class GraphedTrainStep(object):
 
     def _body(self):
         self.reducer.reset()
+        from ..spconv import functional as Fsp
         loss = self.module.training_step(self._static_batch(), 0)
-        if loss.dtype == torch.float32 and loss.dim() == 0:
-            from ..spconv import functional as Fsp
-            torch.autograd.backward(loss, grad_tensors=Fsp.unit_loss_grad(loss.device))   # no ones-fill, no multiply
-        else:
-            loss.backward()
-        self.reducer.pack_all()
+        # weight-gradient slab reductions of the whole backward pass run as ONE launch at pack time (pack_all flushes)
+        Fsp.defer_dw(self.reducer.flat_param is not None)
+        try:
+            if loss.dtype == torch.float32 and loss.dim() == 0:
+                torch.autograd.backward(loss, grad_tensors=Fsp.unit_loss_grad(loss.device))   # no ones-fill, no multiply
+            else:
+                loss.backward()
+            self.reducer.pack_all()
+        finally:
+            Fsp.defer_dw(False)
         if self.in_graph_optimizer:
             self.optimizer.step()
         return loss.detach()

@@ -198,6 +198,66 @@ def scatter_conv(table, K, identity_k, R, X, W, transpose_w, n_out, bias):
 _PENDING_SIDE = []          # (event, tensors kept alive until the join) of launches made on a side stream
 
 
+# ---- parameter gradients written where the optimizer reads them ---------------------------------------------------
+# A runner that keeps all parameters / gradients in ONE flat buffer each (psd/ddp.FlatGradAllReducer) registers the
+# pair here.  Backward passes then allocate a parameter's gradient as a VIEW of its slot in the flat gradient buffer
+# (grad_like), so the kernels write it in place and the runner's pack step has nothing left to copy.
+_GRAD_SLOTS = []          # [(weakref(flat_param), weakref(flat_grad))]
+
+
+def register_grad_slots(flat_param, flat_grad):
+    import weakref
+    _GRAD_SLOTS[:] = [(p, g) for (p, g) in _GRAD_SLOTS if p() is not None and g() is not None]
+    _GRAD_SLOTS.append((weakref.ref(flat_param), weakref.ref(flat_grad)))
+
+
+def grad_like(param, shape=None):
+    """An fp32 tensor of ``shape`` (default: param's) for d loss / d param: the parameter's slot in a registered flat
+    gradient buffer when ``param`` is a contiguous fp32 view into the matching flat parameter buffer, else fresh memory."""
+    shape = tuple(param.shape) if shape is None else tuple(shape)
+    if param is not None and param.is_cuda and param.dtype == torch.float32 and param.is_contiguous():
+        for pref, gref in _GRAD_SLOTS:
+            fp, fg = pref(), gref()
+            if fp is None or fg is None or fp.device != param.device:
+                continue
+            off = param.data_ptr() - fp.data_ptr()
+            if 0 <= off and off + 4 * param.numel() <= 4 * fp.numel() and off % 4 == 0:
+                return fg[off // 4: off // 4 + param.numel()].view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=param.device)
+
+
+# Deferred second stages of gather_dw (include/wfsparse.h, wfs_dw_job): while a runner has deferral switched on, the
+# slab reductions of a whole backward pass are collected and run as ONE launch by flush_deferred_dw() -- only for
+# gradients that live in a registered slot (the runner reads the slot, never the tensor autograd holds).
+_DEFERRED_DW = None       # None: off; else a list of (DwJob, workspace tensor)
+_DEFERRED_SLOTS = set()   # slot addresses written by the last flush
+
+
+def defer_dw(on):
+    global _DEFERRED_DW
+    _DEFERRED_DW = [] if on else None
+    _DEFERRED_SLOTS.clear()
+
+
+def was_deferred(slot_ptr):
+    return slot_ptr in _DEFERRED_SLOTS
+
+
+def flush_deferred_dw():
+    """One launch for every pending slab reduction (no-op when nothing is pending)."""
+    if not _DEFERRED_DW:
+        return
+    lib = _lib.load()
+    jobs = (_lib.DwJob * len(_DEFERRED_DW))(*[j for (j, _ws) in _DEFERRED_DW])
+    for at in range(0, len(_DEFERRED_DW), 16):
+        n = min(16, len(_DEFERRED_DW) - at)
+        _lib.check(lib.wfs_dw_reduce_jobs(ctypes.cast(ctypes.byref(jobs, at * ctypes.sizeof(_lib.DwJob)),
+                                                      ctypes.POINTER(_lib.DwJob)), n, _lib.stream_ptr()))
+    for j, _ws in _DEFERRED_DW:
+        _DEFERRED_SLOTS.add(int(j.dW))
+    del _DEFERRED_DW[:]
+
+
 def join_side_streams():
     """Make the current stream wait for everything launched on side streams (OVERLAP_DW) and release the
     tensors that were kept alive for them."""
@@ -208,13 +268,20 @@ def join_side_streams():
         del _PENDING_SIDE[:]
 
 
-def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False):
+def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False, like=None):
     """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a]).
     overlap=True launches on the side stream (see ops.OVERLAP_DW): memory is allocated on the calling stream
-    and every operand is kept alive until join_side_streams()."""
+    and every operand is kept alive until join_side_streams().  ``like``: the parameter this is the gradient of
+    (grad_like: written straight into its slot of a registered flat gradient buffer)."""
     lib = _lib.load()
     Cs, Cg = int(S.shape[1]), int(G.shape[1])
-    dW = torch.empty((K, Cg, Cs) if swap else (K, Cs, Cg), dtype=torch.float32, device=S.device)
+    shape = (K, Cg, Cs) if swap else (K, Cs, Cg)
+    in_slot = False
+    if like is not None and like.numel() == K * Cs * Cg:
+        dW = grad_like(like, shape)
+        in_slot = dW._base is not None
+    else:
+        dW = torch.empty(shape, dtype=torch.float32, device=S.device)
     assert S.dtype == G.dtype and S.shape[0] == R
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
     if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap:
@@ -222,14 +289,18 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
         ok = _row_ok(R, r_dev, S.device)
         Sv = S if ok is None else torch.where(ok.unsqueeze(1), S, S.new_zeros(()))
         dWk = _mm_f32(Sv.t(), Gk).reshape(Cs, K, Cg).permute(1, 0, 2)                 # [K, Cs, Cg]
-        return dWk.transpose(1, 2).contiguous() if swap else dWk.contiguous()
+        return dW.copy_(dWk.transpose(1, 2) if swap else dWk)
     nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
 
     def launch():
+        defer = _DEFERRED_DW is not None and in_slot and not overlap
+        job = _lib.DwJob() if defer else None
         _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0],
                                      Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
-                                     _lib.ptr(r_dev), _lib.stream_ptr()))
+                                     _lib.ptr(r_dev), ctypes.byref(job) if defer else None, _lib.stream_ptr()))
+        if defer and job.nslabs > 0:
+            _DEFERRED_DW.append((job, ws))          # second stage pending: flush_deferred_dw()
 
     if overlap and ACCOUNT is None:
         from . import ops
@@ -294,16 +365,16 @@ class SparseConvFunction(Function):
                 else:
                     dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev)
             if ctx.needs_input_grad[1]:
-                dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev, ov)
+                dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev, ov, filters)
         else:
             # dW first: with OVERLAP_DW it goes to the side stream and runs beside the dX launched next
             if ctx.needs_input_grad[1]:
                 if features.shape[1] == 2 and dY.shape[1] == 32 and K <= 27 and not rb.has_dup:
                     # narrow input, wide output (first layer): keep the wide dY rows stationary
                     table, kmap = rb.table_by_out()
-                    dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap, rb.m_dev, ov)
+                    dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap, rb.m_dev, ov, filters)
                 else:
-                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov)
+                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov, filters)
             if ctx.needs_input_grad[0]:
                 dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
         if dW is not None:
@@ -410,8 +481,8 @@ class BatchNormReLUFunction(Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         dx = _rows(tuple(x.shape), x, ctx.n_dev)
-        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if weight is not None else None
-        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if bias is not None else None
+        dgamma = grad_like(weight) if weight is not None else None
+        dbeta = grad_like(bias) if bias is not None else None
         ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
         _lib.check(lib.wfs_bn_relu_bwd(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
                                        _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
@@ -470,10 +541,10 @@ class SkinnyLinearFunction(Function):
         g = grad_output.float().contiguous()
         w = weight.detach().float().contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty((O, I), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        dw = grad_like(weight, (O, I)) if ctx.needs_input_grad[1] else None
         ws = torch.empty((max(int(lib.wfs_head_workspace_bytes(B, I, O)), 1),), dtype=torch.uint8, device=x.device)
         want_db = bias is not None and ctx.needs_input_grad[2]
-        db = torch.empty((O,), dtype=torch.float32, device=x.device) if (want_db and dw is not None) else None
+        db = grad_like(bias, (O,)) if (want_db and dw is not None) else None
         _lib.check(lib.wfs_head_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
                                     _lib.dtype_code(x), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
         if want_db and db is None:
