@@ -906,17 +906,19 @@ __global__ void __launch_bounds__(1024) k_slab_reduce_multi(DwJobs jobs) {
     int ji = 0;
     while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first[ji + 1]) ++ji;
     const wfs_dw_job &jb = jobs.j[ji];
-    const int sl = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int nsl = jb.nslabs > 64 ? 32 : 8;          // the slicing (= summation order) of the single-job launches
-    const long long e = (long long)((int)blockIdx.x - jobs.first[ji]) * 32 + lane;
+    const int groups = 32 / nsl;                      // a block serves `groups` x 32 outputs with nsl slices each
+    const int row = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int grp = row / nsl, sl = row % nsl;
+    const long long e = ((long long)((int)blockIdx.x - jobs.first[ji]) * groups + grp) * 32 + lane;
     float s = 0.f;
-    if (e < jb.per && sl < nsl)
+    if (e < jb.per)
         for (long long c = sl; c < jb.nslabs; c += nsl) s += jb.part[c * jb.per + e];
-    sR[sl][lane] = s;
+    sR[row][lane] = s;
     __syncthreads();
     if (sl == 0 && e < jb.per) {
         s = 0.f;
-        for (int q = 0; q < nsl; ++q) s += sR[q][lane];
+        for (int q = 0; q < nsl; ++q) s += sR[grp * nsl + q][lane];
         if (jb.transpose) {
             const long long ab = (long long)jb.A * jb.B;
             const int k = (int)(e / ab), rem = (int)(e % ab);
@@ -937,7 +939,8 @@ int wfs_launch_dw_jobs(const wfs_dw_job *jobs, int n, hipStream_t stream) {
     for (int i = 0; i < n; ++i) {
         dj.j[i] = jobs[i];
         dj.first[i] = blocks;
-        blocks += (int)((jobs[i].per + 31) / 32);
+        const long long per_block = jobs[i].nslabs > 64 ? 32 : 128;       // see k_slab_reduce_multi
+        blocks += (int)((jobs[i].per + per_block - 1) / per_block);
     }
     dj.first[n] = blocks;
     if (blocks == 0) return WFS_OK;
