@@ -258,6 +258,13 @@ int wfs_bn_apply_fwd_fold(const void *X, int64_t N, int32_t C, const float *gamm
                           const wfs_bn_stats *stats, int32_t pending_blocks, int32_t relu, void *Y, int32_t dtype,
                           const int64_t *n_dev, void *stream);
 
+/* After wfs_rulebook_emit of a regular conv whose site table was a direct grid: pointers into `workspace` to the
+ * cell -> output row map of the build (ticket[cell] != 0xFFFFFFFF <=> the output cell b * out_volume + pos is active,
+ * slot_id[cell] = its row).  Returns 1 and sets the pointers, or 0 when this build has no such map.  The map lives as
+ * long as the workspace is kept. */
+int wfs_rulebook_cell_map(const wfs_geometry *g, int64_t N, void *workspace, const uint32_t **ticket,
+                          const int32_t **slot_id, int64_t *cells);
+
 /* SparseConvTensor.dense() -------------------------------------------------------------------
  * Y is [B, C, *spatial] (channels first, contiguous) and must be zero-filled by the caller;
  * rows are assigned, not accumulated.  winner_ws: NULL when coordinates are unique, else int32
@@ -270,6 +277,18 @@ int wfs_to_dense(const void *X, const int32_t *indices, int64_t M, int32_t ndim,
 int wfs_to_dense_bwd(const void *dY, const int32_t *indices, int64_t M, int32_t ndim,
                      const int32_t *spatial_host, int32_t batch_size, int32_t C, void *dX,
                      int32_t dtype, const int64_t *m_dev, void *stream);
+
+/* dense() and its backward through a cell -> row map (wfs_rulebook_cell_map of the conv that produced the rows, whose
+ * coordinates are unique by construction).  Y [B, C, V] need NOT be zero-filled: every cell is written, a block owns 64
+ * cells of one event and stores whole runs per channel.  V = out volume; C % 4 == 0, C <= 128, V even for 16-bit rows;
+ * rows with id >= the valid count (m_dev) are treated as absent. */
+int wfs_to_dense_mapped(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
+                        const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y, int32_t dtype,
+                        void *stream);
+
+int wfs_to_dense_bwd_mapped(const void *dY, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
+                            const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *dX, int32_t dtype,
+                            void *stream);
 
 /* classification head -----------------------------------------------------------------------
  * The reference flattens ToDense's output and applies the LinearBlock (src/models/SPConvNet.py:67-68,

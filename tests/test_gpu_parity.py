@@ -1208,3 +1208,49 @@ def test_c4_deep_stack_config_matches_the_cpu_path(dtype, tol_logits, tol_grad):
             # rows that make dgamma / dbeta cancel heavily; bf16 rows: 1 - 26 %).
             err = float((a.grad.float().cpu() - b.grad).norm() / b.grad.norm().clamp_min(1e-30))
             assert err < tol_grad, (name, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("device_counts", [False, True], ids=["exact", "device_counts"])
+def test_dense_through_the_conv_cell_map_equals_the_row_scatter(dtype, device_counts):
+    """dense() of a regular conv's output goes through the cell -> row map its rulebook build left behind
+    (wfs_rulebook_cell_map + wfs_to_dense_mapped / _bwd_mapped: every cell written once, no zero fill).  It must equal
+    the row-parallel dense() (the same tensor with the map taken away) bit for bit, forward and backward, and the CPU
+    oracle's dense(); odd out volume per 64-cell tile (10 x 7 x 7 = 490 cells), capacity-padded rows with a device count."""
+    from oracle import spconv as osp
+    sp = _sp()
+    rng = np.random.default_rng(99)
+    B, T = 5, 30
+    idx = _waveform_like(rng, B, T)
+    n = len(idx)
+    feat = rng.standard_normal((n, 32)).astype(np.float32)
+    torch.manual_seed(4)
+    ref_conv = osp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False)
+    conv = sp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False).to(DEV)
+    conv.load_state_dict(ref_conv.state_dict())
+    fin = torch.from_numpy(feat).to(dtype)
+    if device_counts:
+        cap = n + 77
+        pi = torch.zeros((cap, 4), dtype=torch.int32, device=DEV)
+        pf = torch.full((cap, 32), float("nan"), dtype=dtype, device=DEV)
+        pi[:n], pf[:n] = torch.from_numpy(idx).to(DEV), fin.to(DEV)
+        x = sp.SparseConvTensor(pf.requires_grad_(True), pi, [14, 11, T], B)
+        x.n_valid = torch.tensor([n], dtype=torch.int64, device=DEV)
+        x.unique = True
+    else:
+        x = sp.SparseConvTensor(fin.to(DEV).requires_grad_(True), torch.from_numpy(idx).to(DEV), [14, 11, T], B)
+    y = conv(x)
+    assert y.cell_map is not None and y.cell_map[3] == 12 * 9 * 7
+    dense_map = y.dense()
+    plain = sp.SparseConvTensor(y.features, y.indices, y.spatial_shape, y.batch_size)
+    plain.unique, plain.n_valid = y.unique, y.n_valid
+    dense_rows = plain.dense()
+    assert torch.equal(dense_map, dense_rows)
+    w = torch.from_numpy(rng.standard_normal(tuple(dense_map.shape)).astype(np.float32)).to(DEV).to(dtype)
+    (g_map,) = torch.autograd.grad((dense_map.float() * w.float()).sum(), y.features, retain_graph=True)
+    (g_rows,) = torch.autograd.grad((dense_rows.float() * w.float()).sum(), y.features, retain_graph=True)
+    m = int(y.n_valid) if y.n_valid is not None else y.features.shape[0]
+    assert torch.equal(g_map[:m], g_rows[:m])
+    if dtype == torch.float32:
+        yr = ref_conv(osp.SparseConvTensor(torch.from_numpy(feat), torch.from_numpy(idx), [14, 11, T], B)).dense()
+        _assert_close(dense_map.detach().cpu().numpy(), yr.detach().numpy(), 1e-5, "dense vs oracle")

@@ -69,6 +69,10 @@ SIGNATURES = {
                                        _i32, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp]),
     "wfs_bn_relu_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
                                        _i32, _vp, _vp]),
+    "wfs_rulebook_cell_map": (ctypes.c_int, [ctypes.POINTER(Geometry), _i64, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                             c_i64p]),
+    "wfs_to_dense_mapped": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i32, _vp]),
+    "wfs_to_dense_bwd_mapped": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i32, _vp]),
     "wfs_to_dense": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "wfs_to_dense_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp, _vp]),
     "wfs_head_workspace_bytes": (_sz, [_i64, _i64, _i32]),

@@ -850,3 +850,20 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
     }
     return WFS_OK;
 }
+
+// The cell -> output row map a regular conv's build leaves in its workspace (direct-grid mode, 32-bit tickets):
+// ticket[cell] != 0xFFFFFFFF <=> the output cell is active, slot_id[cell] = its row.  Valid after wfs_rulebook_emit
+// for as long as the workspace is neither freed nor reused.
+extern "C" int wfs_rulebook_cell_map(const wfs_geometry *g, int64_t N, void *workspace, const uint32_t **ticket,
+                                     const int32_t **slot_id, int64_t *cells) {
+    if (!g || g->subm || N <= 0 || !workspace || !ticket || !slot_id) return 0;
+    Plan p;
+    make_plan(g, N, &p);
+    const bool wide = g->K <= 32 && (long long)N * g->K < (1ll << 32);
+    if (!p.tbl.direct || !wide) return 0;
+    char *ws = (char *)workspace;
+    *ticket = (const uint32_t *)(ws + p.off_ticket);
+    *slot_id = (const int32_t *)(ws + p.off_slot_id);
+    if (cells) *cells = p.cap;
+    return 1;
+}

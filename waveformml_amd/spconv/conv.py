@@ -123,6 +123,8 @@ class SparseConvolution(SparseModule):
         out_tensor.n_valid = out_n_valid
         out_tensor.prefetched = getattr(input, "prefetched", None)
         out_tensor.bn_stats = bn_request if (bn_request is not None and bn_request.stats is not None) else None
+        if not self.subm and not self.inverse:
+            out_tensor.cell_map = getattr(rb, "cell_map", None)      # dense() of THIS row set can use the build's map
         return out_tensor
 
 

@@ -385,17 +385,39 @@ class SparseConvFunction(Function):
         return dX, dW, db, None, None, None
 
 
+def _dense_map_ok(cell_map, spatial, batch_size, C, features):
+    """Shapes wfs_to_dense_mapped covers, and the map must be of THIS dense shape."""
+    v = 1
+    for s_ in spatial:
+        v *= int(s_)
+    pack = 1 if features.dtype == torch.float32 else 2
+    return (cell_map[3] == v and v % pack == 0 and C % 4 == 0 and 4 <= C <= 128 and 1 <= batch_size <= 65535
+            and features.shape[0] > 0)
+
+
 class ToDenseFunction(Function):
     """SparseConvTensor.dense(): [M, C] -> [B, C, *spatial] (A.1)."""
 
     @staticmethod
-    def forward(ctx, features, indices, spatial_shape, batch_size, unique, m_dev=None):
+    def forward(ctx, features, indices, spatial_shape, batch_size, unique, m_dev=None, cell_map=None):
         lib = _lib.load()
         features = _features_ok(features)
         indices = indices.contiguous()
         M, C = features.shape
         ndim = indices.shape[1] - 1
         spatial = [int(s) for s in spatial_shape]
+        ctx.cell_map = None
+        if cell_map is not None and unique and _dense_map_ok(cell_map, spatial, int(batch_size), C, features):
+            # the producing conv's cell -> row map: every cell written once, no zero fill, whole runs per channel
+            ticket, slot, _keep, V = cell_map
+            out = torch.empty([int(batch_size), C] + spatial, dtype=features.dtype, device=features.device)
+            _lib.check(lib.wfs_to_dense_mapped(_lib.ptr(features), ticket, slot, M, _lib.ptr(m_dev), int(batch_size), V,
+                                               C, _lib.ptr(out), _lib.dtype_code(features), _lib.stream_ptr()))
+            ctx.cell_map = cell_map
+            ctx.meta = (spatial, int(batch_size), M, C)
+            ctx.m_dev = m_dev
+            ctx.like = (features.dtype, features.device)
+            return out
         out = torch.zeros([int(batch_size), C] + spatial, dtype=features.dtype, device=features.device)
         winner = None
         if not unique:
@@ -414,14 +436,24 @@ class ToDenseFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         lib = _lib.load()
-        (indices,) = ctx.saved_tensors
         spatial, batch_size, M, C = ctx.meta
+        if ctx.cell_map is not None:
+            ticket, slot, _keep, V = ctx.cell_map
+            dtype, device = ctx.like
+            dY = grad_output.contiguous()
+            if dY.dtype != dtype:
+                dY = dY.to(dtype)
+            dX = torch.empty((M, C), dtype=dtype, device=device)     # every valid row has exactly one cell
+            _lib.check(lib.wfs_to_dense_bwd_mapped(_lib.ptr(dY), ticket, slot, M, _lib.ptr(ctx.m_dev), batch_size, V, C,
+                                                   _lib.ptr(dX), _lib.dtype_code(dX), _lib.stream_ptr()))
+            return dX, None, None, None, None, None, None
+        (indices,) = ctx.saved_tensors
         dY = grad_output.contiguous()
         dX = _rows((M, C), dY, ctx.m_dev)
         _lib.check(lib.wfs_to_dense_bwd(_lib.ptr(dY), _lib.ptr(indices), M, len(spatial), _lib.i32_array(spatial),
                                         batch_size, C, _lib.ptr(dX), _lib.dtype_code(dY), _lib.ptr(ctx.m_dev),
                                         _lib.stream_ptr()))
-        return dX, None, None, None, None, None
+        return dX, None, None, None, None, None, None
 
 
 class BatchNormReLUFunction(Function):
@@ -694,5 +726,5 @@ def indice_inverse_conv(features, filters, bias, rulebook, bn_request=None):
     return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE, bn_request)
 
 
-def to_dense(features, indices, spatial_shape, batch_size, unique, m_dev=None):
-    return ToDenseFunction.apply(features, indices, spatial_shape, batch_size, unique, m_dev)
+def to_dense(features, indices, spatial_shape, batch_size, unique, m_dev=None, cell_map=None):
+    return ToDenseFunction.apply(features, indices, spatial_shape, batch_size, unique, m_dev, cell_map)

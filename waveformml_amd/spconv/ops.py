@@ -104,6 +104,9 @@ class Rulebook(object):
         self.m_dev = None            # int64 [1]: valid output rows (SubM: n_dev itself)
         self.overflow = None         # int32 [1]: set by the build if M exceeded the output capacity
         self.ready = None            # torch.cuda.Event when the build ran on a side stream (prefetch)
+        # regular conv built on a direct grid: (ticket ptr, slot_id ptr, workspace kept alive, out volume) -- the
+        # cell -> output row map of the build, which dense() of the conv's output can use (wfs_to_dense_mapped)
+        self.cell_map = None
         self._pairs = None
         self._pair_num = None
 
@@ -307,6 +310,11 @@ def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, 
         _lib.check(lib.wfs_rulebook_emit(ctypes.byref(g), _lib.ptr(indices), N, rb.M, _lib.ptr(rb.nbr_out),
                                          _lib.ptr(rb.out_indices), _lib.ptr(rb.nbr_in), None, None, _lib.ptr(ws),
                                          ws.numel(), _lib.ptr(rb.n_dev), _lib.ptr(rb.overflow), stream))
+        if not rb.has_dup and N > 0:
+            ticket, slot, cells = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)
+            if lib.wfs_rulebook_cell_map(ctypes.byref(g), N, _lib.ptr(ws), ctypes.byref(ticket), ctypes.byref(slot),
+                                         ctypes.byref(cells)):
+                rb.cell_map = (ticket.value, slot.value, ws, int(np.prod(rb.out_spatial_shape)))
     return rb
 
 

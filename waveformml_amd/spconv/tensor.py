@@ -79,7 +79,8 @@ class SparseConvTensor(object):
 
     def dense(self, channels_first=True):
         out = Fsp.to_dense(self.features, self.indices, self.spatial_shape, self.batch_size,
-                           self.unique is True or self.n_valid is not None, self.n_valid)
+                           self.unique is True or self.n_valid is not None, self.n_valid,
+                           getattr(self, "cell_map", None))
         if channels_first:
             return out
         ndim = len(self.spatial_shape)
