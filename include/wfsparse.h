@@ -302,9 +302,11 @@ size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O);
 int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W, const float *bias, int32_t O,
                  float *Y, int32_t dtype, void *stream);
 
+/* defer (optional): as in wfs_gather_dw -- when dX and dW are both asked for, the sum over the dW partials may be left
+ * to a later wfs_dw_reduce_jobs (defer->nslabs > 0 on return; dW not written yet, the workspace must stay alive). */
 int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const float *W, int32_t O,
                  void *dX, float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes,
-                 void *stream);
+                 wfs_dw_job *defer, void *stream);
 
 /* ToDense + flatten + Linear without the dense tensor ---------------------------------------------------
  * What the reference computes at src/models/SPConvNet.py:65-68 for the last sparse layer's rows X [M, C] (dtype) with

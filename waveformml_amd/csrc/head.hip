@@ -124,6 +124,69 @@ __global__ void __launch_bounds__(TB) k_head_dw(const float *__restrict__ G, con
     for (int o = 0; o < O; ++o) store8<float>(part + ((long long)blockIdx.y * O + o) * I + i, acc[o]);
 }
 
+// dX and the dW partials in ONE launch: blockIdx.y < B serves batch row y of dX, the next NCHUNK values of y the dW
+// chunks (same bodies as k_head_dx / k_head_dw); the first dW block also takes the bias gradient dB[o] = sum_b G[b][o].
+template <typename T, int O>
+__global__ void __launch_bounds__(TB) k_head_bwd(const float *__restrict__ G, const float *__restrict__ W,
+                                                 const T *__restrict__ X, T *__restrict__ dX, float *__restrict__ part,
+                                                 float *__restrict__ dB, long long B, long long I, int rows_per_chunk,
+                                                 int dx_rows) {
+    const long long i = ((long long)blockIdx.x * TB + threadIdx.x) * 8;
+    if ((int)blockIdx.y < dx_rows) {
+        if (i >= I) return;
+        const long long b = blockIdx.y;
+        float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float g = G[b * O + o];
+            float wv[8];
+            load8<float>(W + (long long)o * I + i, wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = fmaf(g, wv[e], out[e]);
+        }
+        store8<T>(dX + b * I + i, out);
+        return;
+    }
+    const int chunk = (int)blockIdx.y - dx_rows;
+    if (dB && chunk == 0 && blockIdx.x == 0) {          // all TB threads: strided rows, butterfly, waves in wave order
+        __shared__ float sdb[TB / 64][MAXO];
+        for (int o = 0; o < O; ++o) {
+            float v = 0.f;
+            for (long long b = threadIdx.x; b < B; b += TB) v += G[b * O + o];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((threadIdx.x & 63) == 0) sdb[threadIdx.x >> 6][o] = v;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < O) {
+            float v = 0.f;
+            for (int w = 0; w < TB / 64; ++w) v += sdb[w][threadIdx.x];
+            dB[threadIdx.x] = v;
+        }
+    }
+    if (i >= I) return;
+    const long long b0 = (long long)chunk * rows_per_chunk;
+    const long long b1 = b0 + rows_per_chunk < B ? b0 + rows_per_chunk : B;
+    float acc[O][8];
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+#pragma unroll 4
+    for (long long b = b0; b < b1; ++b) {
+        float xv[8];
+        load8<T>(X + b * I + i, xv);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float g = G[b * O + o];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(g, xv[e], acc[o][e]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) store8<float>(part + ((long long)chunk * O + o) * I + i, acc[o]);
+}
+
 // also the bias gradient dB[o] = sum_b G[b][o] (block 0; saves the caller a reduction launch)
 __global__ void k_head_dw_reduce(const float *__restrict__ part, int nchunk, long long OI, float *__restrict__ dW,
                                  const float *__restrict__ G, long long B, int O, float *__restrict__ dB) {
@@ -457,7 +520,8 @@ extern "C" int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W,
 }
 
 extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const float *W, int32_t O, void *dX,
-                            float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
+                            float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes,
+                            wfs_dw_job *defer, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
@@ -467,6 +531,30 @@ extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I,
     }
     WFS_REQUIRE(X && G && W, WFS_EINVAL, "NULL device pointer");
     const unsigned gx = (unsigned)wfs_cdiv(I, TB * 8);
+    if (defer) *defer = wfs_dw_job{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
+    if (dX && dW && B + 16 <= 65535) {
+        // one launch for dX and the dW partials (+ dB); the reduction over the partials runs now, or later as one of the
+        // caller's deferred jobs (wfs_dw_reduce_jobs)
+        const int nchunk = head_chunks(B);
+        WFS_REQUIRE(workspace && workspace_bytes >= wfs_head_workspace_bytes(B, I, O), WFS_EWORKSPACE, "workspace too small");
+        const int rpc = (int)wfs_cdiv(B, nchunk);
+        dim3 grid(gx, (unsigned)(B + nchunk)), block(TB);
+        float *part = (float *)workspace;
+#define WFS_HEAD_BWD(T)                                                                                              \
+    WFS_HEAD_DISPATCH(O, (k_head_bwd<T, OO><<<grid, block, 0, stream>>>(G, W, (const T *)X, (T *)dX, part, dB, B, I, rpc, \
+                                                                       (int)B)))
+        if (dtype == WFS_F32) { WFS_HEAD_BWD(float); } else if (dtype == WFS_BF16) { WFS_HEAD_BWD(wfs_bf16); } else { WFS_HEAD_BWD(wfs_f16); }
+#undef WFS_HEAD_BWD
+        WFS_LAUNCH_CHECK();
+        const long long OI = (long long)O * I;
+        if (defer) {
+            *defer = wfs_dw_job{part, nchunk, OI, 1, 1, 1, 0, dW};
+            return WFS_OK;
+        }
+        k_head_dw_reduce<<<dim3((unsigned)wfs_cdiv(OI, TB)), dim3(TB), 0, stream>>>(part, nchunk, OI, dW, G, B, O, nullptr);
+        WFS_LAUNCH_CHECK();
+        return WFS_OK;
+    }
     if (dX) {
         dim3 grid(gx, (unsigned)B), block(TB);
         if (dtype == WFS_F32) {

@@ -577,8 +577,13 @@ class SkinnyLinearFunction(Function):
         ws = torch.empty((max(int(lib.wfs_head_workspace_bytes(B, I, O)), 1),), dtype=torch.uint8, device=x.device)
         want_db = bias is not None and ctx.needs_input_grad[2]
         db = grad_like(bias, (O,)) if (want_db and dw is not None) else None
+        defer = _DEFERRED_DW is not None and dw is not None and dw._base is not None and dx is not None
+        job = _lib.DwJob() if defer else None
         _lib.check(lib.wfs_head_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
-                                    _lib.dtype_code(x), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+                                    _lib.dtype_code(x), _lib.ptr(ws), ws.numel(), ctypes.byref(job) if defer else None,
+                                    _lib.stream_ptr()))
+        if defer and job.nslabs > 0:
+            _DEFERRED_DW.append((job, ws))          # the sum over the dW partials joins the pass's deferred reductions
         if want_db and db is None:
             db = g.sum(0)
         return dx, (dw.to(weight.dtype) if dw is not None else None), (db.to(bias.dtype) if db is not None else None)
