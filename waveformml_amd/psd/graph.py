@@ -20,8 +20,15 @@ def _round_up(v, m):
 
 
 class GraphedTrainStep(object):
-    def __init__(self, module, optimizer, reducer, example_batch, headroom=1.25, granule=None, warmup=2):
+    def __init__(self, module, optimizer, reducer, example_batch, headroom=None, granule=None, warmup=2):
+        # headroom: row capacities = headroom x the example batch's row counts.  Capacity is not free (the
+        # register-resident BatchNorm kernels and the rulebook grids are sized by it: 1.25 -> 1.12 measured -4 % per
+        # step).  The voxel count of an E-event PSD batch varies by sigma ~ 0.5 / sqrt(E) of its mean (3.1 % at 256
+        # events: psd/synthetic, 40 batches), so the default is 6 sigma above the example batch: 1 + 3 / sqrt(E), i.e.
+        # 1.19 at 256 events.  A batch beyond a capacity is detected (check()), never silently cut.
         (coords, feats), labels = example_batch
+        if headroom is None:
+            headroom = max(1.1, 1.0 + 3.0 / max(1.0, float(labels.shape[0])) ** 0.5)
         if granule is None:
             # capacities are rounded up to a granule; padded rows cost real work in the wide-channel (GEMM route) layers
             # of the 2-D nets, whose batches are a few hundred rows, so the granule follows the batch
