@@ -33,7 +33,7 @@ class GraphedTrainStep(object):
             # capacities are rounded up to a granule; padded rows cost real work in the wide-channel (GEMM route) layers
             # of the 2-D nets, whose batches are a few hundred rows, so the granule follows the batch
             n0 = int(coords.shape[0])
-            granule = 4096 if n0 >= 32768 else (256 if n0 >= 2048 else 64)
+            granule = 512 if n0 >= 32768 else (256 if n0 >= 2048 else 64)
         assert coords.is_cuda and feats.is_cuda and labels.is_cuda
         self.module, self.optimizer, self.reducer = module, optimizer, reducer
         dev = coords.device
