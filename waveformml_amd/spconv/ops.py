@@ -34,10 +34,10 @@ PREFETCH_RULEBOOKS = False
 OVERLAP_DW = False
 
 # conv -> nn.BatchNorm1d (training) inside SparseSequential: the conv kernel's epilogue can take the batch statistics
-# (functional.BatchNormRequest; include/wfsparse.h wfs_gather_conv_bnstats), which saves BatchNorm's read of the conv
-# output.  Same results either way.  OFF by default: at the PSD batch sizes (256 events, ~10^5 voxels) the epilogue
-# costs the latency-bound conv kernel more (+4 us) than the 6 us reduction launch it replaces saves once the fold
-# launch is counted (measured: 0.834 vs 0.814 ms/step, profiles/r01_e_*); it pays when the rows no longer fit the L2s.
+# (functional.BatchNormRequest; include/wfsparse.h wfs_gather_conv_bnstats + wfs_bn_apply_fwd_fold), which saves
+# BatchNorm's reduction launch and its read of the conv output.  Same results either way.  OFF by default: at the PSD
+# batch sizes (256 events, ~10^5 voxels) it measured slower in a same-box A/B (0.647 vs 0.638 ms/step, DESIGN.md 4
+# "measured dead ends"); it should pay when the rows no longer fit the L2s.
 FUSE_CONV_BN_STATS = os.environ.get("WFS_FUSE_CONV_BN_STATS", "0") != "0"
 
 _SIDE_STREAMS = {}
