@@ -1259,3 +1259,40 @@ def test_dense_through_the_conv_cell_map_equals_the_row_scatter(dtype, device_co
     if dtype == torch.float32:
         yr = ref_conv(osp.SparseConvTensor(torch.from_numpy(feat), torch.from_numpy(idx), [14, 11, T], B)).dense()
         _assert_close(dense_map.detach().cpu().numpy(), yr.detach().numpy(), 1e-5, "dense vs oracle")
+
+
+def test_trainer_with_captured_steps_follows_the_eager_trainer():
+    """Trainer(capture=True): the fit loop replays one captured HIP graph per step (psd/graph.GraphedTrainStep).  The
+    capture's own calibration / warm-up steps must leave no trace (parameters, BatchNorm buffers and momentum are
+    restored), so six steps over six different batches end where the eager trainer ends (update sizes within 2e-3, see
+    test_graph_captured_step_matches_eager_steps); a batch larger than the captured capacity takes an eager step."""
+    import copy
+    from waveformml_amd.psd import data
+    from waveformml_amd.psd.trainer import Trainer
+    T = 64
+    ds = data.SyntheticPulseDataset(6, 24, T, n_type=3, layout="3d", seed=77)
+    loader = data.make_loader(ds, 1, shuffle=False, pin_memory=False)
+
+    def run(capture):
+        mod = _c2_module(T, 32 * 10 * 7 * 4)
+        start = copy.deepcopy(mod.state_dict())
+        tr = Trainer(max_epochs=1, device=DEV, capture=capture, check_every=2)
+        hist = tr.fit(mod, loader)
+        return mod, start, hist, tr
+
+    mod_e, start, hist_e, _ = run(False)
+    mod_g, _, hist_g, tr = run(True)
+    assert tr._graph is not None and tr.eager_fallbacks == 0
+    assert abs(hist_g[0]["train_loss"] - hist_e[0]["train_loss"]) <= 1e-4 * abs(hist_e[0]["train_loss"])
+    sd_e, sd_g = mod_e.state_dict(), mod_g.state_dict()
+    for name in sd_e:
+        a, b, p0 = sd_e[name].float().cpu(), sd_g[name].float().cpu(), start[name].float().cpu()
+        if a.numel() == 1 and "num_batches_tracked" in name:
+            assert int(a) == int(b) == 6, (name, int(a), int(b))          # warm-up steps of the capture left no trace
+            continue
+        _assert_close((b - p0).numpy(), (a - p0).numpy(), 2e-3, name)
+    # batches that do not fit the captured step (twice the events): ordinary eager steps, training goes on
+    mixed = [b for b in loader][:2] + [b for b in data.make_loader(ds, 2, shuffle=False, pin_memory=False)][:2]
+    tr2 = Trainer(max_epochs=1, device=DEV, capture=True)
+    tr2.fit(mod_g, mixed)
+    assert tr2.eager_fallbacks == 2 and np.isfinite(tr2.history[-1]["train_loss"])
