@@ -1296,3 +1296,51 @@ def test_trainer_with_captured_steps_follows_the_eager_trainer():
     tr2 = Trainer(max_epochs=1, device=DEV, capture=True)
     tr2.fit(mod_g, mixed)
     assert tr2.eager_fallbacks == 2 and np.isfinite(tr2.history[-1]["train_loss"])
+
+
+def test_captured_evaluation_matches_the_eager_loops():
+    """psd/graph.GraphedEvalStep behind evaluate.test_loop(capture=True) and occlusion_sweep(capture=True): the eval-mode
+    forward as replays of a captured graph (sweeps: rulebooks built by the first pass, a forward-only graph for every
+    further occluded column) gives the losses / accuracies of the eager loops -- 3-D C2 net over several batches, one of
+    them too large for the capture (eager fallback), and the 2-D GEP net for the sweep."""
+    import copy
+    import json
+    from waveformml_amd.psd import data, synthetic
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.evaluate import occlusion_sweep, test_loop
+    from waveformml_amd.psd.lit import LitPSD
+    sp = _sp()
+    T = 64
+    mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
+    with torch.no_grad():                                  # non-trivial running statistics for eval mode
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    ds = data.SyntheticPulseDataset(5, 24, T, n_type=3, layout="3d", seed=31)
+    batches = [b for b in data.make_loader(ds, 1, shuffle=False, pin_memory=False)]
+    batches.append([b for b in data.make_loader(ds, 2, shuffle=False, pin_memory=False)][0])      # 48 events: no fit
+    eager = test_loop(mod, batches, DEV)
+    graphed = test_loop(mod, batches, DEV, capture=True)
+    assert graphed["events"] == eager["events"] == 5 * 24 + 48
+    assert abs(graphed["test_loss"] - eager["test_loss"]) <= 1e-5 * abs(eager["test_loss"]), (graphed, eager)
+    assert graphed["test_acc"] == eager["test_acc"]
+    mod.occlude_index = 1
+    assert abs(test_loop(mod, batches, DEV, capture=True)["test_loss"] - test_loop(mod, batches, DEV)["test_loss"]) <= 1e-5
+    mod.occlude_index = None
+    # occlusion sweep on the 2-D net
+    cfg = json.load(open(os.path.join(HERE, "golden", "gep_config.json")))
+    torch.manual_seed(8)
+    gep = LitPSD(load_config(copy.deepcopy(cfg))).to(DEV)
+    c, f, y = synthetic.generate(12, 150, 3, seed=4, layout="2d")
+    batch = ([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV))
+    indices = [None, 0, 17, 150, 299]
+    want = occlusion_sweep(gep, batch, indices)
+    n0 = sp.ops.BUILD_COUNT
+    got = occlusion_sweep(gep, batch, indices, capture=True)
+    for idx in indices:
+        assert abs(got[idx]["test_loss"] - want[idx]["test_loss"]) <= 1e-5 * abs(want[idx]["test_loss"]), (idx, got[idx], want[idx])
+        assert got[idx]["test_acc"] == want[idx]["test_acc"]
+    assert got[17]["test_loss"] != got[None]["test_loss"]
+    # calibration (2 builds, exact sizes) + 2 builds in device-count mode; every later pass and the forward-only capture hit the cache
+    assert sp.ops.BUILD_COUNT - n0 == 4, sp.ops.BUILD_COUNT - n0

@@ -14,30 +14,67 @@ from ..spconv import ops
 from .data import to_device
 
 
+def _score(module, logits, labels):
+    """test_loss / test_acc of reference LitPSD.test_step (:136-141) from the logits."""
+    loss = module.criterion.forward(logits, labels)
+    pred = torch.argmax(module.softmax(logits), dim=1)
+    return loss.detach().float(), (pred == labels).float().mean()          # device scalars: no host sync per batch
+
+
 @torch.no_grad()
-def test_loop(module, loader, device, feature_dtype=None):
+def test_loop(module, loader, device, feature_dtype=None, capture=False):
+    """``capture=True``: the forward runs as replays of one captured HIP graph (psd/graph.GraphedEvalStep); a batch that
+    does not fit the captured capacities takes the ordinary ``test_step``."""
     module.to(device)
     module.eval()
-    tot, acc, n = 0.0, 0.0, 0
+    tot, acc, n = 0.0, 0.0, 0          # tot / acc become device scalars: one read-back at the end of the loop
+    step = None
     for i, batch in enumerate(loader):
         batch = to_device(batch, device, feature_dtype)
-        res = module.test_step(batch, i)
         b = int(batch[1].shape[0])
-        tot += float(res["test_loss"]) * b
-        acc += float(res["test_acc"]) * b
+        if capture:
+            if step is None:
+                from .graph import GraphedEvalStep
+                step = GraphedEvalStep(module, batch)
+            if step.fits(batch):
+                loss, a = _score(module, step(batch, module.occlude_index), batch[1])
+                tot, acc, n = tot + loss * b, acc + a * b, n + b
+                continue
+        res = module.test_step(batch, i)
+        tot = tot + res["test_loss"].detach().float() * b
+        acc = acc + res["test_acc"].detach().float() * b
         n += b
-    return {"test_loss": tot / max(n, 1), "test_acc": acc / max(n, 1), "events": n}
+    if step is not None:
+        step.check()
+    return {"test_loss": float(tot) / max(n, 1), "test_acc": float(acc) / max(n, 1), "events": n}
 
 
 @torch.no_grad()
-def occlusion_sweep(module, batch, occlude_indices):
+def occlusion_sweep(module, batch, occlude_indices, capture=False):
     """{index: {"test_loss", "test_acc"}} for one device-resident batch ``([coords, feats], labels)``.
     ``None`` in ``occlude_indices`` is the unoccluded pass.  Index 0 is passed through as it is: the reference's
-    ``if self.occlude_index:`` treats it as "no occlusion" (LitPSD.py:134), and so does the mirror."""
+    ``if self.occlude_index:`` treats it as "no occlusion" (LitPSD.py:134), and so does the mirror.
+    ``capture=True``: one captured graph builds the batch's rulebooks and runs the first pass, a second, forward-only
+    graph is replayed for every further index (psd/graph.GraphedEvalStep(sweep=True))."""
     (coords, feats), labels = batch
     module.eval()
-    saved = module.occlude_index
     out = {}
+    if capture and len(occlude_indices) > 0:
+        from .graph import GraphedEvalStep
+        step = GraphedEvalStep(module, batch, sweep=True)
+        try:
+            scores = []
+            for n, idx in enumerate(occlude_indices):
+                logits = step(batch, idx) if n == 0 else step.rerun(idx)
+                scores.append(torch.stack(_score(module, logits, labels)))
+            host = torch.stack(scores).cpu()              # one read-back for the whole sweep
+            for idx, row in zip(occlude_indices, host):
+                out[idx] = {"test_loss": float(row[0]), "test_acc": float(row[1])}
+            step.check()
+        finally:
+            step.close()
+        return out
+    saved = module.occlude_index
     try:
         with ops.reuse_rulebooks():
             for idx in occlude_indices:

@@ -151,3 +151,127 @@ class GraphedTrainStep(object):
         """Synchronises; raises if any strided layer produced more rows than its capacity in the last step."""
         if self._overflow and bool(torch.stack([o.reshape(()) for o in self._overflow]).any().item()):
             raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
+
+
+class GraphedEvalStep(object):
+    """Forward-only counterpart for the inference loops (validation, ``test_step``, the occlusion study): the eval-mode
+    forward of ``module.model`` -- rulebook builds included -- captured once over capacity-padded buffers and replayed per
+    batch.  ``logits = step(batch)`` returns the STATIC logits tensor (consume it before the next call).
+
+    ``sweep=True`` additionally captures a forward that REUSES the loaded batch's rulebooks (spconv.ops.reuse_rulebooks:
+    geometry is a function of the coordinates only), for evaluating one batch many times with different features --
+    the reference's occlusion study zeroes one feature column per pass (scripts/RunOcclusionStudy.py ->
+    Evaluate.py --occlude -> LitPSD.test_step, src/engineering/LitPSD.py:133-135):
+
+        step = GraphedEvalStep(module, batch, sweep=True)
+        base = step(batch).clone()                     # rulebooks + forward
+        for idx in columns:
+            logits = step.rerun(occlude_index=idx)     # forward only, column idx of the batch's features zeroed
+    """
+
+    def __init__(self, module, example_batch, headroom=None, granule=None, sweep=False):
+        from ..spconv import ops
+        (coords, feats), labels = example_batch
+        assert coords.is_cuda and feats.is_cuda
+        self.module = module
+        dev = coords.device
+        if headroom is None:
+            headroom = max(1.1, 1.0 + 3.0 / max(1.0, float(labels.shape[0])) ** 0.5)
+        if granule is None:
+            n0 = int(coords.shape[0])
+            granule = 512 if n0 >= 32768 else (256 if n0 >= 2048 else 64)
+        self.n_cap = _round_up(headroom * coords.shape[0], granule)
+        self.coords = torch.zeros((self.n_cap, coords.shape[1]), dtype=coords.dtype, device=dev)
+        self.feats = torch.zeros((self.n_cap, feats.shape[1]), dtype=feats.dtype, device=dev)
+        self.feats_loaded = torch.zeros_like(self.feats) if sweep else None     # the batch's own features (sweeps)
+        self.labels = torch.zeros_like(labels)
+        self.n_valid = torch.zeros((1,), dtype=torch.int64, device=dev)
+        net = getattr(module, "model", None)
+        perm = getattr(net, "permute_tensor", None)
+        self._perm = [int(v) for v in perm.tolist()] if perm is not None else None
+        self.indices = torch.zeros_like(self.coords) if self._perm is not None else None
+        self._convs = [m for m in module.modules()
+                       if hasattr(m, "subm") and hasattr(m, "conv1x1") and not m.subm and not m.conv1x1 and not m.inverse]
+        if torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):     # see GraphedTrainStep "Stream discipline"
+            st = torch.cuda.Stream(dev)
+            st.wait_stream(torch.cuda.default_stream(dev))
+            torch.cuda.set_stream(st)
+        self.stream = torch.cuda.current_stream(dev)
+        self.n_events = int(labels.shape[0])
+        was_training = module.training
+        module.eval()
+        self._reuse = None
+        try:
+            with torch.no_grad():
+                # calibration: an ordinary exact-size forward tells how many rows each strided layer produces
+                if hasattr(net, "batch_size_hint"):
+                    net.batch_size_hint = self.n_events
+                net([coords, feats])
+                for m in self._convs:
+                    m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
+                if self.indices is not None:
+                    net.batch_first_indices = (self.coords, self.indices)
+                self._load(example_batch)
+                if sweep:
+                    self._reuse = ops.reuse_rulebooks()          # stays open for the life of this runner
+                    self._reuse.__enter__()
+                for _ in range(2):
+                    self._forward()
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.logits = self._forward()
+                self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
+                self.graph_fwd = None
+                if sweep:
+                    # second capture inside the same reuse context: every rulebook build is a cache hit (same static
+                    # index buffers, same geometry) -> a graph of the forward kernels alone
+                    before = ops.BUILD_COUNT
+                    self.graph_fwd = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_fwd, stream=self.stream):
+                        self.logits_fwd = self._forward()
+                    assert ops.BUILD_COUNT == before, "the forward-only capture rebuilt a rulebook"
+        finally:
+            module.train(was_training)
+
+    def _forward(self):
+        net = self.module.model
+        if hasattr(net, "batch_size_hint"):
+            net.batch_size_hint = self.n_events
+        return net([self.coords, self.feats, self.n_valid]).float()
+
+    _load = GraphedTrainStep._load
+
+    def fits(self, batch):
+        (coords, _f), labels = batch
+        return coords.shape[0] <= self.n_cap and tuple(labels.shape) == tuple(self.labels.shape)
+
+    def __call__(self, batch, occlude_index=None):
+        if torch.cuda.current_stream(self.coords.device) == torch.cuda.default_stream(self.coords.device):
+            torch.cuda.set_stream(self.stream)
+        self._load(batch)
+        if self.feats_loaded is not None:
+            self.feats_loaded.copy_(self.feats)
+        if occlude_index:                          # falsy for index 0, exactly as the reference (LitPSD.py:134)
+            self.feats[:, occlude_index] = 0
+        self.graph.replay()
+        return self.logits
+
+    def rerun(self, occlude_index=None):
+        """The loaded batch again through the forward-only graph, with one feature column zeroed (None / 0: none)."""
+        if self.graph_fwd is None:
+            raise RuntimeError("GraphedEvalStep(..., sweep=True) captures the forward-only graph that rerun() replays")
+        self.feats.copy_(self.feats_loaded)
+        if occlude_index:
+            self.feats[:, occlude_index] = 0
+        self.graph_fwd.replay()
+        return self.logits_fwd
+
+    def check(self):
+        if self._overflow and bool(torch.stack([o.reshape(()) for o in self._overflow]).any().item()):
+            raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
+
+    def close(self):
+        if self._reuse is not None:
+            self._reuse.__exit__(None, None, None)
+            self._reuse = None
