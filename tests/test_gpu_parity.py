@@ -1277,13 +1277,15 @@ def test_trainer_with_captured_steps_follows_the_eager_trainer():
         mod = _c2_module(T, 32 * 10 * 7 * 4)
         start = copy.deepcopy(mod.state_dict())
         tr = Trainer(max_epochs=1, device=DEV, capture=capture, check_every=2)
-        hist = tr.fit(mod, loader)
+        hist = tr.fit(mod, loader, val_loader=loader)
         return mod, start, hist, tr
 
     mod_e, start, hist_e, _ = run(False)
     mod_g, _, hist_g, tr = run(True)
     assert tr._graph is not None and tr.eager_fallbacks == 0
     assert abs(hist_g[0]["train_loss"] - hist_e[0]["train_loss"]) <= 1e-4 * abs(hist_e[0]["train_loss"])
+    assert abs(hist_g[0]["val_loss"] - hist_e[0]["val_loss"]) <= 1e-3 * abs(hist_e[0]["val_loss"])       # captured validation
+    assert abs(hist_g[0]["val_acc"] - hist_e[0]["val_acc"]) <= 1.0 / 144 + 1e-9
     sd_e, sd_g = mod_e.state_dict(), mod_g.state_dict()
     for name in sd_e:
         a, b, p0 = sd_e[name].float().cpu(), sd_g[name].float().cpu(), start[name].float().cpu()

@@ -110,6 +110,12 @@ class Trainer(object):
 
     @torch.no_grad()
     def validate(self, module, loader):
+        if self.capture and not module.occlude_index:
+            # same numbers as validation_step (loss + accuracy of the eval-mode forward), from replays of a captured
+            # forward (psd/graph.GraphedEvalStep)
+            from .evaluate import test_loop
+            r = test_loop(module, loader, self.device, self.feature_dtype, capture=True)
+            return {"val_loss": r["test_loss"], "val_acc": r["test_acc"]}
         module.eval()
         tot, n, acc = 0.0, 0, 0.0
         for i, batch in enumerate(loader):
