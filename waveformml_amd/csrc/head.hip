@@ -41,16 +41,17 @@ __device__ __forceinline__ void store8(T *p, const float *v) {
 }
 
 // one block per batch row; I % 8 == 0
-template <typename T, int O>
-__global__ void __launch_bounds__(TB) k_head_fwd(const T *__restrict__ X, const float *__restrict__ W,
+// NT threads per batch row: 1024 for long rows (four times the loads in flight per row; the row's 17 passes become 5)
+template <typename T, int O, int NT>
+__global__ void __launch_bounds__(NT) k_head_fwd(const T *__restrict__ X, const float *__restrict__ W,
                                                  const float *__restrict__ bias, float *__restrict__ Y, long long I) {
-    __shared__ float red[TB / 64][O];
+    __shared__ float red[NT / 64][O];
     const long long b = blockIdx.x;
     float acc[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) acc[o] = 0.f;
     const T *x = X + b * I;
-    for (long long i = (long long)threadIdx.x * 8; i < I; i += TB * 8) {
+    for (long long i = (long long)threadIdx.x * 8; i < I; i += NT * 8) {
         float xv[8];
         load8<T>(x + i, xv);
 #pragma unroll
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(TB) k_head_fwd(const T *__restrict__ X, const 
     if (threadIdx.x < O) {
         float v = bias ? bias[threadIdx.x] : 0.f;
 #pragma unroll
-        for (int w = 0; w < TB / 64; ++w) v += red[w][threadIdx.x];
+        for (int w = 0; w < NT / 64; ++w) v += red[w][threadIdx.x];
         Y[b * O + threadIdx.x] = v;
     }
 }
@@ -507,14 +508,15 @@ extern "C" int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W,
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (B == 0) return WFS_OK;
     WFS_REQUIRE(X && W && Y, WFS_EINVAL, "NULL device pointer");
-    dim3 grid((unsigned)B), block(TB);
-    if (dtype == WFS_F32) {
-        WFS_HEAD_DISPATCH(O, (k_head_fwd<float, OO><<<grid, block, 0, stream>>>((const float *)X, W, bias, Y, I)));
-    } else if (dtype == WFS_BF16) {
-        WFS_HEAD_DISPATCH(O, (k_head_fwd<wfs_bf16, OO><<<grid, block, 0, stream>>>((const wfs_bf16 *)X, W, bias, Y, I)));
+    dim3 grid((unsigned)B);
+#define WFS_HEAD_FWD(T, NT)                                                                                          \
+    WFS_HEAD_DISPATCH(O, (k_head_fwd<T, OO, NT><<<grid, dim3(NT), 0, stream>>>((const T *)X, W, bias, Y, I)))
+    if (I >= 8192) {
+        if (dtype == WFS_F32) { WFS_HEAD_FWD(float, 1024); } else if (dtype == WFS_BF16) { WFS_HEAD_FWD(wfs_bf16, 1024); } else { WFS_HEAD_FWD(wfs_f16, 1024); }
     } else {
-        WFS_HEAD_DISPATCH(O, (k_head_fwd<wfs_f16, OO><<<grid, block, 0, stream>>>((const wfs_f16 *)X, W, bias, Y, I)));
+        if (dtype == WFS_F32) { WFS_HEAD_FWD(float, 256); } else if (dtype == WFS_BF16) { WFS_HEAD_FWD(wfs_bf16, 256); } else { WFS_HEAD_FWD(wfs_f16, 256); }
     }
+#undef WFS_HEAD_FWD
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
