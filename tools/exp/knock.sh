@@ -1,6 +1,7 @@
 #!/bin/bash
-# per-phase knock-outs of k_gconv32_bf16 (builds of conv_mfma.hip with -DWFS_KNOCK=bits: 1 no filter staging, 2 no table
-# reads, 4 no gathers / MFMA, 8 no stores), timed by tools/microbench_conv.py inside a replayed graph
+# per-phase knock-outs of k_gconv32_bf16 (`make -C waveformml_amd/csrc knock` builds conv_mfma.hip with -DWFS_KNOCK=bits:
+# 1 no filter staging, 2 no table reads, 4 no gathers / MFMA, 8 no stores), timed by tools/microbench_conv.py inside a
+# replayed graph
 cd "$(dirname "$0")/../.."
 for kn in base 1 2 4 8 6 14 15; do
   if [ $kn = base ]; then unset WFS_LIB; else export WFS_LIB=$PWD/tools/exp/k$kn/libwfsparse.so; fi

@@ -203,6 +203,12 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
     return v;
 }
 
+// Timing knock-outs (tools/exp/knock.sh, profiles/r01_gconv32_bf16_knockouts.txt): -DWFS_KNOCK=bits builds a library
+// whose k_gconv32_bf16 skips a phase -- 1 filter staging, 2 table reads, 4 gathers + MFMA, 8 stores -- to measure what
+// each phase costs inside a replayed graph.  Results are wrong by construction; 0 (the default) compiles to nothing.
+#ifndef WFS_KNOCK
+#define WFS_KNOCK 0
+#endif
 template <typename H, bool TRANSPOSE_W, bool STATS>
 __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
@@ -220,6 +226,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
     // before the first conversion, so a block pays one memory round trip per batch instead of one per fragment
     constexpr int WSB = 5;
     const int nfrag = K * 128;
+    if (!(WFS_KNOCK & 1))
     for (int u0 = threadIdx.x; u0 < nfrag; u0 += nthreads * WSB) {
         float w[WSB][8];
 #pragma unroll
@@ -269,7 +276,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             int kk = k < K ? k : K - 1;
-            v[k] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+            v[k] = (WFS_KNOCK & 2) ? -1 : table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
         }
         unsigned mask = 0;
 #pragma unroll
@@ -284,6 +291,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = bj;
         // ---- phase 2 (the wave's own LDS writes above are visible to its later reads: same wave, in order)
+        if (WFS_KNOCK & 4) mask = 0;
         while (mask != 0) {
             int ks[BF_GROUP];
             uint4 a_lo[BF_GROUP], a_hi[BF_GROUP];
@@ -324,7 +332,8 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
             unsigned packed = (lane & 1) ? wfs_pack2<H>(got, mine1) : wfs_pack2<H>(mine0, got);
             int ri = (lane & 1) ? i + 1 : i;
             long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
-            if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
+            if (!(WFS_KNOCK & 8) || packed == 0x12345678u)
+                if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
         }
         if constexpr (STATS) {
             float vals[16];
