@@ -321,7 +321,7 @@ def main():
     # synthetic events are distinct in-range sites by construction (psd/synthetic.py): skip the index validation
     # read-backs, exactly as spconv (which never validates) does
     _ops.ASSUME_VALID_UNIQUE_INDICES = True
-    _ops.PREFETCH_RULEBOOKS = True        # strided layers' rulebooks build on a side stream beside the first layers
+    _ops.PREFETCH_RULEBOOKS = os.environ.get("WFS_PREFETCH", "1") != "0"    # strided layers' rulebooks on a side stream beside the first layers
     # _ops.OVERLAP_DW stays off: dW and dX each fill the CUs' LDS; side by side they just take twice as long
     if os.environ.get("WFS_OVERLAP_DW") == "1":
         _ops.OVERLAP_DW = True
