@@ -1346,3 +1346,53 @@ def test_captured_evaluation_matches_the_eager_loops():
     assert got[17]["test_loss"] != got[None]["test_loss"]
     # calibration (2 builds, exact sizes) + 2 builds in device-count mode; every later pass and the forward-only capture hit the cache
     assert sp.ops.BUILD_COUNT - n0 == 4, sp.ops.BUILD_COUNT - n0
+
+
+def test_reducer_pack_with_gradients_partly_in_place():
+    """FlatGradAllReducer._pack: the HIP operators write their parameters' gradients straight into the flat buffer
+    (spconv/functional.grad_like), torch-side gradients (a conv bias: column sum of dY) arrive as separate tensors, and a
+    parameter that took no part gets zeros -- the flat buffer must equal the per-parameter gradients of an unflattened
+    twin, with and without deferred weight-gradient reductions."""
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    from waveformml_amd.spconv import functional as Fsp
+    sp = _sp()
+    rng = np.random.default_rng(3)
+    B, T = 4, 32
+    idx = _waveform_like(rng, B, T)
+    feat = torch.from_numpy(rng.standard_normal((len(idx), 2)).astype(np.float32)).to(DEV)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = sp.SparseSequential(
+                sp.SubMConv3d(2, 32, 3, 1, 0, 1, 1, False, "k"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+                sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, True, "k"), torch.nn.ReLU())      # bias=True: a torch-side gradient
+            self.unused = torch.nn.Parameter(torch.ones(5))                              # never reached by backward
+
+        def forward(self, x):
+            return self.body(x).features.float().square().mean()
+
+    torch.manual_seed(9)
+    twin = Net().to(DEV)
+    net = Net().to(DEV)
+    net.load_state_dict(twin.state_dict())
+    x = lambda: sp.SparseConvTensor(feat, torch.from_numpy(idx).to(DEV), [14, 11, T], B)      # noqa: E731
+    twin(x()).backward()
+    want = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in twin.named_parameters()}
+    red = FlatGradAllReducer(net.parameters(), world_size=1)
+    for deferred in (False, True):
+        red.flat_grad.fill_(float("nan"))
+        red.reset()
+        Fsp.defer_dw(deferred)
+        try:
+            net(x()).backward()
+            red.pack_all()
+        finally:
+            Fsp.defer_dw(False)
+        in_place = 0
+        for i, (n, p) in enumerate(net.named_parameters()):
+            o, cnt = red.slices[i]
+            got = red.flat_grad[o:o + cnt].view_as(p)
+            _assert_close(got.cpu().numpy(), want[n].cpu().numpy(), 1e-6, "%s (deferred=%s)" % (n, deferred))
+            in_place += int(p.grad is not None and p.grad.data_ptr() == got.data_ptr())
+        assert in_place >= 4, in_place            # two conv weights, BatchNorm weight and bias were written in place
