@@ -1215,9 +1215,10 @@ def test_c4_deep_stack_config_matches_the_cpu_path(dtype, tol_logits, tol_grad):
             assert err < tol_grad, (name, err)
 
 
+@pytest.mark.parametrize("cout", [32, 12], ids=["c32", "c12"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("device_counts", [False, True], ids=["exact", "device_counts"])
-def test_dense_through_the_conv_cell_map_equals_the_row_scatter(dtype, device_counts):
+def test_dense_through_the_conv_cell_map_equals_the_row_scatter(dtype, device_counts, cout):
     """dense() of a regular conv's output goes through the cell -> row map its rulebook build left behind
     (wfs_rulebook_cell_map + wfs_to_dense_mapped / _bwd_mapped: every cell written once, no zero fill).  It must equal
     the row-parallel dense() (the same tensor with the map taken away) bit for bit, forward and backward, and the CPU
@@ -1230,8 +1231,8 @@ def test_dense_through_the_conv_cell_map_equals_the_row_scatter(dtype, device_co
     n = len(idx)
     feat = rng.standard_normal((n, 32)).astype(np.float32)
     torch.manual_seed(4)
-    ref_conv = osp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False)
-    conv = sp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False).to(DEV)
+    ref_conv = osp.SparseConv3d(32, cout, 3, (1, 1, 4), 0, 1, 1, False)
+    conv = sp.SparseConv3d(32, cout, 3, (1, 1, 4), 0, 1, 1, False).to(DEV)
     conv.load_state_dict(ref_conv.state_dict())
     fin = torch.from_numpy(feat).to(dtype)
     if device_counts:
