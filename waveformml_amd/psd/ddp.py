@@ -168,12 +168,15 @@ class FlatGradAllReducer(object):
         """All-reduce + average an already packed flat gradient buffer (one collective: the PSD nets' gradients
         are well under a megabyte, i.e. latency-bound)."""
         if self.world > 1:
-            if dist.get_backend(self.group) == "nccl":
+            if dist.get_backend(self.group) == "nccl" and getattr(self, "_avg_ok", True):
                 # RCCL averages inside the collective: one launch less than sum + divide on a latency-bound step
-                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat_grad.div_(self.world)
+                try:
+                    dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=self.group)
+                    return
+                except (RuntimeError, ValueError):          # a build without ncclAvg: sum + divide from now on
+                    self._avg_ok = False
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.div_(self.world)
 
     def remove(self):
         for h in self._hooks:
