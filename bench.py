@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
                     help="run the step eagerly instead of replaying it as one captured HIP graph")
+    ap.add_argument("--batches", type=int, default=8,
+                    help="distinct resident batches (different geometry each) the timed loop cycles through")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed --steps region is run this many times; the line reports the median region")
     return ap.parse_args()
 
 
@@ -104,17 +108,24 @@ def measure(env, args, dtype, steps, warmup, roofline):
     opt = module.configure_optimizers()
     optimizer = opt[0][0] if isinstance(opt, tuple) else opt
 
-    # synthetic batch, resident in HBM before the timed region (weak scaling: fixed events per rank)
-    c, f, y = synthetic.generate(args.batch, args.samples, env.cfg["system_config"]["n_type"], seed=1234, rank=rank)
+    # synthetic batches, resident in HBM before the timed region (weak scaling: fixed events per rank).  The timed loop
+    # cycles through `--batches` DIFFERENT batches (own seed each: other hit patterns, other voxel counts), so no step
+    # finds the previous step's gather tables or rows in L2 / Infinity Cache by construction of the benchmark.
     fdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
-    coords = torch.from_numpy(c).to(dev)
-    feats = torch.from_numpy(f).to(dev).to(fdtype)
-    labels = torch.from_numpy(y).to(dev)
-    batch = ([coords, feats], labels)
+    nb = max(1, args.batches)
+    host_batches = [synthetic.generate(args.batch, args.samples, env.cfg["system_config"]["n_type"], seed=1234 + 7919 * i,
+                                       rank=rank) for i in range(nb)]
+    batches = [([torch.from_numpy(c_).to(dev), torch.from_numpy(f_).to(dev).to(fdtype)], torch.from_numpy(y_).to(dev))
+               for (c_, f_, y_) in host_batches]
+    c, f, y = host_batches[0]
+    batch = batches[0]
+    (coords, feats), labels = batch
+    # the captured step is sized on the LARGEST of the resident batches (psd/graph.py adds its headroom on top)
+    example = max(batches, key=lambda b: b[0][0].shape[0])
 
-    def eager_step():
+    def eager_step(b=None):
         reducer.reset()
-        loss = module.training_step(batch, 0)
+        loss = module.training_step(batch if b is None else b, 0)
         loss.backward()
         reducer.finish()
         optimizer.step()
@@ -142,28 +153,42 @@ def measure(env, args, dtype, steps, warmup, roofline):
         # graph over capacity-padded buffers with device-side row counts, replayed per step (psd/graph.py)
         from waveformml_amd.psd.graph import GraphedTrainStep
         try:
-            gstep = GraphedTrainStep(module, optimizer, reducer, batch)
-            step = lambda: gstep(batch)     # noqa: E731
+            gstep = GraphedTrainStep(module, optimizer, reducer, example)
+            step = gstep
             mode = "hipgraph"
         except Exception as e:              # noqa: BLE001 -- report and fall back, the number is then an eager one
             log("graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
+    it = 0
     for _ in range(warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+        step(batches[it % nb])
+        it += 1
+    regions = []
+    for _rep in range(max(1, args.repeats)):
+        # one timed region = EXACTLY `steps` steps between two barrier + synchronize fences; max over ranks
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(batches[it % nb])
+            it += 1
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions.append(float(t.item()))
     if gstep is not None:
         gstep.check()                       # raises if a captured capacity was exceeded
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    log("[%s] timed region (%s): %.3f ms/step" % (dtype, mode, elapsed / steps * 1e3))
+    elapsed = float(np.median(regions))
+    per_step = [r / steps * 1e3 for r in regions]
+    log("[%s] timed regions (%s): median %.3f ms/step (min %.3f, max %.3f over %d regions of %d steps, %d batches)"
+        % (dtype, mode, elapsed / steps * 1e3, min(per_step), max(per_step), len(regions), steps, nb))
+    voxels = [int(b[0][0].shape[0]) for b in batches]
     out = {"value": args.batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "execution": mode,
-           "final_loss": float(loss.item()), "active_voxels_per_rank": int(coords.shape[0])}
+           "final_loss": float(loss.item()), "active_voxels_per_rank": int(np.mean(voxels)),
+           "timing": {"regions": len(regions), "steps_per_region": steps, "statistic": "median region",
+                      "ms_per_step_min": min(per_step), "ms_per_step_max": max(per_step),
+                      "ms_per_step_all": per_step, "distinct_batches": nb,
+                      "voxels_min": min(voxels), "voxels_max": max(voxels)}}
 
     if roofline:
         # per-kernel HIP-event timing.  Event pairs cannot be re-recorded inside a graph replay, so the kernels are
@@ -288,8 +313,56 @@ def parity(cpu_logits, cpu_loss, gpu_logits, gpu_loss):
             "loss_cpu": cpu_loss, "loss_gpu": gpu_loss, "rel_loss_diff": abs(cpu_loss - gpu_loss) / max(abs(cpu_loss), 1e-30)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks here, one child process per
+    GPU, BEFORE this process makes any GPU call (a process that has initialised the GPU must not exec or fork GPU work).
+    Children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT exactly as torch.distributed.run would set
+    them; rank 0's stdout (the JSON line) is this process's stdout; any failing child fails the run."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not os.environ.get("WFS_REHEARSAL_ONE_GPU"):
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (WFS_REHEARSAL_ONE_GPU=1 runs N ranks on one "
+                             "card over gloo as a dry run of the N-rank code path)" % (n, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        # poll instead of waiting rank by rank: one dead rank must not leave the others hanging in a collective
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     if os.environ.get("WFS_WATCHDOG"):         # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["WFS_WATCHDOG"]), exit=True)
@@ -297,6 +370,8 @@ def main():
     env.world = int(os.environ.get("WORLD_SIZE", "1"))
     env.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != env.world:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, env.world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
     if os.environ.get("WFS_REHEARSAL_ONE_GPU"):      # N ranks on ONE card over gloo: a dry run of the N-rank code path
@@ -312,7 +387,6 @@ def main():
             dist.init_process_group("gloo", rank=env.rank, world_size=env.world)
         else:
             dist.init_process_group("nccl", rank=env.rank, world_size=env.world, device_id=env.dev)   # RCCL over xGMI
-    assert args.gpus == env.world, "--gpus %d but WORLD_SIZE %d" % (args.gpus, env.world)
 
     from waveformml_amd import _lib
     from waveformml_amd.spconv import ops as _ops
@@ -344,6 +418,7 @@ def main():
                        "global_batch": args.batch * env.world, "parallelism": "dp%d" % env.world,
                        "final_loss": main_out["final_loss"], "execution": main_out["execution"]},
         }
+        result["timing"] = main_out["timing"]
         if "roofline" in main_out:
             result["roofline"] = main_out["roofline"]
         if single and args.cpu_steps > 0:
@@ -354,7 +429,7 @@ def main():
                 result["parity"] = parity(cpu_logits, cpu_loss, f32_extras["logits0"], f32_extras["loss0"])
                 result["parity"]["path"] = "f32 storage, exact fp32 MFMA: the 1e-5 bar"
                 result["parity_%s" % args.dtype] = parity(cpu_logits, cpu_loss, extras["logits0"], extras["loss0"])
-                result["f32_path"] = {k: f32[k] for k in ("value", "ms_per_step", "execution") if k in f32}
+                result["f32_path"] = {k: f32[k] for k in ("value", "ms_per_step", "execution", "timing") if k in f32}
                 if "roofline" in f32:
                     result["f32_path"]["roofline"] = f32["roofline"]
             else:

@@ -119,3 +119,41 @@ def test_single_process_reducer_packs_gradients_and_flat_optimizer_step():
         torch.testing.assert_close(red.flat_grad[o:o + n].view_as(b), b.grad)
         torch.testing.assert_close(a.detach(), b.detach())
     assert set(net.state_dict()) == set(ref.state_dict())        # checkpoints keep the module's own names
+
+
+def _sampler_worker(rank, world, port, out):
+    from waveformml_amd.psd import data
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = data.SyntheticPulseDataset(8, 3, 16, n_type=3, layout="3d", seed=5)
+        seen = {}
+        for shuffle in (False, True):
+            loader = data.make_loader(ds, 2, shuffle=shuffle, pin_memory=False)
+            assert isinstance(loader.sampler, torch.utils.data.distributed.DistributedSampler)
+            per_epoch = []
+            for epoch in range(2):
+                loader.sampler.set_epoch(epoch)
+                per_epoch.append(list(iter(loader.sampler)))
+                n_events = sum(int(y.shape[0]) for (_cf, y) in loader)
+                assert n_events == 4 * 3                     # 8 items / 2 ranks, 3 events each
+            seen[shuffle] = per_epoch
+        out[rank] = seen
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_read_disjoint_items():
+    """Each rank gets its own 1/N share of the items (an item = one file's event range), as under the reference's
+    Lightning DDP, which swaps DistributedSamplers into the loaders (src/utils/util.py:228-239); a shuffled loader is
+    re-shuffled per epoch by set_epoch -- identically on all ranks, so the shares stay disjoint."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sampler_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for shuffle in (False, True):
+        for epoch in range(2):
+            a, b = out[0][shuffle][epoch], out[1][shuffle][epoch]
+            assert set(a).isdisjoint(b) and sorted(a + b) == list(range(8)), (shuffle, epoch, a, b)
+    assert out[0][True][0] != out[0][True][1]                    # another permutation per epoch
+    assert out[0][False][0] == out[0][False][1] == [0, 2, 4, 6]

@@ -1397,3 +1397,63 @@ def test_reducer_pack_with_gradients_partly_in_place():
             _assert_close(got.cpu().numpy(), want[n].cpu().numpy(), 1e-6, "%s (deferred=%s)" % (n, deferred))
             in_place += int(p.grad is not None and p.grad.data_ptr() == got.data_ptr())
         assert in_place >= 4, in_place            # two conv weights, BatchNorm weight and bias were written in place
+
+
+def test_gradient_slots_with_a_shared_module_and_with_accumulation():
+    """spconv/functional.grad_like hands a parameter's slot of the flat gradient buffer out ONCE per backward pass and
+    only while the parameter has no gradient: (1) a conv module called twice in one graph gets two gradients that
+    autograd adds -- they must not alias (2 * g2 instead of g1 + g2); (2) a second backward() without reset()
+    accumulates ``p.grad += new`` -- again the operands must not alias.  Both with and without deferred dW reductions,
+    against an unflattened twin."""
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    from waveformml_amd.spconv import functional as Fsp
+    sp = _sp()
+    rng = np.random.default_rng(12)
+    B, T = 3, 24
+    idx = _waveform_like(rng, B, T)
+    feat = torch.from_numpy(rng.standard_normal((len(idx), 32)).astype(np.float32)).to(DEV)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k")
+            self.bn = torch.nn.BatchNorm1d(32)
+
+        def forward(self, x):
+            y = self.conv(x)
+            z = sp.SparseConvTensor(torch.relu(self.bn(y.features)), y.indices, y.spatial_shape, y.batch_size)
+            z.indice_dict = y.indice_dict
+            return self.conv(z).features.float().square().mean()          # the SAME conv module again
+
+    torch.manual_seed(2)
+    twin, net = Net().to(DEV), Net().to(DEV)
+    net.load_state_dict(twin.state_dict())
+    x = lambda: sp.SparseConvTensor(feat, torch.from_numpy(idx).to(DEV), [14, 11, T], B)      # noqa: E731
+    twin(x()).backward()
+    once = {n: p.grad.clone() for n, p in twin.named_parameters()}
+    twin(x()).backward()
+    twice = {n: p.grad.clone() for n, p in twin.named_parameters()}
+    red = FlatGradAllReducer(net.parameters(), world_size=1)
+    for deferred in (False, True):
+        red.reset()
+        Fsp.defer_dw(deferred)
+        try:
+            net(x()).backward()
+            red.pack_all()
+        finally:
+            Fsp.defer_dw(False)
+        for i, (n, p) in enumerate(net.named_parameters()):
+            o, cnt = red.slices[i]
+            _assert_close(red.flat_grad[o:o + cnt].view_as(p).cpu().numpy(), once[n].cpu().numpy(), 1e-5,
+                          "%s, module called twice (deferred=%s)" % (n, deferred))
+    # gradient accumulation: a second backward without reset
+    red.reset()
+    net(x()).backward()
+    net(x()).backward()
+    red.pack_all()
+    for i, (n, p) in enumerate(net.named_parameters()):
+        o, cnt = red.slices[i]
+        _assert_close(red.flat_grad[o:o + cnt].view_as(p).cpu().numpy(), twice[n].cpu().numpy(), 1e-5,
+                      "%s, two backward passes" % n)
+    with pytest.raises(TypeError):
+        FlatGradAllReducer(torch.nn.Linear(4, 4).half().to(DEV).parameters(), world_size=1)

@@ -206,3 +206,52 @@ def test_litz_segment_loss_on_the_cpu_restatement():
     assert abs(loss.item() - want) <= 1e-5 * abs(want)
     loss.backward()
     assert all(p.grad is not None for p in m.model.parameters())
+
+
+def test_checkpoint_round_trip_in_lightning_layout(tmp_path):
+    """Trainer.save_checkpoint writes the dictionary Lightning's ModelCheckpoint writes for the reference
+    (``state_dict`` / ``epoch`` / ``global_step`` / ``optimizer_states`` / ``lr_schedulers``, main.py:190-204) under the
+    ``epoch=..-val_loss=...ckpt`` name; ``load_from_checkpoint(path, config)`` (reference Evaluate.py:72) and
+    ``read_checkpoint`` load it -- and a bare ``state_dict`` file -- with ``weights_only=True``."""
+    import copy
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.lit import LitPSD
+    from waveformml_amd.psd.trainer import Trainer, load_from_checkpoint, read_checkpoint
+    with open(os.path.join(HERE, "golden", "gep_config.json")) as f:
+        cfg = json.load(f)
+    cfg["net_config"]["imports"] = ["oracle.spconv" if m == "waveformml_amd.spconv" else m for m in cfg["net_config"]["imports"]]
+    torch.manual_seed(3)
+    mod = LitPSD(load_config(copy.deepcopy(cfg)))
+    opt = mod.configure_optimizers()
+    optimizer, scheduler = (opt[0][0], opt[1][0]) if isinstance(opt, tuple) else (opt, None)
+    # one step so that the optimizer has momentum to save
+    for p in mod.model.parameters():
+        p.grad = torch.full_like(p, 0.01)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    tr = Trainer(device="cpu", default_root_dir=str(tmp_path))
+    tr.global_step = 17
+    path = tr.save_checkpoint(mod, optimizer, scheduler, 4, str(tmp_path / "epoch=4-val_loss=0.12.ckpt"))
+    ck = read_checkpoint(path)
+    assert ck["epoch"] == 4 and ck["global_step"] == 17
+    assert set(ck) >= {"state_dict", "epoch", "global_step", "optimizer_states", "lr_schedulers"}
+    assert set(ck["state_dict"]) == set(mod.state_dict())
+    bufs = [st["momentum_buffer"] for st in ck["optimizer_states"][0]["state"].values()]
+    assert len(bufs) == len(list(mod.model.parameters())) and all(torch.is_tensor(b) for b in bufs)
+    if scheduler is not None:
+        assert ck["lr_schedulers"][0]["last_epoch"] == 1
+    twin = load_from_checkpoint(path, load_config(copy.deepcopy(cfg)))
+    for k, v in mod.state_dict().items():
+        assert torch.equal(twin.state_dict()[k], v), k
+    # optimizer / scheduler state loads back into fresh objects
+    opt2 = twin.configure_optimizers()
+    optimizer2, scheduler2 = (opt2[0][0], opt2[1][0]) if isinstance(opt2, tuple) else (opt2, None)
+    optimizer2.load_state_dict(ck["optimizer_states"][0])
+    if scheduler2 is not None:
+        scheduler2.load_state_dict(ck["lr_schedulers"][0])
+        assert scheduler2.get_last_lr() == scheduler.get_last_lr()
+    # a bare state_dict (round-1 files) is accepted too
+    bare = str(tmp_path / "bare.ckpt")
+    torch.save(mod.state_dict(), bare)
+    assert set(read_checkpoint(bare)["state_dict"]) == set(mod.state_dict())

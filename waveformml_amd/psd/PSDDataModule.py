@@ -16,7 +16,7 @@ import logging
 from torch.utils.data import DataLoader
 
 from .config import DictionaryUtility, ModuleUtility
-from .data import collate_fn, collate_fn_3d  # noqa: F401  (collate_fn is the reference's name)
+from .data import collate_fn, collate_fn_3d, rank_sampler  # noqa: F401  (collate_fn is the reference's name)
 
 
 class PSDDataModule(object):
@@ -77,7 +77,11 @@ class PSDDataModule(object):
         return collate_fn_3d if getattr(dataset, "layout", "2d") == "3d" else collate_fn
 
     def _loader(self, dataset, shuffle):
-        return DataLoader(dataset, shuffle=shuffle, collate_fn=self._collate(dataset), **self._params("dataloader_params"))
+        # one process per GPU: each rank reads its own 1/N share of the items, as under the reference's Lightning DDP
+        # (which replaces the loaders' samplers with DistributedSamplers, src/utils/util.py:228-239)
+        sampler = rank_sampler(dataset, shuffle)
+        return DataLoader(dataset, shuffle=shuffle and sampler is None, sampler=sampler,
+                          collate_fn=self._collate(dataset), **self._params("dataloader_params"))
 
     def train_dataloader(self):
         if not hasattr(self, "train_dataset"):

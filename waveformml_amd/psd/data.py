@@ -58,10 +58,24 @@ class SyntheticPulseDataset(Dataset):
         return [torch.from_numpy(c), torch.from_numpy(f).type(self.valtype)], torch.from_numpy(y)
 
 
+def rank_sampler(dataset, shuffle, seed=0):
+    """Under torch.distributed with more than one rank: a DistributedSampler that gives this rank its 1/N share of the
+    ITEMS (an item = one file's event range, so ranks read disjoint file ranges) -- what Lightning's DDP plugin swaps
+    into the reference's loaders (src/utils/util.py:228-239).  None in a single process.  The Trainer calls
+    ``sampler.set_epoch(epoch)`` so that every epoch is shuffled differently but identically on all ranks."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return None
+    from torch.utils.data.distributed import DistributedSampler
+    return DistributedSampler(dataset, num_replicas=dist.get_world_size(), rank=dist.get_rank(), shuffle=bool(shuffle),
+                              seed=seed)
+
+
 def make_loader(dataset, items_per_batch, num_workers=0, shuffle=False, pin_memory=True):
     fn = collate_fn_3d if getattr(dataset, "layout", "2d") == "3d" else collate_fn
-    return DataLoader(dataset, batch_size=items_per_batch, shuffle=shuffle, num_workers=num_workers,
-                      collate_fn=fn, pin_memory=pin_memory)
+    sampler = rank_sampler(dataset, shuffle)
+    return DataLoader(dataset, batch_size=items_per_batch, shuffle=shuffle and sampler is None, sampler=sampler,
+                      num_workers=num_workers, collate_fn=fn, pin_memory=pin_memory)
 
 
 def to_device(batch, device, feature_dtype=None, non_blocking=True):

@@ -19,14 +19,33 @@ import torch.distributed as dist
 
 
 class FlatGradAllReducer(object):
-    def __init__(self, parameters, n_buckets=2, process_group=None, world_size=None, flatten=True):
+    def __init__(self, parameters, n_buckets=2, process_group=None, world_size=None, flatten=True, exchange=None):
         self.params = [p for p in parameters if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         self.group = process_group
         self.world = world_size if world_size is not None else (
             dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1)
+        # exchange: issue the collectives at all.  Default: only when there is somebody to exchange with; True with a
+        # one-rank group runs the whole bucket / hook / collective machinery against the real backend (tests: the RCCL
+        # call path on a one-GPU box, where two ranks cannot share the card)
+        self.exchange = (self.world > 1) if exchange is None else bool(exchange)
         dev, dtype = self.params[0].device, self.params[0].dtype
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatGradAllReducer keeps fp32 master parameters / gradients (got %s): the HIP "
+                                "operators address gradient slots as 4-byte elements" % p.dtype)
+        # the reduction the backend runs: RCCL averages inside the collective (ncclAvg: one launch less than sum +
+        # divide on a latency-bound step); probed ONCE here on a scratch tensor -- never by catching errors in a step,
+        # which would retry on a communicator that may be dead
+        self._avg = False
+        if self.exchange and dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == "nccl":
+            try:
+                probe = torch.ones(8, dtype=dtype, device=dev)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                self._avg = bool((probe == 1).all().item())
+            except (RuntimeError, ValueError):
+                self._avg = False
         total = sum(p.numel() for p in self.params)
         # reverse order: the LAST layer's gradients are produced first and sit at the front
         order = list(reversed(range(len(self.params))))
@@ -52,7 +71,7 @@ class FlatGradAllReducer(object):
                 from ..spconv import functional as _fsp
                 _fsp.register_grad_slots(self.flat_param, self.flat_grad)
         # contiguous buckets of roughly equal size over that order
-        if self.world <= 1:
+        if not self.exchange:
             n_buckets = 1              # nothing to overlap: pack with one concatenation
         n_buckets = max(1, min(n_buckets, len(self.params)))
         target = total / n_buckets
@@ -71,10 +90,17 @@ class FlatGradAllReducer(object):
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        if self.exchange:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
+
+    def _reduce_op(self):
+        return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+
+    def _all_reduce_bucket(self, b):
+        s, e, _ = self.buckets[b]
+        self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=self._reduce_op(), group=self.group, async_op=True))
 
     # flat view of the gradient buffer (tests / diagnostics)
     @property
@@ -122,9 +148,7 @@ class FlatGradAllReducer(object):
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._pack(b)
-                s, e, _ = self.buckets[b]
-                self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
+                self._all_reduce_bucket(b)
         return hook
 
     def reset(self):
@@ -132,6 +156,9 @@ class FlatGradAllReducer(object):
         instead of launching an add per parameter) and re-arm the buckets."""
         for p in self.params:
             p.grad = None
+        if self.flat_param is not None and self.flat_grad.is_cuda:
+            from ..spconv import functional as _fsp
+            _fsp.reset_grad_slots()
         self._pending = [len(idxs) for (_, _, idxs) in self.buckets]
         self._handles = []
 
@@ -139,18 +166,17 @@ class FlatGradAllReducer(object):
         """Call after backward, before optimizer.step(): pack what is not packed yet, wait for the
         exchanges, average.  Afterwards flat_grad (== flat_param.grad) holds the step's gradient."""
         for b, left in enumerate(self._pending):
-            if left > 0 or self.world <= 1:
-                # world == 1: no hooks ran; world > 1: a parameter without gradient never fires its hook
+            if left > 0 or not self._hooks:
+                # no hooks (nothing to exchange, or remove()d): nothing is packed yet; with hooks: a parameter without
+                # gradient never fires its hook
                 self._pack(b)
-                if self.world > 1:
-                    s, e, _ = self.buckets[b]
-                    self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                         async_op=True))
+                if self.exchange:
+                    self._all_reduce_bucket(b)
                 self._pending[b] = 0
         for h in self._handles:
             h.wait()
         self._handles = []
-        if self.world > 1:
+        if self.exchange and not self._avg and self.world > 1:
             self.flat_grad.div_(self.world)
         if self.flat_param is None:
             for i, p in enumerate(self.params):
@@ -167,16 +193,10 @@ class FlatGradAllReducer(object):
     def exchange_packed(self):
         """All-reduce + average an already packed flat gradient buffer (one collective: the PSD nets' gradients
         are well under a megabyte, i.e. latency-bound)."""
-        if self.world > 1:
-            if dist.get_backend(self.group) == "nccl" and getattr(self, "_avg_ok", True):
-                # RCCL averages inside the collective: one launch less than sum + divide on a latency-bound step
-                try:
-                    dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=self.group)
-                    return
-                except (RuntimeError, ValueError):          # a build without ncclAvg: sum + divide from now on
-                    self._avg_ok = False
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat_grad.div_(self.world)
+        if self.exchange:
+            dist.all_reduce(self.flat_grad, op=self._reduce_op(), group=self.group)
+            if not self._avg and self.world > 1:
+                self.flat_grad.div_(self.world)
 
     def remove(self):
         for h in self._hooks:

@@ -46,6 +46,14 @@ def test_loop(module, loader, device, feature_dtype=None, capture=False):
         n += b
     if step is not None:
         step.check()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # every rank ran its own share of the items (data.rank_sampler): event-weighted sums over all ranks
+        sums = torch.stack([torch.as_tensor(tot, dtype=torch.float64, device=device).reshape(()),
+                            torch.as_tensor(acc, dtype=torch.float64, device=device).reshape(()),
+                            torch.tensor(float(n), dtype=torch.float64, device=device)])
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        tot, acc, n = float(sums[0]), float(sums[1]), int(sums[2])
     return {"test_loss": float(tot) / max(n, 1), "test_acc": float(acc) / max(n, 1), "events": n}
 
 

@@ -11,6 +11,9 @@ shapes and is captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed
     loss = step(batch)            # copies the batch into the static buffers, replays the graph
     step.check()                  # occasionally: raises if a capacity was exceeded (results invalid)
 """
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -49,7 +52,19 @@ class GraphedTrainStep(object):
         self._perm = [int(v) for v in perm.tolist()] if perm is not None else None
         self.indices = torch.zeros_like(self.coords) if self._perm is not None else None
         self.world = reducer.world
-        self.in_graph_optimizer = self.world == 1
+        # Gradient exchange of a captured step (world > 1).  With RCCL the collectives are captured INSIDE the graph:
+        # the reducer's hooks stay armed, so during the captured backward each bucket (reverse layer order) is packed
+        # and its all-reduce issued the moment its last gradient exists -- torch's process group launches it on its own
+        # stream, i.e. a fork off the captured stream right after that bucket's last dW, running beside the rest of
+        # the backward -- and reducer.finish() joins them in front of the optimizer launch, which is then back inside
+        # the graph too.  Other backends (gloo: the one-GPU rehearsal; host copies cannot be captured) exchange the
+        # packed buffer after the replay, followed by an eager optimizer launch.
+        exchange = bool(getattr(reducer, "exchange", self.world > 1))
+        self.in_graph_exchange = (exchange and dist.is_available() and dist.is_initialized()
+                                  and dist.get_backend(reducer.group) == "nccl"
+                                  and os.environ.get("WFS_GRAPH_EXCHANGE", "1") != "0")
+        self.exchange_after = exchange and not self.in_graph_exchange
+        self.in_graph_optimizer = not self.exchange_after
         self._convs = [m for m in module.modules()
                        if hasattr(m, "subm") and hasattr(m, "conv1x1") and not m.subm and not m.conv1x1 and not m.inverse]
         # Stream discipline.  (1) Autograd's AccumulateGrad nodes remember the stream they were created on, and a
@@ -71,21 +86,38 @@ class GraphedTrainStep(object):
         del loss
         for m in self._convs:
             m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
-        if self.world > 1:
+        if self.exchange_after:
             reducer.remove()              # no collectives inside the graph: gradients are exchanged after the replay
         # ---- warm-up in device-count mode, then capture
         if self.indices is not None:
             net.batch_first_indices = (self.coords, self.indices)
         self._load(example_batch)
+        try:
+            self._warm_and_capture(warmup)
+        except Exception as e:            # noqa: BLE001
+            if not self.in_graph_exchange:
+                raise
+            # a collective library that cannot be captured: every rank fails here alike (same software, same call),
+            # so every rank falls back to the exchange after the replay
+            print("[waveformml_amd] in-graph gradient exchange could not be captured (%s: %s); exchanging after the "
+                  "replay" % (type(e).__name__, e), file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            self.in_graph_exchange, self.exchange_after, self.in_graph_optimizer = False, True, False
+            reducer.remove()
+            self._warm_and_capture(warmup)
+        self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
+
+    def _warm_and_capture(self, warmup):
         for _ in range(warmup):
             self._body()
-            if not self.in_graph_optimizer:
+            if self.exchange_after:
                 self._after()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        # thread_local: the process group's watchdog thread queries events while this thread captures
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
             self.loss = self._body()
-        self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
 
     def _static_batch(self):
         return ([self.coords, self.feats, self.n_valid], self.labels)
@@ -101,7 +133,10 @@ class GraphedTrainStep(object):
                 torch.autograd.backward(loss, grad_tensors=Fsp.unit_loss_grad(loss.device))   # no ones-fill, no multiply
             else:
                 loss.backward()
-            self.reducer.pack_all()
+            if self.in_graph_exchange:
+                self.reducer.finish()      # packs what no hook packed, joins the bucket all-reduces, averages
+            else:
+                self.reducer.pack_all()
         finally:
             Fsp.defer_dw(False)
         if self.in_graph_optimizer:
@@ -111,6 +146,24 @@ class GraphedTrainStep(object):
     def _after(self):
         self.reducer.exchange_packed()
         self.optimizer.step()
+
+    def eager_step(self, batch):
+        """The same step on an exact-size batch without the graph (a batch that does not fit the capture), with the
+        SAME sequence of collectives as a replay, so that ranks replaying and ranks stepping eagerly could even mix."""
+        self.reducer.reset()
+        loss = self.module.training_step(batch, 0)
+        loss.backward()
+        if self.exchange_after:
+            self.reducer.pack_all()
+            self.reducer.exchange_packed()
+        else:
+            self.reducer.finish()
+        self.optimizer.step()
+        return loss.detach()
+
+    def fits(self, batch):
+        (coords, _f), labels = batch
+        return coords.shape[0] <= self.n_cap and tuple(labels.shape) == tuple(self.labels.shape)
 
     def _load(self, batch):
         (coords, feats), labels = batch
@@ -143,13 +196,20 @@ class GraphedTrainStep(object):
         if hasattr(self.optimizer, "sync_hyperparameters"):
             self.optimizer.sync_hyperparameters()      # a scheduler's new lr reaches the captured update
         self.graph.replay()
-        if not self.in_graph_optimizer:
+        if self.exchange_after:
             self._after()
         return self.loss
 
     def check(self):
-        """Synchronises; raises if any strided layer produced more rows than its capacity in the last step."""
-        if self._overflow and bool(torch.stack([o.reshape(()) for o in self._overflow]).any().item()):
+        """Synchronises; raises if any strided layer produced more rows than its capacity in the last step -- on ANY
+        rank: the flag is all-reduced first, so every rank raises together instead of one rank leaving its peers
+        blocked in the next collective."""
+        flag = torch.zeros((), dtype=torch.int32, device=self.coords.device)
+        if self._overflow:
+            flag = torch.stack([o.reshape(()) for o in self._overflow]).any().to(torch.int32)
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        if bool(flag.item()):
             raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
 
 

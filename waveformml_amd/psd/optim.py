@@ -37,7 +37,21 @@ class FlatSGD(torch.optim.SGD):
         for g in sd["param_groups"]:
             g.pop("_lr_dev", None)
             g.pop("_lr_host", None)
+        sd["state"] = {k: {n: v for n, v in st.items() if n != "_fresh"} for k, st in sd["state"].items()}
         return sd
+
+    def mark_fresh(self):
+        """The momentum buffers exist (a captured graph holds their addresses) but carry no history: the next EAGER
+        step treats them as torch treats a missing buffer (buf = g, no dampening).  Only matters with dampening != 0 --
+        with dampening 0 a zeroed buffer gives the same first step."""
+        for g in self.param_groups:
+            if g["dampening"] != 0 and g["momentum"] != 0:
+                for p in g["params"]:
+                    if "momentum_buffer" in self.state.get(p, {}):
+                        self.state[p]["_fresh"] = True
+
+    def has_fresh(self):
+        return any(st.get("_fresh", False) for st in self.state.values())
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -56,6 +70,8 @@ class FlatSGD(torch.optim.SGD):
             buf, first = state.get("momentum_buffer"), False
             if g["momentum"] != 0 and buf is None:
                 buf = state["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                first = True
+            if state.pop("_fresh", False) and not torch.cuda.is_current_stream_capturing():
                 first = True
             _lib.check(lib.wfs_sgd_step(_lib.ptr(p), _lib.ptr(grad), _lib.ptr(buf) if g["momentum"] != 0 else None,
                                         p.numel(), _lib.ptr(g["_lr_dev"]), float(g["momentum"]), float(g["dampening"]),

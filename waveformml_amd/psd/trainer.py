@@ -8,7 +8,17 @@ builds, forward, backward, gradient packing and -- on one GPU -- the optimizer i
 above it; the capture's own calibration / warm-up steps are undone (parameters, BatchNorm buffers and optimizer state
 are restored), a batch with more voxels than the capacity takes an ordinary eager step, and every ``check_every``
 steps (and at the end of an epoch) the strided layers' overflow flags are read back: an overflow raises, it is never
-silently truncated."""
+silently truncated.
+
+More than one rank (one process per GPU): each rank reads its own share of the items (data.rank_sampler, re-seeded per
+epoch), whether a step is replayed or taken eagerly is decided by ALL ranks together (a one-element MAX all-reduce of
+"my batch does not fit"), the eager step issues the same collectives as a replay, validation sums are all-reduced
+before the best-checkpoint decision, overflow flags are all-reduced before anybody raises.
+
+Checkpoints are dictionaries shaped like Lightning's (``state_dict``, ``epoch``, ``global_step``, ``optimizer_states``,
+``lr_schedulers``) under Lightning's file name pattern; ``load_from_checkpoint`` / ``Trainer(resume_from_checkpoint=)``
+read them -- and a reference-written ``.ckpt`` 's ``state_dict`` -- with ``torch.load(weights_only=True)``
+(reference: Evaluate.py:72 ``load_from_checkpoint``, main.py ``--load_checkpoint`` -> ``resume_from_checkpoint``)."""
 import os
 
 import torch
@@ -18,17 +28,46 @@ from .data import DevicePrefetcher, to_device
 from .ddp import FlatGradAllReducer, broadcast_parameters
 
 
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def read_checkpoint(path, map_location="cpu"):
+    """A checkpoint file as a dictionary with at least ``state_dict``: this Trainer's files, a reference / Lightning
+    ``.ckpt`` (same keys; anything that needs unpickling of foreign classes is refused by ``weights_only=True``), or a
+    bare ``state_dict`` as round 1 of this repository wrote them."""
+    ck = torch.load(path, map_location=map_location, weights_only=True)
+    if not isinstance(ck, dict):
+        raise ValueError("%s is not a checkpoint dictionary" % path)
+    if "state_dict" not in ck:
+        ck = {"state_dict": ck}
+    return ck
+
+
+def load_from_checkpoint(path, config, module_class=None, map_location="cpu", strict=True):
+    """``LitPSD.load_from_checkpoint(path, config=config)`` of the reference (Evaluate.py:72): builds the module from
+    ``config`` and loads the checkpoint's ``state_dict``."""
+    if module_class is None:
+        from .lit import LitPSD as module_class
+    module = module_class(config)
+    module.load_state_dict(read_checkpoint(path, map_location)["state_dict"], strict=strict)
+    return module
+
+
 class Trainer(object):
     def __init__(self, max_epochs=1, device="cuda:0", default_root_dir=None, feature_dtype=None, log_every=0,
-                 capture=False, check_every=100):
+                 capture=False, check_every=100, resume_from_checkpoint=None):
         self.max_epochs, self.device = max_epochs, torch.device(device)
         self.root = default_root_dir
         self.feature_dtype = feature_dtype
         self.log_every = log_every
         self.capture, self.check_every = bool(capture), int(check_every)
+        self.resume_from_checkpoint = resume_from_checkpoint
         self.history = []
         self._graph = None
         self.eager_fallbacks = 0
+        self.global_step = 0
+        self.last_checkpoint = None
 
     def _capture(self, module, reducer, optimizer, batch):
         """Capture the step on ``batch`` without letting the capture's calibration / warm-up steps train the model."""
@@ -53,15 +92,24 @@ class Trainer(object):
                         for v in optimizer.state.get(p, {}).values():
                             if torch.is_tensor(v):
                                 v.zero_()      # in place: the graph holds these addresses (zero momentum == no history)
+        if hasattr(optimizer, "mark_fresh"):
+            optimizer.mark_fresh()             # dampening != 0: the first real step must be torch's "buf = g" (eager)
         return graph
 
     def _captured_step(self, module, reducer, optimizer, batch, batch_idx):
-        (coords, _feats), _labels = batch
         if self._graph is None:
             self._graph = self._capture(module, reducer, optimizer, batch)
-        if coords.shape[0] > self._graph.n_cap or _labels.shape != self._graph.labels.shape:
-            self.eager_fallbacks += 1           # more voxels than the capacity, or another number of events
-            return self.training_step(module, reducer, optimizer, batch, batch_idx)
+        # more voxels than the capacity, or another number of events -> an ordinary step.  With several ranks the
+        # decision is taken together: a rank replaying while another steps eagerly must never depend on the two paths
+        # happening to issue the same collectives.
+        misfit = not self._graph.fits(batch) or (hasattr(optimizer, "has_fresh") and optimizer.has_fresh())
+        if reducer.world > 1 and reducer.exchange:
+            flag = torch.tensor([1 if misfit else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=reducer.group)
+            misfit = bool(flag.item())
+        if misfit:
+            self.eager_fallbacks += 1
+            return self._graph.eager_step(batch)
         loss = self._graph(batch)
         if self.check_every > 0 and (batch_idx + 1) % self.check_every == 0:
             self._graph.check()
@@ -84,13 +132,20 @@ class Trainer(object):
         optimizer, scheduler = (opt[0][0], opt[1][0]) if isinstance(opt, tuple) else (opt, None)
         best = float("inf")
         self._graph = None                      # a captured step belongs to this fit's optimizer / reducer
-        for epoch in range(self.max_epochs):
+        first_epoch = 0
+        if self.resume_from_checkpoint:
+            first_epoch = self._resume(module, optimizer, scheduler, self.resume_from_checkpoint)
+        for epoch in range(first_epoch, self.max_epochs):
             module.train()
+            sampler = getattr(train_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)        # DistributedSampler: another permutation per epoch, the same on all ranks
             for i, batch in enumerate(DevicePrefetcher(train_loader, self.device, self.feature_dtype)):
                 if self.capture:
                     loss = self._captured_step(module, reducer, optimizer, batch, i)
                 else:
                     loss = self.training_step(module, reducer, optimizer, batch, i)
+                self.global_step += 1
                 if self.log_every and i % self.log_every == 0:
                     print("epoch %d step %d train_loss %.5f" % (epoch, i, loss.item()), flush=True)
             if self._graph is not None:
@@ -99,14 +154,40 @@ class Trainer(object):
                 scheduler.step()
             rec = {"epoch": epoch, "train_loss": float(loss.item())}
             if val_loader is not None:
-                rec.update(self.validate(module, val_loader))
-                if self.root and rec["val_loss"] < best and (not dist.is_initialized() or dist.get_rank() == 0):
+                rec.update(self.validate(module, val_loader))        # all-reduced: every rank sees the same numbers
+                if self.root and rec["val_loss"] < best:
                     best = rec["val_loss"]
-                    os.makedirs(self.root, exist_ok=True)
-                    torch.save(module.state_dict(), os.path.join(self.root, "epoch=%d-val_loss=%.2f.ckpt" % (epoch, best)))
+                    if not dist.is_initialized() or dist.get_rank() == 0:
+                        self.save_checkpoint(module, optimizer, scheduler, epoch,
+                                             os.path.join(self.root, "epoch=%d-val_loss=%.2f.ckpt" % (epoch, best)))
             self.history.append(rec)
         reducer.remove()
         return self.history
+
+    def save_checkpoint(self, module, optimizer, scheduler, epoch, path):
+        """Lightning's checkpoint layout (what the reference's ModelCheckpoint callback writes, main.py:190-204):
+        tensors, numbers, strings, lists and dictionaries only, so ``weights_only=True`` loads it."""
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        ck = {"epoch": int(epoch), "global_step": int(self.global_step),
+              "state_dict": {k: v.detach().cpu().clone() for k, v in module.state_dict().items()},
+              "optimizer_states": [optimizer.state_dict()],
+              "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else []}
+        torch.save(ck, path)
+        self.last_checkpoint = path
+        return path
+
+    def _resume(self, module, optimizer, scheduler, path):
+        """``resume_from_checkpoint`` (reference main.py ``--load_checkpoint``): weights, optimizer state (momentum),
+        scheduler state and the epoch / step counters; training continues with the NEXT epoch.  The parameters are
+        views of the reducer's flat buffer at this point, so ``load_state_dict`` copies into it in place."""
+        ck = read_checkpoint(path, map_location=self.device)
+        module.load_state_dict(ck["state_dict"])
+        if ck.get("optimizer_states"):
+            optimizer.load_state_dict(ck["optimizer_states"][0])
+        if scheduler is not None and ck.get("lr_schedulers"):
+            scheduler.load_state_dict(ck["lr_schedulers"][0])
+        self.global_step = int(ck.get("global_step", 0))
+        return int(ck["epoch"]) + 1 if "epoch" in ck else 0
 
     @torch.no_grad()
     def validate(self, module, loader):
@@ -125,6 +206,11 @@ class Trainer(object):
             tot += float(res["val_loss"]) * b
             acc += float(res["val_acc"]) * b
             n += b
+        if _world() > 1:
+            # each rank validated its own share of the items: event-weighted sums over all ranks
+            sums = torch.tensor([tot, acc, float(n)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            tot, acc, n = float(sums[0]), float(sums[1]), int(sums[2])
         return {"val_loss": tot / max(n, 1), "val_acc": acc / max(n, 1)}
 
     def test(self, module, loader):

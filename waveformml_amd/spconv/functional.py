@@ -211,17 +211,46 @@ def register_grad_slots(flat_param, flat_grad):
     _GRAD_SLOTS.append((weakref.ref(flat_param), weakref.ref(flat_grad)))
 
 
+_SLOTS_WRITTEN = set()    # slot addresses handed out during the current backward pass
+
+
+def reset_grad_slots():
+    """Forget which slots the current / last backward pass wrote (runs at the end of every backward pass that handed
+    one out, and from FlatGradAllReducer.reset())."""
+    _SLOTS_WRITTEN.clear()
+
+
 def grad_like(param, shape=None):
     """An fp32 tensor of ``shape`` (default: param's) for d loss / d param: the parameter's slot in a registered flat
-    gradient buffer when ``param`` is a contiguous fp32 view into the matching flat parameter buffer, else fresh memory."""
+    gradient buffer when ``param`` is a contiguous fp32 view into the matching flat parameter buffer, else fresh memory.
+
+    A slot is handed out ONCE per backward pass and only while the parameter has no gradient yet: a module called twice
+    in one graph (two gradients for one parameter, summed by autograd) or a second backward() without reset (gradient
+    accumulation, ``p.grad += new``) gets fresh memory for the further gradients -- two operands of autograd's add
+    must never alias the same slot."""
     shape = tuple(param.shape) if shape is None else tuple(shape)
-    if param is not None and param.is_cuda and param.dtype == torch.float32 and param.is_contiguous():
+    if (param is not None and param.is_cuda and param.dtype == torch.float32 and param.is_contiguous()
+            and param.grad is None):
         for pref, gref in _GRAD_SLOTS:
             fp, fg = pref(), gref()
-            if fp is None or fg is None or fp.device != param.device:
+            if fp is None or fg is None or fp.device != param.device or fg.dtype != torch.float32:
                 continue
             off = param.data_ptr() - fp.data_ptr()
             if 0 <= off and off + 4 * param.numel() <= 4 * fp.numel() and off % 4 == 0:
+                slot = fg.data_ptr() + off
+                if slot in _SLOTS_WRITTEN:
+                    # a second gradient for this parameter in one pass: autograd is about to ADD it to the first one,
+                    # so a pending (deferred) second stage of the first must land in the slot now, and the slot no
+                    # longer counts as "filled by a deferred reduction" (the sum is wherever autograd puts it)
+                    flush_deferred_dw()
+                    _SHARED_SLOTS.add(slot)
+                    break
+                if not _SLOTS_WRITTEN:
+                    try:
+                        torch.autograd.Variable._execution_engine.queue_callback(reset_grad_slots)
+                    except RuntimeError:          # not inside a backward pass (direct call): the caller resets
+                        pass
+                _SLOTS_WRITTEN.add(slot)
                 return fg[off // 4: off // 4 + param.numel()].view(shape)
     return torch.empty(shape, dtype=torch.float32, device=param.device)
 
@@ -231,16 +260,18 @@ def grad_like(param, shape=None):
 # gradients that live in a registered slot (the runner reads the slot, never the tensor autograd holds).
 _DEFERRED_DW = None       # None: off; else a list of (DwJob, workspace tensor)
 _DEFERRED_SLOTS = set()   # slot addresses written by the last flush
+_SHARED_SLOTS = set()     # slots that received more than one gradient in the pass (grad_like)
 
 
 def defer_dw(on):
     global _DEFERRED_DW
     _DEFERRED_DW = [] if on else None
     _DEFERRED_SLOTS.clear()
+    _SHARED_SLOTS.clear()
 
 
 def was_deferred(slot_ptr):
-    return slot_ptr in _DEFERRED_SLOTS
+    return slot_ptr in _DEFERRED_SLOTS and slot_ptr not in _SHARED_SLOTS
 
 
 def flush_deferred_dw():
