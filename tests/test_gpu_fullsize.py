@@ -6,9 +6,15 @@ oracle.spconv, the restatement of spconv 1.2.1's Native algorithm in fp32 -- wit
 synthetic batch, and ONE training step is compared: logits, loss, every parameter gradient.
 
 Tolerances (stated here, asserted below):
-  * fp32 rows: logits and loss within 1e-5 relative; every gradient tensor within 1e-5 of the TENSOR'S SCALE
-    (|got - want| <= 1e-5 * max|want| element-wise; `_assert_close` is relative to the tensor's max, not per element)
-    for C2; 1e-4 of scale through C4's eight and C5's wide layers (longer fp32 sums in another order).
+  * fp32 rows: logits, loss and EVERY gradient tensor within 1e-5 -- of the tensor's scale: |got - want| <= 1e-5 *
+    max|want| element-wise (`_assert_close` is relative to the tensor's max, not per element) -- of the oracle run in
+    FLOAT64, i.e. of the exact value of the reference's arithmetic.  The oracle in fp32 (what the reference's cpuonly
+    path computes) is itself only good to 1e-3 ... 7e-3 of scale on the filter / BatchNorm gradients of the SubM
+    layers at this size (sums over ~86 k rows in front of a BatchNorm cancel heavily; measured by
+    tools/exp/grad_conditioning.py: GPU vs fp64 <= 1.6e-6 on every tensor, CPU fp32 vs fp64 up to 6.7e-3), so "1e-5 of
+    the fp32 reference" is not a meaningful bar for those tensors; the test therefore also asserts the triangle bound
+    |gpu - cpu32| <= 1e-5 + |cpu32 - fp64| per tensor: the GPU result is never further from the reference's fp32
+    result than the reference's own rounding error.
   * bf16 / fp16 rows against the fp32 oracle fed the same rounded input: logits within 5e-3 of scale; per-tensor
     relative L2 gradient error bounded by GRAD_REL_L2 below.  16-bit activation storage perturbs a gradient tensor as a
     whole (projections in front of BatchNorm cancel heavily), so the bound is on the tensor, not on elements.
@@ -52,32 +58,62 @@ def _pair(cfg, loader):
     return gpu, cpu
 
 
+def _rel(a, b, scale):
+    return float(np.abs(a - b).max()) / scale
+
+
 def _one_step(gpu, cpu, c, f, y, dtype, tol_logits, tol_grad):
+    """One training step on both sides.  fp32: against the oracle in float64 at (tol_logits, tol_grad), plus the
+    triangle bound against the oracle in fp32 (module docstring).  16-bit rows: logits against the fp32 oracle at
+    tol_logits of scale, gradients by per-tensor relative L2 error < tol_grad."""
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     fin = torch.from_numpy(f).to(dtype)
     cg, yg = torch.from_numpy(c).to(DEV), torch.from_numpy(y).to(DEV)
+    exact = dtype == torch.float32
+    sides = [(cpu, fin.float())]
+    if exact:
+        cpu.load_state_dict({k: v.cpu() for k, v in gpu.state_dict().items()})
+        truth = copy.deepcopy(cpu).double()                  # the same restatement, every sum in float64
+        truth.train()
+        sides.append((truth, fin.double()))
     with torch.no_grad():
-        lr = cpu.model([torch.from_numpy(c), fin.float()])
-        lg = gpu.model([cg.clone(), fin.to(DEV)])
-    _assert_close(lg.float().cpu().numpy(), lr.numpy(), tol_logits, "logits")
-    loss_r = cpu.training_step(([torch.from_numpy(c), fin.float()], torch.from_numpy(y)), 0)
+        lr = [m.model([torch.from_numpy(c), x]).double().numpy() for m, x in sides]
+        lg = gpu.model([cg.clone(), fin.to(DEV)]).double().cpu().numpy()
+    scale = max(float(np.abs(lr[-1]).max()), 1e-30)
+    if exact:
+        assert _rel(lg, lr[1], scale) <= tol_logits, ("logits vs fp64", _rel(lg, lr[1], scale))
+        assert _rel(lg, lr[0], scale) <= tol_logits + _rel(lr[0], lr[1], scale), "logits vs the fp32 reference"
+    else:
+        assert _rel(lg, lr[0], scale) <= tol_logits, ("logits", _rel(lg, lr[0], scale))
+    losses = [m.training_step(([torch.from_numpy(c), x], torch.from_numpy(y)), 0) for m, x in sides]
     loss_g = gpu.training_step(([cg, fin.to(DEV)], yg), 0)
-    assert abs(loss_g.item() - loss_r.item()) <= tol_logits * abs(loss_r.item()), (loss_g.item(), loss_r.item())
-    loss_r.backward()
+    want = losses[-1].item()
+    assert abs(loss_g.item() - want) <= tol_logits * abs(want), (loss_g.item(), want)
+    for ls in losses:
+        ls.backward()
     loss_g.backward()
-    worst = ("", 0.0)
-    for (name, a), b in zip(gpu.model.named_parameters(), cpu.model.parameters()):
+    report = []
+    refs = [list(m.model.parameters()) for m, _x in sides]
+    for i, (name, a) in enumerate(gpu.model.named_parameters()):
+        b = refs[0][i]
         if b.grad is None:
             assert a.grad is None, name
             continue
         assert a.grad is not None and bool(torch.isfinite(a.grad).all()), name
-        if dtype == torch.float32:
-            _assert_close(a.grad.cpu().numpy(), b.grad.numpy(), tol_grad, name)
+        ga = a.grad.double().cpu().numpy()
+        if exact:
+            t = refs[1][i].grad.numpy()
+            g32 = b.grad.double().numpy()
+            sc = max(float(np.abs(t).max()), 1e-300)
+            e_gpu, e_ref, e_pair = _rel(ga, t, sc), _rel(g32, t, sc), _rel(ga, g32, sc)
+            report.append((name, e_gpu, e_ref, e_pair))
+            assert e_gpu <= tol_grad, "%s: %.3e of scale from the fp64 oracle (fp32 oracle: %.3e)" % (name, e_gpu, e_ref)
+            assert e_pair <= tol_grad + e_ref, "%s: %.3e from the fp32 oracle, whose own error is %.3e" % (name, e_pair, e_ref)
         else:
             err = float((a.grad.float().cpu() - b.grad).norm() / b.grad.norm().clamp_min(1e-30))
-            worst = max(worst, (name, err), key=lambda t: t[1])
+            report.append((name, err))
             assert err < tol_grad, "%s: relative L2 gradient error %.3f >= %.3f" % (name, err, tol_grad)
-    return worst
+    return report
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -113,7 +149,7 @@ def test_c4_deep_stack_at_config_size(dtype):
     gpu, cpu = _pair(cfg, DictionaryUtility.to_object)
     c, f, y = synthetic.generate(64, 512, 3, seed=99)
     if dtype == torch.float32:
-        _one_step(gpu, cpu, c, f, y, dtype, 1e-5, 1e-4)
+        _one_step(gpu, cpu, c, f, y, dtype, 1e-5, 1e-5)
     else:
         _one_step(gpu, cpu, c, f, y, dtype, 5e-3, GRAD_REL_L2[dtype])
 
@@ -138,7 +174,7 @@ def test_c5_hybrid_net_at_config_size():
     cpu.load_state_dict({k: v.cpu() for k, v in gpu.state_dict().items()})
     c, f, y = synthetic.generate(64, 1024, 3, seed=3, layout="2d")
     assert f.shape[1] == 2048
-    _one_step(gpu, cpu, c, f, y, torch.float32, 1e-5, 1e-4)
+    _one_step(gpu, cpu, c, f, y, torch.float32, 1e-5, 1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------- N ranks, one card
