@@ -265,6 +265,49 @@ int wfs_bn_apply_fwd_fold(const void *X, int64_t N, int32_t C, const float *gamm
 int wfs_rulebook_cell_map(const wfs_geometry *g, int64_t N, void *workspace, const uint32_t **ticket,
                           const int32_t **slot_id, int64_t *cells);
 
+/* rulebook chain ----------------------------------------------------------------------------
+ * The rulebooks of a whole stack of conv layers (what SparseSequential hands spconv one
+ * torch.ops.spconv.get_indice_pairs call per layer for: reference src/models/SPConvBlocks.py:75,134,498,
+ * config "algorithm" lists such as config/psd_c2_3d.json) in TWO launches, one workgroup per EVENT with the
+ * event's site tables in LDS (rulebook_chain.hip).  layers[l].geo.spatial must equal layers[l-1].geo.out_shape;
+ * a SubM layer keeps the site set, a regular layer's outputs (first-seen order, A.3) are the next layer's inputs.
+ * Requirements, verified on the device: the batch column of `indices` is non-decreasing (events contiguous and in
+ * order, as the reference's collate_fn delivers them), no event has more than 2048 rows in any of its site sets,
+ * K <= 32.  A violation sets the error word returned by wfs_rulebook_chain_count(host_flags) (bit 0: rows not
+ * grouped by event or an index out of range; bit 1: event too large) and every regular layer's *overflow_dev; the
+ * caller then builds the layers one by one (wfs_rulebook_plan / _emit).
+ *   wfs_rulebook_chain_count  per event: row range and number of output sites per regular layer -> workspace.
+ *                             host_counts (optional, [nlayers], synchronises): total outputs per layer (0 for SubM).
+ *   wfs_rulebook_chain_build  per event: everything else.  Per layer: nbr_out [K, N_cap] (N_cap = rows of the
+ *                             layer's input set = the previous regular layer's M_cap), and for a regular layer
+ *                             nbr_in [K, M_cap], out_indices [M_cap, ndim+1], *m_dev = min(M, M_cap),
+ *                             *overflow_dev = (M > M_cap or chain error), optionally the cell -> row map
+ *                             cell_ticket / cell_row [batch * out_volume] in the format of wfs_rulebook_cell_map.
+ * Both take the same layers / indices / workspace (wfs_rulebook_chain_workspace_bytes(batch_size) bytes, kept
+ * untouched between the two calls). */
+#define WFS_CHAIN_MAX_LAYERS 4
+typedef struct wfs_chain_layer {
+    wfs_geometry geo;
+    int32_t *nbr_out;
+    int32_t *nbr_in;
+    int32_t *out_indices;
+    int64_t N_cap;
+    int64_t M_cap;
+    int64_t *m_dev;
+    int32_t *overflow_dev;
+    uint32_t *cell_ticket;
+    int32_t *cell_row;
+} wfs_chain_layer;
+
+size_t wfs_rulebook_chain_workspace_bytes(int32_t batch_size);
+
+int wfs_rulebook_chain_count(const wfs_chain_layer *layers, int32_t nlayers, const int32_t *indices, int64_t N,
+                             const int64_t *n_dev, void *workspace, size_t workspace_bytes, int64_t *host_counts,
+                             int32_t *host_flags, void *stream);
+
+int wfs_rulebook_chain_build(const wfs_chain_layer *layers, int32_t nlayers, const int32_t *indices, int64_t N,
+                             const int64_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
+
 /* SparseConvTensor.dense() -------------------------------------------------------------------
  * Y is [B, C, *spatial] (channels first, contiguous) and must be zero-filled by the caller;
  * rows are assigned, not accumulated.  winner_ws: NULL when coordinates are unique, else int32

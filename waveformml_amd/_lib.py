@@ -40,6 +40,12 @@ class DwJob(ctypes.Structure):
                 ("transpose", _i32), ("dW", _vp)]
 
 
+class ChainLayer(ctypes.Structure):
+    """struct wfs_chain_layer"""
+    _fields_ = [("geo", Geometry), ("nbr_out", _vp), ("nbr_in", _vp), ("out_indices", _vp), ("N_cap", _i64),
+                ("M_cap", _i64), ("m_dev", _vp), ("overflow_dev", _vp), ("cell_ticket", _vp), ("cell_row", _vp)]
+
+
 # name -> (restype, argtypes); mirrors include/wfsparse.h one to one
 SIGNATURES = {
     "wfs_abi_version": (ctypes.c_int, []),
@@ -50,6 +56,10 @@ SIGNATURES = {
                                          _vp]),
     "wfs_rulebook_emit": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _sz, _vp, _vp, _vp]),
+    "wfs_rulebook_chain_workspace_bytes": (_sz, [_i32]),
+    "wfs_rulebook_chain_count": (ctypes.c_int, [ctypes.POINTER(ChainLayer), _i32, _vp, _i64, _vp, _vp, _sz, c_i64p, c_i32p,
+                                                _vp]),
+    "wfs_rulebook_chain_build": (ctypes.c_int, [ctypes.POINTER(ChainLayer), _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "wfs_indices_check": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _sz, c_i64p, _vp]),
     "wfs_gather_conv": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _i32,
                                        _vp, _vp, _i32, _vp, _vp]),

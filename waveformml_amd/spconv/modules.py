@@ -91,6 +91,61 @@ class SparseSequential(SparseModule):
                     break                           # ToDense or an unknown sparse module ends the sparse stack
         x.prefetched = plan
 
+    @staticmethod
+    def _chain_rulebooks(mods, x):
+        """The rulebooks of every conv layer of the stack from ONE event-parallel build (ops.build_rulebook_chain) on
+        the current stream; None when the stack or the input is outside what the chain build covers (the layers then
+        build their own)."""
+        from . import ops
+        from .conv import SparseConvolution
+        if x.indice_dict:
+            return None                             # rulebooks from an earlier pass: leave everything to the layers
+        ndim = x.indices.shape[1] - 1
+        specs, owners, flags = [], [], []           # owners[i]: conv modules served by chain entry i
+        site, keys = 0, {}                          # current site-set generation; (site, key / geometry) -> entry
+        last_regular = None
+        for m in mods:
+            if isinstance(m, SparseConvolution):
+                if m.conv1x1:
+                    continue
+                if m.inverse or m.transposed or not ops.chain_spec_ok(ndim, m.kernel_size, m.dilation, m.subm):
+                    break
+                if m.subm:
+                    geo = (site, "subm", tuple(m.kernel_size), tuple(m.dilation))
+                    key = (site, "key", m.indice_key) if m.indice_key is not None else geo
+                    if key in keys:
+                        owners[keys[key]].append(m)
+                        continue
+                    if len(specs) == ops.CHAIN_MAX_LAYERS:
+                        break
+                    keys[key] = len(specs)
+                    specs.append((m.kernel_size, m.stride, m.padding, m.dilation, True))
+                    owners.append([m])
+                    flags.append(False)
+                else:
+                    if len(specs) == ops.CHAIN_MAX_LAYERS:
+                        break
+                    if m.indice_key is not None:
+                        keys[(site, "key", m.indice_key)] = len(specs)
+                    specs.append((m.kernel_size, m.stride, m.padding, m.dilation, False))
+                    owners.append([m])
+                    flags.append(False)
+                    last_regular = len(specs) - 1
+                    site += 1
+            elif isinstance(m, ToDense):
+                if last_regular is not None and last_regular == len(specs) - 1:
+                    flags[last_regular] = True      # dense() of this layer's output can use the build's cell map
+                break
+            elif isinstance(m, SparseModule):
+                break
+        if not specs:
+            return None
+        caps = [getattr(o[0], "out_capacity", None) for o in owners]
+        rbs = ops.build_rulebook_chain(x.indices, x.batch_size, x.spatial_shape, specs, x.n_valid, caps, flags)
+        if rbs is None:
+            return None
+        return {id(m): rb for rb, ms in zip(rbs, owners) for m in ms}
+
     def forward(self, input):
         return self.run(input, list(self._modules.values()))
 
@@ -99,6 +154,12 @@ class SparseSequential(SparseModule):
         trailing ToDense when the head can consume the sparse rows directly)."""
         from . import functional as Fsp
         from . import ops
+        if (ops.EVENT_LOCAL_RULEBOOKS and _is_sparse_tensor(input) and input.features.is_cuda
+                and getattr(input, "prefetched", None) is None and input.indices.shape[0] > 0
+                and (input.n_valid is not None or input.unique is True or ops.ASSUME_VALID_UNIQUE_INDICES)):
+            plan = self._chain_rulebooks(mods, input)
+            if plan:
+                input.prefetched = plan
         want_prefetch = (ops.PREFETCH_RULEBOOKS and _is_sparse_tensor(input) and input.n_valid is not None
                          and getattr(input, "prefetched", None) is None and input.features.is_cuda)
         i = 0

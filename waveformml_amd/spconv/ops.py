@@ -40,6 +40,16 @@ OVERLAP_DW = False
 # "measured dead ends"); it should pay when the rows no longer fit the L2s.
 FUSE_CONV_BN_STATS = os.environ.get("WFS_FUSE_CONV_BN_STATS", "0") != "0"
 
+# The rulebooks of ALL conv layers of a SparseSequential in two launches, one workgroup per event with its site tables
+# in LDS (csrc/rulebook_chain.hip, include/wfsparse.h "rulebook chain"), instead of 3 / 6 chip-wide launches per layer.
+# Needs the batch column to be non-decreasing (events contiguous, in order: the reference's collate_fn output) and
+# events of at most 2048 rows; both are verified on the device.  Exact-size mode falls back to the per-layer builds by
+# itself when the check fails; in device-count mode (no host read-back) a failure sets every layer's overflow flag,
+# which the captured step's check() reports.  WFS_EVENT_LOCAL_RULEBOOKS=0 switches it off.
+EVENT_LOCAL_RULEBOOKS = os.environ.get("WFS_EVENT_LOCAL_RULEBOOKS", "1") != "0"
+CHAIN_MAX_LAYERS = 4
+CHAIN_BUILD_COUNT = 0      # chains actually built (tests / diagnostics)
+
 _SIDE_STREAMS = {}
 
 
@@ -316,6 +326,96 @@ def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, 
                                          ctypes.byref(cells)):
                 rb.cell_map = (ticket.value, slot.value, ws, int(np.prod(rb.out_spatial_shape)))
     return rb
+
+
+def chain_spec_ok(ndim, ksize, dilation, subm):
+    """Layer shapes the event-local chain build covers: K <= 32, and for SubM the mirrored-table form (odd kernel,
+    dilation 1) the compute kernels use without a stored nbr_in."""
+    K = int(np.prod(ksize))
+    if K < 1 or K > 32 or ndim > _lib.WFS_MAX_DIM:
+        return False
+    if subm and not all(int(k) % 2 == 1 and int(d) == 1 for k, d in zip(ksize, dilation)):
+        return False
+    return True
+
+
+def build_rulebook_chain(indices, batch_size, spatial_shape, specs, n_dev=None, capacities=None, cell_maps=None):
+    """Rulebooks of a stack of conv layers from one event-parallel build.
+
+    ``specs``: [(ksize, stride, padding, dilation, subm)] in layer order (per-dim lists); a SubM layer keeps the row
+    set, a regular layer's outputs are the next layer's inputs.  ``capacities``: per layer, rows to reserve for a
+    regular layer's outputs in device-count mode (``n_dev`` given; default: default_out_capacity).  ``cell_maps``: per
+    layer, whether to emit the cell -> row map dense() can use.  Returns [Rulebook] (one per spec), or None when the
+    inputs are not grouped by event / an event is too large (exact-size mode only: device-count mode cannot know and
+    reports through the rulebooks' overflow flags)."""
+    global CHAIN_BUILD_COUNT
+    if not indices.is_cuda or indices.dtype != torch.int32:
+        raise RuntimeError("waveformml_amd.spconv: indices must be int32 on the GPU")
+    indices = indices.contiguous()
+    lib = _lib.load()
+    dev = indices.device
+    ndim = indices.shape[1] - 1
+    L = len(specs)
+    assert 1 <= L <= CHAIN_MAX_LAYERS
+    capacities = list(capacities) if capacities is not None else [None] * L
+    cell_maps = list(cell_maps) if cell_maps is not None else [False] * L
+    layers = (_lib.ChainLayer * L)()
+    geos, shape = [], [int(s_) for s_ in spatial_shape]
+    for l, (ksize, stride, padding, dilation, subm) in enumerate(specs):
+        g = _lib.make_geometry(ndim, batch_size, shape, ksize, stride, padding, dilation, subm)
+        geos.append(g)
+        ctypes.memmove(ctypes.byref(layers[l].geo), ctypes.byref(g), ctypes.sizeof(g))
+        shape = [int(g.out_shape[i]) for i in range(ndim)]
+    N = int(indices.shape[0])
+    if N == 0:
+        return None
+    stream = _lib.stream_ptr()
+    ws = torch.empty((int(lib.wfs_rulebook_chain_workspace_bytes(int(batch_size))),), dtype=torch.uint8, device=dev)
+    exact = n_dev is None
+    counts = (ctypes.c_int64 * L)()
+    flags = ctypes.c_int32(0)
+    _lib.check(lib.wfs_rulebook_chain_count(layers, L, _lib.ptr(indices), N, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
+                                            counts if exact else None, ctypes.byref(flags) if exact else None, stream))
+    if exact and flags.value != 0:
+        return None
+    rbs, keep = [], []
+    cur_idx, cur_n, cur_ndev = indices, N, n_dev
+    for l, g in enumerate(geos):
+        rb = Rulebook()
+        rb.geometry, rb.N, rb.K, rb.subm, rb.indices = g, cur_n, int(g.K), bool(g.subm), cur_idx
+        rb.out_spatial_shape = [int(g.out_shape[i]) for i in range(ndim)]
+        rb.n_dev, rb.has_dup = cur_ndev, False
+        rb.nbr_out = torch.empty((rb.K, cur_n), dtype=torch.int32, device=dev)
+        layers[l].nbr_out = _lib.ptr(rb.nbr_out)
+        layers[l].N_cap = cur_n
+        if g.subm:
+            rb.M, rb.m_dev, rb.out_indices = cur_n, cur_ndev, cur_idx
+            rb.kmap_in = _lib.i32_array([rb.K - 1 - k for k in range(rb.K)])
+            rb.centre_k = rb.K // 2
+        else:
+            cells = int(batch_size) * int(np.prod(rb.out_spatial_shape))
+            M = int(counts[l]) if exact else int(capacities[l] or default_out_capacity(cur_n, rb.K, cells))
+            rb.M = M
+            rb.out_indices = torch.empty((M, ndim + 1), dtype=torch.int32, device=dev)
+            rb.nbr_in = torch.empty((rb.K, M), dtype=torch.int32, device=dev)
+            layers[l].nbr_in, layers[l].out_indices, layers[l].M_cap = _lib.ptr(rb.nbr_in), _lib.ptr(rb.out_indices), M
+            if not exact:
+                rb.m_dev = torch.empty((1,), dtype=torch.int64, device=dev)
+                rb.overflow = torch.empty((1,), dtype=torch.int32, device=dev)
+                layers[l].m_dev, layers[l].overflow_dev = _lib.ptr(rb.m_dev), _lib.ptr(rb.overflow)
+            if cell_maps[l] and M > 0:
+                ticket = torch.empty((cells,), dtype=torch.int32, device=dev)
+                slot = torch.empty((cells,), dtype=torch.int32, device=dev)
+                layers[l].cell_ticket, layers[l].cell_row = _lib.ptr(ticket), _lib.ptr(slot)
+                rb.cell_map = (ticket.data_ptr(), slot.data_ptr(), (ticket, slot), int(np.prod(rb.out_spatial_shape)))
+            cur_idx, cur_n, cur_ndev = rb.out_indices, M, rb.m_dev
+        rbs.append(rb)
+    _lib.check(lib.wfs_rulebook_chain_build(layers, L, _lib.ptr(indices), N, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
+                                            stream))
+    for rb in rbs:
+        rb._chain_ws = ws          # the counts / flags live here until every kernel of the chain has run
+    CHAIN_BUILD_COUNT += 1
+    return rbs
 
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
