@@ -53,6 +53,7 @@ def _pair(cfg, loader):
                                         for m in ref_cfg["net_config"]["imports"]]
     cpu = LitPSD(loader(ref_cfg))
     cpu.load_state_dict(gpu.state_dict())
+    cpu.make_twin = lambda: LitPSD(loader(copy.deepcopy(ref_cfg)))       # another instance of the CPU restatement
     gpu = gpu.to(DEV)
     gpu.train(), cpu.train()
     return gpu, cpu
@@ -73,7 +74,8 @@ def _one_step(gpu, cpu, c, f, y, dtype, tol_logits, tol_grad):
     sides = [(cpu, fin.float())]
     if exact:
         cpu.load_state_dict({k: v.cpu() for k, v in gpu.state_dict().items()})
-        truth = copy.deepcopy(cpu).double()                  # the same restatement, every sum in float64
+        truth = cpu.make_twin().double()                     # the same restatement, every sum in float64
+        truth.load_state_dict(cpu.state_dict())
         truth.train()
         sides.append((truth, fin.double()))
     with torch.no_grad():

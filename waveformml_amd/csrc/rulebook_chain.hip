@@ -27,17 +27,23 @@
 namespace {
 
 constexpr int CH_THREADS = 1024;
-constexpr int CH_SITES = 2048;            // rows of one event in any site set
+constexpr int CH_SITES = 2048;            // rows of one event in any site set (two row chunks of CH_THREADS)
 constexpr int CH_HASH = 4096;             // hash slots per table (load <= 0.5)
-constexpr int CH_GRID = 7168;             // an event's volume up to this uses a direct grid instead
-constexpr int CH_TAB_WORDS = 2 * CH_GRID; // 56 KiB per table: direct [ticket | id] x cells, hash [key | ticket | id] x CH_HASH
+constexpr int CH_GRID = 8192;             // an event's volume up to this uses a direct grid instead
+constexpr int CH_TAB_WORDS = 8192;        // 32 KiB per table: direct [value] x cells, hash [key | value] x CH_HASH
 constexpr unsigned EMPTY = 0xFFFFFFFFu;
-static_assert(3 * CH_HASH <= CH_TAB_WORDS, "hash layout must fit the table memory");
-constexpr size_t CH_LDS_BYTES = (size_t)(2 * CH_TAB_WORDS + 2 * CH_SITES) * 4;
+static_assert(2 * CH_HASH <= CH_TAB_WORDS && CH_GRID <= CH_TAB_WORDS, "table layouts must fit the table memory");
+constexpr int CH_CACHE_ITEMS = 36864;     // (row, offset) candidates whose table slot is parked in LDS (16 bits each)
+// LDS: two site lists (coordinates packed 16 bits per dim, 8 B per site), first-ticket masks, one table, the slot cache
+constexpr size_t CH_LDS_BYTES = (size_t)(4 * CH_SITES + CH_SITES + CH_TAB_WORDS) * 4 + (size_t)CH_CACHE_ITEMS * 2;
 
+// Geometry of one layer, dims RIGHT-ALIGNED to four levels (level 3 = last = fastest dim; missing leading dims are
+// size-1 dummies), so that one four-level loop nest serves every ndim.
 struct Geo {
     int ndim, K;
     int spatial[4], out_shape[4], ksize[4], stride[4], padding[4], dilation[4];
+    int shift[4];                         // log2(stride) if it is a power of two, else -1
+    float inv_stride[4];
     int in_volume, out_volume;
 };
 
@@ -60,28 +66,53 @@ struct Chain {
     long long N;
     const long long *n_dev;
     int *counts;                          // [batch][2 + WFS_CHAIN_MAX_LAYERS]: start, n, outputs of layer l
+    int debug;                            // timing experiments: stop after stage `debug` (0 = run everything)
     int *flags;                           // [0] error bits (1: rows not grouped by event / bad index, 2: event too large)
 };
 constexpr int CW = 2 + WFS_CHAIN_MAX_LAYERS;
 
-// ---- site table in LDS -------------------------------------------------------------------------------------------
+// A layer's geometry as the loops use it: read ONCE per layer from the kernel arguments and pinned in scalar registers.
+// (Left to itself hipcc re-loads every field from the argument segment at every use inside the loops: a dozen dependent
+// s_load + s_waitcnt lgkmcnt(0) per iteration, each also draining the LDS queue.)
+#define WFS_PIN(x) asm volatile("" : "+s"(x))
+struct LGeo {
+    int K;
+    int spatial[4], out_shape[4], ksize[4], stride[4], padding[4], dilation[4], shift[4];
+    float inv_stride[4];
+    __device__ __forceinline__ void load(const Geo &g) {
+        K = g.K;
+        WFS_PIN(K);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            spatial[d] = g.spatial[d];
+            out_shape[d] = g.out_shape[d];
+            ksize[d] = g.ksize[d];
+            stride[d] = g.stride[d];
+            padding[d] = g.padding[d];
+            dilation[d] = g.dilation[d];
+            shift[d] = g.shift[d];
+            inv_stride[d] = g.inv_stride[d];
+            WFS_PIN(spatial[d]);
+            WFS_PIN(out_shape[d]);
+            WFS_PIN(ksize[d]);
+            WFS_PIN(stride[d]);
+            WFS_PIN(padding[d]);
+            WFS_PIN(dilation[d]);
+            WFS_PIN(shift[d]);
+            WFS_PIN(inv_stride[d]);
+        }
+    }
+};
+
+// ---- site table in LDS: one value word per slot.  Output table: EMPTY -> smallest ticket (atomicMin) -> local id;
+// site table of a row set: -1 -> row of the event (atomicMax: the last duplicate wins).  Hash mode adds a key word.
 struct Tab {
     int *w;         // CH_TAB_WORDS words
     int direct;
-    int vol;
-    __device__ __forceinline__ int *keys() const { return w; }                                   // hash only
-    __device__ __forceinline__ unsigned *tk() const { return (unsigned *)(w + (direct ? 0 : CH_HASH)); }
-    __device__ __forceinline__ int *id() const { return w + (direct ? vol : 2 * CH_HASH); }
-    __device__ __forceinline__ int slots() const { return direct ? vol : CH_HASH; }
-    __device__ void clear() const {
-        const int n = slots();
-        unsigned *t = tk();
-        int *d = id();
-        for (int i = threadIdx.x; i < n; i += CH_THREADS) {
-            t[i] = EMPTY;
-            d[i] = -1;
-            if (!direct) w[i] = -1;
-        }
+    __device__ __forceinline__ int *val() const { return w + (direct ? 0 : CH_HASH); }
+    __device__ void clear(int vol) const {
+        const int n = direct ? vol : 2 * CH_HASH;
+        for (int i = threadIdx.x; i < n; i += CH_THREADS) w[i] = -1;
     }
     __device__ __forceinline__ int insert(int key) const {
         if (direct) return key;
@@ -102,60 +133,111 @@ struct Tab {
             s = (s + 1) & (CH_HASH - 1);
         }
     }
+    __device__ __forceinline__ int get(int key) const {                  // value of a key, -1 if absent
+        const int s = find(key);
+        return s >= 0 ? val()[s] : -1;
+    }
 };
 static_assert(CH_HASH == 4096, "hash shift above assumes 4096 slots");
 
-// event-local keys: row-major over the layer's input / output shape, no batch term
-__device__ __forceinline__ void decode(const int *shape, int ndim, int key, int *x) {
-#pragma unroll
-    for (int d = 3; d >= 0; --d) {
-        if (d >= ndim) {
-            x[d] = 0;
-            continue;
-        }
-        x[d] = key % shape[d];
-        key /= shape[d];
-    }
+// coordinates of a site: levels 0,1 in `lo`, levels 2,3 in `hi`, 16 bits each
+struct Site {
+    unsigned lo, hi;
+};
+__device__ __forceinline__ int site_x(const Site &s, int d) {
+    return (int)(((d < 2 ? s.lo : s.hi) >> (16 * (d & 1))) & 0xFFFFu);
 }
-__device__ __forceinline__ void offsets_of(const Geo &g, int k, int *off) {
+__device__ __forceinline__ void site_put(Site &s, int d, int x) {
+    if (d < 2) s.lo |= (unsigned)x << (16 * (d & 1)); else s.hi |= (unsigned)x << (16 * (d & 1));
+}
+
+// t / stride for 0 <= t < 2^16 with full-rate instructions (v_mul_lo / v_mul_hi are quarter rate)
+__device__ __forceinline__ int div_stride(const LGeo &g, int d, int t) {
+    if (g.stride[d] == 1) return t;
+    if (g.shift[d] >= 0) return t >> g.shift[d];
+    int q = (int)(((float)t + 0.5f) * g.inv_stride[d]);
+    if (__mul24(q, g.stride[d]) > t) --q;
+    if (__mul24(q + 1, g.stride[d]) <= t) ++q;
+    return q;
+}
+
+// One level (dim) of a candidate: input coordinate x, kernel offset j -> output coordinate (A.3 getValidOutPos:
+// x + p - j * d = o * s).  Scalar (uniform) branches pick the cheap form for stride 1 / power-of-two strides.
+__device__ __forceinline__ bool out_level(const LGeo &g, int d, int x, int j, int *o) {
+    const int t = x + g.padding[d] - __mul24(j, g.dilation[d]);
+    if (g.stride[d] == 1) {
+        *o = t;
+        return (unsigned)t < (unsigned)g.out_shape[d];
+    }
+    if (g.shift[d] >= 0) {
+        *o = t >> g.shift[d];
+        return t >= 0 && (t & (g.stride[d] - 1)) == 0 && *o < g.out_shape[d];
+    }
+    const int tc = t < 0 ? 0 : t;
+    *o = div_stride(g, d, tc);
+    return t >= 0 && __mul24(*o, g.stride[d]) == t && *o < g.out_shape[d];
+}
+// A PLANE of candidates = all offsets of the last level for fixed offsets of the levels before it.  The levels before
+// the last are evaluated once per plane (dummy leading levels of a < 4-dim geometry are skipped: scalar branch):
+// partial key, validity, partial coordinates.
+struct PlaneHead {
+    int lin;
+    bool ok;
+    Site so;
+};
+__device__ __forceinline__ PlaneHead plane_head(const LGeo &g, int nd, unsigned offs, const Site &x) {
+    PlaneHead h = {0, true, {0u, 0u}};
 #pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d < 4 - nd) continue;
+        int o;
+        const bool okd = out_level(g, d, site_x(x, d), (int)((offs >> (8 * d)) & 0xFFu), &o);
+        h.ok = h.ok && okd;
+        h.lin = __mul24(h.lin, g.out_shape[d]) + o;
+        site_put(h.so, d, o & 0xFFFF);
+    }
+    return h;
+}
+// the candidate of plane head h with last-level offset j3: key or -1, coordinates in *os
+__device__ __forceinline__ int plane_candidate(const LGeo &g, const PlaneHead &h, int x3, int j3, Site *os) {
+    int o;
+    const bool ok = out_level(g, 3, x3, j3, &o) && h.ok;
+    *os = h.so;
+    site_put(*os, 3, o & 0xFFFF);
+    return ok ? __mul24(h.lin, g.out_shape[3]) + o : -1;
+}
+// a single candidate (the rare paths: numbering, events beyond the slot cache)
+__device__ __forceinline__ int out_site(const LGeo &g, int nd, unsigned offs, const Site &x, Site *os) {
+    const PlaneHead h = plane_head(g, nd, offs, x);
+    return plane_candidate(g, h, site_x(x, 3), (int)(offs >> 24), os);
+}
+__device__ __forceinline__ unsigned pack_offsets(const Geo &g, int k) {
+    unsigned p = 0;
     for (int d = 3; d >= 0; --d) {
-        if (d >= g.ndim) {
-            off[d] = 0;
-            continue;
-        }
-        off[d] = k % g.ksize[d];
+        p |= (unsigned)(k % g.ksize[d]) << (8 * d);
         k /= g.ksize[d];
     }
+    return p;
 }
-// output-site key of the candidate (input position x, offset k), or -1 (A.3 getValidOutPos: x + p - off*d = o*s)
-__device__ __forceinline__ int out_key(const Geo &g, int k, const int *x) {
-    int off[4];
-    offsets_of(g, k, off);
+// (k, r) of flat item i = k * n + r without an integer division: exact for i < 2^22 (here i < 2^16)
+__device__ __forceinline__ void split_item(int i, int n, float inv_n, int *k, int *r) {
+    int q = (int)(((float)i + 0.5f) * inv_n);
+    int rem = i - __mul24(q, n);
+    if (rem < 0) {
+        --q;
+        rem += n;
+    } else if (rem >= n) {
+        ++q;
+        rem -= n;
+    }
+    *k = q;
+    *r = rem;
+}
+
+__device__ __forceinline__ int lin_key(const int *shape, const Site &s) {
     int lin = 0;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        if (d >= g.ndim) break;
-        int t = x[d] + g.padding[d] - off[d] * g.dilation[d];
-        if (t < 0) return -1;
-        int o = t / g.stride[d];
-        if (o * g.stride[d] != t || o >= g.out_shape[d]) return -1;
-        lin = lin * g.out_shape[d] + o;
-    }
-    return lin;
-}
-// input-site key that reaches output position o through offset k, or -1
-__device__ __forceinline__ int in_key_of(const Geo &g, int k, const int *o) {
-    int off[4];
-    offsets_of(g, k, off);
-    int lin = 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        if (d >= g.ndim) break;
-        int x = o[d] * g.stride[d] - g.padding[d] + off[d] * g.dilation[d];
-        if (x < 0 || x >= g.spatial[d]) return -1;
-        lin = lin * g.spatial[d] + x;
-    }
+    for (int d = 0; d < 4; ++d) lin = __mul24(lin, shape[d]) + site_x(s, d);
     return lin;
 }
 
@@ -210,23 +292,33 @@ __device__ long long coop_lower_bound(const int *idx, int stride, long long lo, 
     return hi;
 }
 
+// Work is (row, offset)-parallel: item i = k * n + r, so that all 16 waves of the block have LDS operations in flight
+// (a thread-per-row form leaves a 300-row event with 5 busy waves whose 27 dependent LDS round trips per pass run back
+// to back: measured 143 us for the build kernel).  The one expensive step, a candidate's output site (out_site, ~50
+// instructions + the table insert), runs ONCE per item: its slot is parked in LDS as 16 bits and the later passes
+// (first tickets, tables) just read it.
 template <bool COUNT>
 __global__ void __launch_bounds__(CH_THREADS) k_chain(Chain c) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     __shared__ int sMisc[8];
     __shared__ int sW[CH_THREADS / 64];
+    __shared__ unsigned sOff[32];
     __shared__ long long sRed[2 * WFS_CHAIN_MAX_LAYERS + 2];
-    int *keyA = lds, *keyB = lds + CH_SITES;
-    Tab tin = {lds + 2 * CH_SITES, 0, 0}, tout = {lds + 2 * CH_SITES + CH_TAB_WORDS, 0, 0};
+    Site *siteA = (Site *)lds, *siteB = (Site *)lds + CH_SITES;
+    unsigned *rowmask = (unsigned *)(lds + 4 * CH_SITES);
+    Tab tab = {lds + 5 * CH_SITES, 0};
+    unsigned short *slotc = (unsigned short *)(lds + 5 * CH_SITES + CH_TAB_WORDS);
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
-    const int nd0 = c.L[0].g.ndim, stride = nd0 + 1;
+    const int nd = c.L[0].g.ndim, stride = nd + 1;
     const long long nv = valid_rows(c.N, c.n_dev);
     int *cnt = c.counts + (long long)e * CW;
 
     long long start;
     int n;
     long long base[WFS_CHAIN_MAX_LAYERS];
+#pragma unroll
+    for (int l = 0; l < WFS_CHAIN_MAX_LAYERS; ++l) base[l] = 0;
     if (COUNT) {
         start = coop_lower_bound(c.idx, stride, 0, nv, e, &sMisc[0]);
         // the event's rows end within CH_SITES of the start, or the event is too large for the tables anyway
@@ -258,25 +350,25 @@ __global__ void __launch_bounds__(CH_THREADS) k_chain(Chain c) {
         }
         if (tid < 2 * WFS_CHAIN_MAX_LAYERS + 2) sRed[tid] = 0;
         __syncthreads();
+        typedef unsigned long long u64;
 #pragma unroll
         for (int l = 0; l < WFS_CHAIN_MAX_LAYERS; ++l) {
-            // wave-level sums first, one LDS atomic per wave and quantity
-            long long a = pre[l], t = tot[l];
+            long long a = pre[l], t = tot[l];       // wave-level sums first, one LDS atomic per wave and quantity
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 a += __shfl_xor(a, d, 64);
                 t += __shfl_xor(t, d, 64);
             }
             if ((tid & 63) == 0) {
-                atomicAdd((unsigned long long *)&sRed[2 * l], (unsigned long long)a);
-                atomicAdd((unsigned long long *)&sRed[2 * l + 1], (unsigned long long)t);
+                atomicAdd((u64 *)&sRed[2 * l], (u64)a);
+                atomicAdd((u64 *)&sRed[2 * l + 1], (u64)t);
             }
         }
         {
-            long long s = nsum;
+            long long sN = nsum;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            if ((tid & 63) == 0) atomicAdd((unsigned long long *)&sRed[2 * WFS_CHAIN_MAX_LAYERS], (unsigned long long)s);
+            for (int d = 32; d >= 1; d >>= 1) sN += __shfl_xor(sN, d, 64);
+            if ((tid & 63) == 0) atomicAdd((u64 *)&sRed[2 * WFS_CHAIN_MAX_LAYERS], (u64)sN);
         }
         __syncthreads();
 #pragma unroll
@@ -298,84 +390,122 @@ __global__ void __launch_bounds__(CH_THREADS) k_chain(Chain c) {
         n = cnt[1];
     }
 
-    // ---- the event's input rows as keys over the first layer's input shape
+    if (c.debug == 1) return;
+    // ---- the event's input rows, coordinates packed (levels 4 - ndim .. 3)
     {
-        const Geo &g = c.L[0].g;
+        LGeo g;
+        g.load(c.L[0].g);
         bool bad = false;
         for (int r = tid; r < n; r += CH_THREADS) {
             const int *row = c.idx + (start + r) * stride;
             bad = bad || row[0] != e;
-            int lin = 0;
+            Site xs = {0u, 0u};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                if (d >= g.ndim) break;
-                const int x = row[1 + d];
+                const int col = d - (4 - nd);
+                if (col < 0) continue;
+                const int x = row[1 + col];
                 bad = bad || x < 0 || x >= g.spatial[d];
-                lin = lin * g.spatial[d] + (x < 0 ? 0 : (x >= g.spatial[d] ? g.spatial[d] - 1 : x));
+                site_put(xs, d, x < 0 ? 0 : (x >= g.spatial[d] ? g.spatial[d] - 1 : x));
             }
-            keyA[r] = lin;
+            siteA[r] = xs;
         }
         if (COUNT && bad) atomicOr(&c.flags[0], 1);
     }
     long long in_base = start;
-    bool in_built = false;
-    tin.direct = c.L[0].in_direct;
-    tin.vol = c.L[0].g.in_volume;
+    bool tab_is_site_table = false;       // does `tab` hold key -> row for the CURRENT row set?
     __syncthreads();
+    if (c.debug == 2) return;
 
     for (int l = 0; l < c.nlayers; ++l) {
         const Layer &L = c.L[l];
-        const Geo &g = L.g;
+        LGeo g;
+        g.load(L.g);
         const int K = g.K;
-        if (!COUNT && !in_built) {
-            // input site table: key -> row of the event (duplicates: the last row wins, A.3)
-            tin.clear();
+        // the layer's pointers / capacities likewise once, in registers
+        int *const p_nbr_out = L.nbr_out, *const p_nbr_in = L.nbr_in, *const p_out_indices = L.out_indices;
+        const long long N_cap = L.N_cap, M_cap = L.M_cap;
+        const int in_volume = L.g.in_volume, out_volume = L.g.out_volume;
+        const bool is_subm = L.subm != 0;
+        const int items = n * K;
+        const int ks3 = g.ksize[3];                 // offsets of the last level = candidates per plane
+        const int pitems = n * (K / ks3);           // (plane, row) work items
+        const float inv_n = n > 0 ? 1.0f / (float)n : 0.f;
+        if (tid < K) sOff[tid] = pack_offsets(L.g, tid);
+        if (c.debug == 3 + l) return;
+        if (is_subm) {
+            if (COUNT) {
+                __syncthreads();           // sOff is rewritten by the next layer
+                continue;
+            }
+            if (!tab_is_site_table) {
+                // site table of the row set: key -> row of the event (duplicates: the last row wins, A.3)
+                tab.direct = L.in_direct;
+                tab.clear(in_volume);
+                __syncthreads();
+                for (int r = tid; r < n; r += CH_THREADS) atomicMax(&tab.val()[tab.insert(lin_key(g.spatial, siteA[r]))], r);
+                tab_is_site_table = true;
+            }
             __syncthreads();
-            for (int r = tid; r < n; r += CH_THREADS) atomicMax(&tin.id()[tin.insert(keyA[r])], r);
-            __syncthreads();
-            in_built = true;
-        }
-        if (L.subm) {
-            if (!COUNT) {
-                const int items = n * K;
-                for (int i = tid; i < items; i += CH_THREADS) {
-                    const int k = i / n, r = i - k * n;
-                    int x[4];
-                    decode(g.spatial, g.ndim, keyA[r], x);
-                    const int nk = out_key(g, k, x);
+            for (int i = tid; i < pitems; i += CH_THREADS) {
+                int pl, r;
+                split_item(i, n, inv_n, &pl, &r);
+                const Site x = siteA[r];
+                const int k0 = __mul24(pl, ks3), x3 = site_x(x, 3);
+                const PlaneHead h = plane_head(g, nd, sOff[k0], x);
+                int *dst = p_nbr_out + (long long)k0 * N_cap + in_base + r;
+                for (int j3 = 0; j3 < ks3; ++j3) {
+                    Site os;
+                    const int key = plane_candidate(g, h, x3, j3, &os);
                     int res = -1;
-                    if (nk >= 0) {
-                        const int s = tin.find(nk);
-                        if (s >= 0) {
-                            const int rr = tin.id()[s];
-                            if (rr >= 0) res = (int)(in_base + rr);
-                        }
+                    if (key >= 0) {
+                        const int rr = tab.get(key);
+                        if (rr >= 0) res = (int)(in_base + rr);
                     }
-                    L.nbr_out[(long long)k * L.N_cap + in_base + r] = res;
+                    dst[(long long)j3 * N_cap] = res;
                 }
             }
+            __syncthreads();
             continue;          // the site set is unchanged
         }
         // ---- regular conv: output site table
-        tout.direct = L.out_direct;
-        tout.vol = g.out_volume;
-        tout.clear();
+        const bool cached = items <= CH_CACHE_ITEMS;
+        tab.direct = L.out_direct;
+        tab.clear(out_volume);
+        for (int r = tid; r < n; r += CH_THREADS) rowmask[r] = 0u;
         if (tid == 0) sMisc[1] = 0;
         __syncthreads();
-        {
-            const int items = n * K;
-            for (int i = tid; i < items; i += CH_THREADS) {
-                const int k = i / n, r = i - k * n;
-                int x[4];
-                decode(g.spatial, g.ndim, keyA[r], x);
-                const int ok = out_key(g, k, x);
-                if (ok < 0) continue;
-                const int s = tout.insert(ok);
-                const unsigned old = atomicMin(&tout.tk()[s], (unsigned)(r * K + k));
-                if (COUNT && old == EMPTY) {                 // a new site: append it (any order) for the next layer
-                    const int pos = atomicAdd(&sMisc[1], 1);
-                    if (pos < CH_SITES) keyB[pos] = ok;
+        // the slot of candidate i (cache, or evaluated again for an event too large for the cache)
+        auto slot_of = [&](int i, int k, int r) -> int {
+            if (cached) {
+                const int sl = slotc[i];
+                return sl == 0xFFFF ? -1 : sl;
+            }
+            Site os;
+            const int key = out_site(g, nd, sOff[k], siteA[r], &os);
+            return key >= 0 ? tab.find(key) : -1;
+        };
+        // A: tickets -- every candidate offers (row * K + offset) to its output site, the smallest one opens the site
+        for (int i = tid; i < pitems; i += CH_THREADS) {
+            int pl, r;
+            split_item(i, n, inv_n, &pl, &r);
+            const Site x = siteA[r];
+            const int k0 = __mul24(pl, ks3), x3 = site_x(x, 3);
+            const PlaneHead h = plane_head(g, nd, sOff[k0], x);
+            for (int j3 = 0; j3 < ks3; ++j3) {
+                const int k = k0 + j3;
+                Site os;
+                const int key = plane_candidate(g, h, x3, j3, &os);
+                int sl = -1;
+                if (key >= 0) {
+                    sl = tab.insert(key);
+                    const unsigned old = atomicMin((unsigned *)&tab.val()[sl], (unsigned)(__mul24(r, K) + k));
+                    if (COUNT && old == EMPTY) {             // a new site: append it (any order) for the next layer
+                        const int pos = atomicAdd(&sMisc[1], 1);
+                        if (pos < CH_SITES) siteB[pos] = os;
+                    }
                 }
+                if (!COUNT && cached) slotc[__mul24(k, n) + r] = (unsigned short)(sl < 0 ? 0xFFFF : sl);
             }
         }
         __syncthreads();
@@ -388,105 +518,96 @@ __global__ void __launch_bounds__(CH_THREADS) k_chain(Chain c) {
             }
             if (tid == 0) cnt[2 + l] = m;
         } else {
-            // first-seen numbering: rows in order, offsets in order (A.3) = exclusive scan of first-ticket counts
+            // B: first tickets -- bit k of rowmask[r] = candidate (r, k) opened its site
+            for (int i = tid; i < items; i += CH_THREADS) {
+                int k, r;
+                split_item(i, n, inv_n, &k, &r);
+                const int sl = slot_of(i, k, r);
+                if (sl >= 0 && (unsigned)tab.val()[sl] == (unsigned)(r * K + k)) atomicOr(&rowmask[r], 1u << k);
+            }
+            __syncthreads();
+            // C: first-seen numbering -- rows in order, offsets in order (A.3) = exclusive scan of the first-ticket
+            // counts; the ids replace the tickets in the table (no ticket is read after pass B)
             int carry = 0;
             for (int r0 = 0; r0 < n; r0 += CH_THREADS) {
                 const int r = r0 + tid;
-                unsigned mask = 0;
-                int x[4];
-                if (r < n) {
-                    decode(g.spatial, g.ndim, keyA[r], x);
-                    for (int k = 0; k < K; ++k) {
-                        const int ok = out_key(g, k, x);
-                        if (ok < 0) continue;
-                        const int s = tout.find(ok);
-                        if (s >= 0 && tout.tk()[s] == (unsigned)(r * K + k)) mask |= 1u << k;
-                    }
-                }
+                unsigned mask = r < n ? rowmask[r] : 0u;
                 int tot;
                 int ex = block_excl_scan(__popc(mask), &tot, sW) + carry;
                 while (mask) {
                     const int k = __builtin_ctz(mask);
                     mask &= mask - 1;
-                    const int ok = out_key(g, k, x);
-                    tout.id()[tout.find(ok)] = ex;
-                    if (ex < CH_SITES) keyB[ex] = ok;
+                    Site os;
+                    const int key = out_site(g, nd, sOff[k], siteA[r], &os);
+                    tab.val()[tab.find(key)] = ex;
+                    if (ex < CH_SITES) siteB[ex] = os;
                     ++ex;
                 }
                 carry += tot;
-                __syncthreads();
             }
+            __syncthreads();
             m = carry < CH_SITES ? carry : CH_SITES;          // carry > CH_SITES was flagged by the count kernel
             const long long out_base = base[l];
-            // nbr_out: output row of (input row, offset)
+            // nbr_in of the event's output rows starts as "no input"; out_indices
             {
-                const int items = n * K;
-                for (int i = tid; i < items; i += CH_THREADS) {
-                    const int k = i / n, r = i - k * n;
-                    int x[4];
-                    decode(g.spatial, g.ndim, keyA[r], x);
-                    const int ok = out_key(g, k, x);
-                    int res = -1;
-                    if (ok >= 0) {
-                        const int s = tout.find(ok);
-                        const long long gid = out_base + tout.id()[s];
-                        if (gid < L.M_cap) res = (int)gid;
-                    }
-                    L.nbr_out[(long long)k * L.N_cap + in_base + r] = res;
-                }
-            }
-            // nbr_in: input row of (output row, offset), by looking the input position up; out_indices
-            {
-                const int items = m * K;
-                for (int i = tid; i < items; i += CH_THREADS) {
-                    const int k = i / m, o = i - k * m;
+                const int oitems = m * K;
+                const float inv_m = m > 0 ? 1.0f / (float)m : 0.f;
+                for (int i = tid; i < oitems; i += CH_THREADS) {
+                    int k, o;
+                    split_item(i, m, inv_m, &k, &o);
                     const long long gid = out_base + o;
-                    if (gid >= L.M_cap) continue;
-                    int ox[4];
-                    decode(g.out_shape, g.ndim, keyB[o], ox);
-                    const int ik = in_key_of(g, k, ox);
-                    int res = -1;
-                    if (ik >= 0) {
-                        const int s = tin.find(ik);
-                        if (s >= 0) {
-                            const int rr = tin.id()[s];
-                            if (rr >= 0) res = (int)(in_base + rr);
-                        }
-                    }
-                    L.nbr_in[(long long)k * L.M_cap + gid] = res;
+                    if (gid < M_cap) p_nbr_in[(long long)k * M_cap + gid] = -1;
                 }
                 for (int o = tid; o < m; o += CH_THREADS) {
                     const long long gid = out_base + o;
-                    if (gid >= L.M_cap) continue;
-                    int ox[4];
-                    decode(g.out_shape, g.ndim, keyB[o], ox);
-                    int *dst = L.out_indices + gid * (g.ndim + 1);
-                    dst[0] = e;
-                    for (int d = 0; d < g.ndim; ++d) dst[1 + d] = ox[d];
+                    if (gid >= M_cap) continue;
+                    const Site os = siteB[o];
+                    int *oi = p_out_indices + gid * (nd + 1);
+                    oi[0] = e;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int col = d - (4 - nd);
+                        if (col >= 0) oi[1 + col] = site_x(os, d);
+                    }
                 }
             }
+            __syncthreads();          // the fills above have completed (vmcnt(0) + barrier) before the entries below land
+            // D: the tables -- nbr_out[k][input row] = output row, nbr_in[k][output row] = input row (sites are distinct
+            // by the caller's contract; with duplicate coordinates the larger row would have to win, A.3)
+            for (int i = tid; i < items; i += CH_THREADS) {
+                int k, r;
+                split_item(i, n, inv_n, &k, &r);
+                const int sl = slot_of(i, k, r);
+                int res = -1;
+                if (sl >= 0) {
+                    const long long gid = out_base + tab.val()[sl];
+                    if (gid < M_cap) {
+                        res = (int)gid;
+                        p_nbr_in[(long long)k * M_cap + gid] = (int)(in_base + r);
+                    }
+                }
+                p_nbr_out[(long long)k * N_cap + in_base + r] = res;
+            }
             if (L.cell_row) {
-                for (int cell = tid; cell < g.out_volume; cell += CH_THREADS) {
-                    const int s = tout.find(cell);
-                    const int o = s >= 0 ? tout.id()[s] : -1;
+                unsigned *const p_ct = L.cell_ticket;
+                int *const p_cr = L.cell_row;
+                for (int cell = tid; cell < out_volume; cell += CH_THREADS) {
+                    const int o = tab.get(cell);
                     const long long gid = o >= 0 ? out_base + o : -1;
-                    const bool ok = gid >= 0 && gid < L.M_cap;
-                    L.cell_ticket[(long long)e * g.out_volume + cell] = ok ? 0u : EMPTY;
-                    L.cell_row[(long long)e * g.out_volume + cell] = ok ? (int)gid : -1;
+                    const bool ok = gid >= 0 && gid < M_cap;
+                    p_ct[(long long)e * out_volume + cell] = ok ? 0u : EMPTY;
+                    p_cr[(long long)e * out_volume + cell] = ok ? (int)gid : -1;
                 }
             }
             in_base = out_base;
         }
         __syncthreads();
-        // the outputs are the next layer's inputs; the output table (key -> local id) is its input table
-        int *t = keyA;
-        keyA = keyB;
-        keyB = t;
+        // the outputs are the next layer's inputs; the table (key -> local id) is their site table
+        Site *t = siteA;
+        siteA = siteB;
+        siteB = t;
         n = m;
-        Tab tt = tin;
-        tin = tout;
-        tout = tt;
-        in_built = !COUNT;
+        tab_is_site_table = !COUNT;
     }
 }
 
@@ -494,19 +615,31 @@ bool geo_from(const wfs_geometry *g, Geo *G) {
     G->ndim = g->ndim;
     G->K = g->K;
     long long iv = 1, ov = 1;
-    for (int i = 0; i < 4; ++i) {
-        G->spatial[i] = g->spatial[i];
-        G->out_shape[i] = g->out_shape[i];
-        G->ksize[i] = g->ksize[i];
-        G->stride[i] = g->stride[i];
-        G->padding[i] = g->padding[i];
-        G->dilation[i] = g->dilation[i];
-        if (i < g->ndim) {
+    const int lead = 4 - g->ndim;                    // dims are right-aligned to four levels
+    for (int lv = 0; lv < 4; ++lv) {
+        const int i = lv - lead;
+        const bool real = i >= 0;
+        G->spatial[lv] = real ? g->spatial[i] : 1;
+        G->out_shape[lv] = real ? g->out_shape[i] : 1;
+        G->ksize[lv] = real ? g->ksize[i] : 1;
+        G->stride[lv] = real ? g->stride[i] : 1;
+        G->padding[lv] = real ? g->padding[i] : 0;
+        G->dilation[lv] = real ? g->dilation[i] : 1;
+        const int sd = G->stride[lv] > 0 ? G->stride[lv] : 1;
+        G->shift[lv] = -1;
+        for (int b = 0; b < 16; ++b)
+            if ((1 << b) == sd) G->shift[lv] = b;
+        G->inv_stride[lv] = 1.0f / (float)sd;
+        if (real) {
             iv *= g->spatial[i];
             ov *= g->out_shape[i];
+            // coordinates travel packed 16 bits per dim and the index arithmetic is 24-bit
+            if (g->spatial[i] > 32767 || g->out_shape[i] > 32767 || g->padding[i] > 32767 || g->stride[i] > 4096 ||
+                g->dilation[i] > 4096)
+                return false;
         }
     }
-    if (iv >= (1ll << 31) || ov >= (1ll << 31)) return false;
+    if (iv >= (1ll << 24) || ov >= (1ll << 24)) return false;
     G->in_volume = (int)iv;
     G->out_volume = (int)ov;
     return true;
@@ -527,6 +660,7 @@ int fill_chain(const wfs_chain_layer *layers, int nlayers, const int32_t *indice
     c->N = N;
     c->n_dev = (const long long *)n_dev;
     c->flags = (int *)workspace;
+    c->debug = getenv("WFS_CHAIN_DEBUG") ? atoi(getenv("WFS_CHAIN_DEBUG")) : 0;
     c->counts = (int *)workspace + 64;
     const wfs_geometry *prev = nullptr;
     for (int l = 0; l < nlayers; ++l) {
@@ -535,7 +669,7 @@ int fill_chain(const wfs_chain_layer *layers, int nlayers, const int32_t *indice
         WFS_REQUIRE(s.geo.K >= 1 && s.geo.K <= 32, WFS_EINVAL, "layer %d: 1 <= K <= 32 (got %d)", l, s.geo.K);
         WFS_REQUIRE(s.geo.batch_size == batch && s.geo.ndim == layers[0].geo.ndim, WFS_EINVAL,
                     "layer %d: batch size / ndim differ from layer 0", l);
-        WFS_REQUIRE(geo_from(&s.geo, &L.g), WFS_EOVERFLOW, "layer %d: event volume >= 2^31", l);
+        WFS_REQUIRE(geo_from(&s.geo, &L.g), WFS_EOVERFLOW, "layer %d: event volume >= 2^24 cells or a dim beyond 32767", l);
         if (prev)
             for (int d = 0; d < s.geo.ndim; ++d)
                 WFS_REQUIRE(s.geo.spatial[d] == prev->out_shape[d], WFS_EINVAL,

@@ -45,8 +45,13 @@ FUSE_CONV_BN_STATS = os.environ.get("WFS_FUSE_CONV_BN_STATS", "0") != "0"
 # Needs the batch column to be non-decreasing (events contiguous, in order: the reference's collate_fn output) and
 # events of at most 2048 rows; both are verified on the device.  Exact-size mode falls back to the per-layer builds by
 # itself when the check fails; in device-count mode (no host read-back) a failure sets every layer's overflow flag,
-# which the captured step's check() reports.  WFS_EVENT_LOCAL_RULEBOOKS=0 switches it off.
-EVENT_LOCAL_RULEBOOKS = os.environ.get("WFS_EVENT_LOCAL_RULEBOOKS", "1") != "0"
+# which the captured step's check() reports.
+# OFF by default (WFS_EVENT_LOCAL_RULEBOOKS=1 switches it on): bit-exact, but at the PSD batch (256 events on 256 CUs)
+# the largest event (~3x the mean) runs its ~7 passes on ONE compute unit, so the two launches take 35 + 109 us
+# against ~165 us of kernel time for the 15 chip-wide launches, most of which hide beside the first layers on the side
+# stream: measured 0.73 vs 0.57 ms per step (profiles/r02_rulebook_chain_stages.txt).  It pays when there are many more
+# events than compute units (e.g. 2048-event batches).
+EVENT_LOCAL_RULEBOOKS = os.environ.get("WFS_EVENT_LOCAL_RULEBOOKS", "0") != "0"
 CHAIN_MAX_LAYERS = 4
 CHAIN_BUILD_COUNT = 0      # chains actually built (tests / diagnostics)
 
