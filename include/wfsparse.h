@@ -265,6 +265,41 @@ int wfs_bn_apply_fwd_fold(const void *X, int64_t N, int32_t C, const float *gamm
 int wfs_rulebook_cell_map(const wfs_geometry *g, int64_t N, void *workspace, const uint32_t **ticket,
                           const int32_t **slot_id, int64_t *cells);
 
+/* BatchNorm1d (+ ReLU) applied by the CONSUMER of the rows ------------------------------------------------------
+ * The reference's stacks are conv -> nn.BatchNorm1d -> nn.ReLU -> conv ... -> ToDense on `.features`
+ * (src/models/SPConvBlocks.py:498-516).  In training mode the producing conv takes the batch statistics in its
+ * epilogue (wfs_gather_conv_bnstats), and instead of a separate normalisation pass that reads and re-writes every row,
+ * the kernel that reads the rows next applies  y = [relu](gamma * (x - mean) * invstd + beta)  to each row as it
+ * gathers it: the normalised tensor is never materialised.  wfs_row_affine describes that map (device pointers to [C]
+ * floats; gamma / beta may be NULL).  These kernels evaluate it as x * sc + sh with sc = gamma * invstd, sh = beta -
+ * mean * sc (one fused multiply-add per gathered value); wfs_bn_apply_fwd subtracts the mean first, so the two agree to
+ * rounding, not bit for bit.
+ *   wfs_gather_conv_affine    wfs_gather_conv (forward product) / wfs_gather_conv_bnstats (when `stats` is given) with
+ *                             the gathered rows of X read through `in_affine`.  32 -> 32 channels.
+ *   wfs_gather_dw_affine      wfs_gather_dw with the STATIONARY rows S read through `s_affine`.  32 x 32 channels.
+ *   wfs_to_dense_mapped_affine  wfs_to_dense_mapped with the rows read through `in_affine`. */
+typedef struct wfs_row_affine {
+    const float *mean;
+    const float *invstd;
+    const float *gamma;
+    const float *beta;
+    int32_t relu;
+} wfs_row_affine;
+
+int wfs_gather_conv_affine(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
+                           const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in, int32_t Cw_out,
+                           const float *bias, void *Y, int32_t dtype, const int64_t *r_dev,
+                           const wfs_row_affine *in_affine, const wfs_bn_stats *stats, void *stream);
+
+int wfs_gather_dw_affine(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
+                         const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
+                         int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev,
+                         const wfs_row_affine *s_affine, wfs_dw_job *defer, void *stream);
+
+int wfs_to_dense_mapped_affine(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
+                               const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y, int32_t dtype,
+                               const wfs_row_affine *in_affine, void *stream);
+
 /* rulebook chain ----------------------------------------------------------------------------
  * The rulebooks of a whole stack of conv layers (what SparseSequential hands spconv one
  * torch.ops.spconv.get_indice_pairs call per layer for: reference src/models/SPConvBlocks.py:75,134,498,

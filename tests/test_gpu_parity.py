@@ -1457,3 +1457,54 @@ def test_gradient_slots_with_a_shared_module_and_with_accumulation():
                       "%s, two backward passes" % n)
     with pytest.raises(TypeError):
         FlatGradAllReducer(torch.nn.Linear(4, 4).half().to(DEV).parameters(), world_size=1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)],
+                         ids=["f32", "bf16", "f16"])
+def test_batchnorm_deferred_to_the_next_reader(dtype, tol, monkeypatch):
+    """ops.DEFER_BATCH_NORM: conv -> BatchNorm1d -> ReLU -> conv ... -> ToDense with every BatchNorm (+ ReLU) applied
+    by the NEXT reader of the raw rows while it gathers them (functional.RowAffine; wfs_gather_conv_affine,
+    wfs_gather_dw_affine, wfs_to_dense_mapped_affine), the statistics taken by the producing conv's epilogue -- against
+    the same stack with the stand-alone BatchNorm kernels: dense output, input gradient, every parameter gradient and
+    the running statistics (fp32: 1e-5 of scale -- the statistics are summed in another order; 16-bit rows: the
+    rounding of one stored tensor).  A reader that cannot apply the map (here: user code asking for ``.features``)
+    gets the normalised rows."""
+    sp = _sp()
+    rng = np.random.default_rng(41)
+    B, T = 6, 48
+    idx = _waveform_like(rng, B, T)
+    feat = rng.standard_normal((len(idx), 2)).astype(np.float32)
+
+    def build():
+        torch.manual_seed(5)
+        return sp.SparseSequential(
+            sp.SubMConv3d(2, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            sp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            sp.ToDense()).to(DEV)
+
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(sp.ops, "DEFER_BATCH_NORM", on)
+        net = build()
+        f = torch.from_numpy(feat).to(DEV).to(dtype).requires_grad_(True)
+        y = net(sp.SparseConvTensor(f, torch.from_numpy(idx).to(DEV), [14, 11, T], B))
+        w = torch.linspace(-1, 1, y.numel(), device=DEV).reshape(y.shape)
+        (y.float() * w).sum().backward()
+        res.append((y.detach().float().cpu().numpy(), f.grad.float().cpu().numpy(),
+                    [p.grad.float().cpu().numpy() for p in net.parameters()],
+                    [b.float().cpu().numpy() for b in net.buffers()]))
+    (y0, g0, p0, b0), (y1, g1, p1, b1) = res
+    _assert_close(y1, y0, tol, "dense output")
+    _assert_close(g1, g0, tol * 10, "input gradient")
+    for a, b in zip(p1, p0):
+        _assert_close(a, b, tol * 10, "parameter gradient")
+    for a, b in zip(b1, b0):
+        _assert_close(a, b, max(tol, 1e-5), "running statistics")
+    # a reader that cannot apply the map gets the normalised rows
+    monkeypatch.setattr(sp.ops, "DEFER_BATCH_NORM", True)
+    head = sp.SparseSequential(sp.SubMConv3d(2, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU()).to(DEV)
+    out = head(sp.SparseConvTensor(torch.from_numpy(feat).to(DEV).to(dtype), torch.from_numpy(idx).to(DEV), [14, 11, T], B))
+    assert out._pending is not None
+    rows = out.features
+    assert out._pending is None and float(rows.float().min()) >= 0.0 and rows.shape == (len(idx), 32)

@@ -40,6 +40,11 @@ class DwJob(ctypes.Structure):
                 ("transpose", _i32), ("dW", _vp)]
 
 
+class RowAffine(ctypes.Structure):
+    """struct wfs_row_affine"""
+    _fields_ = [("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp), ("relu", _i32)]
+
+
 class ChainLayer(ctypes.Structure):
     """struct wfs_chain_layer"""
     _fields_ = [("geo", Geometry), ("nbr_out", _vp), ("nbr_in", _vp), ("out_indices", _vp), ("N_cap", _i64),
@@ -66,6 +71,12 @@ SIGNATURES = {
     "wfs_conv_stats_workspace_bytes": (_sz, [_i64, _i32]),
     "wfs_gather_conv_bnstats": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp,
                                                _i32, _vp, ctypes.POINTER(BnStats), c_i32p, _vp]),
+    "wfs_gather_conv_affine": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i32,
+                                              _vp, ctypes.POINTER(RowAffine), ctypes.POINTER(BnStats), _vp]),
+    "wfs_gather_dw_affine": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
+                                            _sz, _vp, ctypes.POINTER(RowAffine), ctypes.POINTER(DwJob), _vp]),
+    "wfs_to_dense_mapped_affine": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i32,
+                                                  ctypes.POINTER(RowAffine), _vp]),
     "wfs_bn_apply_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "wfs_bn_apply_fwd_fold": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, ctypes.POINTER(BnStats), _i32, _i32, _vp, _i32,
                                              _vp, _vp]),

@@ -35,17 +35,29 @@ __device__ __forceinline__ long long valid_rows(long long R, const long long *r_
 // ------------------------------------------------------------------------------------------ 32 -> 32
 // LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
 // (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
-template <bool TRANSPOSE_W, bool STATS>
+// AFFINE: the gathered rows are the RAW output of the producing conv; each is read as [relu](x * sc + sh) (the
+// BatchNorm1d + ReLU between the two layers, include/wfsparse.h wfs_row_affine), sc / sh per channel in LDS.
+template <bool TRANSPOSE_W, bool STATS, bool AFFINE>
 __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                       long long R, const long long *__restrict__ r_dev,
                                                       const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                       float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
-                                                      WfsStatsArgs sa) {
+                                                      WfsStatsArgs sa, WfsAffine aff) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
+    __shared__ __attribute__((aligned(16))) float sAff[AFFINE ? 64 : 4];          // sc[32] | sh[32]
     WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     const int nthreads = blockDim.x;
+    if constexpr (AFFINE) {
+        if (threadIdx.x < 32) {
+            float sc, sh;
+            wfs_bn_scale_shift(aff.gamma ? aff.gamma[threadIdx.x] : 1.f, aff.beta ? aff.beta[threadIdx.x] : 0.f,
+                               aff.mean[threadIdx.x], aff.invstd[threadIdx.x], sc, sh);
+            sAff[threadIdx.x] = sc;
+            sAff[32 + threadIdx.x] = sh;
+        }
+    }
     if (!TRANSPOSE_W) {
         for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
             int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;
@@ -123,6 +135,29 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
                 unsigned m2 = mask & (mask - 1);
                 int k_nn = m2 ? __builtin_ctz(m2) : k_next;
                 int nb_nn = entry(k_nn);
+                if constexpr (AFFINE) {
+                    const f32x4 *scp = (const f32x4 *)(sAff + h * 16), *shp = (const f32x4 *)(sAff + 32 + h * 16);
+                    const bool rl = aff.relu != 0;
+#define WFS_AFF4(a, q)                                                    \
+    {                                                                     \
+        const f32x4 sc = scp[q], sh = shp[q];                             \
+        a.x = fmaf(a.x, sc.x, sh.x);                                      \
+        a.y = fmaf(a.y, sc.y, sh.y);                                      \
+        a.z = fmaf(a.z, sc.z, sh.z);                                      \
+        a.w = fmaf(a.w, sc.w, sh.w);                                      \
+        if (rl) {                                                         \
+            a.x = a.x > 0.f ? a.x : 0.f;                                  \
+            a.y = a.y > 0.f ? a.y : 0.f;                                  \
+            a.z = a.z > 0.f ? a.z : 0.f;                                  \
+            a.w = a.w > 0.f ? a.w : 0.f;                                  \
+        }                                                                 \
+    }
+                    WFS_AFF4(a0, 0)
+                    WFS_AFF4(a1, 1)
+                    WFS_AFF4(a2, 2)
+                    WFS_AFF4(a3, 3)
+#undef WFS_AFF4
+                }
                 if (nb_cur < 0) a0 = a1 = a2 = a3 = zero4;
                 const f32x4 *bp = (const f32x4 *)(sW + (((k_cur * 2 + h) * 4) * 32 + r) * 4);
                 f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
@@ -209,16 +244,51 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 #ifndef WFS_KNOCK
 #define WFS_KNOCK 0
 #endif
-template <typename H, bool TRANSPOSE_W, bool STATS>
-__global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K, int identity_k,
+// [relu](x * sc + sh) on the 8 packed 16-bit values of v (channels c0 .. c0 + 7 of a gathered row): per dword two
+// unpacks, one v_pk_fma_f32, two v_max_f32 (against `floor` = 0 with ReLU, -inf without: no branch), one packed convert.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <typename H>
+__device__ __forceinline__ unsigned affine2(unsigned w, f32x2 sc, f32x2 sh, float floor) {
+    f32x2 x;
+    if constexpr (__is_same(H, wfs_f16)) {
+        x = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2);
+    } else {
+        x = f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+    }
+    f32x2 y = __builtin_elementwise_fma(x, sc, sh);
+    y = __builtin_elementwise_max(y, f32x2{floor, floor});
+    if constexpr (__is_same(H, wfs_f16))
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(y, f16x2_t));
+    else
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2_t));
+}
+template <typename H>
+__device__ __forceinline__ uint4 affine8(uint4 v, const float *sc, const float *sh, float floor) {
+    v.x = affine2<H>(v.x, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]}, floor);
+    v.y = affine2<H>(v.y, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]}, floor);
+    v.z = affine2<H>(v.z, f32x2{sc[4], sc[5]}, f32x2{sh[4], sh[5]}, floor);
+    v.w = affine2<H>(v.w, f32x2{sc[6], sc[7]}, f32x2{sh[6], sh[7]}, floor);
+    return v;
+}
+__device__ __forceinline__ float relu_floor(int relu) { return relu ? 0.f : -__builtin_inff(); }
+
+// AFFINE: see k_gconv32_f32; here sc / sh of the lane's 16 channels live in registers (blocks of at most 768 threads)
+template <typename H, bool TRANSPOSE_W, bool STATS, bool AFFINE>
+__global__ void __launch_bounds__(AFFINE ? 768 : 1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
+                                                       int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
                                                        const H *__restrict__ X,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                        H *__restrict__ Y, long long ntiles,
-                                                       long long tiles_per_xcd, WfsStatsArgs sa) {
+                                                       long long tiles_per_xcd, WfsStatsArgs sa, WfsAffine aff) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
     WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
+    float asc[AFFINE ? 16 : 1], ash[AFFINE ? 16 : 1];
+    if constexpr (AFFINE) wfs_affine_load<16>(aff, ((threadIdx.x & 63) >> 5) * 16, asc, ash);
+    const float afloor = relu_floor(aff.relu);
     uint4 *sWb = reinterpret_cast<uint4 *>(smem);                           // K * 128 fragments of 16 B
     int *sNb = reinterpret_cast<int *>(smem + (size_t)K * 2048);            // [waves][K][32]
     const int nthreads = blockDim.x;
@@ -313,6 +383,10 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
             for (int g = 0; g < BF_GROUP; ++g)
                 if (ks[g] >= 0) {
                     uint4 lo = a_lo[g], hi = a_hi[g];
+                    if constexpr (AFFINE) {
+                        lo = affine8<H>(lo, asc, ash, afloor);
+                        hi = affine8<H>(hi, asc + 8, ash + 8, afloor);
+                    }
                     lo = keep_if(lo, nbs[g] >= 0);
                     hi = keep_if(hi, nbs[g] >= 0);
                     const uint4 *bp = sWb + (size_t)ks[g] * 128 + h * 32 + r;
@@ -398,14 +472,18 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
 constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator registers)
 constexpr int DW_WAVES = 8;
 
-template <typename T>
+// AFFINE: the stationary rows S are raw conv outputs read as [relu](x * sc + sh) (wfs_row_affine)
+template <typename T, bool AFFINE>
 __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
                                                   const long long *__restrict__ r_dev, const T *__restrict__ S,
                                                   const T *__restrict__ G,
-                                                  float *__restrict__ part, int ngroups, long long tiles_per_block) {
+                                                  float *__restrict__ part, int ngroups, long long tiles_per_block,
+                                                  WfsAffine aff) {
     __shared__ float sRed[DW_WAVES * 1024];                           // block reduction staging, 32 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
+    float asc[1], ash[1];
+    if constexpr (AFFINE) wfs_affine_load<1>(aff, j, asc, ash);
     const int g = blockIdx.y;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
@@ -433,6 +511,10 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
         for (int s = 0; s < 16; ++s) {
             long long row = row0 + 2 * s + h;
             float t = wfs_ld(S + (row < R ? row : R - 1) * 32 + j);
+            if constexpr (AFFINE) {
+                t = fmaf(t, asc[0], ash[0]);
+                if (aff.relu) t = t > 0.f ? t : 0.f;
+            }
             a[s] = row < R ? t : 0.f;
         }
         bool any = false;
@@ -611,15 +693,20 @@ __device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename H>
+template <typename H, bool AFFINE>
 __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int K, int identity_k,
                                                      long long Rcap, const long long *__restrict__ r_dev,
                                                      const H *__restrict__ S, const H *__restrict__ G,
-                                                     float *__restrict__ part, int ngroups, long long tiles_per_block) {
+                                                     float *__restrict__ part, int ngroups, long long tiles_per_block,
+                                                     WfsAffine aff) {
     __shared__ __attribute__((aligned(16))) unsigned short sTiles[DWB_WAVES][2][32 * 32];   // per wave: S tile, G tile
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;          // fragment coordinates
     const int grow = lane >> 2, gchunk = lane & 3;   // staging coordinates: rows grow and grow+16, 16-B chunk gchunk
+    // AFFINE is applied to the S FRAGMENTS: after the transposed LDS read a lane holds 16 rows of ONE channel (c), so it
+    // needs a single (sc, sh) pair (at staging time a lane holds 8 channels: 16 more registers, and the kernel spilled)
+    float asc[1] = {1.f}, ash[1] = {0.f};
+    if constexpr (AFFINE) wfs_affine_load<1>(aff, c, asc, ash);
     unsigned short *sS = sTiles[wid][0], *sG = sTiles[wid][1];
     const int g = blockIdx.y;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
@@ -663,6 +750,33 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
         *(uint4 *)(sS + grow * 32 + gchunk * 8) = keep_if(s0, la);
         *(uint4 *)(sS + (grow + 16) * 32 + gchunk * 8) = keep_if(s1, lb);
         __builtin_amdgcn_wave_barrier();
+        bf16x8 a0, a1;
+        if constexpr (AFFINE) {
+            // the S fragments first (their ~60 conversion instructions need registers the gathers would hold)
+            a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
+        {
+            // element j of k-step s is row 16 s + 8 h + j of the tile; rows beyond the valid count stay zero
+            const int left = (int)(R - row0 < 32 ? R - row0 : 32);          // 32-bit: 64-bit row compares spilled
+            const f32x2 sc2 = {asc[0], asc[0]}, sh2 = {ash[0], ash[0]};
+            const float fl = relu_floor(aff.relu);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint4 v = __builtin_bit_cast(uint4, st ? a1 : a0);
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int rr = 16 * st + 8 * h + 2 * m;
+                    unsigned o = affine2<H>(w[m], sc2, sh2, fl);
+                    o = rr < left ? o : 0u;                              // rows beyond the valid count stay zero
+                    o = rr + 1 < left ? o : (o & 0xFFFFu);
+                    w[m] = o;
+                }
+                const uint4 o4 = {w[0], w[1], w[2], w[3]};
+                if (st) a1 = __builtin_bit_cast(bf16x8, o4); else a0 = __builtin_bit_cast(bf16x8, o4);
+            }
+        }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // the gathers of ALL the block's offsets are issued together and unconditionally (clamped rows): one memory
         // round trip per tile; a load under the per-offset branch would cost one per offset (hipcc waits vmcnt(0))
         uint4 g0[DWB_KG], g1[DWB_KG];
@@ -671,7 +785,7 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
             g0[q] = *(const uint4 *)(G + (long long)(ta[q] >= 0 ? ta[q] : 0) * 32 + gchunk * 8);
             g1[q] = *(const uint4 *)(G + (long long)(tb[q] >= 0 ? tb[q] : 0) * 32 + gchunk * 8);
         }
-        const bf16x8 a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
+        if constexpr (!AFFINE) a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
 #pragma unroll
         for (int q = 0; q < DWB_KG; ++q) {
             if (act[q] == 0ull) continue;
@@ -975,11 +1089,12 @@ static int launch_big_lds(KernelT kernel, bool *attr_done, dim3 grid, dim3 block
 }
 
 // grid of the two 32 -> 32 kernels: <= 256 persistent blocks (multiple of 8: one slice of the row range per XCD)
-static void gconv32_grid(long long R, long long *ntiles, int *wpb, long long *nblk, long long *tiles_per_xcd) {
+static void gconv32_grid(long long R, long long *ntiles, int *wpb, long long *nblk, long long *tiles_per_xcd,
+                         int max_waves) {
     *ntiles = (R + 31) >> 5;
     // waves per block: enough tiles per SIMD without leaving CUs idle on small inputs
     int w = (int)((*ntiles + 255) / 256);
-    w = w < 4 ? 4 : (w > 16 ? 16 : (w + 3) / 4 * 4);
+    w = w < 4 ? 4 : (w > max_waves ? max_waves : (w + 3) / 4 * 4);
     long long nb = (*ntiles + w - 1) / w;
     if (nb > 256) nb = 256;
     nb = (nb + 7) / 8 * 8;
@@ -1027,57 +1142,75 @@ static WfsStatsArgs stats_args(const wfs_bn_stats *st, long long nblk) {
 
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
-    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
+    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
     const size_t lds = (size_t)K * 4096;
-    static bool attr[3] = {false, false, false};
+    static bool attr[5] = {false, false, false, false, false};
     const WfsStatsArgs sa = stats_args(stats, nblk);
+    const WfsAffine aff = affine ? *affine : WfsAffine{nullptr, nullptr, nullptr, nullptr, 0};
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
-        return launch_big_lds(k_gconv32_f32<true, false>, &attr[0], grid, block, lds, stream, table, mirror, K, identity_k,
-                              R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
+        return launch_big_lds(k_gconv32_f32<true, false, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+    int rc;
     if (stats) {
-        int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
+        if (affine)
+            rc = launch_big_lds(k_gconv32_f32<false, true, true>, &attr[3], grid, block, lds, stream, table, mirror, K,
+                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+        else
+            rc = launch_big_lds(k_gconv32_f32<false, true, false>, &attr[1], grid, block, lds, stream, table, mirror, K,
+                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
-    return launch_big_lds(k_gconv32_f32<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K, identity_k, R,
-                          r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
+    if (affine)
+        return launch_big_lds(k_gconv32_f32<false, false, true>, &attr[4], grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+    return launch_big_lds(k_gconv32_f32<false, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
+                          identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
 }
 
 template <typename H>
 static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                               const H *Xb, const float *W, int transpose_w, const float *bias, H *Yb,
-                              const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
+                              const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
-    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd);
+    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, affine ? 12 : 16);     // the AFFINE kernels: <= 768 threads
     const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
-    static bool attr[3] = {false, false, false};          // per instantiation of this template, i.e. per H
+    static bool attr[5] = {false, false, false, false, false};          // per instantiation of this template, i.e. per H
     const WfsStatsArgs sa = stats_args(stats, nblk);
+    const WfsAffine aff = affine ? *affine : WfsAffine{nullptr, nullptr, nullptr, nullptr, 0};
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
-        return launch_big_lds(k_gconv32_bf16<H, true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+        return launch_big_lds(k_gconv32_bf16<H, true, false, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+    int rc;
     if (stats) {
-        int rc = launch_big_lds(k_gconv32_bf16<H, false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+        if (affine)
+            rc = launch_big_lds(k_gconv32_bf16<H, false, true, true>, &attr[3], grid, block, lds, stream, table, mirror, K,
+                                identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+        else
+            rc = launch_big_lds(k_gconv32_bf16<H, false, true, false>, &attr[1], grid, block, lds, stream, table, mirror,
+                                K, identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
-    return launch_big_lds(k_gconv32_bf16<H, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
-                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+    if (affine)
+        return launch_big_lds(k_gconv32_bf16<H, false, false, true>, &attr[4], grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+    return launch_big_lds(k_gconv32_bf16<H, false, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
+                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
 }
 
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream) {
     if (dtype == WFS_F16)
         return launch_gconv32_h16<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, transpose_w,
-                                           bias, (wfs_f16 *)Y, stats, pending, stream);
+                                           bias, (wfs_f16 *)Y, stats, pending, affine, stream);
     return launch_gconv32_h16<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, transpose_w, bias,
-                                        (wfs_bf16 *)Y, stats, pending, stream);
+                                        (wfs_bf16 *)Y, stats, pending, affine, stream);
 }
 
 // 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.
@@ -1153,20 +1286,27 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
 }
 
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
-                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream) {
+                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer,
+                     const WfsAffine *s_affine, hipStream_t stream) {
     const long long nblk = dw32_blocks(R);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
-    if (dtype == WFS_F32)
-        k_gdw32<float><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(512), 0, stream>>>(
-            table, K, identity_k, R, r_dev, (const float *)S, (const float *)G, part, ngroups, tiles_per_block);
-    else if (dtype == WFS_BF16)
-        k_gdw32_bf16<wfs_bf16><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(1024), 0, stream>>>(
-            table, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups, tiles_per_block);
-    else
-        k_gdw32_bf16<wfs_f16><<<dim3((unsigned)nblk, (unsigned)ngroups), dim3(1024), 0, stream>>>(
-            table, K, identity_k, R, r_dev, (const wfs_f16 *)S, (const wfs_f16 *)G, part, ngroups, tiles_per_block);
+    const WfsAffine aff = s_affine ? *s_affine : WfsAffine{nullptr, nullptr, nullptr, nullptr, 0};
+    const dim3 grid((unsigned)nblk, (unsigned)ngroups);
+#define WFS_DW32(KERNEL, T, THREADS)                                                                                  \
+    {                                                                                                                 \
+        if (s_affine)                                                                                                 \
+            KERNEL<T, true><<<grid, dim3(THREADS), 0, stream>>>(table, K, identity_k, R, r_dev, (const T *)S,          \
+                                                                (const T *)G, part, ngroups, tiles_per_block, aff);    \
+        else                                                                                                          \
+            KERNEL<T, false><<<grid, dim3(THREADS), 0, stream>>>(table, K, identity_k, R, r_dev, (const T *)S,         \
+                                                                 (const T *)G, part, ngroups, tiles_per_block, aff);   \
+    }
+    if (dtype == WFS_F32) WFS_DW32(k_gdw32, float, 512)
+    else if (dtype == WFS_BF16) WFS_DW32(k_gdw32_bf16, wfs_bf16, 1024)
+    else WFS_DW32(k_gdw32_bf16, wfs_f16, 1024)
+#undef WFS_DW32
     WFS_LAUNCH_CHECK();
     const long long per = (long long)K * 1024;
     if (defer) {

@@ -61,9 +61,32 @@ class BatchNormRequest(object):
     the conv kernel's epilogue takes the batch statistics (include/wfsparse.h, wfs_gather_conv_bnstats), the
     BatchNorm step then only normalises.  ``stats`` is filled by the convolution that honoured the request."""
 
-    def __init__(self, bn):
+    def __init__(self, bn, allow_pending=True):
         self.bn = bn
-        self.stats = None          # (save_mean, save_invstd)
+        self.stats = None          # (save_mean, save_invstd, pending partials or None)
+        # allow_pending: the per-block partials may stay unfolded for the BatchNorm apply kernel to fold; False when
+        # the statistics are consumed by a kernel that expects save_mean / save_invstd (a deferred BatchNorm, RowAffine)
+        self.allow_pending = allow_pending
+
+
+class RowAffine(object):
+    """"Read these raw rows as [relu](BatchNorm(row))": the training-mode nn.BatchNorm1d (+ nn.ReLU) that sits between
+    the conv that produced the rows -- whose epilogue took the batch statistics -- and whoever reads them next
+    (include/wfsparse.h, wfs_row_affine).  The reader applies the map while it gathers; the normalised tensor is never
+    written.  ``save_mean`` / ``save_invstd``: fp32 [C] tensors filled by the producing launch."""
+
+    def __init__(self, bn, relu, save_mean, save_invstd):
+        self.bn, self.relu, self.save_mean, self.save_invstd = bn, bool(relu), save_mean, save_invstd
+
+    def struct(self, weight=None, bias=None):
+        w = self.bn.weight if weight is None else weight
+        b = self.bn.bias if bias is None else bias
+        return _lib.RowAffine(_lib.ptr(self.save_mean), _lib.ptr(self.save_invstd), _lib.ptr(w), _lib.ptr(b),
+                              1 if self.relu else 0)
+
+
+def _affine_struct(mean, invstd, weight, bias, relu):
+    return _lib.RowAffine(_lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), 1 if relu else 0)
 
 
 def can_take_batch_norm_stats(bn, features):
@@ -136,9 +159,10 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None):
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, affine=None):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
-    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only)."""
+    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only).
+    ``affine`` (a wfs_row_affine struct): the rows of X are raw conv outputs read through a BatchNorm (+ ReLU)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
     Cy = Cw_in if transpose_w else Cw_out
@@ -147,6 +171,26 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
+    if affine is not None:
+        assert not transpose_w and R > 0
+        st = None
+        if bn_request is not None:
+            bn = bn_request.bn
+            track = bn.track_running_stats and bn.running_mean is not None
+            save_mean = torch.empty((Cy,), dtype=torch.float32, device=X.device)
+            save_invstd = torch.empty((Cy,), dtype=torch.float32, device=X.device)
+            ws = torch.empty((int(lib.wfs_conv_stats_workspace_bytes(R, Cy)),), dtype=torch.uint8, device=X.device)
+            st = _lib.BnStats(_lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(bn.running_mean) if track else None,
+                              _lib.ptr(bn.running_var) if track else None,
+                              _lib.ptr(bn.num_batches_tracked) if (track and bn.training) else None,
+                              float(bn.momentum), float(bn.eps), _lib.ptr(ws), ws.numel())
+            bn_request.stats = (save_mean, save_invstd, None)
+        _lib.check(lib.wfs_gather_conv_affine(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
+                                              _lib.ptr(W), Cw_in, Cw_out, _lib.ptr(bias), _lib.ptr(Y), _lib.dtype_code(X),
+                                              _lib.ptr(r_dev), ctypes.byref(affine),
+                                              ctypes.byref(st) if st is not None else None, _lib.stream_ptr()))
+        _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
+        return Y
     if _gemm_route(X.shape[1], Cy, K, R, r_dev, table) and bn_request is None:
         G = _gathered(table, kmap, K, identity_k, R, X, r_dev)                       # [R, K * Cx]
         Wk = (W.transpose(1, 2) if transpose_w else W).reshape(K * X.shape[1], Cy)   # [K * Cx, Cy]
@@ -168,7 +212,8 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
         _lib.check(lib.wfs_gather_conv_bnstats(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0],
                                                X.shape[1], _lib.ptr(W), Cw_in, Cw_out, _lib.ptr(bias), _lib.ptr(Y),
                                                _lib.dtype_code(X), _lib.ptr(r_dev), ctypes.byref(st),
-                                               ctypes.byref(pending), _lib.stream_ptr()))
+                                               ctypes.byref(pending) if bn_request.allow_pending else None,
+                                               _lib.stream_ptr()))
         # pending > 0: the per-block partial statistics are still in `ws`; the BatchNorm step's own kernel folds them
         # (one launch less than folding here)
         bn_request.stats = (save_mean, save_invstd, (int(pending.value), ws) if pending.value > 0 else None)
@@ -299,7 +344,7 @@ def join_side_streams():
         del _PENDING_SIDE[:]
 
 
-def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False, like=None):
+def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False, like=None, s_affine=None):
     """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a]).
     overlap=True launches on the side stream (see ops.OVERLAP_DW): memory is allocated on the calling stream
     and every operand is kept alive until join_side_streams().  ``like``: the parameter this is the gradient of
@@ -315,7 +360,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
         dW = torch.empty(shape, dtype=torch.float32, device=S.device)
     assert S.dtype == G.dtype and S.shape[0] == R
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
-    if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap:
+    if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap and s_affine is None:
         Gk = _gathered(table, kmap, K, identity_k, R, G, r_dev)                      # [R, K * Cg]
         ok = _row_ok(R, r_dev, S.device)
         Sv = S if ok is None else torch.where(ok.unsqueeze(1), S, S.new_zeros(()))
@@ -327,9 +372,15 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
     def launch():
         defer = _DEFERRED_DW is not None and in_slot and not overlap
         job = _lib.DwJob() if defer else None
-        _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0],
-                                     Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
-                                     _lib.ptr(r_dev), ctypes.byref(job) if defer else None, _lib.stream_ptr()))
+        if s_affine is not None:
+            _lib.check(lib.wfs_gather_dw_affine(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G),
+                                                G.shape[0], Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S),
+                                                _lib.ptr(ws), ws.numel(), _lib.ptr(r_dev), ctypes.byref(s_affine),
+                                                ctypes.byref(job) if defer else None, _lib.stream_ptr()))
+        else:
+            _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0],
+                                         Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
+                                         _lib.ptr(r_dev), ctypes.byref(job) if defer else None, _lib.stream_ptr()))
         if defer and job.nslabs > 0:
             _DEFERRED_DW.append((job, ws))          # second stage pending: flush_deferred_dw()
 
@@ -414,6 +465,104 @@ class SparseConvFunction(Function):
             # dY has one row per OUTPUT of this product: rb.N rows for an inverse conv, rb.M otherwise
             db = _masked_column_sum(dY, rb.n_dev if mode == INVERSE else rb.m_dev).to(bias.dtype)
         return dX, dW, db, None, None, None
+
+
+class AffineSparseConvFunction(Function):
+    """conv([relu](BatchNorm1d(features))) with the BatchNorm (+ ReLU) applied while the conv GATHERS the raw rows
+    (RowAffine; reference: the plain nn.BatchNorm1d / nn.ReLU modules between two spconv layers of a SparseSequential,
+    src/models/SPConvBlocks.py:498-516).  features: the producing conv's raw output [N, 32]; the batch statistics were
+    taken by that conv's epilogue.  Backward: dA through the transposed filters, dW with the stationary rows read
+    through the same map, then the BatchNorm backward on (features, dA) -> d features, d gamma, d beta."""
+
+    @staticmethod
+    def forward(ctx, features, filters, bias, bn_weight, bn_bias, rulebook, mode, spec, bn_request):
+        rb = rulebook
+        features = _features_ok(features)
+        assert mode in (CONV, SUBM) and not rb.has_dup and features.shape[0] == rb.N
+        K = rb.K
+        W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        ident = rb.centre_k if rb.subm else -1
+        aff = _affine_struct(spec.save_mean, spec.save_invstd, bn_weight, bn_bias, spec.relu)
+        table, kmap = rb.table_by_out()
+        out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev, bn_request, affine=aff)
+        ctx.save_for_backward(features, filters, bias, bn_weight, bn_bias, spec.save_mean, spec.save_invstd)
+        ctx.rb, ctx.relu = rb, spec.relu
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, filters, bias, bn_weight, bn_bias, save_mean, save_invstd = ctx.saved_tensors
+        rb, relu = ctx.rb, ctx.relu
+        K = rb.K
+        dY = grad_output.contiguous()
+        if dY.dtype != features.dtype:
+            dY = dY.to(features.dtype)
+        W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
+        ident = rb.centre_k if rb.subm else -1
+        dX = dW = db = dgamma = dbeta = None
+        if ctx.needs_input_grad[1]:
+            aff = _affine_struct(save_mean, save_invstd, bn_weight, bn_bias, relu)
+            dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, False, filters, s_affine=aff)
+            dW = dW.reshape(filters.shape).to(filters.dtype)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            dA = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
+            dX, dgamma, dbeta = bn_relu_backward(features, dA, bn_weight, bn_bias, save_mean, save_invstd, True, relu,
+                                                 rb.n_dev)
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = _masked_column_sum(dY, rb.m_dev).to(bias.dtype)
+        return dX, dW, db, dgamma, dbeta, None, None, None, None
+
+
+def affine_indice_conv(features, filters, bias, rulebook, subm, spec, bn_request=None):
+    return AffineSparseConvFunction.apply(features, filters, bias, spec.bn.weight, spec.bn.bias, rulebook,
+                                          SUBM if subm else CONV, spec, bn_request)
+
+
+class AffineToDenseFunction(Function):
+    """dense([relu](BatchNorm1d(features))) through the producing conv's cell -> row map, the BatchNorm (+ ReLU) applied
+    while the rows are read (RowAffine); empty cells are zero, as SparseConvTensor.dense() leaves them."""
+
+    @staticmethod
+    def forward(ctx, features, bn_weight, bn_bias, spec, cell_map, spatial_shape, batch_size, m_dev):
+        lib = _lib.load()
+        features = _features_ok(features)
+        M, C = features.shape
+        spatial = [int(s_) for s_ in spatial_shape]
+        ticket, slot, _keep, V = cell_map
+        aff = _affine_struct(spec.save_mean, spec.save_invstd, bn_weight, bn_bias, spec.relu)
+        out = torch.empty([int(batch_size), C] + spatial, dtype=features.dtype, device=features.device)
+        _lib.check(lib.wfs_to_dense_mapped_affine(_lib.ptr(features), ticket, slot, M, _lib.ptr(m_dev), int(batch_size), V,
+                                                  C, _lib.ptr(out), _lib.dtype_code(features), ctypes.byref(aff),
+                                                  _lib.stream_ptr()))
+        ctx.save_for_backward(features, bn_weight, bn_bias, spec.save_mean, spec.save_invstd)
+        ctx.meta = (cell_map, int(batch_size), M, C, m_dev, spec.relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        features, bn_weight, bn_bias, save_mean, save_invstd = ctx.saved_tensors
+        cell_map, batch_size, M, C, m_dev, relu = ctx.meta
+        ticket, slot, _keep, V = cell_map
+        dY = grad_output.contiguous()
+        if dY.dtype != features.dtype:
+            dY = dY.to(features.dtype)
+        dA = torch.empty((M, C), dtype=features.dtype, device=features.device)
+        _lib.check(lib.wfs_to_dense_bwd_mapped(_lib.ptr(dY), ticket, slot, M, _lib.ptr(m_dev), batch_size, V, C,
+                                               _lib.ptr(dA), _lib.dtype_code(dA), _lib.stream_ptr()))
+        dX, dgamma, dbeta = bn_relu_backward(features, dA, bn_weight, bn_bias, save_mean, save_invstd, True, relu, m_dev)
+        return dX, dgamma, dbeta, None, None, None, None, None
+
+
+def affine_to_dense(features, spec, cell_map, spatial_shape, batch_size, m_dev):
+    return AffineToDenseFunction.apply(features, spec.bn.weight, spec.bn.bias, spec, cell_map, spatial_shape, batch_size,
+                                       m_dev)
+
+
+def materialize_affine(features, spec, n_dev=None):
+    """The normalised rows themselves (a reader that cannot apply the map while it reads)."""
+    return batch_norm_relu(features, spec.bn, spec.relu, n_dev, (spec.save_mean, spec.save_invstd, None))
 
 
 def _dense_map_ok(cell_map, spatial, batch_size, C, features):
@@ -536,22 +685,29 @@ class BatchNormReLUFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        lib = _lib.load()
         x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         training, relu = ctx.flags
-        N, C = x.shape
-        dy = grad_output.contiguous()
-        if dy.dtype != x.dtype:
-            dy = dy.to(x.dtype)
-        dx = _rows(tuple(x.shape), x, ctx.n_dev)
-        dgamma = grad_like(weight) if weight is not None else None
-        dbeta = grad_like(bias) if bias is not None else None
-        ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.wfs_bn_relu_bwd(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
-                                       _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
-                                       1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
-                                       ws.numel(), _lib.dtype_code(x), _lib.ptr(ctx.n_dev), _lib.stream_ptr()))
+        dx, dgamma, dbeta = bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, ctx.n_dev)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, n_dev):
+    """(dx, dgamma, dbeta) of y = [relu](BatchNorm1d(x)) over the active rows, given dL/dy (two launches: the sums
+    sum(g), sum(g * xhat) with the ReLU mask recomputed from x, then the elementwise pass)."""
+    lib = _lib.load()
+    N, C = x.shape
+    dy = grad_output.contiguous()
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    dx = _rows(tuple(x.shape), x, n_dev)
+    dgamma = grad_like(weight) if weight is not None else None
+    dbeta = grad_like(bias) if bias is not None else None
+    ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.wfs_bn_relu_bwd(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
+                                   _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
+                                   1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
+                                   ws.numel(), _lib.dtype_code(x), _lib.ptr(n_dev), _lib.stream_ptr()))
+    return dx, dgamma, dbeta
 
 
 def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):

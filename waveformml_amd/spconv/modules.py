@@ -166,12 +166,12 @@ class SparseSequential(SparseModule):
         while i < len(mods):
             module = mods[i]
             if isinstance(module, SparseModule):
-                if (ops.FUSE_CONV_BN_STATS and _is_sparse_tensor(input) and i + 1 < len(mods)
+                if ((ops.FUSE_CONV_BN_STATS or ops.DEFER_BATCH_NORM) and _is_sparse_tensor(input) and i + 1 < len(mods)
                         and isinstance(mods[i + 1], nn.BatchNorm1d)
                         and getattr(module, "weight", None) is not None
-                        and Fsp.can_take_batch_norm_stats(mods[i + 1], input.features)):
+                        and Fsp.can_take_batch_norm_stats(mods[i + 1], input._features)):
                     # conv -> BatchNorm1d (training): the conv's epilogue takes the batch statistics
-                    input.bn_request = Fsp.BatchNormRequest(mods[i + 1])
+                    input.bn_request = Fsp.BatchNormRequest(mods[i + 1], allow_pending=not ops.DEFER_BATCH_NORM)
                 input = module(input)
                 if want_prefetch and _is_sparse_tensor(input):
                     # the first layer has built its own rulebook and launched its conv on this stream; the
@@ -186,7 +186,13 @@ class SparseSequential(SparseModule):
                         req = getattr(input, "bn_stats", None)
                         stats = req.stats if (req is not None and req.bn is module) else None
                         input.bn_stats = None
-                        input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats)
+                        if (ops.DEFER_BATCH_NORM and stats is not None and stats[2] is None and module.training
+                                and module.num_features == 32 and module.weight is not None):
+                            # the producing conv took the statistics: leave the rows raw, the next reader (conv, dense())
+                            # applies the normalisation while it gathers them (functional.RowAffine)
+                            input.defer_affine(Fsp.RowAffine(module, relu, stats[0], stats[1]))
+                        else:
+                            input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats)
                         if relu:
                             i += 1
                     else:

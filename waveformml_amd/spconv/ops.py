@@ -55,6 +55,20 @@ EVENT_LOCAL_RULEBOOKS = os.environ.get("WFS_EVENT_LOCAL_RULEBOOKS", "0") != "0"
 CHAIN_MAX_LAYERS = 4
 CHAIN_BUILD_COUNT = 0      # chains actually built (tests / diagnostics)
 
+# conv -> nn.BatchNorm1d (training) -> nn.ReLU -> next reader inside a SparseSequential: the conv's epilogue takes the
+# batch statistics and the normalisation is DEFERRED to whoever reads the rows next -- the next 32 -> 32 conv (forward
+# gathers and the stationary rows of its dW) or dense() apply  [relu](x * sc + sh)  on the fly (functional.RowAffine,
+# include/wfsparse.h wfs_row_affine), so the normalised tensor is never written.  A reader that cannot do it (1 x 1 convs,
+# other channel counts, duplicate sites, user code touching ``.features``) gets the rows materialised as before.
+# OFF by default (WFS_DEFER_BATCH_NORM=1 switches it on): same results, but at the PSD batch a row is gathered by ~10
+# (tile, offset) pairs, so normalising on the fly does ~10x the arithmetic of the separate pass it removes -- isolated
+# launches (profiles/r02_microbench_conv_bf16.txt): forward 16.2 us plain, +1.8 statistics epilogue, +6.0 gathered rows
+# through the map, +6.3 for the launch that folds the block partials = 30.3 us against 16.2 + 5.9 + 8.7 = 30.8 us for
+# conv + reduce + apply; the dW kernel, already at its register limit, spills with the map (36.8 vs 17.1 us).  Whole
+# step 0.65 vs 0.57 ms.  It should pay where rows are gathered by few offsets (1 x 1 / strided stacks) or no longer fit
+# the caches.
+DEFER_BATCH_NORM = os.environ.get("WFS_DEFER_BATCH_NORM", "0") != "0"
+
 _SIDE_STREAMS = {}
 
 
