@@ -300,6 +300,26 @@ int wfs_to_dense_mapped_affine(const void *X, const uint32_t *ticket, const int3
                                const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y, int32_t dtype,
                                const wfs_row_affine *in_affine, void *stream);
 
+/* BatchNorm backward sums taken by the launch that produces dL/dy --------------------------------------------
+ * Backward of conv -> BatchNorm1d (+ ReLU) -> conv: the second conv's dX launch writes dL/dy of the BatchNorm; the
+ * BatchNorm backward then needs sum(g) and sum(g * xhat) over the rows (g = dL/dy masked by the ReLU) before its
+ * elementwise pass.  wfs_gather_conv_bnbwd is the dX product of a 32 -> 32 layer (wfs_gather_conv with transpose_w = 1,
+ * no bias) whose epilogue takes those sums from the tile it holds in registers and the BatchNorm's input rows `bn_x`
+ * (same row set as Y; `bn` = its statistics / parameters / relu flag), leaving *nblk per-block partials [nblk][2][32]
+ * in `partial` (wfs_gather_conv_bnbwd_partial_bytes() bytes).  wfs_bn_relu_bwd_sums is the elementwise half of
+ * wfs_bn_relu_bwd fed with such partials: one launch and one read of both tensors less per BatchNorm. */
+size_t wfs_gather_conv_bnbwd_partial_bytes(void);
+
+int wfs_gather_conv_bnbwd(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
+                          const void *X, int64_t X_rows, const float *W, void *Y, int32_t dtype, const int64_t *r_dev,
+                          const wfs_row_affine *bn, const void *bn_x, float *partial, size_t partial_bytes,
+                          int32_t *nblk, void *stream);
+
+int wfs_bn_relu_bwd_sums(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma, const float *beta,
+                         const float *save_mean, const float *save_invstd, int32_t training, int32_t relu, void *dX,
+                         float *dgamma, float *dbeta, const float *partial, int32_t nblk, int32_t dtype,
+                         const int64_t *n_dev, void *stream);
+
 /* rulebook chain ----------------------------------------------------------------------------
  * The rulebooks of a whole stack of conv layers (what SparseSequential hands spconv one
  * torch.ops.spconv.get_indice_pairs call per layer for: reference src/models/SPConvBlocks.py:75,134,498,

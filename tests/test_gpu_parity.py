@@ -1508,3 +1508,57 @@ def test_batchnorm_deferred_to_the_next_reader(dtype, tol, monkeypatch):
     assert out._pending is not None
     rows = out.features
     assert out._pending is None and float(rows.float().min()) >= 0.0 and rows.shape == (len(idx), 32)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-5), (torch.float16, 1e-5)],
+                         ids=["f32", "bf16", "f16"])
+def test_batchnorm_backward_sums_taken_by_the_dx_launch(dtype, tol, monkeypatch):
+    """ops.FUSE_BN_BACKWARD_SUMS: in conv -> BatchNorm1d -> ReLU -> conv the second conv's dX launch takes sum(g) and
+    sum(g * xhat) of the BatchNorm backward in its epilogue (wfs_gather_conv_bnbwd + wfs_bn_relu_bwd_sums, functional
+    .BnLink) instead of a separate reduction launch.  Same values as the two-launch backward: the sums are taken from the
+    same stored gradients with the same mask expression, only the fp32 summation order differs (2e-6 of scale in fp32;
+    16-bit rows: the elementwise pass rounds identical fp32 results, so nearly every element is bit-equal).  SubM and
+    strided consumers, odd row counts, capacity-padded rows with a device-side count."""
+    sp = _sp()
+    rng = np.random.default_rng(77)
+    B, T = 5, 40
+    idx = _waveform_like(rng, B, T)
+    n = len(idx)
+    feat = rng.standard_normal((n, 32)).astype(np.float32)
+
+    def build():
+        torch.manual_seed(9)
+        return sp.SparseSequential(
+            sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
+            sp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False), torch.nn.BatchNorm1d(32),
+            sp.SparseConv3d(32, 32, 3, (1, 1, 2), 0, 1, 1, False)).to(DEV)
+
+    for padded in (False, True):
+        res = []
+        for on in (False, True):
+            monkeypatch.setattr(sp.ops, "FUSE_BN_BACKWARD_SUMS", on)
+            net = build()
+            f = torch.from_numpy(feat).to(DEV).to(dtype)
+            if padded:
+                cap = n + 45
+                pf = torch.full((cap, 32), float("nan"), dtype=dtype, device=DEV)
+                pi = torch.zeros((cap, 4), dtype=torch.int32, device=DEV)
+                pf[:n], pi[:n] = f, torch.from_numpy(idx).to(DEV)
+                f = pf.requires_grad_(True)
+                x = sp.SparseConvTensor(f, pi, [14, 11, T], B)
+                x.n_valid = torch.tensor([n], dtype=torch.int64, device=DEV)
+                x.unique = True
+            else:
+                f = f.requires_grad_(True)
+                x = sp.SparseConvTensor(f, torch.from_numpy(idx).to(DEV), [14, 11, T], B)
+            y = net(x)
+            m = int(y.n_valid) if y.n_valid is not None else y.features.shape[0]
+            w = torch.linspace(-1, 1, m * 32, device=DEV).reshape(m, 32)
+            (y.features[:m].float() * w).sum().backward()
+            res.append((f.grad[:n].float().cpu().numpy(), [p.grad.float().cpu().numpy() for p in net.parameters()]))
+        (g0, p0), (g1, p1) = res
+        assert np.isfinite(g1).all()
+        _assert_close(g1, g0, tol, "input gradient (padded=%s)" % padded)
+        for a, b in zip(p1, p0):
+            _assert_close(a, b, tol * 5, "parameter gradient (padded=%s)" % padded)

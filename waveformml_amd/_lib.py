@@ -77,6 +77,11 @@ SIGNATURES = {
                                             _sz, _vp, ctypes.POINTER(RowAffine), ctypes.POINTER(DwJob), _vp]),
     "wfs_to_dense_mapped_affine": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i32,
                                                   ctypes.POINTER(RowAffine), _vp]),
+    "wfs_gather_conv_bnbwd_partial_bytes": (_sz, []),
+    "wfs_gather_conv_bnbwd": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _vp, _vp, _i32, _vp,
+                                             ctypes.POINTER(RowAffine), _vp, _vp, _sz, c_i32p, _vp]),
+    "wfs_bn_relu_bwd_sums": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
+                                            _i32, _vp, _vp]),
     "wfs_bn_apply_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "wfs_bn_apply_fwd_fold": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, ctypes.POINTER(BnStats), _i32, _i32, _vp, _i32,
                                              _vp, _vp]),

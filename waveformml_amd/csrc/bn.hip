@@ -923,6 +923,52 @@ static int bn_bwd_slice(const void *X, const void *dY, int64_t N, int32_t C, lon
     return WFS_OK;
 }
 
+// The elementwise half of wfs_bn_relu_bwd alone: the two sums arrive as `nblk` per-block partials [nblk][2][C] left
+// by the launch that produced dY (wfs_gather_conv_bnbwd).  C == 32, nblk <= 256.
+extern "C" int wfs_bn_relu_bwd_sums(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
+                                    const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
+                                    int32_t relu, void *dX, float *dgamma, float *dbeta, const float *partial,
+                                    int32_t nblk, int32_t dtype, const int64_t *n_dev_, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long *n_dev = (const long long *)n_dev_;
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(C == 32 && nblk >= 1 && nblk <= 256, WFS_EINVAL, "C == 32 and 1 .. 256 partials (C %d, %d partials)", C, nblk);
+    WFS_REQUIRE(N > 0 && X && dY && dX && save_mean && save_invstd && partial, WFS_EINVAL, "NULL device pointer / no rows");
+    const dim3 block(TB);
+    long long rb = 0;
+    const int per = rr_plan(N, C, dtype == WFS_F32 ? 8 : 16, &rb);
+    if (per) {
+        const dim3 g2((unsigned)rb);
+#define WFS_BN_SUMS_RR(T, PER)                                                                                       \
+    k_bn_bwd_apply_rr<T, PER><<<g2, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, partial, (int)nblk, \
+                                                        save_mean, save_invstd, gamma, beta, training, relu, (T *)dX, \
+                                                        dgamma, dbeta)
+#define WFS_BN_SUMS_RR_T(T)                                                                                          \
+    if (per == 2) WFS_BN_SUMS_RR(T, 2); else if (per == 4) WFS_BN_SUMS_RR(T, 4); else if (per == 8) WFS_BN_SUMS_RR(T, 8); \
+    else WFS_BN_SUMS_RR(T, 16)
+        if (dtype == WFS_F32) { WFS_BN_SUMS_RR_T(float); } else if (dtype == WFS_BF16) { WFS_BN_SUMS_RR_T(wfs_bf16); } else { WFS_BN_SUMS_RR_T(wfs_f16); }
+#undef WFS_BN_SUMS_RR_T
+#undef WFS_BN_SUMS_RR
+    } else {
+        const long long nblk_a = bn_apply_blocks(N), rpb_a = wfs_cdiv(N, nblk_a);
+        const dim3 grid_a((unsigned)nblk_a);
+        if (dtype == WFS_F32)
+            k_bn_bwd_apply<float, 4><<<grid_a, block, 0, stream>>>((const float *)X, (const float *)dY, N, n_dev, C, C, rpb_a,
+                                                                   partial, (int)nblk, save_mean, save_invstd, gamma, beta,
+                                                                   training, relu, (float *)dX, dgamma, dbeta);
+        else if (dtype == WFS_BF16)
+            k_bn_bwd_apply<wfs_bf16, 4><<<grid_a, block, 0, stream>>>((const wfs_bf16 *)X, (const wfs_bf16 *)dY, N, n_dev, C, C,
+                                                                      rpb_a, partial, (int)nblk, save_mean, save_invstd, gamma,
+                                                                      beta, training, relu, (wfs_bf16 *)dX, dgamma, dbeta);
+        else
+            k_bn_bwd_apply<wfs_f16, 4><<<grid_a, block, 0, stream>>>((const wfs_f16 *)X, (const wfs_f16 *)dY, N, n_dev, C, C,
+                                                                     rpb_a, partial, (int)nblk, save_mean, save_invstd, gamma,
+                                                                     beta, training, relu, (wfs_f16 *)dX, dgamma, dbeta);
+    }
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
 extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
                                const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
                                int32_t relu, void *dX, float *dgamma, float *dbeta, void *workspace,

@@ -37,15 +37,25 @@ __device__ __forceinline__ long long valid_rows(long long R, const long long *r_
 // (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
 // AFFINE: the gathered rows are the RAW output of the producing conv; each is read as [relu](x * sc + sh) (the
 // BatchNorm1d + ReLU between the two layers, include/wfsparse.h wfs_row_affine), sc / sh per channel in LDS.
-template <bool TRANSPOSE_W, bool STATS, bool AFFINE>
+template <bool TRANSPOSE_W, bool STATS, bool AFFINE, bool BNBWD = false>
 __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                       long long R, const long long *__restrict__ r_dev,
                                                       const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                       float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
-                                                      WfsStatsArgs sa, WfsAffine aff) {
+                                                      WfsStatsArgs sa, WfsAffine aff, const float *__restrict__ bn_x,
+                                                      float *__restrict__ bn_partial) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
+    __shared__ float sBn[BNBWD ? 16 * 64 : 1];          // BNBWD: see k_gconv32_bf16
+    float bm = 0.f, bis = 0.f, bga = 1.f, bbe = 0.f, bsa = 0.f, bsb = 0.f;
+    if constexpr (BNBWD) {
+        const int ch = threadIdx.x & 31;
+        bm = aff.mean[ch];
+        bis = aff.invstd[ch];
+        bga = aff.gamma ? aff.gamma[ch] : 1.f;
+        bbe = aff.beta ? aff.beta[ch] : 0.f;
+    }
     __shared__ __attribute__((aligned(16))) float sAff[AFFINE ? 64 : 4];          // sc[32] | sh[32]
     WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     const int nthreads = blockDim.x;
@@ -196,8 +206,41 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
             const long long left = Rv - tile * 32;
             wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
+        if constexpr (BNBWD) {
+            const int left = (int)(Rv - tile * 32 < 32 ? Rv - tile * 32 : 32);
+            float bx[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                bx[i] = bn_x[(orow < Rv ? orow : 0) * 32 + r];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float xh = (bx[i] - bm) * bis;
+                const bool pass = !aff.relu || fmaf(bga, xh, bbe) > 0.f;
+                const float gm = (rr < left && pass) ? acc[i] : 0.f;
+                bsa += gm;
+                bsb = fmaf(gm, xh, bsb);
+            }
+        }
     }
     if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
+    if constexpr (BNBWD) {
+        bsa += __shfl_xor(bsa, 32, 64);
+        bsb += __shfl_xor(bsb, 32, 64);
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = blockDim.x >> 6;
+        if (ln < 32) {
+            sBn[wv * 64 + ln] = bsa;
+            sBn[wv * 64 + 32 + ln] = bsb;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float t = 0.f;
+            for (int w = 0; w < nwv; ++w) t += sBn[w * 64 + threadIdx.x];
+            bn_partial[(long long)blockIdx.x * 64 + threadIdx.x] = t;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ 32 -> 32, bf16
@@ -275,17 +318,32 @@ __device__ __forceinline__ uint4 affine8(uint4 v, const float *sc, const float *
 __device__ __forceinline__ float relu_floor(int relu) { return relu ? 0.f : -__builtin_inff(); }
 
 // AFFINE: see k_gconv32_f32; here sc / sh of the lane's 16 channels live in registers (blocks of at most 768 threads)
-template <typename H, bool TRANSPOSE_W, bool STATS, bool AFFINE>
-__global__ void __launch_bounds__(AFFINE ? 768 : 1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
+// BNBWD (dX launches): the rows this launch produces are dL/dA of a BatchNorm1d (+ ReLU) whose INPUT rows are bn_x
+// (same row set, 32 channels; `aff` holds its statistics and parameters).  The epilogue takes the two sums the BatchNorm
+// backward needs -- sum(g) and sum(g * xhat) over the rows, g masked by the ReLU -- from the output tile it holds in
+// registers and the tile's own bn_x rows, and leaves them as per-block partials [gridDim.x][2][32] in the layout of the
+// stand-alone reduction (bn.hip k_bn_reduce*), so wfs_bn_relu_bwd_sums skips that launch and its read of both tensors.
+template <typename H, bool TRANSPOSE_W, bool STATS, bool AFFINE, bool BNBWD = false>
+__global__ void __launch_bounds__((AFFINE || BNBWD) ? 768 : 1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
                                                        int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
                                                        const H *__restrict__ X,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                        H *__restrict__ Y, long long ntiles,
-                                                       long long tiles_per_xcd, WfsStatsArgs sa, WfsAffine aff) {
+                                                       long long tiles_per_xcd, WfsStatsArgs sa, WfsAffine aff,
+                                                       const H *__restrict__ bn_x, float *__restrict__ bn_partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
+    __shared__ float sBn[BNBWD ? 16 * 64 : 1];
     WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
+    float bm = 0.f, bis = 0.f, bga = 1.f, bbe = 0.f, bsa = 0.f, bsb = 0.f;
+    if constexpr (BNBWD) {
+        const int ch = threadIdx.x & 31;
+        bm = aff.mean[ch];
+        bis = aff.invstd[ch];
+        bga = aff.gamma ? aff.gamma[ch] : 1.f;
+        bbe = aff.beta ? aff.beta[ch] : 0.f;
+    }
     float asc[AFFINE ? 16 : 1], ash[AFFINE ? 16 : 1];
     if constexpr (AFFINE) wfs_affine_load<16>(aff, ((threadIdx.x & 63) >> 5) * 16, asc, ash);
     const float afloor = relu_floor(aff.relu);
@@ -341,6 +399,7 @@ __global__ void __launch_bounds__(AFFINE ? 768 : 1024) k_gconv32_bf16(const int 
         const long long row = tile * 32 + r;
         const bool live = row < Rv;
         const long long rowc = live ? row : 0;
+        H bx[BNBWD ? 16 : 1];
         // ---- phase 1
         int v[32];
 #pragma unroll
@@ -395,6 +454,16 @@ __global__ void __launch_bounds__(AFFINE ? 768 : 1024) k_gconv32_bf16(const int 
                     acc = mfma16<H>(hi, b1, acc);
                 }
         }
+        if constexpr (BNBWD) {
+            // the BatchNorm input at (row of register i, column r).  Asked for AFTER the last gather: these rows were
+            // written a whole forward pass ago (HBM), and loads return in order -- issued at the top of the tile they
+            // held up the table reads and gathers behind them (30 vs 22 us per launch inside the step)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                bx[i] = bn_x[(orow < Rv ? orow : 0) * 32 + r];
+            }
+        }
         // ---- epilogue: reg i holds (row (i&3) + 8(i>>2) + 4h, col r).  Neighbouring columns are paired with one
         // lane exchange so that every lane stores one packed dword: even lanes row(i), odd lanes row(i+1).
         unsigned *Yw = reinterpret_cast<unsigned *>(Y);
@@ -416,8 +485,37 @@ __global__ void __launch_bounds__(AFFINE ? 768 : 1024) k_gconv32_bf16(const int 
             const long long left = Rv - tile * 32;
             wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
+        if constexpr (BNBWD) {
+            const int left = (int)(Rv - tile * 32 < 32 ? Rv - tile * 32 : 32);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float g = wfs_round_to<H>(acc[i]);                         // the gradient as stored
+                const float xh = (wfs_ld(&bx[i]) - bm) * bis;
+                const bool pass = !aff.relu || fmaf(bga, xh, bbe) > 0.f;        // the mask expression of bn.hip
+                const float gm = (rr < left && pass) ? g : 0.f;
+                bsa += gm;
+                bsb = fmaf(gm, xh, bsb);
+            }
+        }
     }
     if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
+    if constexpr (BNBWD) {
+        // lanes (r, 0) and (r, 1) hold the two row halves of column r; waves are added in wave order
+        bsa += __shfl_xor(bsa, 32, 64);
+        bsb += __shfl_xor(bsb, 32, 64);
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = blockDim.x >> 6;
+        if (ln < 32) {
+            sBn[wv * 64 + ln] = bsa;
+            sBn[wv * 64 + 32 + ln] = bsb;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float t = 0.f;
+            for (int w = 0; w < nwv; ++w) t += sBn[w * 64 + threadIdx.x];
+            bn_partial[(long long)blockIdx.x * 64 + threadIdx.x] = t;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ 2 -> 32
@@ -1153,22 +1251,22 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
         return launch_big_lds(k_gconv32_f32<true, false, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
     int rc;
     if (stats) {
         if (affine)
             rc = launch_big_lds(k_gconv32_f32<false, true, true>, &attr[3], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
         else
             rc = launch_big_lds(k_gconv32_f32<false, true, false>, &attr[1], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
     if (affine)
         return launch_big_lds(k_gconv32_f32<false, false, true>, &attr[4], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
     return launch_big_lds(k_gconv32_f32<false, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
-                          identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff);
+                          identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
 }
 
 template <typename H>
@@ -1185,22 +1283,22 @@ static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
         return launch_big_lds(k_gconv32_bf16<H, true, false, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
     int rc;
     if (stats) {
         if (affine)
             rc = launch_big_lds(k_gconv32_bf16<H, false, true, true>, &attr[3], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+                                identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
         else
             rc = launch_big_lds(k_gconv32_bf16<H, false, true, false>, &attr[1], grid, block, lds, stream, table, mirror,
-                                K, identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+                                K, identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
     if (affine)
         return launch_big_lds(k_gconv32_bf16<H, false, false, true>, &attr[4], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
     return launch_big_lds(k_gconv32_bf16<H, false, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
-                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff);
+                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
 }
 
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
@@ -1211,6 +1309,46 @@ int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, 
                                            bias, (wfs_f16 *)Y, stats, pending, affine, stream);
     return launch_gconv32_h16<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, transpose_w, bias,
                                         (wfs_bf16 *)Y, stats, pending, affine, stream);
+}
+
+// dX (transposed filters) of a 32 -> 32 layer whose epilogue takes the sums of the BatchNorm backward in front of it
+// (BNBWD above): partial [*nblk][2][32] floats, *nblk <= 256
+size_t wfs_conv_bnbwd_partial_bytes(void) { return (size_t)256 * 64 * sizeof(float); }
+
+template <typename H>
+static int launch_gconv32_h16_bnbwd(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                                    const H *Xb, const float *W, H *Yb, const WfsAffine &bn, const H *bn_x, float *partial,
+                                    int *nblk_out, hipStream_t stream) {
+    long long ntiles, nblk, tiles_per_xcd;
+    int wpb;
+    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, 12);
+    const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
+    static bool attr = false;
+    const WfsStatsArgs sa = stats_args(nullptr, nblk);
+    *nblk_out = (int)nblk;
+    return launch_big_lds(k_gconv32_bf16<H, true, false, false, true>, &attr, dim3((unsigned)nblk), dim3(wpb * 64), lds, stream,
+                          table, mirror, K, identity_k, R, r_dev, Xb, W, (const float *)nullptr, Yb, ntiles, tiles_per_xcd, sa,
+                          bn, bn_x, partial);
+}
+
+int wfs_launch_gconv32_bnbwd(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                             const void *X, const float *W, void *Y, int dtype, const WfsAffine *bn, const void *bn_x,
+                             float *partial, int *nblk_out, hipStream_t stream) {
+    if (dtype == WFS_F16)
+        return launch_gconv32_h16_bnbwd<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, (wfs_f16 *)Y,
+                                                 *bn, (const wfs_f16 *)bn_x, partial, nblk_out, stream);
+    if (dtype == WFS_BF16)
+        return launch_gconv32_h16_bnbwd<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W,
+                                                  (wfs_bf16 *)Y, *bn, (const wfs_bf16 *)bn_x, partial, nblk_out, stream);
+    long long ntiles, nblk, tiles_per_xcd;
+    int wpb;
+    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
+    static bool attr = false;
+    const WfsStatsArgs sa = stats_args(nullptr, nblk);
+    *nblk_out = (int)nblk;
+    return launch_big_lds(k_gconv32_f32<true, false, false, true>, &attr, dim3((unsigned)nblk), dim3(wpb * 64),
+                          (size_t)K * 4096, stream, table, mirror, K, identity_k, R, r_dev, (const float *)X, W,
+                          (const float *)nullptr, (float *)Y, ntiles, tiles_per_xcd, sa, *bn, (const float *)bn_x, partial);
 }
 
 // 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.

@@ -320,6 +320,36 @@ extern "C" int wfs_gather_conv_affine(const int32_t *table, const int32_t *kmap_
     return wfs_launch_bn_stats(Y, R, Cw_out, dtype, (const long long *)r_dev, stats, (hipStream_t)stream);
 }
 
+extern "C" size_t wfs_gather_conv_bnbwd_partial_bytes(void) { return wfs_conv_bnbwd_partial_bytes(); }
+
+extern "C" int wfs_gather_conv_bnbwd(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                                     int64_t R, const void *X, int64_t X_rows, const float *W, void *Y, int32_t dtype,
+                                     const int64_t *r_dev, const wfs_row_affine *bn, const void *bn_x, float *partial,
+                                     size_t partial_bytes, int32_t *nblk, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)X_rows;
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(bn && bn->mean && bn->invstd && bn_x && partial && nblk, WFS_EINVAL, "incomplete BatchNorm description");
+    WFS_REQUIRE(partial_bytes >= wfs_conv_bnbwd_partial_bytes(), WFS_EWORKSPACE, "partial buffer %zu < %zu", partial_bytes,
+                wfs_conv_bnbwd_partial_bytes());
+    WFS_REQUIRE(R > 0 && table && X && W && Y, WFS_EINVAL, "NULL device pointer / no rows");
+    WFS_REQUIRE(K >= 1 && (dtype == WFS_F32 ? wfs_mfma_gconv32_ok(K) : K <= 27), WFS_EINVAL, "kernel volume %d not covered", K);
+    bool is_ident = true, is_mirror = true;
+    for (int k = 0; k < K; ++k) {
+        const int v = kmap_host ? kmap_host[k] : k;
+        is_ident = is_ident && v == k;
+        is_mirror = is_mirror && v == K - 1 - k;
+    }
+    WFS_REQUIRE(is_ident || is_mirror, WFS_EINVAL, "column map must be the identity or the SubM mirror");
+    WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
+    const WfsAffine a = wfs_affine_from(bn);
+    int nb = 0;
+    int rc = wfs_launch_gconv32_bnbwd(table, is_ident ? 0 : 1, K, identity_k, R, (const long long *)r_dev, X, W, Y, dtype, &a,
+                                      bn_x, partial, &nb, stream);
+    *nblk = nb;
+    return rc;
+}
+
 extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X,
                                 int32_t Cx, const float *W, int32_t Cw_in, int32_t Cw_out, int32_t transpose_w,
                                 float *Y_accum, int32_t dtype, void *stream_) {

@@ -150,6 +150,10 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
                            const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream);
+size_t wfs_conv_bnbwd_partial_bytes(void);
+int wfs_launch_gconv32_bnbwd(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
+                             const void *X, const float *W, void *Y, int dtype, const WfsAffine *bn, const void *bn_x,
+                             float *partial, int *nblk_out, hipStream_t stream);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
                            const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream);

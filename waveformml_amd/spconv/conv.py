@@ -128,10 +128,10 @@ class SparseConvolution(SparseModule):
                 input._features, input._pending = raw, spec      # the input still stands for its normalised rows
                 out_unique = input.unique if self.subm else True
             elif self.subm:
-                out_features = Fsp.indice_subm_conv(features, self.weight, self.bias, rb, bn_request)
+                out_features = Fsp.indice_subm_conv(features, self.weight, self.bias, rb, bn_request, input.bn_link)
                 out_unique = input.unique
             else:
-                out_features = Fsp.indice_conv(features, self.weight, self.bias, rb, bn_request)
+                out_features = Fsp.indice_conv(features, self.weight, self.bias, rb, bn_request, input.bn_link)
                 out_unique = True      # a regular conv numbers DISTINCT output sites
             out_n_valid = rb.m_dev
         out_tensor = SparseConvTensor(out_features, out_indices, out_spatial_shape, batch_size)

@@ -85,6 +85,22 @@ class RowAffine(object):
                               1 if self.relu else 0)
 
 
+class BnLink(object):
+    """Hand-over between the backward of a fused BatchNorm1d (+ ReLU) and the dX launch of the conv that consumed its
+    output (SparseSequential: conv -> BatchNorm1d -> ReLU -> conv).  The BatchNorm's forward fills in what describes it
+    (its raw input rows, parameters, statistics); the next conv's backward, which produces dL/dy of that BatchNorm, takes
+    the two sums the BatchNorm backward needs in its epilogue (wfs_gather_conv_bnbwd) and leaves them here; the
+    BatchNorm's backward, which runs right after, then skips its reduction launch (wfs_bn_relu_bwd_sums).  Nothing
+    changes if either side does not take part: without partials the BatchNorm reduces as before."""
+
+    def __init__(self):
+        self.x = self.weight = self.bias = self.save_mean = self.save_invstd = None
+        self.relu = False
+        self.partial = None        # float32 buffer with `nblk` per-block partials, set by the dX launch
+        self.nblk = 0
+        self.dy_ptr = None         # address of the dL/dy tensor the partials belong to
+
+
 def _affine_struct(mean, invstd, weight, bias, relu):
     return _lib.RowAffine(_lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), 1 if relu else 0)
 
@@ -159,7 +175,8 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, affine=None):
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, affine=None,
+                bn_link=None):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
     With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only).
     ``affine`` (a wfs_row_affine struct): the rows of X are raw conv outputs read through a BatchNorm (+ ReLU)."""
@@ -171,6 +188,18 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
+    if bn_link is not None:
+        assert transpose_w and bias is None and R > 0 and bn_link.x.shape[0] == R
+        st = _affine_struct(bn_link.save_mean, bn_link.save_invstd, bn_link.weight, bn_link.bias, bn_link.relu)
+        part = torch.empty((int(lib.wfs_gather_conv_bnbwd_partial_bytes()) // 4,), dtype=torch.float32, device=X.device)
+        nblk = ctypes.c_int32(0)
+        _lib.check(lib.wfs_gather_conv_bnbwd(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], _lib.ptr(W),
+                                             _lib.ptr(Y), _lib.dtype_code(X), _lib.ptr(r_dev), ctypes.byref(st),
+                                             _lib.ptr(bn_link.x), _lib.ptr(part), part.numel() * 4, ctypes.byref(nblk),
+                                             _lib.stream_ptr()))
+        bn_link.partial, bn_link.nblk, bn_link.dy_ptr = part, int(nblk.value), Y.data_ptr()
+        _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
+        return Y
     if affine is not None:
         assert not transpose_w and R > 0
         st = None
@@ -407,9 +436,10 @@ class SparseConvFunction(Function):
     """features [n_in, Cin], filters [*k, Cin, Cout] fp32, bias [Cout] or None -> [n_out, Cout]."""
 
     @staticmethod
-    def forward(ctx, features, filters, bias, rulebook, mode, bn_request=None):
+    def forward(ctx, features, filters, bias, rulebook, mode, bn_request=None, bn_link=None):
         rb = rulebook
         features = _features_ok(features)
+        ctx.bn_link = bn_link
         K = rb.K
         W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
@@ -458,13 +488,20 @@ class SparseConvFunction(Function):
                 else:
                     dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov, filters)
             if ctx.needs_input_grad[0]:
-                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
+                link = ctx.bn_link
+                if (link is not None and link.x is not None and features.shape[1] == 32 and dY.shape[1] == 32
+                        and not rb.has_dup and K <= 27 and link.x.shape[0] == rb.N and link.x.dtype == dY.dtype):
+                    # `features` is the output of a fused BatchNorm1d (+ ReLU): this launch produces its dL/dy and
+                    # takes the sums its backward needs (BnLink)
+                    dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev, bn_link=link)
+                else:
+                    dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
             # dY has one row per OUTPUT of this product: rb.N rows for an inverse conv, rb.M otherwise
             db = _masked_column_sum(dY, rb.n_dev if mode == INVERSE else rb.m_dev).to(bias.dtype)
-        return dX, dW, db, None, None, None
+        return dX, dW, db, None, None, None, None
 
 
 class AffineSparseConvFunction(Function):
@@ -642,10 +679,11 @@ class BatchNormReLUFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, n_dev=None,
-                batches_tracked=None, stats=None):
+                batches_tracked=None, stats=None, link=None):
         lib = _lib.load()
         x = _features_ok(x)
         N, C = x.shape
+        ctx.link = link
         y = _rows(tuple(x.shape), x, n_dev)
         for t in (weight, bias, running_mean, running_var):
             assert t is None or (t.dtype == torch.float32 and t.numel() == C and t.is_contiguous())
@@ -668,6 +706,7 @@ class BatchNormReLUFunction(Function):
             ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
             ctx.flags = (True, bool(relu))
             ctx.n_dev = n_dev
+            _fill_link(link, x, weight, bias, save_mean, save_invstd, relu, True)
             return y
         save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
@@ -681,27 +720,49 @@ class BatchNormReLUFunction(Function):
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.flags = (bool(training), bool(relu))
         ctx.n_dev = n_dev
+        _fill_link(link, x, weight, bias, save_mean, save_invstd, relu, training)
         return y
 
     @staticmethod
     def backward(ctx, grad_output):
         x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         training, relu = ctx.flags
-        dx, dgamma, dbeta = bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, ctx.n_dev)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        link, sums = ctx.link, None
+        if link is not None:
+            if link.partial is not None and link.dy_ptr == grad_output.data_ptr() and grad_output.is_contiguous():
+                sums = (link.partial, link.nblk)      # taken by the launch that produced grad_output
+            link.partial = link.x = None              # one backward pass, one hand-over
+        dx, dgamma, dbeta = bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, ctx.n_dev,
+                                             sums)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
-def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, n_dev):
+def _fill_link(link, x, weight, bias, save_mean, save_invstd, relu, training):
+    if link is not None and training and x.shape[1] == 32:
+        link.x, link.weight, link.bias = x.detach(), weight, bias
+        link.save_mean, link.save_invstd, link.relu = save_mean, save_invstd, bool(relu)
+
+
+def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, n_dev, sums=None):
     """(dx, dgamma, dbeta) of y = [relu](BatchNorm1d(x)) over the active rows, given dL/dy (two launches: the sums
-    sum(g), sum(g * xhat) with the ReLU mask recomputed from x, then the elementwise pass)."""
+    sum(g), sum(g * xhat) with the ReLU mask recomputed from x, then the elementwise pass).  ``sums`` = (partials,
+    count) when the launch that produced dL/dy already took the sums (BnLink): the elementwise pass alone."""
     lib = _lib.load()
     N, C = x.shape
     dy = grad_output.contiguous()
     if dy.dtype != x.dtype:
-        dy = dy.to(x.dtype)
+        dy, sums = dy.to(x.dtype), None
     dx = _rows(tuple(x.shape), x, n_dev)
     dgamma = grad_like(weight) if weight is not None else None
     dbeta = grad_like(bias) if bias is not None else None
+    if sums is not None and C == 32 and N > 0:
+        part, nblk = sums
+        _lib.check(lib.wfs_bn_relu_bwd_sums(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
+                                            _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
+                                            1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                            _lib.ptr(part), int(nblk), _lib.dtype_code(x), _lib.ptr(n_dev),
+                                            _lib.stream_ptr()))
+        return dx, dgamma, dbeta
     ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
     _lib.check(lib.wfs_bn_relu_bwd(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
                                    _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
@@ -710,7 +771,7 @@ def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, train
     return dx, dgamma, dbeta
 
 
-def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
+def batch_norm_relu(features, bn, relu, n_dev=None, stats=None, link=None):
     """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features
     (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts";
     ``stats``: (save_mean, save_invstd) already taken by the producing convolution)."""
@@ -718,7 +779,8 @@ def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
     tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # bumped by the kernel
     return BatchNormReLUFunction.apply(
         features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats)
+        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats,
+        link)
 
 
 def can_fuse_batch_norm(bn, features):
@@ -906,12 +968,12 @@ def cross_entropy_mean(logits, target, ignore_index=-100):
 
 # 16-bit storage: bf16, and fp16 for the reference's ``half_precision`` / ``use_half`` (float16 features,
 # src/datasets/HDF5Dataset.py:227-228).  Both have native kernels (fp32 accumulate, fp32 master filters).
-def indice_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request)
+def indice_conv(features, filters, bias, rulebook, bn_request=None, bn_link=None):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request, bn_link)
 
 
-def indice_subm_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request)
+def indice_subm_conv(features, filters, bias, rulebook, bn_request=None, bn_link=None):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request, bn_link)
 
 
 def indice_inverse_conv(features, filters, bias, rulebook, bn_request=None):

@@ -192,7 +192,12 @@ class SparseSequential(SparseModule):
                             # applies the normalisation while it gathers them (functional.RowAffine)
                             input.defer_affine(Fsp.RowAffine(module, relu, stats[0], stats[1]))
                         else:
-                            input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats)
+                            # training mode: the conv that reads these rows next can take the sums of this BatchNorm's
+                            # backward in its dX launch (functional.BnLink)
+                            link = Fsp.BnLink() if (ops.FUSE_BN_BACKWARD_SUMS and module.training
+                                                    and module.num_features == 32) else None
+                            input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats, link)
+                            input.bn_link = link
                         if relu:
                             i += 1
                     else:

@@ -69,6 +69,15 @@ CHAIN_BUILD_COUNT = 0      # chains actually built (tests / diagnostics)
 # the caches.
 DEFER_BATCH_NORM = os.environ.get("WFS_DEFER_BATCH_NORM", "0") != "0"
 
+# Backward of conv -> BatchNorm1d (+ ReLU) -> conv: the second conv's dX launch, which produces dL/dy of the BatchNorm,
+# also takes the two sums the BatchNorm backward needs (sum g, sum g * xhat) from the tile it holds in registers
+# (functional.BnLink, include/wfsparse.h wfs_gather_conv_bnbwd), so the BatchNorm backward is one launch instead of two.
+# Same numbers up to the order of the fp32 sums.  OFF by default (WFS_FUSE_BN_BACKWARD_SUMS=1: on): isolated the dX
+# launch grows 17.9 -> 20.1 us and a 7.7 us reduction launch goes away, but inside the step the BatchNorm's input rows
+# it has to read were written a whole forward pass earlier (HBM, 2-byte strided reads) and the launch takes 30 us (22 us
+# with those reads issued after the last gather): 0.570 vs 0.566 ms per step, same-box A/B.
+FUSE_BN_BACKWARD_SUMS = os.environ.get("WFS_FUSE_BN_BACKWARD_SUMS", "0") != "0"
+
 _SIDE_STREAMS = {}
 
 

@@ -55,6 +55,7 @@ class SparseConvTensor(object):
         """
         self._features = features
         self._pending = None        # functional.RowAffine: BatchNorm (+ ReLU) still to be applied to the raw rows
+        self.bn_link = None         # functional.BnLink of the fused BatchNorm that produced `features`, if any
         self.indices = indices
         if self.indices.dtype != torch.int32:
             self.indices = self.indices.int()
@@ -81,6 +82,7 @@ class SparseConvTensor(object):
     def features(self, value):
         self._features = value
         self._pending = None
+        self.bn_link = None         # whoever assigns new rows says if a BatchNorm produced them (SparseSequential)
 
     def defer_affine(self, spec):
         """Keep the raw rows and remember the BatchNorm (+ ReLU) the next reader has to apply."""
