@@ -136,7 +136,8 @@ def _conv_pair(case, Cin, Cout, n, B, seed, dtype=torch.float32, bias=True):
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "D%d_k%s_s%s_p%s_d%s_%s" % (c[0], c[2], c[3], c[4], c[5], "subm" if c[6] else "conv"))
-@pytest.mark.parametrize("chan", [(2, 32), (32, 32), (5, 7)], ids=lambda c: "c%dx%d" % c)
+@pytest.mark.parametrize("chan", [(2, 32), (32, 32), (5, 7), (24, 16), (64, 48), (252, 158), (130, 146), (300, 33)],
+                         ids=lambda c: "c%dx%d" % c)
 def test_conv_forward_backward_fp32(case, chan):
     Cin, Cout = chan
     B = 3

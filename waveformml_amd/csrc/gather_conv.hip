@@ -194,11 +194,211 @@ __global__ void k_dw_reduce(const float *__restrict__ part, long long nchunks, i
         dW[e] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------ shape-generic MFMA kernels
+// Any Cin / Cout, any K, fp32 / bf16 / fp16 rows, exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma
+// chain, MI355X_MICROARCH.md "Matrix cores").  These carry the layers the 32-channel kernels of conv_mfma.hip do not:
+// the reference's wide 2-D stacks (config/examples/GEP.json: 252 -> 158 -> 64 channels through
+// src/models/SPConvBlocks.py:450-516; the SparseConv2DPreserve stacks of 130 ... 154 channels, :730-822) and any
+// 16 / 24 / 64-channel 3-D layer.  Channel counts need not be multiples of anything (edge tiles are masked).
+typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GM_WAVES = 8;         // waves of a block = shares of the contraction of ONE 32 x 32 output tile
+constexpr int GM_CHUNK = 256;       // input channels staged per pass
+constexpr int GM_BATCH = 16;        // MFMA steps of a wave per pass: 256 channels = 128 pairs over 8 waves
+static_assert(GM_BATCH * GM_WAVES * 2 >= GM_CHUNK, "one batch must cover a wave's share of a pass");
+
+// forward / dX: block = (32 output rows, 32 output channels).  Per active kernel offset the 32 gathered input rows are
+// staged once into LDS (whole rows, coalesced), the block's 8 waves take interleaved pairs of the Cin contraction
+// (A from LDS, B = filter values straight from L2: 128-B coalesced across a wave for the forward, a lane's own filter
+// row for dX), and their 8 accumulators are added through LDS in wave order (deterministic, no atomics, no workspace).
+template <typename T, bool TRANSPOSE_W>
+__global__ void __launch_bounds__(64 * GM_WAVES) k_gconv_mfma(const int *__restrict__ table, KMap kmap, int K, int identity_k,
+                                                              long long R, const long long *__restrict__ r_dev,
+                                                              const T *__restrict__ X, int Cx, const float *__restrict__ W,
+                                                              int Cw_in, int Cw_out, const float *__restrict__ bias,
+                                                              T *__restrict__ Y, int Cy) {
+    __shared__ float sA[32][GM_CHUNK + 1];
+    __shared__ float sRed[GM_WAVES][1024];
+    __shared__ int sNb[128][32];            // the tile's table entries for every offset: ONE round trip, not K
+    __shared__ int sAct[128];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long tile = blockIdx.x;
+    const int col0 = blockIdx.y * 32, col = col0 + r;
+    const bool col_ok = col < Cy;
+    const long long Rv = valid_rows(R, r_dev);
+    for (int e = threadIdx.x; e < K * 32; e += 64 * GM_WAVES) {
+        const int k = e >> 5;
+        const long long row = tile * 32 + (e & 31);
+        int nb = -1;
+        if (row < Rv) nb = (k == identity_k) ? (int)row : table[(long long)kmap.v[k] * R + row];
+        sNb[k][e & 31] = nb;
+    }
+    __syncthreads();
+    for (int k = wid; k < K; k += GM_WAVES) {
+        const unsigned long long any = __ballot(lane < 32 && sNb[k][r] >= 0);
+        if (lane == 0) sAct[k] = any != 0ull;
+    }
+    __syncthreads();
+    gm_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // A stage = (active offset k, pass c0 over the input channels).  A wave stages rows wid, wid + 8, wid + 16, wid + 24,
+    // a lane the columns lane, lane + 64, ... of the pass.  Software pipeline: while the MFMAs of stage s run, the rows of
+    // stage s + 1 are already on their way from L2 into registers.
+    auto next_stage = [&](int &k, int &c0) {
+        c0 += GM_CHUNK;
+        if (c0 >= Cx) {
+            c0 = 0;
+            do ++k; while (k < K && !sAct[k]);
+        }
+    };
+    // fetch() only ASKS for the values (raw, from clamped addresses); validity is applied when they are written to LDS
+    // one stage later -- a select right behind the load would make the wave wait for the prefetch before its MFMAs
+    float pre[4][GM_CHUNK / 64];
+    auto fetch = [&](int k, int c0) {
+        const int cn = Cx - c0 < GM_CHUNK ? Cx - c0 : GM_CHUNK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int src = sNb[k][wid + q * GM_WAVES];
+            const T *xrow = X + (long long)(src >= 0 ? src : 0) * Cx + c0;
+#pragma unroll
+            for (int j = 0; j < GM_CHUNK / 64; ++j) {
+                const int c = lane + 64 * j;
+                pre[q][j] = wfs_ld(xrow + (c < cn ? c : 0));
+            }
+        }
+    };
+    int k = -1, c0 = Cx;               // "before the first stage"
+    next_stage(k, c0);
+    if (k < K) fetch(k, c0);
+    while (k < K) {
+        const int cn = Cx - c0 < GM_CHUNK ? Cx - c0 : GM_CHUNK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool row_ok = sNb[k][wid + q * GM_WAVES] >= 0;
+#pragma unroll
+            for (int j = 0; j < GM_CHUNK / 64; ++j)
+                sA[wid + q * GM_WAVES][lane + 64 * j] = (row_ok && lane + 64 * j < cn) ? pre[q][j] : 0.f;
+        }
+        __syncthreads();
+        const float *Wk = W + (long long)k * Cw_in * Cw_out;
+        const int cc0 = c0;
+        // This wave's share of the pass: `iters` <= GM_BATCH consecutive pairs of channels (a pass is at most 256
+        // channels = 128 pairs over 8 waves).  Order matters: loads return in order, so the filter values of THIS stage
+        // are asked for first, the rows of the NEXT stage second -- the MFMAs then wait for the former only.
+        const int iters = (((cn + 1) >> 1) + GM_WAVES - 1) / GM_WAVES;
+        float av[GM_BATCH], bv[GM_BATCH];
+#pragma unroll
+        for (int u = 0; u < GM_BATCH; ++u) {
+            const int c = 2 * (wid * iters + u) + h;
+            const bool ok = c < cn && u < iters;
+            const int cc = ok ? c : 0;
+            const long long cw = cc0 + cc;
+            const float b = TRANSPOSE_W ? Wk[(long long)(col_ok ? col : 0) * Cw_out + cw]
+                                        : Wk[cw * Cw_out + (col_ok ? col : 0)];
+            bv[u] = (ok && col_ok) ? b : 0.f;
+            av[u] = ok ? sA[r][cc] : 0.f;
+        }
+        next_stage(k, c0);
+        if (k < K) fetch(k, c0);       // in flight during the MFMAs below
+#pragma unroll
+        for (int u = 0; u < GM_BATCH; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sRed[wid][((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = acc[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 64 * GM_WAVES) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < GM_WAVES; ++w) v += sRed[w][e];
+        const long long row = tile * 32 + (e >> 5);
+        const int cc = col0 + (e & 31);
+        if (row < Rv && cc < Cy) wfs_st(Y + row * Cy + cc, v + (bias ? bias[cc] : 0.f));
+    }
+}
+
+// dW: one wave = one 32 x 32 tile of dW[k] over a chunk of rows; the rows are the MFMA contraction (two per
+// instruction): A[a][kk] = S[row][a0 + a], B[kk][b] = G[table[k][row]][b0 + b], both whole 128-B row pieces per
+// half-wave straight from L2.  Same slab layout as k_gather_dw (part[chunk][k][Cs][Cg]) -> k_dw_reduce.
+template <typename T>
+__global__ void __launch_bounds__(64) k_gdw_mfma(const int *__restrict__ table, int K, int identity_k, long long R,
+                                                 const long long *__restrict__ r_dev, long long rows_per_chunk,
+                                                 const T *__restrict__ S, int Cs, const T *__restrict__ G, int Cg,
+                                                 float *__restrict__ part, int tiles_b) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int k = blockIdx.y;
+    const int a0 = (blockIdx.z / tiles_b) * 32, b0 = (blockIdx.z % tiles_b) * 32;
+    const long long chunk = blockIdx.x;
+    const long long Rv = valid_rows(R, r_dev);
+    const long long r_begin = chunk * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < Rv ? r_begin + rows_per_chunk : Rv;
+    const bool a_ok = a0 + j < Cs, b_ok = b0 + j < Cg;
+    const int ac = a_ok ? a0 + j : 0, bc = b_ok ? b0 + j : 0;
+    gm_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // groups of 64 rows, software-pipelined: the 64 row pieces of group g + 1 are asked for before the 32 MFMAs of group
+    // g run (unconditional clamped loads + select: a load under a per-element branch costs a round trip each)
+    float av[32], bv[32], an[32], bn[32];
+    auto fetch = [&](long long base, float (&A)[32], float (&B)[32]) {
+        const long long row = base + lane;
+        int nbv = -1;
+        if (row < r_end) nbv = (k == identity_k) ? (int)row : table[(long long)k * R + row];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int n0 = __builtin_amdgcn_readlane(nbv, 2 * s), n1 = __builtin_amdgcn_readlane(nbv, 2 * s + 1);
+            const int nb = h ? n1 : n0;
+            const long long rr = base + 2 * s + h;
+            const float a = wfs_ld(S + (nb >= 0 ? rr : r_begin) * Cs + ac);
+            const float b = wfs_ld(G + (long long)(nb >= 0 ? nb : 0) * Cg + bc);
+            A[s] = (nb >= 0 && a_ok) ? a : 0.f;
+            B[s] = (nb >= 0 && b_ok) ? b : 0.f;
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin, av, bv);
+    for (long long base = r_begin; base < r_end; base += 64) {
+        const bool more = base + 64 < r_end;
+        if (more) fetch(base + 64, an, bn);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                av[s] = an[s];
+                bv[s] = bn[s];
+            }
+        }
+    }
+    float *p = part + ((long long)chunk * K + k) * Cs * Cg;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int a = a0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (a < Cs && b_ok) p[(long long)a * Cg + b0 + j] = acc[i];
+    }
+}
+
+// shapes the generic MFMA kernels take over from the VALU ones
+inline bool gm_shape(int Ca, int Cb) { return Ca >= 8 && Cb >= 8 && (long long)Ca * Cb >= 256; }
+
 long long dw_chunks(long long R) {
     long long chunks = wfs_cdiv(R, 4096);
     if (chunks < 1) chunks = 1;
     if (chunks > 512) chunks = 512;
     return chunks;
+}
+// the MFMA dW: one wave per (chunk, offset, 32 x 32 tile) -- short inputs get chunks of 256 rows so that the launch has
+// enough waves, the slabs stay under 32 MiB
+long long dw_chunks_mfma(long long R, int K, int Cs, int Cg) {
+    long long chunks = wfs_cdiv(R, 256);
+    const long long per = (long long)K * Cs * Cg * 4;
+    const long long cap = per > 0 ? (32ll << 20) / per : 1;
+    if (chunks > 64) chunks = 64;
+    if (chunks > cap) chunks = cap;
+    const long long base = dw_chunks(R);
+    return chunks < base ? base : chunks;
 }
 
 }  // namespace
@@ -245,6 +445,22 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
         return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stats, stats_done,
                                       pending, stream);
+    if (gm_shape(Cx, Cy) && table) {
+        const dim3 g((unsigned)wfs_cdiv(R, 32), (unsigned)wfs_cdiv(Cy, 32)), b(64 * GM_WAVES);
+#define WFS_GM(T, TR)                                                                                            \
+    k_gconv_mfma<T, TR><<<g, b, 0, stream>>>(table, km, K, identity_k, R, r_dev, (const T *)X, Cx, W, Cw_in, Cw_out, \
+                                             bias, (T *)Y, Cy)
+        if (dtype == WFS_F32) {
+            if (transpose_w) WFS_GM(float, true); else WFS_GM(float, false);
+        } else if (dtype == WFS_BF16) {
+            if (transpose_w) WFS_GM(wfs_bf16, true); else WFS_GM(wfs_bf16, false);
+        } else {
+            if (transpose_w) WFS_GM(wfs_f16, true); else WFS_GM(wfs_f16, false);
+        }
+#undef WFS_GM
+        WFS_LAUNCH_CHECK();
+        return WFS_OK;
+    }
     dim3 grid((unsigned)wfs_cdiv(R, 64), (unsigned)wfs_cdiv(Cy, 4 * CT)), block(TB);
 #define WFS_GC(T, TR)                                                                                           \
     k_gather_conv<T, TR><<<grid, block, 0, stream>>>(table, km, K, identity_k, R, r_dev, (const T *)X, Cx, W,  \
@@ -377,7 +593,7 @@ extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identit
 }
 
 extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg) {
-    size_t generic = (size_t)dw_chunks(R) * K * Cs * Cg * sizeof(float);
+    size_t generic = (size_t)(gm_shape(Cs, Cg) ? dw_chunks_mfma(R, K, Cs, Cg) : dw_chunks(R)) * K * Cs * Cg * sizeof(float);
     size_t fast = wfs_dw_fast_workspace(K, R, Cs, Cg);
     return generic > fast ? generic : fast;
 }
@@ -415,13 +631,24 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
         return wfs_launch_gdw_c32c2(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace,
                                     dtype, defer, stream);
     WFS_REQUIRE(is_ident, WFS_EINVAL, "a column map is only supported by the 32 x 2 dW kernel");
-    long long chunks = dw_chunks(R);
+    long long chunks = gm_shape(Cs, Cg) ? dw_chunks_mfma(R, K, Cs, Cg) : dw_chunks(R);
     long long rows_per_chunk = wfs_cdiv(wfs_cdiv(R, chunks), DW_ROWS) * DW_ROWS;
     int tiles_a = (int)wfs_cdiv(Cs, DW_TA), tiles_b = (int)wfs_cdiv(Cg, DW_TBB);
     WFS_REQUIRE((long long)tiles_a * tiles_b <= 65535, WFS_EINVAL, "channel tile grid too large");
     dim3 grid((unsigned)chunks, (unsigned)K, (unsigned)(tiles_a * tiles_b)), block(TB);
     float *part = (float *)workspace;
-    if (dtype == WFS_F32)
+    if (gm_shape(Cs, Cg) && table) {
+        const dim3 b64(64);
+        if (dtype == WFS_F32)
+            k_gdw_mfma<float><<<grid, b64, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk, (const float *)S, Cs,
+                                                        (const float *)G, Cg, part, tiles_b);
+        else if (dtype == WFS_BF16)
+            k_gdw_mfma<wfs_bf16><<<grid, b64, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk,
+                                                           (const wfs_bf16 *)S, Cs, (const wfs_bf16 *)G, Cg, part, tiles_b);
+        else
+            k_gdw_mfma<wfs_f16><<<grid, b64, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk, (const wfs_f16 *)S,
+                                                          Cs, (const wfs_f16 *)G, Cg, part, tiles_b);
+    } else if (dtype == WFS_F32)
         k_gather_dw<float><<<grid, block, 0, stream>>>(table, K, identity_k, R, r_dev, rows_per_chunk, (const float *)S,
                                                        Cs, (const float *)G, Cg, part, tiles_a, tiles_b);
     else if (dtype == WFS_BF16)

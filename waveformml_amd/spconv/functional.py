@@ -115,17 +115,23 @@ def can_take_batch_norm_stats(bn, features):
             and (bn.training or bn.running_mean is None))
 
 
-# Wide-channel layers on few rows (the reference's 2-D nets: 300 -> 252 -> 158 -> 64 channels on a few hundred rows,
-# config/examples/GEP.json) are small dense GEMMs per kernel offset.  They go to the library GEMM (rocBLAS / hipBLASLt
-# batched fp32, i.e. MFMA) on rows gathered through the SAME tables -- still output-stationary, no atomics, deterministic.
-# The hand-written kernels keep the shapes they are built for (32- and 2-channel rows) and everything else that does
-# not fit this route (device-side row counts, huge K * R * C).  Measured on GEP at batch 32: 741 us -> ~40 us per layer.
-GEMM_ROUTE_MIN_CHANNELS = 48
+# Layers wider than 512 channels (the hybrid net's 2048 -> 1821 -> ... stack, BASELINE configs[4]) are GEMMs of tens of
+# GFLOP per launch: they go to the library GEMM (rocBLAS / hipBLASLt) on rows gathered through the SAME tables -- still
+# output-stationary, no atomics, deterministic.  Everything up to 512 channels, whatever the channel counts, runs in
+# libwfsparse: the 32- and 2-channel MFMA kernels of conv_mfma.hip, the shape-generic MFMA kernels of gather_conv.hip
+# (k_gconv_mfma / k_gdw_mfma: the reference's GEP.json 252 -> 158 -> 64 stack, SparseConv2DPreserve's 130 ... 154
+# channels, 16 / 24 / 64-channel 3-D layers).
+GEMM_ROUTE_MIN_CHANNELS = 513
 GEMM_ROUTE_MAX_ELEMENTS = 1 << 27
 
 
+def _fast_shape(Cx, Cy):
+    """Channel pairs with shape-specialised kernels (conv_mfma.hip)."""
+    return (Cx == 32 and Cy == 32) or (Cx == 2 and Cy == 32) or (Cx == 32 and Cy == 2)
+
+
 def _gemm_route(Cx, Cy, K, R, r_dev, table):
-    fast = (Cx == 32 and Cy == 32) or (Cx == 2 and Cy == 32) or (Cx == 32 and Cy == 2)
+    fast = _fast_shape(Cx, Cy)
     return (not fast and table is not None and R > 0 and max(Cx, Cy) >= GEMM_ROUTE_MIN_CHANNELS
             and K * R * max(Cx, Cy) <= GEMM_ROUTE_MAX_ELEMENTS and ACCOUNT is None)
 
@@ -182,6 +188,12 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     ``affine`` (a wfs_row_affine struct): the rows of X are raw conv outputs read through a BatchNorm (+ ReLU)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
+    if transpose_w and bn_link is None and not _fast_shape(Cw_out, Cw_in):
+        # the shape-generic MFMA kernel reads the filter with the OUTPUT channel on the lanes: for dX that is a strided
+        # walk over W[k] (a new 128-B line per lane and step; 47 vs 26 us measured at 64 channels) -- hand it W[k]^T
+        # instead (one small transpose launch: the filters are at most a few MB)
+        W, transpose_w = W.transpose(1, 2).contiguous(), False
+        Cw_in, Cw_out = Cw_out, Cw_in
     Cy = Cw_in if transpose_w else Cw_out
     Y = _rows((R, Cy), X, r_dev)
     assert W.dtype == torch.float32 and W.is_contiguous()
