@@ -1,10 +1,11 @@
-"""``LitZ``: host-side mirror of the reference's per-segment regression module (src/engineering/LitZ.py:31-139 on
-src/engineering/LitBase.py:13-55,124-174): ``SingleEndedZConv`` predicts a dense [B, 1, 14, 11] map, the loss compares
-it with the targets of the ACTIVE segments only -- both the mask and the dense target come from
-``SparseConvTensor(...).dense()`` (wfs_to_dense) -- with a sum-reduced criterion divided by the number of rows.
+"""``LitZ`` and ``LitEZ``: host-side mirrors of the reference's per-segment regression modules
+(src/engineering/LitZ.py:31-139, src/engineering/LitEZ.py:8-91, on src/engineering/LitBase.py:13-55,110-174): the net
+predicts a dense [B, out, 14, 11] map, the loss compares it with the targets of the ACTIVE segments only -- both the mask
+and the dense target come from ``SparseConvTensor(...).dense()`` (wfs_to_dense) -- with a sum-reduced criterion divided by
+the number of rows (``net_config.SELoss``: of the single-ended segments only, psd/segments.py).
 
-As psd/lit.LitPSD this is a plain ``nn.Module`` with Lightning's step methods (Lightning is not installable offline);
-the evaluators (ZEvaluator*, histogram / plot plumbing) are out of scope, SURVEY.md 2.
+As psd/lit.LitPSD these are plain ``nn.Module``s with Lightning's step methods (Lightning is not installable offline);
+the evaluators (ZEvaluator*, EZEvaluator*, histogram / plot plumbing) are out of scope, SURVEY.md 2.
 """
 import logging
 
@@ -12,10 +13,14 @@ import torch
 from torch import nn
 
 from .config import DictionaryUtility, ModuleUtility
-from .znet import SingleEndedZConv
+from .segments import SE_DEAD_PMTS, segment_status, single_ended_mask
+from .znet import SingleEndedEZConv, SingleEndedZConv
 
 
-class LitZ(nn.Module):
+class LitSegmentBase(nn.Module):
+    """What LitZ and LitEZ share of the reference's LitBase with ``event_predictions=False`` (LitBase.py:13-55)."""
+    model_class = None
+
     def __init__(self, config, trial=None):
         super().__init__()
         self.trial = trial
@@ -25,12 +30,15 @@ class LitZ(nn.Module):
         self.lr = config.optimize_config.lr
         self.modules_util = ModuleUtility(config.net_config.imports + config.dataset_config.imports +
                                           config.optimize_config.imports)
-        self.model = SingleEndedZConv(config)
+        self.model = type(self).model_class(config)
         criterion_class = self.modules_util.retrieve_class(config.net_config.criterion_class)
         self.criterion = criterion_class(*config.net_config.criterion_params, reduction="sum")   # event_predictions=False
         self.occlude_index = getattr(config.dataset_config, "occlude_index", None)
-        if getattr(config.net_config, "SELoss", False):
-            raise NotImplementedError("the single-ended-only loss needs the evaluator's segment status table")
+        self.SE_only = bool(getattr(config.net_config, "SELoss", False))
+        if self.SE_only:
+            # the reference takes the table from its SingleEndedEvaluator; `net_config.SE_dead_pmts` replaces the default
+            dead = getattr(config.net_config, "SE_dead_pmts", SE_DEAD_PMTS)
+            self.register_buffer("SE_mask", single_ended_mask(segment_status(dead, self.nx, self.ny)))
         if hasattr(config.net_config, "UseFFT"):
             raise NotImplementedError("UseFFT feeds complex features; not on the mirrored path")
         self.logged = {}
@@ -58,7 +66,7 @@ class LitZ(nn.Module):
             return [optimizer], [scheduler]
         return optimizer
 
-    # reference LitBase._calc_segment_loss, :124-174 (SE_only branch excluded)
+    # reference LitBase._calc_segment_loss, :124-174
     def _calc_segment_loss(self, coo, predictions, target, use_float=True, target_index=None, sparse_mask=None):
         sp = self.model.spconv
         batch_size = int(coo[-1, -1]) + 1
@@ -78,8 +86,16 @@ class LitZ(nn.Module):
         else:
             want = target_tensor[:, target_index, :, :]
             want = want.unsqueeze(1) if use_float else want
-        loss = self.criterion.forward(predictions, want)
+        if self.SE_only:
+            loss = self.criterion.forward(self.SE_mask * predictions, self.SE_mask * want)
+            num_predictions = torch.sum(self.SE_mask * sparse_mask)
+        else:
+            loss = self.criterion.forward(predictions, want)
         return loss / num_predictions, target_tensor, predictions, sparse_mask
+
+
+class LitZ(LitSegmentBase):
+    model_class = SingleEndedZConv
 
     # reference LitZ._process_batch, :89-108
     def _process_batch(self, batch, target_index=None):
@@ -106,5 +122,54 @@ class LitZ(nn.Module):
     def test_step(self, batch, batch_idx):
         loss = self._process_batch(batch)[0]
         results = {"test_loss": loss}
+        self.log_dict(results, on_epoch=True, logger=True)
+        return results
+
+
+class LitEZ(LitSegmentBase):
+    """Energy + z regression: a 2-plane prediction map, the loss the sum of the two per-plane segment losses
+    (reference LitEZ._process_batch, :57-73; the second call reuses the first call's active-segment mask)."""
+    model_class = SingleEndedEZConv
+
+    def __init__(self, config, trial=None):
+        super().__init__(config, trial)
+        nc = config.net_config
+        self.zscale = getattr(nc, "zscale", 1200.)
+        self.escale = getattr(nc, "escale", 12.)
+        self.e_adjust = getattr(nc, "e_adjust", 12.)
+        self.e_factor = self.escale / self.e_adjust
+        self.phys_coord = nc.algorithm == "features"
+
+    def _process_batch(self, batch):
+        (c, f), target = batch
+        if self.phys_coord and self.e_factor != 1.:
+            f[:, 0] *= self.e_factor
+            f[:, 2] *= self.e_factor
+            f[:, 3] *= self.e_factor
+        if self.occlude_index:
+            f[:, self.occlude_index] = 0
+        predictions = self.model([c, f])
+        ZLoss, target_z, predictions_z, sparse_mask = self._calc_segment_loss(c, predictions[:, 0].unsqueeze(1),
+                                                                              target[:, 0])
+        ELoss, target_E, predictions_E, _ = self._calc_segment_loss(c, predictions[:, 1].unsqueeze(1), target[:, 1],
+                                                                    sparse_mask=sparse_mask)
+        predictions = torch.cat((predictions_z, predictions_E), dim=1)
+        target_tensor = torch.cat((target_z, target_E), dim=1)
+        return c, f, predictions, target_tensor, ZLoss + ELoss, ELoss, ZLoss
+
+    def training_step(self, batch, batch_idx):
+        loss = self._process_batch(batch)[4]
+        self.log("train_loss", loss, on_epoch=True, prog_bar=True, logger=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        _, _, _, _, loss, ELoss, ZLoss = self._process_batch(batch)
+        results = {"val_loss": loss, "val_MAE_E": ELoss, "val_MAE_z": ZLoss}
+        self.log_dict(results, on_epoch=True, prog_bar=True, logger=True)
+        return results
+
+    def test_step(self, batch, batch_idx):
+        _, _, _, _, loss, ELoss, ZLoss = self._process_batch(batch)
+        results = {"test_loss": loss, "test_MAE_E": ELoss, "test_MAE_z": ZLoss}
         self.log_dict(results, on_epoch=True, logger=True)
         return results

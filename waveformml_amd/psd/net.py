@@ -11,8 +11,41 @@ import logging
 import torch
 from torch import nn
 
-from .blocks import LinearBlock, SparseConv2DBlock
+from .blocks import LinearBlock, SparseConv2DBlock, SparseConv2DPreserve
 from .config import DictionaryUtility, ModuleUtility
+
+
+class SPConvPreserveNet(nn.Module):
+    """Mirror of the reference's ``SPConvPreserveNet`` (src/models/SPConvNet.py:8-25): a SparseConv2DPreserve stack
+    from 2 * n_samples channels down to n_type on the 14 x 11 grid; the output is the per-ROW feature matrix [N, n_type]
+    (per-segment predictions; config/examples/IoniClassifierCNN.json).  The operator package is the module the config's
+    ``imports`` binds to ``spconv`` (default: waveformml_amd.spconv)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.log = logging.getLogger(__name__)
+        self.system_config = config.system_config
+        self.net_config = config.net_config
+        self.nsamples = self.system_config.n_samples
+        self.ntype = self.system_config.n_type
+        self.modules_util = ModuleUtility(self.net_config.imports)
+        if "spconv" in self.modules_util.modules:
+            self.spconv = self.modules_util.modules["spconv"]
+        else:
+            import waveformml_amd.spconv as sp
+            self.spconv = sp
+        hparams = DictionaryUtility.to_dict(self.net_config.hparams.conv_params)
+        self.model = SparseConv2DPreserve(self.spconv, self.nsamples * 2, self.ntype, self.net_config.hparams.n_conv,
+                                          **hparams)
+        self.spatial_size = [14, 11]
+        self.register_buffer("permute_tensor", torch.LongTensor([2, 0, 1]), persistent=False)   # batch index first
+
+    def forward(self, x, batch_size=None):
+        coords, feats = x[0], x[1]
+        if batch_size is None:
+            batch_size = int(coords[-1, -1]) + 1
+        st = self.spconv.SparseConvTensor(feats, coords[:, self.permute_tensor].contiguous(), self.spatial_size, batch_size)
+        return self.model(st).features
 
 
 class SPConvNet(nn.Module):
