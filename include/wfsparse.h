@@ -231,6 +231,17 @@ int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_
  * gamma / beta may be NULL (affine=False).  C <= 1024.                                           */
 size_t wfs_bn_workspace_bytes(int64_t N, int32_t C);
 
+/* OPTIONAL single-launch form (off by default; wfs_bn_set_single_launch(1) or WFS_BN_SINGLE_LAUNCH=1): batches whose
+ * rows fit the register files of <= 256 workgroups take ONE launch per direction -- the reduction and the elementwise
+ * pass share the loaded rows and are separated by a grid-wide barrier (all workgroups resident: one per compute unit);
+ * same partial sums folded in the same order, so the results are bit-identical to the two-launch path.  On MI355X the
+ * barrier (device-scope atomics + L2 write-back / invalidate across 8 XCDs) costs more than the kernel boundary it
+ * replaces (measured dead ends), hence the default.  The barrier's wait is bounded;
+ * wfs_bn_barrier_timeouts() returns how many waits gave up since the library was loaded (0 in a healthy run; it
+ * synchronises with the device).                                                                                      */
+void wfs_bn_set_single_launch(int32_t on);
+int64_t wfs_bn_barrier_timeouts(void);
+
 int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, int64_t *num_batches_tracked,
                     float momentum, float eps,

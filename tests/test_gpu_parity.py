@@ -1563,3 +1563,41 @@ def test_batchnorm_backward_sums_taken_by_the_dx_launch(dtype, tol, monkeypatch)
         _assert_close(g1, g0, tol, "input gradient (padded=%s)" % padded)
         for a, b in zip(p1, p0):
             _assert_close(a, b, tol * 5, "parameter gradient (padded=%s)" % padded)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("N,C,padded", [(1, 32, False), (300, 32, False), (30011, 32, True), (70000, 32, False),
+                                         (110000, 32, True), (9000, 64, False), (5000, 252, True), (40000, 8, False)])
+def test_batchnorm_single_launch_equals_the_two_launch_path(N, C, padded, dtype):
+    """The optional one-launch-per-direction form (reduction | grid barrier | elementwise pass from the same registers,
+    include/wfsparse.h wfs_bn_set_single_launch; off by default, slower on this GPU) against the two-launch path: same partial sums folded in the same order,
+    so outputs, statistics, running statistics and all gradients are BIT-identical; no barrier wait gave up."""
+    from waveformml_amd import _lib
+    from waveformml_amd.spconv import functional as Fsp
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    cap = N + 513 if padded else N
+    x = torch.from_numpy((rng.standard_normal((cap, C)) * 2 + 5).astype(np.float32)).to(DEV).to(dtype)
+    g = torch.from_numpy(rng.standard_normal((cap, C)).astype(np.float32)).to(DEV).to(dtype)
+    n_dev = torch.tensor([N], dtype=torch.int64, device=DEV) if padded else None
+    outs = []
+    try:
+        for single in (0, 1):
+            lib.wfs_bn_set_single_launch(single)
+            torch.manual_seed(1)
+            bn = torch.nn.BatchNorm1d(C).to(DEV)
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.5, 0.5)
+            xin = x.clone().requires_grad_(True)
+            y = Fsp.batch_norm_relu(xin, bn, True, n_dev=n_dev)
+            y.backward(g)
+            torch.cuda.synchronize()
+            outs.append([y.detach()[:N].clone(), xin.grad[:N].clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                         bn.running_mean.clone(), bn.running_var.clone()])
+    finally:
+        lib.wfs_bn_set_single_launch(0)
+    for a, b, what in zip(outs[0], outs[1], ["y", "dx", "dgamma", "dbeta", "running_mean", "running_var"]):
+        assert torch.equal(a, b), what
+    assert float(outs[1][0].abs().sum()) > 0
+    assert lib.wfs_bn_barrier_timeouts() == 0
