@@ -986,7 +986,7 @@ __global__ void __launch_bounds__(256) k_gdw_c32c2(const int *__restrict__ table
 constexpr int C2_WAVES = 8;
 
 template <typename H>
-__global__ void __launch_bounds__(512, 4) k_gdw_c32c2_bf16(const int *__restrict__ table, int mirror, int K,
+__global__ void __launch_bounds__(512, 2) k_gdw_c32c2_bf16(const int *__restrict__ table, int mirror, int K,
                                                           int identity_k, long long Rcap,
                                                           const long long *__restrict__ r_dev,
                                                           const H *__restrict__ S, const H *__restrict__ G,
