@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense (same guide, "Peak FP32 (matrix)")
 _T0 = time.perf_counter()
 
 
@@ -229,6 +230,13 @@ def measure(env, args, dtype, steps, warmup, roofline):
                            "tflops": by["flops"] / max(by["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                            "timed_in": "eager pass after the timed region (HIP events on the launch stream)",
                            "per_step_ms": {k: timers[k][0] / nprof for k in timers}}
+        if dtype == "f32":
+            # the exact-fp32 path contracts on v_mfma_f32_32x32x2_f32, 1/16 of the bf16 matrix rate: next to the HBM
+            # view, its launches priced against the fp32 MATRIX peak (MI355X_MICROARCH.md "Peak FP32 (matrix)")
+            tf = out["roofline"]["tflops"]
+            out["roofline"]["mfma"] = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tf / F32_MFMA_PEAK_TFLOPS,
+                                       "flops_per_launch": by["flops"] / max(by["launches"], 1)}
     extras = {"init_state": init_state, "batch_np": (c, f, y), "logits0": logits0, "loss0": loss0}
     return out, extras
 
@@ -237,8 +245,13 @@ def pmc_traffic(kind, dtype):
     """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for 16-B-per-lane reads on gfx950),
     launch-weighted over the kernels of that class.  None when no PMC summary for this dtype is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_%s.json" % dtype)
-    if not os.path.exists(path):
+    path = None
+    for rnd in ("r02", "r01"):                      # the newest committed summary
+        cand = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%s.json" % (rnd, dtype))
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
         return None, None
     with open(path) as f:
         pmc = json.load(f)

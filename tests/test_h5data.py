@@ -231,3 +231,18 @@ def test_data_module_split_excludes_and_half_precision():
         bad = _dm_config("PulseDataset.PulseDataset2D", dataset_config={key: "shuffle"})
         with pytest.raises(NotImplementedError):
             PSDDataModule(bad, "cpu")
+
+
+def test_packed_loader_hands_over_the_same_batches():
+    """psd/data.PackedLoader (one shared-memory buffer per batch between worker and trainer process) against the plain
+    DataLoader with the reference's collate: identical tensors, dtypes and shapes, for both layouts."""
+    from torch.utils.data import DataLoader
+    from waveformml_amd.psd import data
+    for layout, fn in (("3d", data.collate_fn_3d), ("2d", data.collate_fn)):
+        ds = data.SyntheticPulseDataset(5, 4, 24, layout=layout)
+        plain = list(DataLoader(ds, batch_size=2, collate_fn=fn))
+        packed = list(data.PackedLoader(ds, fn, batch_size=2, num_workers=2))
+        assert len(plain) == len(packed) == 3
+        for a, b in zip(plain, packed):
+            for x, y in ((a[0][0], b[0][0]), (a[0][1], b[0][1]), (a[1], b[1])):
+                assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)

@@ -16,7 +16,7 @@ import logging
 from torch.utils.data import DataLoader
 
 from .config import DictionaryUtility, ModuleUtility
-from .data import collate_fn, collate_fn_3d, rank_sampler  # noqa: F401  (collate_fn is the reference's name)
+from .data import PackedLoader, collate_fn, collate_fn_3d, rank_sampler  # noqa: F401  (collate_fn is the reference's name)
 
 
 class PSDDataModule(object):
@@ -80,8 +80,13 @@ class PSDDataModule(object):
         # one process per GPU: each rank reads its own 1/N share of the items, as under the reference's Lightning DDP
         # (which replaces the loaders' samplers with DistributedSamplers, src/utils/util.py:228-239)
         sampler = rank_sampler(dataset, shuffle)
+        params = self._params("dataloader_params")
+        if params.get("num_workers", 0) > 0 and getattr(self.config.dataset_config, "pack_batches", True):
+            # worker processes hand a batch over as ONE shared-memory buffer (psd/data.PackedLoader); same batches
+            return PackedLoader(dataset, self._collate(dataset), shuffle=shuffle and sampler is None, sampler=sampler,
+                                **params)
         return DataLoader(dataset, shuffle=shuffle and sampler is None, sampler=sampler,
-                          collate_fn=self._collate(dataset), **self._params("dataloader_params"))
+                          collate_fn=self._collate(dataset), **params)
 
     def train_dataloader(self):
         if not hasattr(self, "train_dataset"):

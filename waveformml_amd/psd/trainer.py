@@ -20,6 +20,7 @@ Checkpoints are dictionaries shaped like Lightning's (``state_dict``, ``epoch``,
 read them -- and a reference-written ``.ckpt`` 's ``state_dict`` -- with ``torch.load(weights_only=True)``
 (reference: Evaluate.py:72 ``load_from_checkpoint``, main.py ``--load_checkpoint`` -> ``resume_from_checkpoint``)."""
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -136,6 +137,7 @@ class Trainer(object):
         if self.resume_from_checkpoint:
             first_epoch = self._resume(module, optimizer, scheduler, self.resume_from_checkpoint)
         for epoch in range(first_epoch, self.max_epochs):
+            t_epoch = time.perf_counter()
             module.train()
             sampler = getattr(train_loader, "sampler", None)
             if hasattr(sampler, "set_epoch"):
@@ -152,7 +154,8 @@ class Trainer(object):
                 self._graph.check()
             if scheduler is not None:
                 scheduler.step()
-            rec = {"epoch": epoch, "train_loss": float(loss.item())}
+            rec = {"epoch": epoch, "train_loss": float(loss.item()),           # .item(): the epoch's work is done
+                   "train_seconds": time.perf_counter() - t_epoch, "steps": i + 1}
             if val_loader is not None:
                 rec.update(self.validate(module, val_loader))        # all-reduced: every rank sees the same numbers
                 if self.root and rec["val_loss"] < best:
