@@ -13,8 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --cpu-steps 0 --no-roofline --steps 100 > $O/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --cpu-steps 0 --no-roofline --steps 20 > $O/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --cpu-steps 0 --no-roofline --steps 20 > $O/pmc_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -- python3 $R/bench.py --dtype f32 --cpu-steps 0 --no-roofline --steps 100 > $O/stats_f32.log 2>&1 || exit 1
 cd $R
 cp $(ls $O/stats/*/*kernel_stats.csv | tail -n 1) $O/kernel_stats.csv
+cp $(ls $O/stats_f32/*/*kernel_stats.csv | tail -n 1) $O/kernel_stats_f32.csv
 python tools/pmc_summary.py $(ls $O/pmc_fetch/*/*counter_collection.csv | tail -n 1) $(ls $O/pmc_write/*/*counter_collection.csv | tail -n 1) $O/pmc_hbm_traffic_bf16.json
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write
+rm -rf $O/stats $O/stats_f32 $O/pmc_fetch $O/pmc_write
 cut -c1-400 $O/bench_default.json

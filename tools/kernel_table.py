@@ -1,8 +1,8 @@
 """Per-step kernel table from a rocprofv3 kernel_stats.csv of bench.py: calls per step, average time, time per step.
-usage: python tools/kernel_table.py <kernel_stats.csv> <steps profiled>"""
+usage: python tools/kernel_table.py <kernel_stats.csv> [steps profiled]      (default: the number of k_sgd_step launches)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = float(sys.argv[2])
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else float(sum(int(r["Calls"]) for r in rows if "k_sgd_step" in r["Name"]) or 1)
 tot = 0.0
 out = []
 for r in rows:
