@@ -240,8 +240,30 @@ def _rank_batches(rank, dev, n=3):
     return out
 
 
+def _trainer_run(rank, world, dev):
+    """Trainer(capture=True) over 5 batches of which the THIRD has twice the events on rank 1 only: that rank's batch does
+    not fit the captured step, so both ranks must take the eager step for it -- together."""
+    from waveformml_amd import _lib
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.trainer import Trainer
+    _lib.load()
+    mod = _small_c2()
+    batches = []
+    for s in range(5):
+        n = 32 if (s == 2 and rank == 1) else 16
+        c, f, y = synthetic.generate(n, 64, 3, seed=400 + s, rank=rank)
+        batches.append(([torch.from_numpy(c), torch.from_numpy(f)], torch.from_numpy(y)))
+    tr = Trainer(max_epochs=1, device=str(dev), capture=True, check_every=2)
+    hist = tr.fit(mod, batches)
+    torch.cuda.synchronize()
+    return {"params": torch.cat([p.detach().reshape(-1).cpu() for p in mod.model.parameters()]),
+            "eager_fallbacks": tr.eager_fallbacks, "loss": hist[-1]["train_loss"]}
+
+
 def _rank_run(rank, world, mode, dev):
     """Body of one rank (child process) and of the single-process reference (world = 1, rank = which shard)."""
+    if mode == "trainer_misfit":
+        return _trainer_run(rank, world, dev)
     from waveformml_amd import _lib
     from waveformml_amd.psd.ddp import FlatGradAllReducer, broadcast_parameters
     from waveformml_amd.psd.graph import GraphedTrainStep
@@ -324,6 +346,38 @@ def test_two_ranks_step_the_hip_net_on_one_card(mode, tmp_path):
     g = [_rank_run(r, 1, "eager", dev)["grads"][0] for r in range(2)]
     want = (g[0] + g[1]) / 2
     _assert_close(r0["grads"][0].numpy(), want.numpy(), 1e-5 if mode == "eager" else 1e-4, "averaged gradient, step 1")
+
+
+def _launch_two_ranks(tmp_path, mode):
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WFS_REHEARSAL_ONE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, cwd=ROOT))
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [torch.load(out + ".rank%d" % r, weights_only=True) for r in range(2)]
+
+
+def test_two_rank_trainer_takes_the_eager_step_together_when_one_rank_misfits(tmp_path):
+    """Trainer(capture=True) on two ranks (gloo, one card): the third batch is oversized on rank 1 ONLY.  The misfit is
+    agreed on collectively, so both ranks step eagerly for it (one fallback each, the same exchange), nobody hangs in a
+    mismatched collective, and the replicas end bit-identical."""
+    r0, r1 = _launch_two_ranks(tmp_path, "trainer_misfit")
+    assert r0["eager_fallbacks"] == 1 and r1["eager_fallbacks"] == 1
+    assert torch.equal(r0["params"], r1["params"])
+    assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"])
 
 
 def test_nccl_backend_world_one_exchange_and_in_graph_capture(tmp_path):
