@@ -396,6 +396,64 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply(const T *__restrict__ X, co
 // (first + i * stride) and issues ALL its loads -- rows (bounded by the capacity, not by the count), count, shift,
 // partials, affine parameters -- back to back at the top: one round trip, then arithmetic and stores.
 constexpr int RR_BLOCKS = 256;
+// Timing knock-outs (tools/exp/knock_bn.sh, profiles/r02_bn_knockouts.txt): -DWFS_BN_KNOCK=bits builds a library whose
+// register-resident BatchNorm kernels skip a phase -- 1 the fold of the partials, 2 the row loads, 4 the row stores,
+// 8 the block reduction + partial store of the reduce kernel.  Results are wrong by construction; 0 = nothing.
+#ifndef WFS_BN_KNOCK
+#define WFS_BN_KNOCK 0
+#endif
+
+// Block sums of the per-thread (sa, sb)[VEC] of the register-resident kernels; thread = (row slot, channel group),
+// groups = C / VEC.  Returns true in the threads (threadIdx.x < groups) that end up holding the block's sums of their
+// channel group.  When `groups` divides the wave, the slots a wave holds are added by lane exchanges (xor over the slot
+// bits: a fixed tree) and the TB / 64 wave sums through LDS in wave order; otherwise slot 0 adds the slots serially.
+template <int VEC>
+__device__ __forceinline__ bool rr_block_sums(float *sa, float *sb, float (&red)[2][TB][VEC], int groups, bool active) {
+    const bool fast = groups <= 64 && (groups & (groups - 1)) == 0;            // TB is a multiple of 64: all active
+    if (fast) {
+        for (int off = groups; off < 64; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sa[i] += __shfl_xor(sa[i], off, 64);
+                sb[i] += __shfl_xor(sb[i], off, 64);
+            }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane < groups) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                red[0][wv * groups + lane][i] = sa[i];
+                red[1][wv * groups + lane][i] = sb[i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < groups) {
+#pragma unroll
+            for (int w = 1; w < TB / 64; ++w)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    sa[i] += red[0][w * groups + threadIdx.x][i];
+                    sb[i] += red[1][w * groups + threadIdx.x][i];
+                }
+        }
+        return threadIdx.x < groups;
+    }
+    const int slots = TB / groups, grp = threadIdx.x % groups, slot = threadIdx.x / groups;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        red[0][threadIdx.x][i] = sa[i];
+        red[1][threadIdx.x][i] = sb[i];
+    }
+    __syncthreads();
+    if (active && slot == 0) {
+        for (int q = 1; q < slots; ++q)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sa[i] += red[0][q * groups + grp][i];
+                sb[i] += red[1][q * groups + grp][i];
+            }
+    }
+    return active && slot == 0;
+}
 
 template <typename T>
 struct Raw4 {                                     // four 16-bit channels (bf16 / fp16) as loaded
@@ -430,7 +488,7 @@ __global__ void __launch_bounds__(TB) k_bn_reduce_rr(const T *__restrict__ X, co
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const long long r = first + i * stride;
-        const long long rc = (active && r < Ncap) ? r : 0;
+        const long long rc = ((WFS_BN_KNOCK & 2) || !(active && r < Ncap)) ? 0 : r;
         x[i].load(X + rc * C + c0);
         if (MODE == 1) g[i].load(dY + rc * C + c0);
     }
@@ -472,19 +530,11 @@ __global__ void __launch_bounds__(TB) k_bn_reduce_rr(const T *__restrict__ X, co
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        red[0][threadIdx.x][i] = sa[i];
-        red[1][threadIdx.x][i] = sb[i];
+    if (WFS_BN_KNOCK & 8) {
+        if (sa[0] == 1.2345e30f) partial[0] = sb[0];
+        return;
     }
-    __syncthreads();
-    if (active && slot == 0) {
-        for (int q = 1; q < slots; ++q)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                sa[i] += red[0][q * groups + grp][i];
-                sb[i] += red[1][q * groups + grp][i];
-            }
+    if (rr_block_sums<VEC>(sa, sb, red, groups, active)) {
         float *p = partial + (long long)blockIdx.x * 2 * C;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -517,7 +567,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const long long r = first + i * stride;
-        x[i].load(X + ((active && r < Ncap) ? r : 0) * C + c0);
+        x[i].load(X + (((WFS_BN_KNOCK & 2) || !(active && r < Ncap)) ? 0 : r) * C + c0);
     }
     const long long N = valid_rows(Ncap, n_dev);
     float ga[VEC], be[VEC];
@@ -566,6 +616,9 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
             sB[c] = tb;                     // sum of (x - m0)^2
         }
         __syncthreads();
+    } else if (WFS_BN_KNOCK & 1) {
+        for (int c = threadIdx.x; c < C; c += TB) sA[c] = sB[c] = 1.f;
+        __syncthreads();
     } else {
         fold_partials(partial, nblk, C, sSlice, sA, sB);             // its loads join the ones above
     }
@@ -610,7 +663,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
                 float t = fmaf(ga[q], (v[q] - m[q]) * is[q], be[q]);
                 y[q] = (relu && !(t > 0.f)) ? 0.f : t;
             }
-            store_vec<T, VEC>(Y + r * C + c0, y);
+            if (!(WFS_BN_KNOCK & 4) || y[0] == 1.2345e30f) store_vec<T, VEC>(Y + r * C + c0, y);
         }
     }
 }
@@ -635,7 +688,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply_rr(const T *__restrict__ X,
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const long long r = first + i * stride;
-        const long long rc = (active && r < Ncap) ? r : 0;
+        const long long rc = ((WFS_BN_KNOCK & 2) || !(active && r < Ncap)) ? 0 : r;
         x[i].load(X + rc * C + c0);
         g[i].load(dY + rc * C + c0);
     }
@@ -648,7 +701,12 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply_rr(const T *__restrict__ X,
         ga[i] = (gamma && active) ? gamma[c0 + i] : 1.f;
         be[i] = (beta && active) ? beta[c0 + i] : 0.f;
     }
-    fold_partials(partial, nblk, C, sSlice, sA, sB);
+    if (WFS_BN_KNOCK & 1) {
+        for (int c = threadIdx.x; c < C; c += TB) sA[c] = sB[c] = 1.f;
+        __syncthreads();
+    } else {
+        fold_partials(partial, nblk, C, sSlice, sA, sB);
+    }
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += TB) {
             if (dbeta) dbeta[c] = sA[c];
@@ -677,7 +735,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply_rr(const T *__restrict__ X,
                 if (relu && !(fmaf(ga[q], xh, be[q]) > 0.f)) gi = 0.f;
                 o[q] = ga[q] * is[q] * (gi - k1[q] - xh * k2[q]);
             }
-            store_vec<T, VEC>(dX + r * C + c0, o);
+            if (!(WFS_BN_KNOCK & 4) || o[0] == 1.2345e30f) store_vec<T, VEC>(dX + r * C + c0, o);
         }
     }
 }
@@ -769,19 +827,7 @@ __global__ void __launch_bounds__(TB) k_bn_fwd_one(const T *__restrict__ X, long
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        red[0][threadIdx.x][i] = sa[i];
-        red[1][threadIdx.x][i] = sb[i];
-    }
-    __syncthreads();
-    if (active && slot == 0) {
-        for (int q = 1; q < slots; ++q)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                sa[i] += red[0][q * groups + grp][i];
-                sb[i] += red[1][q * groups + grp][i];
-            }
+    if (rr_block_sums<VEC>(sa, sb, red, groups, active)) {
         float *p = partial + (long long)blockIdx.x * 2 * C;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -889,19 +935,7 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_one(const T *__restrict__ X, cons
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        red[0][threadIdx.x][i] = sa[i];
-        red[1][threadIdx.x][i] = sb[i];
-    }
-    __syncthreads();
-    if (active && slot == 0) {
-        for (int q = 1; q < slots; ++q)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                sa[i] += red[0][q * groups + grp][i];
-                sb[i] += red[1][q * groups + grp][i];
-            }
+    if (rr_block_sums<VEC>(sa, sb, red, groups, active)) {
         float *p = partial + (long long)blockIdx.x * 2 * C;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
