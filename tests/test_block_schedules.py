@@ -88,6 +88,9 @@ def test_ioni_classifier_schedule_is_the_one_survey_quotes():
     g = GOLD["preserve"][0]
     convs = [l for l in g["layers"] if l["cls"] == "SparseConv2d"]
     assert [l["args"][0] for l in convs] + [convs[-1]["args"][1]] == [130, 138, 146, 154, 104, 54, 5]
+    assert [l["args"][2] for l in convs] == [3, 3, 2, 2, 2, 2]            # kernels (SURVEY.md 8c i)
+    assert [l["args"][4] for l in convs] == [1, 1, 0, 0, 0, 0]            # paddings
+    assert [l["args"][3] for l in convs] == [1] * 6                        # strides
     inv = [l for l in g["layers"] if l["cls"] == "SparseInverseConv2d"]
     assert [l["args"][3] for l in inv] == [c["kwargs"]["indice_key"] for c in convs] == ["ind_%d" % i for i in range(6)]
 

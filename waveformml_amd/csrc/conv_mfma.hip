@@ -662,6 +662,57 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
     }
 }
 
+// ------------------------------------------------------------------------------------------ 2 -> 32, fp32 MFMA
+// First layer in exact fp32 on the matrix cores: Y[row][co] = b[co] + sum_k sum_ch X[nb(k,row)][ch] W[k][ch][co] is, per
+// kernel offset, ONE v_mfma_f32_32x32x2_f32 on the 32-row tile (contraction = the 2 input channels): lane (r, h) supplies
+// A[row r][ch h] = the gathered element and B[ch h][co r] = W[k][h][r], which it keeps in a register per offset.  One
+// tile per wave: all K table entries of the lane's row are asked for together, then all K gathers (two memory round
+// trips per tile; the VALU form walked its rows one after the other, two round trips EACH: 38 us -> see DESIGN.md 4).
+__global__ void __launch_bounds__(256) k_gconv_c2c32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                         long long R, const long long *__restrict__ r_dev,
+                                                         const float *__restrict__ X, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    float wreg[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) wreg[k] = k < K ? W[((long long)k * 2 + h) * 32 + r] : 0.f;
+    const float bj = bias ? bias[r] : 0.f;
+    const long long Rv = valid_rows(R, r_dev);
+    const long long ntiles = (Rv + 31) >> 5;
+    for (long long tile = (long long)blockIdx.x * nw + wid; tile < ntiles; tile += (long long)gridDim.x * nw) {
+        const long long row = tile * 32 + r;
+        const bool live = row < Rv;
+        const long long rowc = live ? row : 0;
+        int nb[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const int kk = k < K ? k : K - 1;
+            nb[k] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+        }
+        float xv[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const int n = (k == identity_k) ? (int)rowc : nb[k];
+            const bool ok = live && k < K && n >= 0;
+            nb[k] = ok ? 1 : 0;
+            xv[k] = X[(long long)(ok ? n : 0) * 2 + h];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bj;
+#pragma unroll
+        for (int k = 0; k < 27; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[k] ? xv[k] : 0.f, wreg[k], acc, 0, 0, 0);
+        // reg i holds (row (i & 3) + 8 (i >> 2) + 4 h, column r): 32 lanes store one 128-byte row
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (orow < Rv) Y[orow * 32 + r] = acc[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 2 -> 32, bf16 MFMA
 // First layer on the matrix cores: the K offsets x 2 input channels form a 64-wide contraction (54 used), so one
 // 32-row tile is 4 x v_mfma_f32_32x32x16_bf16.  A-fragment of lane (r, h), k-step s = the 4 gathered dwords
@@ -1087,6 +1138,92 @@ __global__ void __launch_bounds__(512, 2) k_gdw_c32c2_bf16(const int *__restrict
     }
 }
 
+// fp32 form of the first-layer dW on the matrix cores (exact fp32, v_mfma_f32_32x32x2_f32 with the tile's ROWS as the
+// contraction): D[col = 2 k + ch][b] += sum_rows Xg[row][col] * dY[row][b].  Lane (c, h) supplies, for row pair s,
+// A = Xg[2 s + h][col = c (+ 32)] and B = dY[2 s + h][b = c] -- the dY rows straight from global memory (whole 128-byte
+// rows), the gathered 2-channel rows through the tile's table entries, which are read coalesced and turned around
+// through a padded LDS image.  32 MFMAs per tile, one tile per wave, two memory round trips per tile.
+constexpr int C2F_WAVES = 8;
+__global__ void __launch_bounds__(512, 2) k_gdw_c32c2_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                         long long Rcap, const long long *__restrict__ r_dev,
+                                                         const float *__restrict__ S, const float *__restrict__ G,
+                                                         float *__restrict__ part) {
+    __shared__ int sNbT[C2F_WAVES][28 * 33];                     // [k][row], row stride 33: conflict-free both ways
+    __shared__ float sRed[C2F_WAVES][1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    int *myNb = sNbT[wid];
+    const long long R = valid_rows(Rcap, r_dev);
+    const long long ntiles = (R + 31) >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+    // the two columns this lane feeds: col0 = c (offset c >> 1), col1 = 32 + c (offset 16 + (c >> 1)), channel c & 1
+    const int k0 = c >> 1, k1 = 16 + (c >> 1), ch = c & 1;
+    for (long long tile = (long long)blockIdx.x * C2F_WAVES + wid; tile < ntiles; tile += (long long)gridDim.x * C2F_WAVES) {
+        const long long row0 = tile * 32;
+        const long long trow = row0 + c < R ? row0 + c : R - 1;
+        const bool tlive = row0 + c < R;
+        int nb[14];
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const int k = 2 * t + h;
+            const int kk = k < K ? k : K - 1;
+            nb[t] = table[(long long)(mirror ? K - 1 - kk : kk) * Rcap + trow];
+        }
+        float bv[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const long long row = row0 + 2 * s2 + h;
+            const float t = S[(row < R ? row : R - 1) * 32 + c];
+            bv[s2] = row < R ? t : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();            // the previous tile's reads of the image are done (LDS is in order)
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const int k = 2 * t + h;
+            const int n = (k == identity_k) ? (int)trow : nb[t];
+            myNb[k * 33 + c] = (tlive && k < K && n >= 0) ? n : -1;       // k = 27 (h = 1, t = 13): never read as valid
+        }
+        __builtin_amdgcn_wave_barrier();
+        float x0[16], x1[16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int ri = 2 * s2 + h;
+            const int n0 = myNb[k0 * 33 + ri];
+            const int n1 = k1 < 28 ? myNb[(k1 < 28 ? k1 : 27) * 33 + ri] : -1;
+            const float v0 = G[(long long)(n0 >= 0 ? n0 : 0) * 2 + ch];
+            const float v1 = G[(long long)(n1 >= 0 ? n1 : 0) * 2 + ch];
+            x0[s2] = n0 >= 0 ? v0 : 0.f;
+            x1[s2] = (n1 >= 0 && k1 < K) ? v1 : 0.f;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[s2], bv[s2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[s2], bv[s2], acc1, 0, 0, 0);
+        }
+    }
+    // deterministic block reduction in two halves (columns 0..31, 32..63), waves added in wave order
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int col = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sRed[wid][col * 32 + c] = half ? acc1[i] : acc0[i];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 1024; e += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < C2F_WAVES; ++w) v += sRed[w][e];
+            const int ee = half * 1024 + e;                       // = (2 k + ch) * 32 + b
+            if (ee < K * 64) part[(long long)blockIdx.x * K * 64 + ee] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // dW[k][a][b] (swap==0) or dW[k][b][a] (swap==1) = sum over slabs of part[slab][k][a][b]; blockDim.x / 32 slab slices
 // per output (8, or 32 when there are many slabs) are summed in parallel and folded in slice order (deterministic).
 __global__ void __launch_bounds__(1024) k_slab_reduce(const float *__restrict__ part, long long nslabs, long long per,
@@ -1387,6 +1524,14 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
         WFS_LAUNCH_CHECK();
         return WFS_OK;
     }
+    if (dtype == WFS_F32 && K <= 27 && (is_ident || is_mirror)) {
+        long long nb = ((R + 31) / 32 + 3) / 4;              // one 32-row tile per wave, 4 waves per block
+        if (nb > 4096) nb = 4096;
+        k_gconv_c2c32_f32<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(table, is_ident ? 0 : 1, K, identity_k, R, r_dev,
+                                                                        (const float *)X, W, bias, (float *)Y);
+        WFS_LAUNCH_CHECK();
+        return WFS_OK;
+    }
     long long nblk = (R + 31) / 32;
     if (nblk > 8192) nblk = 8192;
     if (dtype == WFS_F32)
@@ -1462,8 +1607,11 @@ int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, lo
     long long chunks = dwc2_chunks(R);
     const long long rows_per_chunk = (R + chunks - 1) / chunks;
     if (dtype == WFS_F32) {
-        k_gdw_c32c2<float><<<dim3((unsigned)chunks), dim3(256), 0, stream>>>(
-            table, mirror, K, identity_k, R, r_dev, rows_per_chunk, (const float *)S, (const float *)G, part);
+        const long long ntiles = (R + 31) >> 5;
+        chunks = (ntiles + C2F_WAVES - 1) / C2F_WAVES;        // one tile per wave, at most 512 blocks (= slabs)
+        if (chunks > 512) chunks = 512;
+        k_gdw_c32c2_f32<<<dim3((unsigned)chunks), dim3(512), 0, stream>>>(table, mirror, K, identity_k, R, r_dev,
+                                                                          (const float *)S, (const float *)G, part);
     } else {
         const long long ntiles = (R + 31) >> 5;
         chunks = (ntiles + C2_WAVES - 1) / C2_WAVES;          // one tile per wave, at most 512 blocks (= slabs)
