@@ -572,7 +572,7 @@ constexpr int DW_WAVES = 8;
 
 // AFFINE: the stationary rows S are raw conv outputs read as [relu](x * sc + sh) (wfs_row_affine)
 template <typename T, bool AFFINE>
-__global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
+__global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
                                                   const long long *__restrict__ r_dev, const T *__restrict__ S,
                                                   const T *__restrict__ G,
                                                   float *__restrict__ part, int ngroups, long long tiles_per_block,
@@ -625,20 +625,27 @@ __global__ void __launch_bounds__(512, 2) k_gdw32(const int *__restrict__ table,
             any = any || (__ballot(nb >= 0) != 0ull);
         }
         if (!any) continue;
+        // the gathers of all the wave's ACTIVE offsets are issued together, ahead of the first MFMA: one memory round
+        // trip per tile (with load and MFMA under the same per-offset branch it was one per offset); inactive offsets
+        // (most of a SubM tile's) issue nothing
+        float b[DW_KG][16];
 #pragma unroll
         for (int q = 0; q < DW_KG; ++q) {
             if (__ballot(nbv[q] >= 0) == 0ull) continue;
-            float b[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 int n0 = __builtin_amdgcn_readlane(nbv[q], 2 * s);
                 int n1 = __builtin_amdgcn_readlane(nbv[q], 2 * s + 1);
                 int nb = h ? n1 : n0;
                 float t = wfs_ld(G + (long long)(nb >= 0 ? nb : 0) * 32 + j);
-                b[s] = nb >= 0 ? t : 0.f;
+                b[q][s] = nb >= 0 ? t : 0.f;
             }
+        }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[q], 0, 0, 0);
+        for (int q = 0; q < DW_KG; ++q) {
+            if (__ballot(nbv[q] >= 0) == 0ull) continue;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[q][s], acc[q], 0, 0, 0);
         }
     }
     // deterministic block reduction, one offset at a time: the 8 waves park that offset's accumulator in LDS, then
