@@ -1,6 +1,6 @@
 """The shape-generic MFMA conv kernels (gather_conv.hip k_gconv_mfma / k_gdw_mfma) on the reference's 2-D layer shapes
 (GEP.json: 252 -> 158 and 158 -> 64 channels, 3 x 3, a few hundred rows) against the route they replace (rows gathered
-with torch index kernels into [R, K * C] + one library GEMM).  usage: python tools/microbench_generic.py [events] [dtype]"""
+with torch index kernels into [R, K * C] + one library GEMM).  usage: python tools/microbench_generic.py [events] [dtype] [wide]      (wide: the hybrid net's 1697 -> 1021 -> 345 layers)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -37,7 +37,8 @@ def timeit(name, fn, reps=10, iters=20):
     print("%-46s %8.1f us" % (name, a.elapsed_time(b) / (iters * reps) * 1e3), flush=True)
 
 
-for (ci, co) in ((252, 158), (158, 64), (64, 64), (130, 138)):
+SHAPES = ((1697, 1021), (1021, 345)) if (len(sys.argv) > 3 and sys.argv[3] == "wide") else ((252, 158), (158, 64), (64, 64), (130, 138))
+for (ci, co) in SHAPES:
     X = torch.randn(N, ci, device=dev).to(DT)
     dY = torch.randn(M, co, device=dev).to(DT)
     W = torch.randn(K, ci, co, device=dev) * 0.05
