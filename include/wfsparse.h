@@ -212,6 +212,13 @@ int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int
 /* Second stage of up to 16 deferred wfs_gather_dw calls in one launch (deterministic: fixed summation order). */
 int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream);
 
+/* Conv bias gradient: out[c] = sum over the valid rows of X[r][c] (fp32 sums of fp32 / bf16 / fp16 rows; r_dev as
+ * everywhere: NULL = R exact, else R is the capacity).  What autograd computes for spconv's `out_features += bias`
+ * (reference layers with trainable_weights=True, src/models/SPConvBlocks.py:498).  Deterministic (fixed orders).      */
+size_t wfs_column_sum_workspace_bytes(int32_t C);
+int wfs_column_sum(const void *X, int64_t R, int32_t C, float *out, void *workspace, size_t workspace_bytes,
+                   int32_t dtype, const int64_t *r_dev, void *stream);
+
 /* Scatter form with fp32 atomics, used ONLY when the input holds duplicate coordinates (then
  * the inverse of a gather table is not a function):
  *     Y_accum[table[k, r], :] += X[r, :] . W[k]  (or W[k]^T)      Y_accum fp32, caller-initialised */

@@ -1601,3 +1601,24 @@ def test_batchnorm_single_launch_equals_the_two_launch_path(N, C, padded, dtype)
         assert torch.equal(a, b), what
     assert float(outs[1][0].abs().sum()) > 0
     assert lib.wfs_bn_barrier_timeouts() == 0
+
+
+@pytest.mark.parametrize("R,C,dtype,padded", [(1, 5, torch.float32, False), (777, 32, torch.float32, True),
+                                               (40000, 300, torch.bfloat16, True), (5000, 7, torch.float16, False),
+                                               (0, 9, torch.float32, False)])
+def test_column_sum_for_the_conv_bias_gradient(R, C, dtype, padded):
+    """wfs_column_sum (the conv bias gradient: sum of dY over the valid rows) against a float64 sum of the same rounded
+    rows; rows beyond a device-side count are ignored; deterministic (two calls agree bit for bit)."""
+    from waveformml_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(3)
+    cap = R + 100 if padded else R
+    x = torch.from_numpy(rng.standard_normal((cap, C)).astype(np.float32)).to(DEV).to(dtype)
+    if padded:
+        x[R:] = 1e4                                              # must not be read into the sum
+    r_dev = torch.tensor([R], dtype=torch.int64, device=DEV) if padded else None
+    got = Fsp._masked_column_sum(x, r_dev)
+    again = Fsp._masked_column_sum(x, r_dev)
+    want = x[:R].double().sum(0).cpu().numpy()
+    assert got.dtype == torch.float32 and got.shape == (C,)
+    assert torch.equal(got, again)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-5 * max(1.0, float(np.abs(x[:R].float().cpu().numpy()).sum(0).max() if R else 1.0)))

@@ -91,6 +91,8 @@ SIGNATURES = {
     "wfs_dw_reduce_jobs": (ctypes.c_int, [ctypes.POINTER(DwJob), _i32, _vp]),
     "wfs_scatter_conv": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "wfs_bn_workspace_bytes": (_sz, [_i64, _i32]),
+    "wfs_column_sum_workspace_bytes": (_sz, [_i32]),
+    "wfs_column_sum": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _sz, _i32, _vp, _vp]),
     "wfs_bn_set_single_launch": (None, [_i32]),
     "wfs_bn_barrier_timeouts": (_i64, []),
     "wfs_bn_relu_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32,

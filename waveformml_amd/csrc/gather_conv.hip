@@ -698,3 +698,67 @@ extern "C" int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *strea
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, (hipStream_t)stream);
     return wfs_launch_dw_jobs(live, m, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------ conv bias gradient
+// db[c] = sum over the valid rows of dY[r][c] (spconv's backward leaves this to autograd's `+ bias`; reference layers
+// built with trainable_weights=True have a bias, SPConvBlocks.py:498).  Two launches, deterministic: per-block column
+// sums over interleaved rows, then one block adds the partials in block order.  workspace: 128 * C floats.
+namespace {
+constexpr int CS_BLOCKS = 128;
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum_partial(const T *__restrict__ X, long long Rcap,
+                                                        const long long *__restrict__ r_dev, int C,
+                                                        float *__restrict__ partial) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const long long R = r_dev ? (*r_dev < Rcap ? *r_dev : Rcap) : Rcap;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;              // four independent chains, added in a fixed order
+    long long r = blockIdx.x;
+    const long long st = gridDim.x;
+    for (; r + 3 * st < R; r += 4 * st) {
+        s0 += wfs_ld(X + r * C + c);
+        s1 += wfs_ld(X + (r + st) * C + c);
+        s2 += wfs_ld(X + (r + 2 * st) * C + c);
+        s3 += wfs_ld(X + (r + 3 * st) * C + c);
+    }
+    for (; r < R; r += st) s0 += wfs_ld(X + r * C + c);
+    partial[(long long)blockIdx.x * C + c] = (s0 + s1) + (s2 + s3);
+}
+__global__ void __launch_bounds__(256) k_colsum_fold(const float *__restrict__ partial, int nblk, int C,
+                                                     float *__restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * C + c];
+    out[c] = s;
+}
+}  // namespace
+
+extern "C" size_t wfs_column_sum_workspace_bytes(int32_t C) { return (size_t)CS_BLOCKS * (size_t)(C > 0 ? C : 1) * sizeof(float); }
+
+extern "C" int wfs_column_sum(const void *X, int64_t R, int32_t C, float *out, void *workspace, size_t workspace_bytes,
+                              int32_t dtype, const int64_t *r_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(C >= 1 && out, WFS_EINVAL, "bad channel count %d / NULL output", C);
+    if (R == 0) {
+        WFS_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), stream));
+        return WFS_OK;
+    }
+    WFS_REQUIRE(X && workspace, WFS_EINVAL, "NULL device pointer");
+    WFS_REQUIRE(workspace_bytes >= wfs_column_sum_workspace_bytes(C), WFS_EWORKSPACE, "workspace too small");
+    long long nblk = wfs_cdiv(R, 64);
+    if (nblk > CS_BLOCKS) nblk = CS_BLOCKS;
+    const dim3 grid((unsigned)nblk, (unsigned)wfs_cdiv(C, 256)), block(256);
+    float *partial = (float *)workspace;
+    const long long *rd = (const long long *)r_dev;
+    if (dtype == WFS_F32)
+        k_colsum_partial<float><<<grid, block, 0, stream>>>((const float *)X, R, rd, C, partial);
+    else if (dtype == WFS_BF16)
+        k_colsum_partial<wfs_bf16><<<grid, block, 0, stream>>>((const wfs_bf16 *)X, R, rd, C, partial);
+    else
+        k_colsum_partial<wfs_f16><<<grid, block, 0, stream>>>((const wfs_f16 *)X, R, rd, C, partial);
+    k_colsum_fold<<<dim3((unsigned)wfs_cdiv(C, 256)), block, 0, stream>>>(partial, (int)nblk, C, out);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}

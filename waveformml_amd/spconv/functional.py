@@ -43,17 +43,20 @@ def _features_ok(t):
 
 def _rows(shape, like, r_dev):
     """Row-dimensioned output.  In device-count mode rows beyond the valid count are never written NOR read
-    by the kernels, so they can stay uninitialised; the one torch-side reduction over rows (the conv bias
-    gradient) masks them itself (_masked_column_sum)."""
+    by the kernels, so they can stay uninitialised (the conv bias gradient's column sum honours the count too)."""
     return torch.empty(shape, dtype=like.dtype, device=like.device)
 
 
 def _masked_column_sum(t, r_dev):
-    """sum over the valid rows of t [R, C] (fp32)."""
-    if r_dev is None:
-        return t.float().sum(0)
-    valid = (torch.arange(t.shape[0], device=t.device) < r_dev).unsqueeze(1)
-    return torch.where(valid, t.float(), torch.zeros((), device=t.device)).sum(0)
+    """sum over the valid rows of t [R, C] (fp32): the conv bias gradient (include/wfsparse.h wfs_column_sum)."""
+    lib = _lib.load()
+    t = t.contiguous()
+    R, C = int(t.shape[0]), int(t.shape[1])
+    out = torch.empty((C,), dtype=torch.float32, device=t.device)
+    ws = torch.empty((int(lib.wfs_column_sum_workspace_bytes(C)),), dtype=torch.uint8, device=t.device)
+    _lib.check(lib.wfs_column_sum(_lib.ptr(t), R, C, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.dtype_code(t),
+                                  _lib.ptr(r_dev), _lib.stream_ptr()))
+    return out
 
 
 class BatchNormRequest(object):
