@@ -462,6 +462,15 @@ int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, const float
                 int32_t levels, int32_t k, void *dX, float *partial, int32_t dtype, float dropout_p,
                 const int64_t *seed_dev, void *stream);
 
+/* Weight norm of the front end's taps (torch.nn.utils.weight_norm around every Conv1d of the reference's TemporalBlock,
+ * src/models/ConvBlocks.py:118-131: w = g v / |v|), all convolutions in one launch each way.  param_ptrs: device array
+ * of n_conv records of six device addresses {v [k], g [1], b [1] or 0, dv [k], dg [1], db [1] (each 0 = not wanted)},
+ * convolution c = 2 * level + which.  wfs_tcn_taps_fwd fills taps [n_conv][k] and bias [n_conv] as wfs_tcn_fwd / _bwd
+ * take them; wfs_tcn_taps_bwd sums wfs_tcn_bwd's partial [N][n_conv][k + 1] over the rows (fixed order) and writes
+ * dv, dg, db.  n_conv <= 16, k <= 8.                                                                                  */
+int wfs_tcn_taps_fwd(const void *param_ptrs, int32_t n_conv, int32_t k, float *taps, float *bias, void *stream);
+int wfs_tcn_taps_bwd(const void *param_ptrs, int32_t n_conv, int32_t k, const float *partial, int64_t N, void *stream);
+
 /* loss ---------------------------------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(reduction='mean') as the reference's LitPSD applies it to the [B, n_type] logits
  * (src/engineering/LitBase.py:38-43, LitPSD.py:102), forward AND d loss / d logits in one launch (torch runs six:

@@ -114,6 +114,8 @@ SIGNATURES = {
     "wfs_sparse_head_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                            _i32, _vp, _vp]),
     "wfs_tcn_lds_bytes": (_sz, [_i32, _i32, _i32]),
+    "wfs_tcn_taps_fwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "wfs_tcn_taps_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "wfs_tcn_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _i32, ctypes.c_float, _vp, _vp]),
     "wfs_tcn_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, ctypes.c_float, _vp,
                                     _vp]),

@@ -979,60 +979,7 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
 // ------------------------------------------------------------------------------------------ dW 32 x 2
 // First layer (Cin = 2): the STATIONARY rows are the 32-channel ones (dY, read once, coalesced) and the 2-channel
 // input rows are gathered through the by-output table:  part[chunk][k][c][b] = sum_i G[table[km(k)][i]][c] * S[i][b]
-// with c in {0,1}.  Thread = (row slot, b); 2*K accumulators in registers (K <= 27).
-template <typename T>
-__global__ void __launch_bounds__(256) k_gdw_c32c2(const int *__restrict__ table, int mirror, int K, int identity_k,
-                                                   long long R, const long long *__restrict__ r_dev,
-                                                   long long rows_per_chunk, const T *__restrict__ S,
-                                                   const T *__restrict__ G, float *__restrict__ part) {
-    __shared__ float sRed[8][32];
-    const int slot = threadIdx.x >> 5, b = threadIdx.x & 31;
-    const long long Rv = valid_rows(R, r_dev);
-    const long long r_begin = (long long)blockIdx.x * rows_per_chunk;
-    const long long r_end = r_begin + rows_per_chunk < Rv ? r_begin + rows_per_chunk : Rv;
-    float acc0[27], acc1[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc0[k] = acc1[k] = 0.f;
-    for (long long row = r_begin + slot; row < r_end; row += 8) {
-        const float gv = wfs_ld(S + row * 32 + b);
-        int nb[27];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            int kk = k < K ? k : K - 1;
-            nb[k] = table[(long long)(mirror ? K - 1 - kk : kk) * R + row];
-        }
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            int n = (k == identity_k) ? (int)row : nb[k];
-            bool ok = k < K && n >= 0;
-            const T *xp = G + (long long)(ok ? n : 0) * 2;
-            float x0 = wfs_ld(xp), x1 = wfs_ld(xp + 1);
-            x0 = ok ? x0 : 0.f;
-            x1 = ok ? x1 : 0.f;
-            acc0[k] = fmaf(x0, gv, acc0[k]);
-            acc1[k] = fmaf(x1, gv, acc1[k]);
-        }
-    }
-    // fold the 8 row slots in a fixed order, one (k, c) plane at a time
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float v = 0.f;
-#pragma unroll
-            for (int q = 0; q < 27; ++q)
-                if (q == k) v = c ? acc1[q] : acc0[q];
-            sRed[slot][b] = v;
-            __syncthreads();
-            if (slot == 0) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) s += sRed[w][b];
-                part[((long long)blockIdx.x * K + k) * 64 + c * 32 + b] = s;
-            }
-            __syncthreads();
-        }
-    }
-}
+// with c in {0,1}; both forms below run on the matrix cores.
 
 // bf16 form of the first-layer dW on the matrix cores.  Per 32-row tile the wave builds, in its own LDS region,
 //   A [32 rows][64]: column k*2+c = channel c of the row gathered through table[km(k)][row] (2 x bf16 = one dword
@@ -1612,7 +1559,6 @@ int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, lo
                          const void *S, const void *G, int swap, float *dW, float *part, int dtype,
                          wfs_dw_job *defer, hipStream_t stream) {
     long long chunks = dwc2_chunks(R);
-    const long long rows_per_chunk = (R + chunks - 1) / chunks;
     if (dtype == WFS_F32) {
         const long long ntiles = (R + 31) >> 5;
         chunks = (ntiles + C2F_WAVES - 1) / C2F_WAVES;        // one tile per wave, at most 512 blocks (= slabs)

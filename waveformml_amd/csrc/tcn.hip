@@ -342,3 +342,86 @@ extern "C" int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, 
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
+
+// ------------------------------------------------------------------------------------------ weight norm of the taps
+// The reference's TemporalBlock wraps its convolutions in torch.nn.utils.weight_norm (src/models/ConvBlocks.py:118-131):
+// w = g v / |v| per output channel.  For the single-channel front end that is, per convolution, k taps from k + 1
+// parameters -- torch spends ~16 launches per step on it (forward) and more on its backward.  Here: ONE launch gathers
+// all convolutions' (v, g, b) through a pointer table into the [n_conv][k] taps / [n_conv] biases the fused kernels take,
+// and ONE launch turns the per-row partial sums of the backward into dv, dg, db, written straight to where the caller
+// wants them (the parameters' gradient slots).
+struct TcnParamPtrs {           // one convolution: device addresses (0 = absent)
+    const float *v, *g, *b;
+    float *dv, *dg, *db;
+};
+
+__global__ void __launch_bounds__(64) k_tcn_taps(const TcnParamPtrs *__restrict__ pp, int n_conv, int k,
+                                                 float *__restrict__ taps, float *__restrict__ bias) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= n_conv) return;
+    const TcnParamPtrs p = pp[c];
+    float n2 = 0.f;
+    for (int j = 0; j < k; ++j) n2 = fmaf(p.v[j], p.v[j], n2);
+    const float scale = p.g[0] / sqrtf(n2);
+    for (int j = 0; j < k; ++j) taps[c * k + j] = p.v[j] * scale;
+    bias[c] = p.b ? p.b[0] : 0.f;
+}
+
+// partial [N][n_conv][k + 1] (d taps, d bias per row, from k_tcn_bwd): block c sums its convolution's columns over the
+// rows (256 threads, interleaved rows, LDS tree: a fixed order), then thread 0 applies the weight-norm backward:
+//   dg = (dw . v) / |v|,   dv = g / |v| * (dw - v (dw . v) / |v|^2),   db = sum of the bias column
+__global__ void __launch_bounds__(256) k_tcn_taps_bwd(const TcnParamPtrs *__restrict__ pp, int n_conv, int k,
+                                                      const float *__restrict__ partial, long long N) {
+    __shared__ float sR[256][9];
+    const int c = blockIdx.x;
+    float acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+    const long long stride = (long long)n_conv * (k + 1);
+    for (long long n = threadIdx.x; n < N; n += 256) {
+        const float *q = partial + n * stride + (long long)c * (k + 1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j <= k) acc[j] += q[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sR[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if (threadIdx.x < half)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sR[threadIdx.x][j] += sR[threadIdx.x + half][j];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const TcnParamPtrs p = pp[c];
+    float n2 = 0.f, dot = 0.f;
+    for (int j = 0; j < k; ++j) {
+        n2 = fmaf(p.v[j], p.v[j], n2);
+        dot = fmaf(sR[0][j], p.v[j], dot);
+    }
+    const float inv = 1.f / sqrtf(n2), g = p.g[0];
+    if (p.dg) p.dg[0] = dot * inv;
+    if (p.dv)
+        for (int j = 0; j < k; ++j) p.dv[j] = g * inv * (sR[0][j] - p.v[j] * dot * inv * inv);
+    if (p.db) p.db[0] = sR[0][k];
+}
+
+extern "C" int wfs_tcn_taps_fwd(const void *param_ptrs, int32_t n_conv, int32_t k, float *taps, float *bias, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(n_conv >= 1 && n_conv <= 16 && k >= 1 && k <= 8, WFS_EINVAL, "1 .. 16 convolutions of 1 .. 8 taps (%d, %d)", n_conv, k);
+    WFS_REQUIRE(param_ptrs && taps && bias, WFS_EINVAL, "NULL device pointer");
+    k_tcn_taps<<<dim3(1), dim3(64), 0, stream>>>((const TcnParamPtrs *)param_ptrs, n_conv, k, taps, bias);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" int wfs_tcn_taps_bwd(const void *param_ptrs, int32_t n_conv, int32_t k, const float *partial, int64_t N,
+                                void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(n_conv >= 1 && n_conv <= 16 && k >= 1 && k <= 8, WFS_EINVAL, "1 .. 16 convolutions of 1 .. 8 taps (%d, %d)", n_conv, k);
+    WFS_REQUIRE(param_ptrs && (partial || N == 0), WFS_EINVAL, "NULL device pointer");
+    k_tcn_taps_bwd<<<dim3((unsigned)n_conv), dim3(256), 0, stream>>>((const TcnParamPtrs *)param_ptrs, n_conv, k, partial, N);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}

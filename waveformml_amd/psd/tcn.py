@@ -52,7 +52,8 @@ class TemporalBlock(nn.Module):
 
 
 class FusedTCNFunction(Function):
-    """rows [N, L], effective taps [levels, 2, k] and biases [levels, 2] (fp32, on the GPU) -> rows [N, L].
+    """The two fused kernels on EFFECTIVE taps (what the module's FusedNormedTCNFunction wraps with the weight norm):
+    rows [N, L], effective taps [levels, 2, k] and biases [levels, 2] (fp32, on the GPU) -> rows [N, L].
     ``dropout`` > 0 with ``seed`` (int64 [1] on the GPU) applies the levels' dropout inside the kernels."""
 
     @staticmethod
@@ -85,6 +86,85 @@ class FusedTCNFunction(Function):
                                    _lib.stream_ptr()))
         sums = partial.sum(0)
         return dx, sums[:, :, :k].contiguous(), sums[:, :, k].contiguous(), None, None
+
+
+def _ptr_table(cache, key, rows, device):
+    """Device array of pointer records for wfs_tcn_taps_* (six int64 per convolution), cached by the addresses it holds:
+    in a captured step parameters and gradient slots never move, so the table is built (one small H2D copy) during the
+    eager warm-up only."""
+    tab = cache.get(key)
+    if tab is None:
+        if len(cache) > 64:
+            cache.clear()
+        tab = torch.tensor(rows, dtype=torch.int64, device=device)
+        cache[key] = tab
+    return tab
+
+
+class FusedNormedTCNFunction(Function):
+    """rows [N, L] through the whole front end.  ``params``: per convolution (2 per level) the weight-norm parameters
+    weight_v [1, 1, k], weight_g [1, 1, 1] and the bias [1] (or None) -- the effective taps w = g v / |v| are formed by ONE
+    launch (wfs_tcn_taps_fwd), the backward's per-row partial sums are turned into d weight_v, d weight_g, d bias by ONE
+    launch (wfs_tcn_taps_bwd) that writes straight into the parameters' gradient slots (spconv/functional.grad_like).
+    ``dropout`` > 0 with ``seed`` (int64 [1] on the GPU) applies the levels' dropout inside the kernels."""
+
+    @staticmethod
+    def forward(ctx, x, k, dropout, seed, cache, *params):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, L = x.shape
+        n_conv = len(params) // 3
+        levels = n_conv // 2
+        rows = []
+        for c in range(n_conv):
+            v, g, b = params[3 * c: 3 * c + 3]
+            assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == k and g.numel() == 1
+            rows.append([v.data_ptr(), g.data_ptr(), b.data_ptr() if b is not None else 0, 0, 0, 0])
+        tab = _ptr_table(cache, ("fwd",) + tuple(r[0] for r in rows) + tuple(r[1] for r in rows) + tuple(r[2] for r in rows),
+                         rows, x.device)
+        taps = torch.empty((levels, 2, k), dtype=torch.float32, device=x.device)
+        bias = torch.empty((levels, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.wfs_tcn_taps_fwd(_lib.ptr(tab), n_conv, k, _lib.ptr(taps), _lib.ptr(bias), _lib.stream_ptr()))
+        y = torch.empty_like(x)
+        _lib.check(lib.wfs_tcn_fwd(_lib.ptr(x), N, L, _lib.ptr(taps), _lib.ptr(bias), levels, k, _lib.ptr(y),
+                                   _lib.dtype_code(x), float(dropout), _lib.ptr(seed), _lib.stream_ptr()))
+        ctx.save_for_backward(x, taps, bias)
+        ctx.params = params
+        ctx.dropout, ctx.seed, ctx.k, ctx.cache = float(dropout), seed, k, cache
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from ..spconv.functional import grad_like
+        lib = _lib.load()
+        x, taps, bias = ctx.saved_tensors
+        params, k = ctx.params, ctx.k
+        N, L = x.shape
+        levels = taps.shape[0]
+        n_conv = 2 * levels
+        dy = grad_output.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        partial = torch.empty((N, levels, 2, k + 1), dtype=torch.float32, device=x.device)
+        _lib.check(lib.wfs_tcn_bwd(_lib.ptr(x), _lib.ptr(dy), N, L, _lib.ptr(taps), _lib.ptr(bias), levels, k, _lib.ptr(dx),
+                                   _lib.ptr(partial), _lib.dtype_code(x), ctx.dropout, _lib.ptr(ctx.seed),
+                                   _lib.stream_ptr()))
+        grads, rows = [], []
+        for c in range(n_conv):
+            v, g, b = params[3 * c: 3 * c + 3]
+            need = ctx.needs_input_grad[5 + 3 * c: 5 + 3 * c + 3]
+            dv = grad_like(v) if need[0] else None
+            dg = grad_like(g) if need[1] else None
+            db = grad_like(b) if (b is not None and need[2]) else None
+            grads += [dv, dg, db]
+            rows.append([v.data_ptr(), g.data_ptr(), b.data_ptr() if b is not None else 0,
+                         dv.data_ptr() if dv is not None else 0, dg.data_ptr() if dg is not None else 0,
+                         db.data_ptr() if db is not None else 0])
+        if any(t is not None for t in grads):
+            tab = _ptr_table(ctx.cache, ("bwd",) + tuple(x_ for r in rows for x_ in r), rows, x.device)
+            _lib.check(lib.wfs_tcn_taps_bwd(_lib.ptr(tab), n_conv, k, _lib.ptr(partial), N, _lib.stream_ptr()))
+        return (dx, None, None, None, None) + tuple(grads)
 
 
 class TemporalConvNet(nn.Module):
@@ -122,14 +202,31 @@ class TemporalConvNet(nn.Module):
         levels = len(self.network)
         return torch.stack(taps).reshape(levels, 2, -1).float(), torch.stack(bias).reshape(levels, 2).float()
 
+    def _norm_params(self):
+        """(weight_v, weight_g, bias) of every convolution, level by level -- None unless they are what the fused
+        weight-norm kernels read: contiguous fp32 tensors on one device."""
+        out = []
+        for blk in self.network:
+            for conv in blk.convs:
+                v, g, b = conv.weight_v, conv.weight_g, conv.bias
+                for t in (v, g) + ((b,) if b is not None else ()):
+                    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                        return None
+                out += [v, g, b]
+        return out
+
     def forward(self, x):
         if self._can_fuse(x):
-            taps, bias = self.effective_taps()
-            rows = x.reshape(x.shape[0], x.shape[2])
-            if self.training and self.dropout > 0:
-                # a fresh 64-bit seed per call from torch's CUDA generator (reproducible under torch.manual_seed, and a
-                # captured graph draws a new one per replay); the kernels derive every mask from it
-                seed = torch.randint(-2 ** 62, 2 ** 62, (1,), dtype=torch.int64, device=x.device)
-                return FusedTCNFunction.apply(rows, taps, bias, self.dropout, seed).reshape(x.shape)
-            return FusedTCNFunction.apply(rows, taps, bias).reshape(x.shape)
+            params = self._norm_params()
+            if params is not None:
+                rows = x.reshape(x.shape[0], x.shape[2])
+                seed, p = None, 0.0
+                if self.training and self.dropout > 0:
+                    # a fresh 64-bit seed per call from torch's CUDA generator (reproducible under torch.manual_seed, and a
+                    # captured graph draws a new one per replay); the kernels derive every mask from it
+                    seed = torch.randint(-2 ** 62, 2 ** 62, (1,), dtype=torch.int64, device=x.device)
+                    p = self.dropout
+                if not hasattr(self, "_ptr_cache"):
+                    self._ptr_cache = {}
+                return FusedNormedTCNFunction.apply(rows, self.kernel_size, p, seed, self._ptr_cache, *params).reshape(x.shape)
         return self.network(x)
