@@ -77,11 +77,19 @@ typedef struct wfs_geometry {
     int32_t stride[WFS_MAX_DIM];
     int32_t padding[WFS_MAX_DIM];
     int32_t dilation[WFS_MAX_DIM];
+    int32_t transposed;                 /* != 0: spconv's SparseConvTranspose geometry (subm must be 0)   */
+    int32_t output_padding[WFS_MAX_DIM];/* transposed only                                                  */
 } wfs_geometry;
 
 /* Validates and completes a geometry (replaces the Python front door of
  * spconv.ops.get_indice_pairs, A.2).  WFS_EINVAL if a dim has stride>1 and dilation>1,
- * WFS_EOVERFLOW if batch*prod(out_shape) >= 2^31.                                            */
+ * WFS_EOVERFLOW if batch*prod(out_shape) >= 2^31.
+ * transposed != 0 (spconv.SparseConvTranspose{2,3}d -- named by the reference at src/utils/ModelValidation.py:30-31):
+ * out_shape = (i - 1) s - 2 p + k + output_padding (spconv's get_deconv_output_size: dilation does not enter), input
+ * (x, offset o) reaches output x s - p + o d, outputs numbered first-seen with the offsets of a row visited from the
+ * LAST to the first (getValidOutPosTranspose walks from the upper corner down).  PARITY UNPINNED on that order: the
+ * spconv source is not available here and the reference never constructs one; values are pinned by dense
+ * torch conv_transpose (tests).                                                                                       */
 int wfs_geometry_init(wfs_geometry *g);
 
 /* rulebook ---------------------------------------------------------------------------------

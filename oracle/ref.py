@@ -38,6 +38,8 @@ def lib():
         L.wfo_rulebook_conv.restype = ctypes.c_int64
         L.wfo_rulebook_conv.argtypes = [i32p, ctypes.c_int64, ctypes.c_int, i32p, i32p, i32p, i32p,
                                         i32p, i32p, i32p, i32p]
+        L.wfo_rulebook_conv_transpose.restype = ctypes.c_int64
+        L.wfo_rulebook_conv_transpose.argtypes = L.wfo_rulebook_conv.argtypes
         L.wfo_indice_conv_fwd.restype = ctypes.c_int
         L.wfo_indice_conv_fwd.argtypes = [f32p, f32p, i32p, i32p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
@@ -102,8 +104,9 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     for d, s in zip(dilation, stride):
         assert s == 1 or d == 1, "don't support this."
     if transpose:
-        raise NotImplementedError("transposed rulebook is outside Appendix A")
-    if subm:
+        assert not subm
+        out_shape = deconv_output_shape(spatial_shape, ksize, stride, padding, dilation, out_padding)
+    elif subm:
         out_shape = list(spatial_shape)
     else:
         out_shape = conv_output_shape(spatial_shape, ksize, stride, padding, dilation)
@@ -125,7 +128,8 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
             raise RuntimeError("wfo_rulebook_subm failed: %d" % rc)
         return indices, pairs, num
     out_idx = np.zeros((max(N * K, 1), ndim + 1), dtype=np.int32)
-    M = L.wfo_rulebook_conv(_p(indices, i32), N, ndim, _p(_i32(out_shape), i32),
+    fn = L.wfo_rulebook_conv_transpose if transpose else L.wfo_rulebook_conv
+    M = fn(_p(indices, i32), N, ndim, _p(_i32(out_shape), i32),
                             _p(_i32(ksize), i32), _p(_i32(stride), i32), _p(_i32(padding), i32),
                             _p(_i32(dilation), i32), _p(out_idx, i32), _p(pairs, i32), _p(num, i32))
     if M < 0:

@@ -240,6 +240,8 @@ def _mk_inv(name, ndim):
 
 SparseInverseConv2d = _mk_inv("SparseInverseConv2d", 2)
 SparseInverseConv3d = _mk_inv("SparseInverseConv3d", 3)
+SparseConvTranspose2d = _mk("SparseConvTranspose2d", 2, transposed=True)
+SparseConvTranspose3d = _mk("SparseConvTranspose3d", 3, transposed=True)
 
 
 class ToDense(SparseModule):

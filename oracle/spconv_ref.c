@@ -104,6 +104,48 @@ static int wfo_valid_out_pos(const int32_t *in_pos, int ndim, const int32_t *ksi
     return point_counter;
 }
 
+/* getValidOutPosTranspose (spconv 1.2.1 include/spconv/geometry.h, restated from memory of upstream: the source is not
+ * in this container -- PARITY UNPINNED on the enumeration order): per dim lower = x*s - p, upper = lower + (k-1)*d;
+ * candidates val_j = upper_j - counter_j*d_j, LAST dim fastest, i.e. from the highest kernel offset down;
+ * offset = sum_j m_j*((val_j - lower_j)/d_j) with m the row-major strides of the kernel; kept iff inside out_shape.  */
+static int wfo_valid_out_pos_transpose(const int32_t *in_pos, int ndim, const int32_t *ksize,
+                                       const int32_t *stride, const int32_t *padding,
+                                       const int32_t *dilation, const int32_t *out_shape, int32_t *out) {
+    int32_t lowers[WFO_MAX_DIM], uppers[WFO_MAX_DIM], counter[WFO_MAX_DIM], csize[WFO_MAX_DIM];
+    int32_t num_points = 1;
+    int point_counter = 0;
+    for (int i = 0; i < ndim; ++i) {
+        lowers[i] = in_pos[i] * stride[i] - padding[i];
+        uppers[i] = lowers[i] + (ksize[i] - 1) * dilation[i];
+    }
+    for (int i = 0; i < ndim; ++i) {
+        csize[i] = (uppers[i] - lowers[i]) / dilation[i] + 1;
+        num_points *= csize[i];
+        counter[i] = 0;
+    }
+    for (int32_t i = 0; i < num_points; ++i) {
+        int valid = 1;
+        int32_t m = 1, offset = 0;
+        for (int j = ndim - 1; j >= 0; --j) {
+            int32_t val = uppers[j] - counter[j] * dilation[j];
+            out[point_counter * (ndim + 1) + j] = val;
+            if (val < 0 || val > out_shape[j] - 1) valid = 0;
+            offset += m * (val - lowers[j]) / dilation[j];
+            m *= ksize[j];
+        }
+        out[point_counter * (ndim + 1) + ndim] = offset;
+        if (valid) ++point_counter;
+        counter[ndim - 1] += 1;
+        for (int c = ndim - 1; c >= 0; --c) {
+            if (counter[c] == csize[c] && c > 0) {
+                counter[c - 1] += 1;
+                counter[c] = 0;
+            }
+        }
+    }
+    return point_counter;
+}
+
 static int64_t wfo_row_major(const int32_t *pos, int ndim, const int32_t *shape) {
     int64_t idx = 0;
     for (int i = 0; i < ndim; ++i) idx = idx * shape[i] + pos[i];
@@ -163,10 +205,32 @@ int wfo_rulebook_subm(const int32_t *indices, int64_t N, int ndim, const int32_t
  * enumeration order: unseen key -> next output id (first-seen numbering), record
  * out_indices[id] = (batch, out_pos); append (j, id) to that offset.
  * out_indices int32 [>= M, ndim+1] (capacity N*K rows is always enough). Returns M (or <0). */
+static int64_t wfo_rulebook_conv_impl(const int32_t *indices, int64_t N, int ndim, const int32_t *out_shape,
+                                      const int32_t *ksize, const int32_t *stride, const int32_t *padding,
+                                      const int32_t *dilation, int32_t *out_indices, int32_t *pairs,
+                                      int32_t *pair_num, int transpose);
+
 int64_t wfo_rulebook_conv(const int32_t *indices, int64_t N, int ndim, const int32_t *out_shape,
                           const int32_t *ksize, const int32_t *stride, const int32_t *padding,
                           const int32_t *dilation, int32_t *out_indices, int32_t *pairs,
                           int32_t *pair_num) {
+    return wfo_rulebook_conv_impl(indices, N, ndim, out_shape, ksize, stride, padding, dilation, out_indices, pairs,
+                                  pair_num, 0);
+}
+
+/* Transposed conv (SparseConvTranspose): the same sequential first-seen numbering over getValidOutPosTranspose. */
+int64_t wfo_rulebook_conv_transpose(const int32_t *indices, int64_t N, int ndim, const int32_t *out_shape,
+                                    const int32_t *ksize, const int32_t *stride, const int32_t *padding,
+                                    const int32_t *dilation, int32_t *out_indices, int32_t *pairs,
+                                    int32_t *pair_num) {
+    return wfo_rulebook_conv_impl(indices, N, ndim, out_shape, ksize, stride, padding, dilation, out_indices, pairs,
+                                  pair_num, 1);
+}
+
+static int64_t wfo_rulebook_conv_impl(const int32_t *indices, int64_t N, int ndim, const int32_t *out_shape,
+                                      const int32_t *ksize, const int32_t *stride, const int32_t *padding,
+                                      const int32_t *dilation, int32_t *out_indices, int32_t *pairs,
+                                      int32_t *pair_num, int transpose) {
     if (ndim < 1 || ndim > WFO_MAX_DIM) return -1;
     int64_t K = 1, volume = 1;
     for (int i = 0; i < ndim; ++i) {
@@ -179,7 +243,8 @@ int64_t wfo_rulebook_conv(const int32_t *indices, int64_t N, int ndim, const int
     int64_t M = 0;
     for (int64_t j = 0; j < N; ++j) {
         const int32_t *row = indices + j * (ndim + 1);
-        int n = wfo_valid_out_pos(row + 1, ndim, ksize, stride, padding, dilation, out_shape, pts);
+        int n = transpose ? wfo_valid_out_pos_transpose(row + 1, ndim, ksize, stride, padding, dilation, out_shape, pts)
+                          : wfo_valid_out_pos(row + 1, ndim, ksize, stride, padding, dilation, out_shape, pts);
         for (int i = 0; i < n; ++i) {
             const int32_t *p = pts + i * (ndim + 1);
             int32_t off = p[ndim];

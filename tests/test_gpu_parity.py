@@ -1622,3 +1622,63 @@ def test_column_sum_for_the_conv_bias_gradient(R, C, dtype, padded):
     assert got.dtype == torch.float32 and got.shape == (C,)
     assert torch.equal(got, again)
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-5 * max(1.0, float(np.abs(x[:R].float().cpu().numpy()).sum(0).max() if R else 1.0)))
+
+
+TRANSPOSED = [(2, (7, 6), 3, 2, 1, 1), (2, (14, 11), (2, 3), (1, 2), 0, 1), (3, (4, 5, 6), 3, (1, 1, 2), (1, 0, 1), 1),
+              (2, (9, 9), 3, 1, 0, 2), (1, (33,), 4, 3, 1, 1), (3, (12, 9, 16), 3, (1, 1, 4), 0, 1)]
+
+
+@pytest.mark.parametrize("case", TRANSPOSED, ids=lambda c: "D%d_k%s_s%s_p%s_d%s" % (c[0], c[2], c[3], c[4], c[5]))
+def test_transposed_rulebook_bitexact_and_layer_parity(case):
+    """spconv.SparseConvTranspose{2,3}d (the reference names them at src/utils/ModelValidation.py:30-31): rulebook -- output
+    indices, indice_pairs, indice_pair_num -- bit for bit against the CPU restatement of get_indice_pairs(transpose=True);
+    forward, dX, dW, db of the layer within 1e-5; device-count mode gives the same rows."""
+    from oracle import ref
+    from oracle import spconv as osp
+    sp = _sp()
+    ndim, shape, k, s, p, d = case
+    rng = np.random.default_rng(77)
+    B = 4
+    n = min(600, B * int(np.prod(shape)) // 2)
+    idx = rand_coords(rng, B, shape, n)
+    want = ref.get_indice_pairs(idx, B, shape, k, s, p, d, 0, False, True)
+    got = sp.ops.get_indice_pairs(torch.from_numpy(idx).to(DEV), B, list(shape), k, s, p, d, 0, False, True)
+    for g, w, name in zip(got, want, ("out_indices", "indice_pairs", "indice_pair_num")):
+        assert np.array_equal(g.cpu().numpy(), w), name
+    Cin, Cout = 6, 9
+    feat = rng.standard_normal((n, Cin)).astype(np.float32)
+    torch.manual_seed(5)
+    if ndim == 1:
+        mk = lambda mod: mod.SparseConvolution(1, Cin, Cout, k, s, p, d, 1, True, transposed=True)      # noqa: E731
+    else:
+        mk = lambda mod: getattr(mod, "SparseConvTranspose%dd" % ndim)(Cin, Cout, k, s, p, d, 1, True)  # noqa: E731
+    ref_layer = mk(osp)
+    layer = mk(sp)
+    layer.load_state_dict(ref_layer.state_dict())
+    layer = layer.to(DEV)
+    fr = torch.from_numpy(feat).requires_grad_(True)
+    fg = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+    yr = ref_layer(osp.SparseConvTensor(fr, torch.from_numpy(idx), list(shape), B))
+    yg = layer(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), list(shape), B))
+    assert list(yg.spatial_shape) == list(yr.spatial_shape)
+    assert np.array_equal(yg.indices.cpu().numpy(), yr.indices.numpy())
+    _assert_close(yg.features.detach().cpu().numpy(), yr.features.detach().numpy(), 1e-5, "forward")
+    g = rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)
+    yr.features.backward(torch.from_numpy(g))
+    yg.features.backward(torch.from_numpy(g).to(DEV))
+    _assert_close(fg.grad.cpu().numpy(), fr.grad.numpy(), 1e-5, "dX")
+    _assert_close(layer.weight.grad.cpu().numpy(), ref_layer.weight.grad.numpy(), 1e-5, "dW")
+    _assert_close(layer.bias.grad.cpu().numpy(), ref_layer.bias.grad.numpy(), 1e-5, "db")
+    # dense() of the transposed layer's output (cell map of the build) against the restatement's
+    assert torch.equal(yg.dense().detach().cpu() != 0, yr.dense().detach() != 0)
+    # device-count mode: capacity-padded rows, nothing read back
+    cap = n + 37
+    buf = torch.zeros((cap, ndim + 1), dtype=torch.int32, device=DEV)
+    buf[:n] = torch.from_numpy(idx).to(DEV)
+    n_dev = torch.tensor([n], dtype=torch.int64, device=DEV)
+    kk, ss, pp, dd = (norm(v, ndim) for v in (k, s, p, d))
+    rb = sp.ops.build_rulebook(buf, B, list(shape), kk, ss, pp, dd, False, n_dev=n_dev, transposed=True)
+    m = int(rb.m_dev)
+    assert m == len(want[0]) and int(rb.overflow) == 0
+    assert np.array_equal(rb.out_indices[:m].cpu().numpy(), want[0])
+    assert np.array_equal(rb.indice_pair_num.cpu().numpy(), want[2])

@@ -24,7 +24,8 @@ class Geometry(ctypes.Structure):
     _fields_ = [("ndim", _i32), ("batch_size", _i32), ("subm", _i32), ("K", _i32),
                 ("spatial", _i32 * WFS_MAX_DIM), ("out_shape", _i32 * WFS_MAX_DIM),
                 ("ksize", _i32 * WFS_MAX_DIM), ("stride", _i32 * WFS_MAX_DIM),
-                ("padding", _i32 * WFS_MAX_DIM), ("dilation", _i32 * WFS_MAX_DIM)]
+                ("padding", _i32 * WFS_MAX_DIM), ("dilation", _i32 * WFS_MAX_DIM),
+                ("transposed", _i32), ("output_padding", _i32 * WFS_MAX_DIM)]
 
 
 class BnStats(ctypes.Structure):
@@ -186,12 +187,15 @@ def i32_array(values):
     return (ctypes.c_int32 * len(values))(*[int(v) for v in values])
 
 
-def make_geometry(ndim, batch_size, spatial, ksize, stride, padding, dilation, subm):
+def make_geometry(ndim, batch_size, spatial, ksize, stride, padding, dilation, subm, transposed=False,
+                  output_padding=None):
     g = Geometry()
     g.ndim, g.batch_size, g.subm = int(ndim), int(batch_size), int(bool(subm))
+    g.transposed = int(bool(transposed))
     for i in range(ndim):
         g.spatial[i], g.ksize[i] = int(spatial[i]), int(ksize[i])
         g.stride[i], g.padding[i], g.dilation[i] = int(stride[i]), int(padding[i]), int(dilation[i])
+        g.output_padding[i] = int(output_padding[i]) if output_padding is not None else 0
     check(load().wfs_geometry_init(ctypes.byref(g)))
     return g
 

@@ -25,6 +25,7 @@ extern "C" int wfs_geometry_init(wfs_geometry *g) {
     WFS_REQUIRE(g->ndim >= 1 && g->ndim <= WFS_MAX_DIM, WFS_EINVAL, "ndim %d not in [1,%d]", g->ndim,
                 WFS_MAX_DIM);
     WFS_REQUIRE(g->batch_size >= 0, WFS_EINVAL, "negative batch_size");
+    WFS_REQUIRE(!(g->subm && g->transposed), WFS_EINVAL, "a submanifold convolution cannot be transposed");
     int64_t K = 1, vol = 1;
     for (int i = 0; i < g->ndim; ++i) {
         WFS_REQUIRE(g->ksize[i] >= 1 && g->stride[i] >= 1 && g->dilation[i] >= 1 && g->padding[i] >= 0 &&
@@ -36,6 +37,12 @@ extern "C" int wfs_geometry_init(wfs_geometry *g) {
             g->stride[i] = 1;
             g->padding[i] = g->ksize[i] / 2;
             g->out_shape[i] = g->spatial[i];
+        } else if (g->transposed) {
+            WFS_REQUIRE(g->output_padding[i] >= 0, WFS_EINVAL, "negative output_padding in dim %d", i);
+            const int64_t o = ((int64_t)g->spatial[i] - 1) * g->stride[i] - 2 * (int64_t)g->padding[i] + g->ksize[i] +
+                              g->output_padding[i];            // spconv's get_deconv_output_size (no dilation term)
+            WFS_REQUIRE(o >= 1 && o < ((int64_t)1 << 31), WFS_EINVAL, "deconv output size %lld in dim %d", (long long)o, i);
+            g->out_shape[i] = (int32_t)o;
         } else {
             int64_t o = (int64_t)g->spatial[i] + 2 * g->padding[i] - (int64_t)g->dilation[i] * (g->ksize[i] - 1) - 1;
             // python floor division, as spconv's get_conv_output_size

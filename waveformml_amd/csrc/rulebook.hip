@@ -25,6 +25,7 @@ constexpr int TB = 256;  // threads per block everywhere in this file
 
 struct Geo {
     int ndim, K;
+    int transposed;      // != 0: offsets are handled REVERSED inside the build (see offset_key), the tables flipped at the end
     int spatial[4], out_shape[4], ksize[4], stride[4], padding[4], dilation[4];
     long long in_volume, out_volume;
 };
@@ -79,10 +80,16 @@ struct Walker {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             if (d >= g.ndim) break;
-            int t = x[d] + g.padding[d] - off[d] * g.dilation[d];
-            if (t < 0) return -1;
-            int o = t / g.stride[d];
-            if (o * g.stride[d] != t || o >= g.out_shape[d]) return -1;
+            int o;
+            if (g.transposed) {
+                o = x[d] * g.stride[d] - g.padding[d] + (g.ksize[d] - 1 - off[d]) * g.dilation[d];
+                if (o < 0 || o >= g.out_shape[d]) return -1;
+            } else {
+                int t = x[d] + g.padding[d] - off[d] * g.dilation[d];
+                if (t < 0) return -1;
+                o = t / g.stride[d];
+                if (o * g.stride[d] != t || o >= g.out_shape[d]) return -1;
+            }
             lin = lin * g.out_shape[d] + o;
         }
         return (int)lin;
@@ -174,10 +181,19 @@ __device__ __forceinline__ int offset_key(const Geo &g, int k, const int *x, int
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         if (d >= g.ndim) break;
-        int t = x[d] + g.padding[d] - off[d] * g.dilation[d];
-        if (t < 0) return -1;
-        int o = t / g.stride[d];
-        if (o * g.stride[d] != t || o >= g.out_shape[d]) return -1;
+        int o;
+        if (g.transposed) {
+            // transposed conv: (x, offset) reaches x s - p + offset d.  spconv visits a row's offsets from the last to the
+            // first; inside the build the offset index is REVERSED (k' = K - 1 - k) so that "first seen" keeps meaning
+            // "smallest ticket j K + k'"; wfs_rulebook_emit flips the finished tables back to spconv's offset order
+            o = x[d] * g.stride[d] - g.padding[d] + (g.ksize[d] - 1 - off[d]) * g.dilation[d];
+            if (o < 0 || o >= g.out_shape[d]) return -1;
+        } else {
+            int t = x[d] + g.padding[d] - off[d] * g.dilation[d];
+            if (t < 0) return -1;
+            o = t / g.stride[d];
+            if (o * g.stride[d] != t || o >= g.out_shape[d]) return -1;
+        }
         lin = lin * g.out_shape[d] + o;
     }
     return (int)lin;
@@ -509,6 +525,17 @@ __global__ void __launch_bounds__(TB) k_conv_rowbase(long long N, const unsigned
     }
 }
 
+// rows k <-> K - 1 - k of a [K, n] table (transposed conv: the build works with reversed offsets)
+__global__ void __launch_bounds__(TB) k_flip_rows(int K, long long n, const long long *n_dev, int *__restrict__ t) {
+    const long long j = (long long)blockIdx.x * TB + threadIdx.x;
+    const int k = blockIdx.y;
+    const long long nv = n_dev ? (*n_dev < n ? *n_dev : n) : n;
+    if (j >= nv || 2 * k + 1 >= K) return;
+    const int a = t[(long long)k * n + j], b = t[(long long)(K - 1 - k) * n + j];
+    t[(long long)k * n + j] = b;
+    t[(long long)(K - 1 - k) * n + j] = a;
+}
+
 // ---------------------------------------------------------------- compaction to spconv's encoding
 // tile = TB consecutive input rows.  tcount[k * ntiles + tile] = valid entries of column k in tile.
 __global__ void k_compact_count(int K, long long N, const long long *n_dev, long long ntiles, const int *nbr_out,
@@ -597,6 +624,7 @@ void make_plan(const wfs_geometry *g, long long N, Plan *p) {
     Geo &G = p->geo;
     G.ndim = g->ndim;
     G.K = g->K;
+    G.transposed = g->transposed ? 1 : 0;
     G.in_volume = G.out_volume = 1;
     for (int i = 0; i < 4; ++i) {
         G.spatial[i] = g->spatial[i];
@@ -838,6 +866,15 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
     } else if (nbr_in) {
         k_invert_table<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, nbr_in);
         WFS_LAUNCH_CHECK();
+    }
+    if (g->transposed && g->K > 1) {
+        // back to spconv's offset order (see offset_key); rows beyond the valid counts hold nothing anyone reads
+        k_flip_rows<<<dim3((unsigned)wfs_cdiv(N, TB), (unsigned)(g->K / 2)), block, 0, stream>>>(g->K, N, nd, nbr_out);
+        WFS_LAUNCH_CHECK();
+        if (nbr_in && M > 0) {
+            k_flip_rows<<<dim3((unsigned)wfs_cdiv(M, TB), (unsigned)(g->K / 2)), block, 0, stream>>>(g->K, M, nullptr, nbr_in);
+            WFS_LAUNCH_CHECK();
+        }
     }
     if (indice_pairs || indice_pair_num) {
         WFS_REQUIRE(indice_pair_num, WFS_EINVAL, "indice_pair_num is required with indice_pairs");

@@ -39,8 +39,6 @@ class SparseConvolution(SparseModule):
         self.algo = algo
         for d, s in zip(self.dilation, self.stride):
             assert any([s == 1, d == 1]), "don't support this."
-        if transposed:
-            raise NotImplementedError("SparseConvTranspose is not on the PSD path (no rulebook for it here)")
         self.weight = nn.Parameter(torch.Tensor(*self.kernel_size, in_channels, out_channels))
         if bias:
             self.bias = nn.Parameter(torch.Tensor(out_channels))
@@ -71,7 +69,10 @@ class SparseConvolution(SparseModule):
         indices = input.indices
         spatial_shape = input.spatial_shape
         batch_size = input.batch_size
-        if not self.subm:
+        if self.transposed:
+            out_spatial_shape = ops.get_deconv_output_size(spatial_shape, self.kernel_size, self.stride,
+                                                           self.padding, self.dilation, self.output_padding)
+        elif not self.subm:
             out_spatial_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride,
                                                          self.padding, self.dilation)
         else:
@@ -114,7 +115,8 @@ class SparseConvolution(SparseModule):
             else:
                 rb = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
                                         self.padding, self.dilation, self.subm, known_unique=input.unique,
-                                        n_dev=input.n_valid, out_capacity=getattr(self, "out_capacity", None))
+                                        n_dev=input.n_valid, out_capacity=getattr(self, "out_capacity", None),
+                                        transposed=self.transposed, output_padding=self.output_padding)
                 self.last_rulebook = rb          # capacity calibration / overflow checks of graph-captured steps
                 input.unique = not rb.has_dup
                 input.indice_dict[self.indice_key] = IndiceData(rb, spatial_shape)

@@ -182,6 +182,7 @@ class Rulebook(object):
         g = _lib.Geometry()
         ctypes.memmove(ctypes.byref(g), ctypes.byref(self.geometry), ctypes.sizeof(g))
         g.subm = 1
+        g.transposed = 0           # ... and the tables are already in spconv's offset order (emit flipped them once)
         return g
 
     @property
@@ -240,9 +241,13 @@ def reused(tag, source, make):
 
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                   known_unique=None, n_dev=None, out_capacity=None):
+                   known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None):
     """Cached front of :func:`_build_rulebook` (see :class:`reuse_rulebooks`)."""
     global BUILD_COUNT
+    if transposed:
+        BUILD_COUNT += 1
+        return _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, False,
+                               known_unique, n_dev, out_capacity, True, output_padding)
     if _REUSE is None:
         BUILD_COUNT += 1
         return _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
@@ -263,7 +268,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
 
 
 def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                    known_unique=None, n_dev=None, out_capacity=None):
+                    known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None):
     """Builds the device rulebook.  ``known_unique``: True if the caller knows the index rows are
     distinct sites (skips the duplicate check a regular conv would otherwise run once).
 
@@ -279,7 +284,8 @@ def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, 
     lib = _lib.load()
     N, ndim = indices.shape[0], indices.shape[1] - 1
     spatial_shape = [int(s) for s in spatial_shape]
-    g = _lib.make_geometry(ndim, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    g = _lib.make_geometry(ndim, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, transposed,
+                           output_padding)
     rb = Rulebook()
     rb.geometry, rb.N, rb.K, rb.subm, rb.indices = g, N, int(g.K), bool(subm), indices
     rb.out_spatial_shape = [int(g.out_shape[i]) for i in range(ndim)]
@@ -455,6 +461,9 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     for d, s in zip(dilation, stride):
         assert any([s == 1, d == 1]), "don't support this."
     if transpose:
-        raise NotImplementedError("transposed (deconv) rulebooks are not on the PSD path")
-    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+        assert not subm
+        rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, False,
+                            transposed=True, output_padding=_listify(out_padding, ndim))
+    else:
+        rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
     return rb.out_indices, rb.indice_pairs, rb.indice_pair_num
