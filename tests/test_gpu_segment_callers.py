@@ -165,3 +165,34 @@ def test_litez_matches_the_cpu_path(version, se_only):
     rows, c, f = segment_rows(rng, 32, 6, 40)
     t = torch.from_numpy(rng.standard_normal((len(rows), 2)).astype(np.float32))
     _compare_step(gpu, cpu, c, f, t)
+
+
+def test_segment_classifier_trains_through_the_captured_step():
+    """Trainer(capture=True) with one label per ROW (LitSegClassifier): the captured step pads rows and labels to its
+    capacity (labels beyond the valid rows = the criterion's ignore_index, an upper bound for the event count) and must
+    follow the eager trainer on the same batches: same losses, same parameters, no eager fallback, no overflow."""
+    from waveformml_amd.psd.config import load_config
+    from waveformml_amd.psd.litseg import LitSegClassifier
+    from waveformml_amd.psd.trainer import Trainer
+    cfg = _swap_imports(IONI, "waveformml_amd.spconv")
+    cfg["optimize_config"].update(lr=0.01, optimizer_params={"momentum": 0.9, "nesterov": True})
+    rng = np.random.default_rng(12)
+    batches = []
+    for s in range(6):
+        rows, c, f = segment_rows(rng, 40 + 3 * (s % 3), 5, 130)
+        batches.append(([c, f], torch.from_numpy(rng.integers(0, 5, len(rows)))))
+    first = max(range(len(batches)), key=lambda i: batches[i][0][0].shape[0])
+    batches.insert(0, batches.pop(first))                      # the capture sizes itself on its first batch
+    runs = []
+    for capture in (False, True):
+        torch.manual_seed(7)
+        mod = LitSegClassifier(load_config(copy.deepcopy(cfg)))
+        tr = Trainer(max_epochs=2, device=DEV, capture=capture, check_every=2)
+        hist = tr.fit(mod, [([c.clone(), f.clone()], y.clone()) for (c, f), y in batches])
+        torch.cuda.synchronize()
+        runs.append((hist, torch.cat([p.detach().reshape(-1).cpu() for p in mod.model.parameters()]), tr.eager_fallbacks))
+    (h0, p0, _), (h1, p1, fb) = runs
+    assert fb == 0
+    for a, b in zip(h0, h1):
+        assert abs(a["train_loss"] - b["train_loss"]) <= 1e-4 * abs(a["train_loss"]), (a, b)
+    _close(p1.numpy(), p0.numpy(), 1e-4, "parameters after two epochs")

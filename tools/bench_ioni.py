@@ -1,6 +1,6 @@
 """The reference's per-segment classifier (config/examples/IoniClassifierCNN.json: SPConvPreserveNet, six conv -> inverse
 conv layers 130 -> 138 -> 146 -> 154 -> 104 -> 54 -> 5 on the 14 x 11 grid, one logit row per active segment) as a
-training step on the GPU (eager; every layer in libwfsparse's shape-generic MFMA kernels) beside the CPU restatement on
+training step on the GPU (eager and as a captured HIP graph; every layer in libwfsparse's shape-generic MFMA kernels) beside the CPU restatement on
 the host cores.  A parity case with a timing, not the headline bench.   usage: python tools/bench_ioni.py [events] [steps]"""
 import copy, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,6 +59,27 @@ for _ in range(steps):
     step(gpu, og, ([cg, fg], yg))
 torch.cuda.synchronize()
 gpu_ms = (time.perf_counter() - t0) / steps * 1e3
+# the same step captured into a HIP graph (psd/graph.GraphedTrainStep: labels padded per row, flat parameters, FlatSGD)
+from waveformml_amd.psd.ddp import FlatGradAllReducer
+from waveformml_amd.psd.graph import GraphedTrainStep
+from waveformml_amd.spconv import ops
+ops.ASSUME_VALID_UNIQUE_INDICES = True
+torch.manual_seed(0)
+gmod = build("waveformml_amd.spconv").to(dev)
+red = FlatGradAllReducer(gmod.model.parameters())
+gmod.optimizer_parameters = red.optimizer_parameters()
+gopt = gmod.configure_optimizers()
+gopt = gopt[0][0] if isinstance(gopt, tuple) else gopt
+gstep = GraphedTrainStep(gmod, gopt, red, ([cg, fg], yg))
+for _ in range(3):
+    gstep(([cg, fg], yg))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    gstep(([cg, fg], yg))
+torch.cuda.synchronize()
+graph_ms = (time.perf_counter() - t0) / steps * 1e3
+gstep.check()
 torch.set_num_threads(host_cores())
 n_cpu = max(3, steps // 10)
 t0 = time.perf_counter()
@@ -67,5 +88,5 @@ for _ in range(n_cpu):
 cpu_ms = (time.perf_counter() - t0) / n_cpu * 1e3
 print(json.dumps({"config": "IoniClassifierCNN.json (SPConvPreserveNet, float32 rows)", "events": B, "rows": int(len(c)),
                   "rel_loss_diff_first_step": abs(lg0 - lc0) / abs(lc0), "gpu_eager_ms_per_step": round(gpu_ms, 3),
-                  "gpu_events_per_s": round(B / gpu_ms * 1e3), "cpu_ms_per_step": round(cpu_ms, 2),
+                  "gpu_graph_ms_per_step": round(graph_ms, 3), "gpu_events_per_s": round(B / graph_ms * 1e3), "cpu_ms_per_step": round(cpu_ms, 2),
                   "cpu_events_per_s": round(B / cpu_ms * 1e3), "cpu_threads": host_cores()}))

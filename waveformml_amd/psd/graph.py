@@ -43,11 +43,23 @@ class GraphedTrainStep(object):
         self.n_cap = _round_up(headroom * coords.shape[0], granule)
         self.coords = torch.zeros((self.n_cap, coords.shape[1]), dtype=coords.dtype, device=dev)
         self.feats = torch.zeros((self.n_cap, feats.shape[1]), dtype=feats.dtype, device=dev)
-        self.labels = torch.zeros_like(labels)
+        # targets: one per EVENT (LitPSD: a fixed number per batch), or one per ROW (per-segment modules with
+        # ``per_row_targets``: LitSegClassifier) -- then the buffer has the rows' capacity and everything beyond the valid
+        # rows holds the criterion's ignore_index, so that the padding rows neither count nor receive a gradient
+        self.per_row = bool(getattr(module, "per_row_targets", False)) and labels.shape[0] == coords.shape[0]
+        if self.per_row:
+            self.ignore_index = int(getattr(getattr(module, "criterion", None), "ignore_index", -100))
+            self.labels = torch.full((self.n_cap,) + tuple(labels.shape[1:]), self.ignore_index, dtype=labels.dtype, device=dev)
+        else:
+            self.labels = torch.zeros_like(labels)
         self.n_valid = torch.zeros((1,), dtype=torch.int64, device=dev)
         # the coordinates in the reference's batch-first column order, written by the same hand-over launch; the net
         # takes them instead of permuting when it is given exactly self.coords (psd/net.py)
         net = getattr(module, "model", None)
+        if self.per_row and net is not None and hasattr(net, "batch_size_hint"):
+            # the nets read the number of events off the last coordinate row (a host read-back of a padding row here).
+            # All the site tables need is an upper bound, and every event has at least one row: the row capacity is one
+            net.batch_size_hint = self.n_cap
         perm = getattr(net, "permute_tensor", None)
         self._perm = [int(v) for v in perm.tolist()] if perm is not None else None
         self.indices = torch.zeros_like(self.coords) if self._perm is not None else None
@@ -163,6 +175,8 @@ class GraphedTrainStep(object):
 
     def fits(self, batch):
         (coords, _f), labels = batch
+        if self.per_row:
+            return coords.shape[0] <= self.n_cap and labels.shape[0] == coords.shape[0]
         return coords.shape[0] <= self.n_cap and tuple(labels.shape) == tuple(self.labels.shape)
 
     def _load(self, batch):
@@ -170,6 +184,15 @@ class GraphedTrainStep(object):
         n = coords.shape[0]
         if n > self.n_cap:
             raise RuntimeError("batch has %d voxels, the captured step holds %d" % (n, self.n_cap))
+        if self.per_row:
+            self.coords[:n].copy_(coords, non_blocking=True)
+            self.feats[:n].copy_(feats, non_blocking=True)
+            self.labels.fill_(self.ignore_index)
+            self.labels[:n].copy_(labels, non_blocking=True)
+            self.n_valid.fill_(n)
+            if self.indices is not None:
+                self.indices[:n].copy_(coords[:, self._perm], non_blocking=True)
+            return
         if (coords.is_cuda and coords.dtype == torch.int32 and coords.is_contiguous() and feats.is_cuda
                 and feats.is_contiguous() and feats.dtype == self.feats.dtype and labels.is_cuda
                 and labels.dtype == torch.int64 and labels.is_contiguous() and labels.shape == self.labels.shape):

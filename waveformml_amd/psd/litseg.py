@@ -11,6 +11,8 @@ from .segments import SE_DEAD_PMTS, segment_status, single_ended_mask
 
 
 class LitSegClassifier(LitPSD):
+    per_row_targets = True            # one label per active segment (row): psd/graph.GraphedTrainStep pads them per row
+
     def __init__(self, config, trial=None):
         super().__init__(config, trial)
         self.softmax = torch.nn.Softmax(dim=1)
@@ -21,18 +23,24 @@ class LitSegClassifier(LitPSD):
 
     # reference LitSegClassifier._process_batch, :36-63
     def _process_batch(self, batch):
-        (c, f), target = batch
+        inputs, target = batch
+        c, f = inputs[0], inputs[1]
+        n_valid = inputs[2] if len(inputs) > 2 else None       # capacity-padded batch of a captured step (psd/graph.py)
         additional_fields = None
         if isinstance(f, list):
             additional_fields, f = f[1:], f[0]
         if self.occlude_index:
             f[:, self.occlude_index] = 0
-        predictions = self.model([c, f])
+        predictions = self.model([c, f, n_valid] if n_valid is not None else [c, f])
+        logits = predictions if predictions.dtype == torch.float32 else predictions.float()
         if self.SE_only:
+            # the reference indexes predictions[se_inds] / target[se_inds]; the same mean over the same rows with a
+            # static shape: every other row's target becomes the criterion's ignore_index
             se_inds = self.SE_mask[0, 0, c[:, 0].long(), c[:, 1].long()] == 1.0
-            loss = self.criterion.forward(predictions[se_inds], target[se_inds])
+            ignore = torch.full_like(target, getattr(self.criterion, "ignore_index", -100))
+            loss = self._loss(logits, torch.where(se_inds, target, ignore))
         else:
-            loss = self._loss(predictions, target)
+            loss = self._loss(logits, target)
         return loss, predictions, target, c, f, additional_fields
 
     def training_step(self, batch, batch_idx):

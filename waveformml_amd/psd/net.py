@@ -39,12 +39,22 @@ class SPConvPreserveNet(nn.Module):
                                           **hparams)
         self.spatial_size = [14, 11]
         self.register_buffer("permute_tensor", torch.LongTensor([2, 0, 1]), persistent=False)   # batch index first
+        self.batch_size_hint = None            # an upper bound on the events of a batch (captured steps, psd/graph.py)
 
     def forward(self, x, batch_size=None):
         coords, feats = x[0], x[1]
         if batch_size is None:
-            batch_size = int(coords[-1, -1]) + 1
-        st = self.spconv.SparseConvTensor(feats, coords[:, self.permute_tensor].contiguous(), self.spatial_size, batch_size)
+            batch_size = self.batch_size_hint
+        if batch_size is None:
+            batch_size = int(coords[-1, -1]) + 1          # one device->host read, as the reference's
+        handed = getattr(self, "batch_first_indices", None)
+        if handed is not None and handed[0] is coords:
+            indices = handed[1]                # psd/graph.py wrote the batch-first columns next to the coordinates
+        else:
+            indices = coords[:, self.permute_tensor].contiguous()
+        st = self.spconv.SparseConvTensor(feats, indices, self.spatial_size, batch_size)
+        if len(x) > 2 and x[2] is not None:    # [coords, feats, n_valid]: rows beyond n_valid[0] are padding
+            st.n_valid = x[2]
         return self.model(st).features
 
 
