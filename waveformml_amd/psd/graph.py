@@ -184,7 +184,7 @@ class GraphedTrainStep(object):
         n = coords.shape[0]
         if n > self.n_cap:
             raise RuntimeError("batch has %d voxels, the captured step holds %d" % (n, self.n_cap))
-        if self.per_row:
+        if getattr(self, "per_row", False):
             self.coords[:n].copy_(coords, non_blocking=True)
             self.feats[:n].copy_(feats, non_blocking=True)
             self.labels.fill_(self.ignore_index)
