@@ -246,3 +246,24 @@ def test_packed_loader_hands_over_the_same_batches():
         for a, b in zip(plain, packed):
             for x, y in ((a[0][0], b[0][0]), (a[0][1], b[0][1]), (a[1], b[1])):
                 assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
+
+
+def test_packed_loader_exposes_its_sampler_for_per_epoch_reshuffling():
+    """The Trainer calls ``loader.sampler.set_epoch(epoch)`` on whatever loader it is given (rank sharding under
+    torch.distributed); a PackedLoader hands its DataLoader's sampler through, and two ranks' shares stay disjoint."""
+    from torch.utils.data.distributed import DistributedSampler
+    from waveformml_amd.psd import data
+    ds = data.SyntheticPulseDataset(8, 2, 16, layout="3d")
+    seen = []
+    for rank in (0, 1):
+        sampler = DistributedSampler(ds, num_replicas=2, rank=rank, shuffle=True, seed=3)
+        loader = data.PackedLoader(ds, data.collate_fn_3d, batch_size=1, num_workers=1, sampler=sampler)
+        assert loader.sampler is sampler and len(loader) == 4
+        sampler.set_epoch(0)
+        e0 = list(iter(sampler))
+        sampler.set_epoch(1)
+        e1 = list(iter(sampler))
+        assert sorted(e0) != sorted(range(8)) and e0 != e1            # a share, reshuffled per epoch
+        assert sum(1 for _ in loader) == 4
+        seen.append(set(e1))
+    assert seen[0].isdisjoint(seen[1]) and seen[0] | seen[1] == set(range(8))
