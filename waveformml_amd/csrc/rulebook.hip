@@ -17,6 +17,8 @@
 //
 // Site lookup uses either a direct grid (slot == key, when batch*volume is small next to N) or an
 // open-addressing hash of 32-bit keys (batch*volume < 2^31 is asserted by the front door).
+#include <stdlib.h>
+
 #include "wfs_common.h"
 
 namespace {
@@ -214,6 +216,53 @@ __global__ void __launch_bounds__(TB) k_subm_lookup2(Geo g, int batch, const int
         if (s != 0xFFFFFFFFu) res = vals[s];
     }
     nbr_out[(long long)k * N + j] = res;
+}
+
+// Direct-grid SubM lookups by RUNS along the last dimension: the cells an input row looks up for the kl offsets of the
+// last dimension (same offsets in the leading dimensions, dilation 1) are ADJACENT in the grid (key, key - 1, ...), so one
+// thread serves a (row, leading offsets) pair: one row read and one key computation for kl neighbouring lookups instead
+// of kl of each (the waveform nets' 3 x 3 x 3 kernels: 9 threads per row instead of 27).  Table rows stay coalesced over
+// the rows.  q = leading-offset index (offset k = q * kl + o, last dimension fastest, as everywhere).
+constexpr int RUN_MAX = 8;
+__global__ void __launch_bounds__(TB) k_subm_lookup_runs(Geo g, int batch, const int *__restrict__ idx, long long N,
+                                                         const long long *n_dev, const int *__restrict__ vals,
+                                                         int *__restrict__ nbr_out) {
+    const int last = g.ndim - 1;
+    const int kl = g.ksize[last];
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (q * kl >= g.K || j >= valid_rows(N, n_dev)) return;
+    int x[4], b;
+    bool ok = load_row(g, idx, j, x, b, batch);
+    // leading offsets of q (row-major over the leading kernel dims), prefix of the key
+    int rem = q;
+    long long lin = b;
+    int off[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+        if (d >= last) continue;
+        off[d] = rem % g.ksize[d];
+        rem /= g.ksize[d];
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d >= last) break;
+        const int o = x[d] + g.padding[d] - off[d] * g.dilation[d];
+        ok = ok && o >= 0 && o < g.out_shape[d];
+        lin = lin * g.out_shape[d] + o;
+    }
+    const int xl = x[last] + g.padding[last];                 // cell of offset 0 in the last dimension; offset o: xl - o
+    const long long base = lin * g.out_shape[last];
+    int res[RUN_MAX];
+#pragma unroll
+    for (int o = 0; o < RUN_MAX; ++o) {
+        const int c = xl - o;
+        const bool in = ok && o < kl && c >= 0 && c < g.out_shape[last];
+        res[o] = in ? vals[base + c] : -1;
+    }
+#pragma unroll
+    for (int o = 0; o < RUN_MAX; ++o)
+        if (o < kl) nbr_out[(long long)(q * kl + o) * N + j] = res[o];
 }
 
 // the (row, offset)-parallel kernels keep 32-bit tickets (the host checks N*K < 2^32): native 32-bit atomicMin
@@ -769,8 +818,15 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         int *vals = (int *)(ws + p.off_vals);
         k_site_insert<<<grid, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, info);
         WFS_LAUNCH_CHECK();
-        dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
-        k_subm_lookup2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, nbr_out);
+        const int kl = g->ksize[g->ndim - 1];
+        static const bool runs_on = [] { const char *e = getenv("WFS_SUBM_RUNS"); return !(e && e[0] == '0'); }();
+        if (runs_on && p.tbl.direct && g->dilation[g->ndim - 1] == 1 && kl >= 2 && kl <= RUN_MAX) {
+            dim3 grid_r((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K / kl, 4));
+            k_subm_lookup_runs<<<grid_r, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, vals, nbr_out);
+        } else {
+            dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
+            k_subm_lookup2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, vals, nbr_out);
+        }
         WFS_LAUNCH_CHECK();
         if (m_dev && n_dev && m_dev != n_dev)
             WFS_HIP_CHECK(hipMemcpyAsync(m_dev, n_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
