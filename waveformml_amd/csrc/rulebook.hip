@@ -285,6 +285,59 @@ __global__ void __launch_bounds__(TB) k_conv_insert2(Geo g, int batch, const int
     nbr_out[(long long)k * N + j] = slot;
 }
 
+// The same insert with one thread per (row, leading offsets): along the LAST dimension (dilation 1, stride s) only the
+// offsets o = (x + p) mod s, + s, ... reach an output cell at all -- for the waveform nets' k = 3, s = 4 layers at most
+// one of the three, and none for a quarter of the rows -- so a thread visits just those and writes -1 for the rest,
+// instead of three threads each loading the row and dividing to find out.  Same tickets, same table.
+__global__ void __launch_bounds__(TB) k_conv_insert_runs(Geo g, int batch, const int *__restrict__ idx, long long N,
+                                                         const long long *n_dev, Table t, unsigned *__restrict__ ticket,
+                                                         int *__restrict__ nbr_out, long long *info) {
+    const int last = g.ndim - 1;
+    const int kl = g.ksize[last], sl = g.stride[last];
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (q * kl >= g.K || j >= valid_rows(N, n_dev)) return;
+    int x[4], b;
+    bool ok = load_row(g, idx, j, x, b, batch);
+    if (!ok) info[2] = 1;
+    int rem = q;
+    long long lin = b;
+    int off[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+        if (d >= last) continue;
+        off[d] = rem % g.ksize[d];
+        rem /= g.ksize[d];
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d >= last) break;
+        const int tt = x[d] + g.padding[d] - off[d] * g.dilation[d];
+        const int o = tt >= 0 ? tt / g.stride[d] : -1;
+        ok = ok && tt >= 0 && o * g.stride[d] == tt && o < g.out_shape[d];
+        lin = lin * g.out_shape[d] + (o >= 0 ? o : 0);
+    }
+    const int xl = x[last] + g.padding[last];
+    const int r0 = xl % sl;                          // the offsets that divide: r0, r0 + sl, ...
+    const long long base = lin * g.out_shape[last];
+#pragma unroll
+    for (int o = 0; o < RUN_MAX; ++o) {
+        if (o >= kl) break;
+        int slot = -1;
+        const int tt = xl - o;
+        if (ok && o >= r0 && (o - r0) % sl == 0 && tt >= 0) {
+            const int oc = tt / sl;
+            if (oc < g.out_shape[last]) {
+                const int k = q * kl + o;
+                const unsigned sidx = tbl_insert(t, (int)(base + oc));
+                atomicMin(&ticket[sidx], (unsigned)(j * g.K + k));
+                slot = (int)sidx;
+            }
+        }
+        nbr_out[(long long)(q * kl + o) * N + j] = slot;
+    }
+}
+
 __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const long long *n_dev, long long M_cap,
                                                      const int *__restrict__ nbr_out, const unsigned *__restrict__ rowmask,
                                                      const int *__restrict__ rowbase, Table t, int *__restrict__ slot_id,
@@ -839,8 +892,16 @@ extern "C" int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, 
         dim3 grid2((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K, 4));
         const long long mcap = M_cap > 0 ? M_cap : (1ll << 62);
         if (wide) {
-            k_conv_insert2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, (unsigned *)ticket,
-                                                        nbr_out, info);
+            const int kl = g->ksize[g->ndim - 1];
+            static const bool runs_on = [] { const char *e = getenv("WFS_CONV_RUNS"); return !(e && e[0] == '0'); }();
+            if (runs_on && !g->transposed && g->dilation[g->ndim - 1] == 1 && kl >= 2 && kl <= RUN_MAX) {
+                dim3 grid_r((unsigned)wfs_cdiv(N, 64), (unsigned)wfs_cdiv(g->K / kl, 4));
+                k_conv_insert_runs<<<grid_r, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl,
+                                                                 (unsigned *)ticket, nbr_out, info);
+            } else {
+                k_conv_insert2<<<grid2, block, 0, stream>>>(p.geo, g->batch_size, indices, N, nd, p.tbl, (unsigned *)ticket,
+                                                            nbr_out, info);
+            }
             WFS_LAUNCH_CHECK();
             k_conv_first_bsum<<<grid, block, 0, stream>>>(g->K, N, nd, nbr_out, (const unsigned *)ticket,
                                                           (unsigned *)rowfirst, bsum);
