@@ -379,6 +379,11 @@ def main():
     if os.environ.get("WFS_WATCHDOG"):         # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["WFS_WATCHDOG"]), exit=True)
+    # stdout carries ONE line, the JSON: whatever libraries print there (gloo announces its connections on stdout) goes
+    # to stderr from here on, the JSON goes to the descriptor saved now
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     env = Env()
     env.world = int(os.environ.get("WORLD_SIZE", "1"))
     env.rank = int(os.environ.get("RANK", "0"))
@@ -447,7 +452,7 @@ def main():
                     result["f32_path"]["roofline"] = f32["roofline"]
             else:
                 result["parity"] = parity(cpu_logits, cpu_loss, extras["logits0"], extras["loss0"])
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=json_out, flush=True)
     if env.world > 1:
         dist.barrier()
         dist.destroy_process_group()
