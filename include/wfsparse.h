@@ -156,6 +156,39 @@ int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, i
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
                     int32_t dtype, const int64_t *r_dev, void *stream);
 
+/* Event-local form of the same product (round 3; csrc/evconv.hip).
+ * A sparse convolution never crosses events (the rulebook key includes the batch index) and the
+ * reference's collate_fn concatenates the items of a batch in order (src/engineering/PSDDataModule.py:10-20), so the
+ * rows of one event are one contiguous range of every row set of the net.  wfs_event_offsets finds those ranges,
+ * wfs_event_conv runs ONE WORKGROUP PER EVENT: the event's input rows are streamed into LDS once and every matrix-core
+ * operand is read from there, instead of ~10 gathers of each row from L2.
+ *
+ * wfs_event_offsets: indices int32 [N, ndim + 1] batch-first (n_dev as everywhere) -> offsets int32
+ *   [wfs_event_offsets_ints(batch_size)] = { first row of event 0 .. batch_size - 1, number of valid rows,
+ *   WFS_EVENT_FLAG_WORDS flag words }; a flag word != 0 <=> the batch column is NOT non-decreasing / in range: the
+ *   consumers then fall back, inside the same launch, to tile-parallel gathers (same results, old speed).  Verified on
+ *   the device by every launch; nothing is read back.
+ * wfs_slot_table: re-encodes a gather table [K, R] per event for wfs_event_conv: one 64-byte record per row of the
+ *   table's row set, 32 uint16 slots, slot k = 1 + (table[mirror ? K-1-k : k][r] - first row of r's event in the
+ *   gathered set), 0 = no neighbour; identity_k >= 0: the row itself.  slots: R * 64 bytes.
+ * wfs_event_conv: Y[r] = bias + sum_k X[table[mirror ? K-1-k : k, r]] . W[k] (^T if transpose_w) for 32 -> 32
+ *   channels, 16-bit rows, K <= 27 (wfs_event_conv_ok).  out_events / in_events: offsets of the row set of Y (table
+ *   columns) and of X (table entries); the same array for SubM.  `slots` = wfs_slot_table of the same table.  Events
+ *   whose input rows exceed the LDS capacity (~1350 rows) and row sets that are not grouped by event gather from X
+ *   through `table` inside the same launch.  Same arithmetic and summation order as wfs_gather_conv.               */
+#define WFS_EVENT_FLAG_WORDS 64
+size_t wfs_event_offsets_ints(int32_t batch_size);
+int wfs_event_offsets(const int32_t *indices, int64_t N, int32_t ndim, int32_t batch_size, const int64_t *n_dev,
+                      int32_t *offsets, void *stream);
+int wfs_slot_table(const int32_t *table, int32_t mirror, int32_t K, int32_t identity_k, int64_t R,
+                   const int32_t *out_events, const int32_t *in_events, int32_t batch_size, const int64_t *r_dev,
+                   void *slots, void *stream);
+int wfs_event_conv_ok(int32_t K, int32_t Cx, int32_t Cw_in, int32_t Cw_out, int32_t dtype, int32_t batch_size);
+int wfs_event_conv(const int32_t *table, int32_t mirror, int32_t K, int32_t identity_k, int64_t R, const void *slots,
+                   const int32_t *out_events, const int32_t *in_events, int32_t batch_size, const void *X,
+                   const float *W, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
+                   const int64_t *r_dev, void *stream);
+
 /* The same product when an nn.BatchNorm1d in TRAINING mode directly follows the convolution inside
  * spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508, SURVEY.md 8a rows a9 + a12): the conv
  * kernel's epilogue also takes the per-channel batch statistics of the rows it stores, so BatchNorm needs no
