@@ -189,6 +189,18 @@ int wfs_event_conv(const int32_t *table, int32_t mirror, int32_t K, int32_t iden
                    const float *W, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
                    const int64_t *r_dev, void *stream);
 
+/* Event-local rulebook builds (round 3; csrc/evrulebook.hip): torch.ops.spconv.get_indice_pairs for index sets that are
+ * grouped by event, ONE WORKGROUP PER EVENT with the event's site table in LDS -- no site grid over the batch in HBM, no
+ * clearing launch, no global atomics.  Bit-identical tables to wfs_rulebook_plan / _emit (SURVEY.md A.3 order).
+ * `events` = wfs_event_offsets of `indices`.  flags int32 [4], zeroed by the caller, SET by the launch: [0] the index set
+ * is not grouped by event or an event has more rows than the LDS tables cover (2048) -- the tables are then incomplete and
+ * the caller takes wfs_rulebook_plan instead; [1] duplicate coordinates; [2] an index outside the spatial shape.
+ * slots (may be NULL): the per-event records wfs_event_conv consumes (wfs_slot_table of nbr_out with identity mapping, no
+ * mirror), written in the same pass. */
+int wfs_event_rulebook_ok(const wfs_geometry *g);
+int wfs_event_rulebook_subm(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
+                            const int32_t *events, int32_t *nbr_out, void *slots, int32_t *flags, void *stream);
+
 /* The same product when an nn.BatchNorm1d in TRAINING mode directly follows the convolution inside
  * spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508, SURVEY.md 8a rows a9 + a12): the conv
  * kernel's epilogue also takes the per-channel batch statistics of the rows it stores, so BatchNorm needs no
