@@ -74,3 +74,74 @@ timeit("subm build, chip-wide (3 launches)", lambda: ops.build_rulebook(idx, NB,
 timeit("subm build, event-local + slots", lambda: ev_subm(True))
 timeit("subm build, event-local", lambda: ev_subm(False))
 timeit("event offsets", lambda: offsets(idx, N))
+
+# ---- strided conv, two layers (the PSD net's k3 s(1,1,4) stack)
+def ev_conv(geo, indices, n, n_dev, ev_i, m_cap, cell=False, slots=False):
+    K = int(geo.K)
+    out = dict(nbr_out=torch.full((K, n), -7, dtype=torch.int32, device=dev),
+               nbr_in=torch.full((K, m_cap), -7, dtype=torch.int32, device=dev),
+               out_indices=torch.full((m_cap, 4), -7, dtype=torch.int32, device=dev),
+               out_ev=torch.full((int(lib.wfs_event_offsets_ints(NB)),), -7, dtype=torch.int32, device=dev),
+               info=torch.zeros((4,), dtype=torch.int64, device=dev), m_dev=torch.zeros((1,), dtype=torch.int64, device=dev),
+               overflow=torch.zeros((1,), dtype=torch.int32, device=dev), flags=torch.zeros((4,), dtype=torch.int32, device=dev))
+    vo = int(np.prod([geo.out_shape[i] for i in range(3)]))
+    if cell:
+        out["ticket"] = torch.full((NB * vo,), 7, dtype=torch.int32, device=dev)
+        out["rowmap"] = torch.full((NB * vo,), -7, dtype=torch.int32, device=dev)
+    if slots:
+        out["slots"] = torch.full((n, 32), -1, dtype=torch.int16, device=dev)
+    ws = torch.empty((int(lib.wfs_event_rulebook_conv_workspace_bytes(NB)),), dtype=torch.uint8, device=dev)
+
+    def run():
+        _lib.check(lib.wfs_event_rulebook_conv(ctypes.byref(geo), _lib.ptr(indices), n, _lib.ptr(n_dev), _lib.ptr(ev_i),
+                                               _lib.ptr(out["nbr_out"]), _lib.ptr(out["nbr_in"]), _lib.ptr(out["out_indices"]),
+                                               m_cap, _lib.ptr(out["out_ev"]), _lib.ptr(out["info"]), _lib.ptr(out["m_dev"]),
+                                               _lib.ptr(out["overflow"]), _lib.ptr(out["flags"]), _lib.ptr(out.get("ticket")),
+                                               _lib.ptr(out.get("rowmap")), _lib.ptr(out.get("slots")), _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr()))
+    out["run"] = run
+    return out
+
+
+rb1 = ops.build_rulebook(idx, NB, SP, [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, known_unique=True)
+g1 = _lib.make_geometry(3, NB, SP, [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False)
+M1 = rb1.M
+cap1 = M1 + 1000
+c1 = ev_conv(g1, idx, N, nv, ev, cap1, slots=True)
+c1["run"]()
+torch.cuda.synchronize()
+assert c1["flags"].tolist() == [0, 0, 0, 0], c1["flags"].tolist()
+assert int(c1["info"][0]) == M1 and int(c1["m_dev"][0]) == M1 and int(c1["overflow"][0]) == 0, (int(c1["info"][0]), M1)
+assert torch.equal(c1["out_indices"][:M1], rb1.out_indices), "conv1 out_indices differ"
+assert torch.equal(c1["nbr_out"], rb1.nbr_out), "conv1 nbr_out differs"
+assert torch.equal(c1["nbr_in"][:, :M1], rb1.nbr_in), "conv1 nbr_in differs"
+ev1_ref = offsets(rb1.out_indices, M1)
+assert torch.equal(c1["out_ev"][:NB + 1 + 64], ev1_ref[:NB + 1 + 64]), "conv1 output event offsets differ"
+ref_s = torch.empty((N, 32), dtype=torch.int16, device=dev)
+_lib.check(lib.wfs_slot_table(_lib.ptr(rb1.nbr_out), 0, 27, -1, N, _lib.ptr(ev), _lib.ptr(ev1_ref), NB, None, _lib.ptr(ref_s),
+                              _lib.stream_ptr()))
+assert torch.equal(c1["slots"], ref_s), "conv1 dX slot records differ"
+print("conv s4 layer 1: event-local tables BIT-EQUAL (M %d)" % M1)
+SP1 = rb1.out_spatial_shape
+rb2 = ops.build_rulebook(rb1.out_indices, NB, SP1, [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, known_unique=True)
+g2 = _lib.make_geometry(3, NB, SP1, [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False)
+M2 = rb2.M
+idx1 = c1["out_indices"]
+c2 = ev_conv(g2, idx1, cap1, c1["m_dev"], c1["out_ev"], M2 + 500, cell=True)
+c2["run"]()
+torch.cuda.synchronize()
+assert c2["flags"].tolist() == [0, 0, 0, 0] and int(c2["info"][0]) == M2, (c2["flags"].tolist(), int(c2["info"][0]), M2)
+assert torch.equal(c2["out_indices"][:M2], rb2.out_indices) and torch.equal(c2["nbr_out"][:, :M1], rb2.nbr_out)
+assert torch.equal(c2["nbr_in"][:, :M2], rb2.nbr_in)
+vo2 = int(np.prod(rb2.out_spatial_shape))
+dense_ref = torch.full((NB * vo2,), -1, dtype=torch.int32, device=dev)
+oi = rb2.out_indices.long()
+lin = ((oi[:, 0] * rb2.out_spatial_shape[0] + oi[:, 1]) * rb2.out_spatial_shape[1] + oi[:, 2]) * rb2.out_spatial_shape[2] + oi[:, 3]
+dense_ref[lin] = torch.arange(M2, device=dev, dtype=torch.int32)
+assert torch.equal(c2["rowmap"], dense_ref) and torch.equal(c2["ticket"] != -1, dense_ref >= 0), "cell map differs"
+print("conv s4 layer 2: event-local tables and cell map BIT-EQUAL (M %d)" % M2)
+timeit("conv s4 layer 1 build, chip-wide (6 launches)", lambda: ops.build_rulebook(idx, NB, SP, [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, n_dev=nv, out_capacity=cap1))
+timeit("conv s4 layer 1 build, event-local (2)", c1["run"])
+m1d = c1["m_dev"]
+timeit("conv s4 layer 2 build, chip-wide", lambda: ops.build_rulebook(idx1, NB, SP1, [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, n_dev=m1d, out_capacity=M2 + 500))
+timeit("conv s4 layer 2 build, event-local + cell map", c2["run"])

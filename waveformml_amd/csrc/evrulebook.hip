@@ -232,6 +232,253 @@ __global__ void __launch_bounds__(ER_THREADS) k_ev_subm(EGeo g, EQTab qt, int Q,
     }
 }
 
+// ------------------------------------------------------------------------------------------ regular / strided conv
+// Output sites of ONE event on a direct LDS grid (Vo = prod(out_shape) cells): tick[site] = smallest ticket
+// (local row * K + offset) of the candidates that reach the site (ds_min), ids[site] = rank of that ticket among the
+// event's first tickets = the site's first-seen number inside the event (A.3).  Two launches:
+//   COUNT   passes 1-3 per event -> cnt[e] = number of output sites of event e
+//   EMIT    passes 1-3 again (LDS only, a few us), base = sum of cnt[e' < e], then everything is written once: nbr_out,
+//           nbr_in, out_indices, the outputs' event offsets, optionally the cell -> row map of dense() and the slot
+//           records of the event-local conv's dX
+// (a single launch would have to pass the bases between workgroups: a spin-wait on other workgroups' progress, a stamp
+// that tells this launch's words from the last one's -- the recount is cheaper than either is safe.)
+// Shapes: ndim <= 3, kernel <= 3 per dim, Vo * 6 bytes of LDS (<= ER_CONV_LDS).  Inputs are taken to be distinct sites
+// (a regular conv's input: checked by the SubM build of the same index set, or the output of another regular conv).
+constexpr int ER_CONV_LDS = 96 * 1024;
+
+template <int ND, bool EMIT>
+__global__ void __launch_bounds__(ER_THREADS) k_ev_conv(EGeo g, int Vo, const int *__restrict__ idx, long long N,
+                                                        const long long *__restrict__ n_dev, const int *__restrict__ in_ev,
+                                                        int B, int *__restrict__ cnt, int *__restrict__ nbr_out,
+                                                        int *__restrict__ nbr_in, int *__restrict__ out_indices,
+                                                        long long M_cap, int *__restrict__ out_ev, long long *info,
+                                                        long long *m_dev, int *overflow, int *__restrict__ flags,
+                                                        unsigned *__restrict__ cell_ticket, int *__restrict__ cell_row,
+                                                        unsigned long long *__restrict__ slots_bwd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
+    unsigned *tick = reinterpret_cast<unsigned *>(csm);
+    unsigned short *ids = reinterpret_cast<unsigned short *>(csm + (size_t)Vo * 4);
+    __shared__ int sCount[ER_THREADS / 64 + 1];
+    __shared__ int sBase;
+    const int Nv = (int)valid_rows(N, n_dev);
+    const bool structured = ev_structured(in_ev, B);
+    if (!structured && threadIdx.x == 0) flags[0] = 1;
+    const int cols = ND + 1, K = g.K;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // power-of-two strides divide by a shift
+    int sh[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sh[d] = (d < ND && (g.stride[d] & (g.stride[d] - 1)) == 0) ? __builtin_ctz(g.stride[d]) : -1;
+    const int ks0 = g.ksize[0], ks1 = ND > 1 ? g.ksize[1] : 1, ks2 = ND > 2 ? g.ksize[2] : 1;
+
+    // output coordinate reached by input coordinate xd through offset o of dim d, or -1
+    auto out_coord = [&](int d, int xd, int o) -> int {
+        const int tt = xd + g.padding[d] - o * g.dilation[d];
+        if (o >= g.ksize[d] || tt < 0) return -1;
+        const int q = sh[d] >= 0 ? (tt >> sh[d]) : (int)((unsigned)tt / (unsigned)g.stride[d]);
+        return (q * g.stride[d] == tt && q < g.out_shape[d]) ? q : -1;
+    };
+    // walks the candidates of a row in increasing k: f(k, site or -1, valid digits)
+    auto walk = [&](const int *x, auto f) {
+        int oc[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) oc[d][o] = d < ND ? out_coord(d, x[d], o) : (o == 0 ? 0 : -1);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < (ND > 1 ? 3 : 1); ++b)
+#pragma unroll
+                for (int c = 0; c < (ND > 2 ? 3 : 1); ++c) {
+                    if (a >= ks0 || b >= ks1 || c >= ks2) continue;
+                    const int k = (a * ks1 + b) * ks2 + c;
+                    const bool ok = oc[0][a] >= 0 && (ND < 2 || oc[1][b] >= 0) && (ND < 3 || oc[2][c] >= 0);
+                    int site = oc[0][a];
+                    if (ND > 1) site = site * g.out_shape[1] + oc[1][b];
+                    if (ND > 2) site = site * g.out_shape[2] + oc[2][c];
+                    f(k, ok ? site : -1);
+                }
+    };
+    auto load_x = [&](int row, int *x) -> bool {
+        const int *r = idx + (long long)row * cols;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            x[d] = d < ND ? r[1 + d] : 0;
+            if (d < ND) ok = ok && x[d] >= 0 && x[d] < g.spatial[d];
+        }
+        return ok;
+    };
+
+    for (int e = blockIdx.x; e < B; e += gridDim.x) {
+        int i0 = 0, n = 0;
+        if (structured) {
+            i0 = in_ev[e];
+            int i1 = in_ev[e + 1];
+            i1 = i1 < Nv ? i1 : Nv;
+            n = i1 - i0;
+            n = n > 0 ? n : 0;
+        }
+        const bool big = (long long)n * K >= (1ll << 32);
+        if (big) {
+            if (threadIdx.x == 0) flags[0] = 1;
+            n = 0;
+        }
+        __syncthreads();                                      // the previous event's grid is no longer read
+        for (int s_ = threadIdx.x; s_ < Vo; s_ += ER_THREADS) tick[s_] = 0xFFFFFFFFu;
+        __syncthreads();
+        // pass 2: tickets
+#pragma unroll 1
+        for (int j = threadIdx.x; j < n; j += ER_THREADS) {
+            int x[3];
+            if (!load_x(i0 + j, x)) {
+                flags[2] = 1;
+                continue;
+            }
+            walk(x, [&](int k, int site) {
+                if (site >= 0) atomicMin(&tick[site], (unsigned)(j * K + k));
+            });
+        }
+        __syncthreads();
+        // pass 3: first tickets -> ids (512 consecutive rows per round: a block scan gives their bases in row order)
+        int carry = 0;
+        for (int j0 = 0; j0 < n; j0 += ER_THREADS) {
+            const int j = j0 + threadIdx.x;
+            int x[3];
+            const bool live = j < n && load_x(i0 + j, x);
+            unsigned mask = 0;
+            if (live)
+                walk(x, [&](int k, int site) {
+                    if (site >= 0 && tick[site] == (unsigned)(j * K + k)) mask |= 1u << k;
+                });
+            const int c = __popc(mask);
+            // exclusive scan of c over the block
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            if (lane == 63) sCount[wid] = incl;
+            __syncthreads();
+            int base = carry, tot = 0;
+#pragma unroll
+            for (int w = 0; w < ER_THREADS / 64; ++w) {
+                const int cw = sCount[w];
+                if (w < wid) base += cw;
+                tot += cw;
+            }
+            const int rowbase = base + incl - c;
+            if (live && mask)
+                walk(x, [&](int k, int site) {
+                    if (site >= 0 && ((mask >> k) & 1u)) ids[site] = (unsigned short)(rowbase + __popc(mask & ((1u << k) - 1u)));
+                });
+            carry += tot;
+            __syncthreads();
+        }
+        const int Me = carry;
+        if (Me > 65535 && threadIdx.x == 0) flags[0] = 1;          // ids are 16 bits
+        if constexpr (!EMIT) {
+            if (threadIdx.x == 0) cnt[e] = Me;
+            continue;
+        } else {
+            // base of this event's outputs = sum of the counts of the events in front (fixed order: lane-strided, then a
+            // wave reduction, then the waves in order)
+            int part = 0;
+            for (int q = threadIdx.x; q < e; q += ER_THREADS) part += cnt[q];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+            if (lane == 0) sCount[wid] = part;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int b_ = 0;
+                for (int w = 0; w < ER_THREADS / 64; ++w) b_ += sCount[w];
+                sBase = b_;
+            }
+            __syncthreads();
+            const long long base = sBase;
+            if (threadIdx.x == 0) {
+                out_ev[e] = (int)(base < M_cap ? base : M_cap);
+                if (e == B - 1) {
+                    const long long M = base + Me;
+                    out_ev[B] = (int)(M < M_cap ? M : M_cap);
+                    if (info) info[0] = M;
+                    if (m_dev) *m_dev = M < M_cap ? M : M_cap;
+                    if (overflow) *overflow = M > M_cap ? 1 : 0;
+                }
+            }
+            if (e == 0 && threadIdx.x < WFS_EVENT_FLAG_WORDS) out_ev[B + 1 + threadIdx.x] = structured ? 0 : 1;
+            // pass 4a: no input anywhere yet in this event's nbr_in columns
+            if (nbr_in) {
+                for (int q = threadIdx.x; q < Me * K; q += ER_THREADS) {
+                    const int k = q / Me, id = q - k * Me;
+                    const long long gid = base + id;
+                    if (gid < M_cap) nbr_in[(long long)k * M_cap + gid] = -1;
+                }
+                // ... and those stores have LANDED before any wave stores a row index to the same words
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // pass 4b: the tables
+#pragma unroll 1
+            for (int j = threadIdx.x; j < n; j += ER_THREADS) {
+                int x[3];
+                const bool okx = load_x(i0 + j, x);
+                const int row = i0 + j;
+                unsigned long long acc = 0ull;
+                unsigned long long *srec = slots_bwd ? slots_bwd + (long long)row * 8 : nullptr;
+                walk(x, [&](int k, int site) {
+                    int gid = -1;
+                    unsigned lid1 = 0;
+                    if (okx && site >= 0) {
+                        const int lid = ids[site];
+                        const long long gg = base + lid;
+                        if (gg < M_cap) {
+                            gid = (int)gg;
+                            lid1 = (unsigned)lid + 1u;
+                            if (nbr_in) nbr_in[(long long)k * M_cap + gg] = row;
+                            if (tick[site] == (unsigned)(j * K + k)) {          // first ticket: this row introduces the site
+                                int *o = out_indices + gg * cols;
+                                int rem = site;
+#pragma unroll
+                                for (int d = ND - 1; d >= 0; --d) {
+                                    o[1 + d] = rem % g.out_shape[d];
+                                    rem /= g.out_shape[d];
+                                }
+                                o[0] = e;
+                            }
+                        }
+                    }
+                    int *col = nbr_out + (long long)k * N;
+                    col[(unsigned)row] = gid;
+                    if (srec) {
+                        acc = (acc >> 16) | ((unsigned long long)lid1 << 48);
+                        if ((k & 3) == 3) srec[k >> 2] = acc;
+                    }
+                });
+                if (srec) {
+                    // the last, partial group of four and the unused tail of the 32-slot record
+                    const int kq = K >> 2;
+                    if (K & 3) srec[kq] = acc >> (16 * (4 - (K & 3)));
+                    for (int q = kq + ((K & 3) ? 1 : 0); q < 8; ++q) srec[q] = 0ull;
+                }
+            }
+            // pass 4c: cell -> row map of this event (dense() of the outputs)
+            if (cell_ticket) {
+                for (int s_ = threadIdx.x; s_ < Vo; s_ += ER_THREADS) {
+                    const unsigned tk = tick[s_];
+                    const long long gg = base + ids[s_];
+                    const bool act = tk != 0xFFFFFFFFu && gg < M_cap;
+                    cell_ticket[(long long)e * Vo + s_] = act ? tk : 0xFFFFFFFFu;
+                    cell_row[(long long)e * Vo + s_] = act ? (int)gg : -1;
+                }
+            }
+        }
+    }
+}
+
 EGeo make_egeo(const wfs_geometry *g) {
     EGeo G;
     G.ndim = g->ndim;
@@ -322,5 +569,72 @@ extern "C" int wfs_event_rulebook_subm(const wfs_geometry *g, const int32_t *ind
     if (kl == 1) WFS_EVS(1); else if (kl == 2) WFS_EVS(2); else WFS_EVS(3);
 #undef WFS_EVS
     WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+extern "C" size_t wfs_event_rulebook_conv_workspace_bytes(int32_t batch_size) {
+    return (size_t)(batch_size > 0 ? batch_size : 1) * sizeof(int32_t);
+}
+
+extern "C" int wfs_event_rulebook_conv_ok(const wfs_geometry *g) {
+    if (!g || g->subm || g->transposed || g->K < 1 || g->K > 27 || g->ndim < 1 || g->ndim > 3) return 0;
+    long long vo = 1;
+    for (int d = 0; d < g->ndim; ++d) {
+        if (g->ksize[d] > 3 || g->stride[d] < 1) return 0;
+        vo *= g->out_shape[d];
+    }
+    return vo * 6 <= ER_CONV_LDS;
+}
+
+extern "C" int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
+                                       const int32_t *in_events, int32_t *nbr_out, int32_t *nbr_in, int32_t *out_indices,
+                                       int64_t M_cap, int32_t *out_events, int64_t *info, int64_t *m_dev,
+                                       int32_t *overflow_dev, int32_t *flags, uint32_t *cell_ticket, int32_t *cell_row,
+                                       void *slots_bwd, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(g && wfs_event_rulebook_conv_ok(g), WFS_EINVAL,
+                "wfs_event_rulebook_conv: regular conv, ndim <= 3, kernel <= 3 per dim, out volume * 6 B of LDS");
+    WFS_REQUIRE(N >= 0 && (long long)g->K * N < (1ll << 31) && M_cap >= 0 && (long long)g->K * M_cap < (1ll << 31),
+                WFS_EINVAL, "N / M_cap out of range");
+    const int B = g->batch_size;
+    WFS_REQUIRE(workspace && workspace_bytes >= wfs_event_rulebook_conv_workspace_bytes(B), WFS_EWORKSPACE,
+                "workspace too small");
+    WFS_REQUIRE(in_events && out_events && flags && nbr_out && (indices || N == 0), WFS_EINVAL, "NULL device pointer");
+    WFS_REQUIRE((cell_ticket == nullptr) == (cell_row == nullptr), WFS_EINVAL, "cell_ticket and cell_row come together");
+    WfsTimerScope timer(WFS_TIMER_RULEBOOK, stream);
+    long long vo = 1;
+    for (int d = 0; d < g->ndim; ++d) vo *= g->out_shape[d];
+    const int Vo = (int)vo;
+    const size_t lds = (size_t)Vo * 6;
+    const int nblk = B < 1024 ? B : 1024;
+    const EGeo G = make_egeo(g);
+    int *cnt = (int *)workspace;
+    const dim3 grid((unsigned)nblk), block(ER_THREADS);
+    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+#define WFS_EVC(ND, EM)                                                                                                  \
+    do {                                                                                                                 \
+        auto kern = k_ev_conv<ND, EM>;                                                                                   \
+        if (!attr_done[ND - 1][EM ? 1 : 0]) {                                                                            \
+            WFS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                              ER_CONV_LDS));                                                             \
+            attr_done[ND - 1][EM ? 1 : 0] = true;                                                                        \
+        }                                                                                                                \
+        kern<<<grid, block, lds, stream>>>(G, Vo, indices, N, (const long long *)n_dev, in_events, B, cnt, nbr_out,      \
+                                           nbr_in, out_indices, M_cap, out_events, (long long *)info,                    \
+                                           (long long *)m_dev, overflow_dev, flags, cell_ticket, cell_row,               \
+                                           (unsigned long long *)slots_bwd);                                             \
+        WFS_LAUNCH_CHECK();                                                                                              \
+    } while (0)
+    if (g->ndim == 1) {
+        WFS_EVC(1, false);
+        WFS_EVC(1, true);
+    } else if (g->ndim == 2) {
+        WFS_EVC(2, false);
+        WFS_EVC(2, true);
+    } else {
+        WFS_EVC(3, false);
+        WFS_EVC(3, true);
+    }
+#undef WFS_EVC
     return WFS_OK;
 }
