@@ -200,21 +200,23 @@ int wfs_event_conv(const int32_t *table, int32_t mirror, int32_t K, int32_t iden
 int wfs_event_rulebook_ok(const wfs_geometry *g);
 int wfs_event_rulebook_subm(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
                             const int32_t *events, int32_t *nbr_out, void *slots, int32_t *flags, void *stream);
-/* Regular / strided conv (ndim <= 3, kernel <= 3 per dim, prod(out_shape) * 6 bytes of LDS: wfs_event_rulebook_conv_ok):
+/* Regular / strided conv (ndim <= 3, kernel 3 in every dim, prod(out_shape) * 6 bytes of LDS: wfs_event_rulebook_conv_ok):
  * the whole of wfs_rulebook_plan + wfs_rulebook_emit in two launches.  Inputs are taken to be distinct sites.  Writes
  * nbr_out [K, N] (-1 where an output lies beyond M_cap), nbr_in [K, M_cap], out_indices [M_cap, ndim + 1] (first-seen
  * order, A.3), out_events = the event offsets of the OUTPUT rows (same layout as wfs_event_offsets), info[0] = M,
  * *m_dev = min(M, M_cap), *overflow_dev = M > M_cap (each may be NULL), and optionally the cell -> row map of dense()
  * (cell_ticket / cell_row [batch * prod(out_shape)], see wfs_rulebook_cell_map) and slots_bwd, the records
- * wfs_event_conv's dX consumes (per INPUT row: its outputs, local to the event).  flags as for the SubM build.
+ * wfs_event_conv's dX consumes (per INPUT row: its outputs, local to the event) and slots_fwd, the forward's (per OUTPUT
+ * row: its inputs; M_cap records).  flags as for the SubM build; [0] also: an event with more outputs than the LDS image
+ * of its nbr_in columns holds (>= 1024).
  * workspace: wfs_event_rulebook_conv_workspace_bytes(batch) bytes.                                                     */
 int wfs_event_rulebook_conv_ok(const wfs_geometry *g);
 size_t wfs_event_rulebook_conv_workspace_bytes(int32_t batch_size);
 int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
                             const int32_t *in_events, int32_t *nbr_out, int32_t *nbr_in, int32_t *out_indices,
                             int64_t M_cap, int32_t *out_events, int64_t *info, int64_t *m_dev, int32_t *overflow_dev,
-                            int32_t *flags, uint32_t *cell_ticket, int32_t *cell_row, void *slots_bwd, void *workspace,
-                            size_t workspace_bytes, void *stream);
+                            int32_t *flags, uint32_t *cell_ticket, int32_t *cell_row, void *slots_bwd, void *slots_fwd,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same product when an nn.BatchNorm1d in TRAINING mode directly follows the convolution inside
  * spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508, SURVEY.md 8a rows a9 + a12): the conv
