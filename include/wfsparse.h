@@ -156,67 +156,33 @@ int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, i
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
                     int32_t dtype, const int64_t *r_dev, void *stream);
 
-/* Event-local form of the same product (round 3; csrc/evconv.hip).
+/* Event-local rulebook build (round 3; csrc/evrulebook.hip).
  * A sparse convolution never crosses events (the rulebook key includes the batch index) and the
  * reference's collate_fn concatenates the items of a batch in order (src/engineering/PSDDataModule.py:10-20), so the
- * rows of one event are one contiguous range of every row set of the net.  wfs_event_offsets finds those ranges,
- * wfs_event_conv runs ONE WORKGROUP PER EVENT: the event's input rows are streamed into LDS once and every matrix-core
- * operand is read from there, instead of ~10 gathers of each row from L2.
- *
+ * rows of one event are one contiguous range of the index set.
  * wfs_event_offsets: indices int32 [N, ndim + 1] batch-first (n_dev as everywhere) -> offsets int32
  *   [wfs_event_offsets_ints(batch_size)] = { first row of event 0 .. batch_size - 1, number of valid rows,
- *   WFS_EVENT_FLAG_WORDS flag words }; a flag word != 0 <=> the batch column is NOT non-decreasing / in range: the
- *   consumers then fall back, inside the same launch, to tile-parallel gathers (same results, old speed).  Verified on
- *   the device by every launch; nothing is read back.
- * wfs_slot_table: re-encodes a gather table [K, R] per event for wfs_event_conv: one 64-byte record per row of the
- *   table's row set, 32 uint16 slots, slot k = 1 + (table[mirror ? K-1-k : k][r] - first row of r's event in the
- *   gathered set), 0 = no neighbour; identity_k >= 0: the row itself.  slots: R * 64 bytes.
- * wfs_event_conv: Y[r] = bias + sum_k X[table[mirror ? K-1-k : k, r]] . W[k] (^T if transpose_w) for 32 -> 32
- *   channels, 16-bit rows, K <= 27 (wfs_event_conv_ok).  out_events / in_events: offsets of the row set of Y (table
- *   columns) and of X (table entries); the same array for SubM.  `slots` = wfs_slot_table of the same table.  Events
- *   whose input rows exceed the LDS capacity (~1350 rows) and row sets that are not grouped by event gather from X
- *   through `table` inside the same launch.  Same arithmetic and summation order as wfs_gather_conv.               */
+ *   WFS_EVENT_FLAG_WORDS flag words }; a flag word != 0 <=> the batch column is NOT non-decreasing / in range.  Verified
+ *   on the device by every launch; every word is written by every launch; nothing is read back.
+ * wfs_event_rulebook_subm: torch.ops.spconv.get_indice_pairs(subm=True) for an index set grouped by event, ONE
+ *   WORKGROUP PAIR PER EVENT with the event's site table in LDS (cell -> sample array, direct addressing) -- no site
+ *   grid over the batch in HBM, no clearing launch, no global atomics: HBM traffic = the coordinates in, the table out.
+ *   nbr_out is bit-identical to wfs_rulebook_plan's.  `events` = wfs_event_offsets of `indices`.
+ *   flags: int32 [wfs_event_rulebook_flag_ints(batch)] = 3 x blocks words, every word written by every launch; any
+ *   word != 0 in [0, blocks): the index set is not grouped by event or an event exceeds the LDS tables (64 KiB of
+ *   sample arrays: 128 active cells at 256 samples) -- nbr_out is then incomplete and the caller takes wfs_rulebook_plan instead;
+ *   in [blocks, 2 blocks): duplicate coordinates (same remedy: "the last row wins" is resolved by the chip-wide build);
+ *   in [2 blocks, 3 blocks): an index outside the spatial shape.
+ *   slots (may be NULL): 64-byte records per row, 32 uint16 slots = 1 + neighbour's row within the event, 0 = none (the
+ *   operand form of the event-local conv experiment, tools/exp/event_local/).                                       */
 #define WFS_EVENT_FLAG_WORDS 64
 size_t wfs_event_offsets_ints(int32_t batch_size);
 int wfs_event_offsets(const int32_t *indices, int64_t N, int32_t ndim, int32_t batch_size, const int64_t *n_dev,
                       int32_t *offsets, void *stream);
-int wfs_slot_table(const int32_t *table, int32_t mirror, int32_t K, int32_t identity_k, int64_t R,
-                   const int32_t *out_events, const int32_t *in_events, int32_t batch_size, const int64_t *r_dev,
-                   void *slots, void *stream);
-int wfs_event_conv_ok(int32_t K, int32_t Cx, int32_t Cw_in, int32_t Cw_out, int32_t dtype, int32_t batch_size);
-int wfs_event_conv(const int32_t *table, int32_t mirror, int32_t K, int32_t identity_k, int64_t R, const void *slots,
-                   const int32_t *out_events, const int32_t *in_events, int32_t batch_size, const void *X,
-                   const float *W, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
-                   const int64_t *r_dev, void *stream);
-
-/* Event-local rulebook builds (round 3; csrc/evrulebook.hip): torch.ops.spconv.get_indice_pairs for index sets that are
- * grouped by event, ONE WORKGROUP PER EVENT with the event's site table in LDS -- no site grid over the batch in HBM, no
- * clearing launch, no global atomics.  Bit-identical tables to wfs_rulebook_plan / _emit (SURVEY.md A.3 order).
- * `events` = wfs_event_offsets of `indices`.  flags int32 [4], zeroed by the caller, SET by the launch: [0] the index set
- * is not grouped by event or an event has more rows than the LDS tables cover (2048) -- the tables are then incomplete and
- * the caller takes wfs_rulebook_plan instead; [1] duplicate coordinates; [2] an index outside the spatial shape.
- * slots (may be NULL): the per-event records wfs_event_conv consumes (wfs_slot_table of nbr_out with identity mapping, no
- * mirror), written in the same pass. */
 int wfs_event_rulebook_ok(const wfs_geometry *g);
+size_t wfs_event_rulebook_flag_ints(int32_t batch_size);
 int wfs_event_rulebook_subm(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
                             const int32_t *events, int32_t *nbr_out, void *slots, int32_t *flags, void *stream);
-/* Regular / strided conv (ndim <= 3, kernel 3 in every dim, prod(out_shape) * 6 bytes of LDS: wfs_event_rulebook_conv_ok):
- * the whole of wfs_rulebook_plan + wfs_rulebook_emit in two launches.  Inputs are taken to be distinct sites.  Writes
- * nbr_out [K, N] (-1 where an output lies beyond M_cap), nbr_in [K, M_cap], out_indices [M_cap, ndim + 1] (first-seen
- * order, A.3), out_events = the event offsets of the OUTPUT rows (same layout as wfs_event_offsets), info[0] = M,
- * *m_dev = min(M, M_cap), *overflow_dev = M > M_cap (each may be NULL), and optionally the cell -> row map of dense()
- * (cell_ticket / cell_row [batch * prod(out_shape)], see wfs_rulebook_cell_map) and slots_bwd, the records
- * wfs_event_conv's dX consumes (per INPUT row: its outputs, local to the event) and slots_fwd, the forward's (per OUTPUT
- * row: its inputs; M_cap records).  flags as for the SubM build; [0] also: an event with more outputs than the LDS image
- * of its nbr_in columns holds (>= 1024).
- * workspace: wfs_event_rulebook_conv_workspace_bytes(batch) bytes.                                                     */
-int wfs_event_rulebook_conv_ok(const wfs_geometry *g);
-size_t wfs_event_rulebook_conv_workspace_bytes(int32_t batch_size);
-int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
-                            const int32_t *in_events, int32_t *nbr_out, int32_t *nbr_in, int32_t *out_indices,
-                            int64_t M_cap, int32_t *out_events, int64_t *info, int64_t *m_dev, int32_t *overflow_dev,
-                            int32_t *flags, uint32_t *cell_ticket, int32_t *cell_row, void *slots_bwd, void *slots_fwd,
-                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same product when an nn.BatchNorm1d in TRAINING mode directly follows the convolution inside
  * spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508, SURVEY.md 8a rows a9 + a12): the conv

@@ -1,0 +1,183 @@
+"""GPU parity of the event-local SubM rulebook build (csrc/evrulebook.hip, include/wfsparse.h "Event-local rulebook
+build") through the C ABI: event offsets against numpy, nbr_out BIT-EXACT against the CPU oracle's spconv order
+(oracle/spconv_ref.c) and against the chip-wide build, the failure flags (batch column not sorted,
+duplicate coordinates, more active cells than the LDS tables hold), and a captured training step that must be
+bit-identical with the build on and off (same tables -> same arithmetic).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rand_coords
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from waveformml_amd import _lib
+    return _lib, _lib.load()
+
+
+def _offsets(idx_t, B, n_dev=None):
+    from waveformml_amd.spconv import ops
+    return ops.event_offsets(idx_t, B, n_dev)
+
+
+def _sorted_by_event(idx):
+    return np.ascontiguousarray(idx[np.argsort(idx[:, 0], kind="stable")])
+
+
+def _ev_subm(idx_t, B, shape, ksize, dilation=1, n_dev=None):
+    L, lib = _lib()
+    ndim = len(shape)
+    g = L.make_geometry(ndim, B, list(shape), [ksize] * ndim if np.isscalar(ksize) else list(ksize), [1] * ndim, [0] * ndim,
+                        [dilation] * ndim, True)
+    assert lib.wfs_event_rulebook_ok(ctypes.byref(g))
+    N = idx_t.shape[0]
+    ev = _offsets(idx_t, B, n_dev)
+    nbr = torch.full((int(g.K), N), -7, dtype=torch.int32, device=DEV)
+    flags = torch.full((int(lib.wfs_event_rulebook_flag_ints(B)),), 7, dtype=torch.int32, device=DEV)
+    L.check(lib.wfs_event_rulebook_subm(ctypes.byref(g), L.ptr(idx_t), N, L.ptr(n_dev), L.ptr(ev), L.ptr(nbr), None,
+                                        L.ptr(flags), L.stream_ptr()))
+    torch.cuda.synchronize()
+    nb = flags.numel() // 3
+    f = flags.cpu().numpy()
+    return nbr, (int(f[:nb].any()), int(f[nb:2 * nb].any()), int(f[2 * nb:].any())), ev
+
+
+def _oracle_nbr_out(idx, B, shape, ksize, dilation=1):
+    """nbr_out [K, N] from the oracle's indice_pairs (spconv's encoding): column k lists (input row, output row)."""
+    from oracle import ref
+    _out, pairs, num = ref.get_indice_pairs(idx, B, shape, ksize, 1, 0, dilation, 0, True)
+    K, N = pairs.shape[1], idx.shape[0]
+    nbr = np.full((K, N), -1, np.int32)
+    for k in range(K):
+        n = int(num[k])
+        nbr[k, pairs[0, k, :n]] = pairs[1, k, :n]
+    return nbr
+
+
+def test_event_offsets_against_numpy_and_flags():
+    rng = np.random.default_rng(5)
+    B = 37
+    b = np.sort(rng.integers(0, B, size=5000)).astype(np.int32)
+    b = b[(b != 3) & (b != 36)]                      # empty events in the middle and at the end
+    idx = np.stack([b, rng.integers(0, 9, len(b)), rng.integers(0, 64, len(b))], 1).astype(np.int32)
+    t = torch.from_numpy(idx).to(DEV)
+    ev = _offsets(t, B).cpu().numpy()
+    assert np.array_equal(ev[:B + 1], np.searchsorted(b, np.arange(B + 1)))
+    assert not ev[B + 1:].any()
+    # device-side row count: rows beyond it do not count
+    nv = torch.tensor([3000], dtype=torch.int64, device=DEV)
+    ev = _offsets(t, B, nv).cpu().numpy()
+    assert np.array_equal(ev[:B + 1], np.minimum(np.searchsorted(b, np.arange(B + 1)), 3000)) and not ev[B + 1:].any()
+    # not grouped by event / out of range -> a flag word is set
+    bad = idx.copy()
+    bad[[100, 2000]] = bad[[2000, 100]]
+    assert _offsets(torch.from_numpy(bad).to(DEV), B).cpu().numpy()[B + 1:].any()
+    bad = idx.copy()
+    bad[-1, 0] = B
+    assert _offsets(torch.from_numpy(bad).to(DEV), B).cpu().numpy()[B + 1:].any()
+    # no rows at all
+    ev = _offsets(torch.zeros((0, 3), dtype=torch.int32, device=DEV), B).cpu().numpy()
+    assert not ev.any()
+
+
+@pytest.mark.parametrize("shape,ksize,dilation", [((14, 11, 64), 3, 1), ((9, 40), 3, 1), ((50,), 3, 1), ((6, 5, 33), (3, 1, 3), 1),
+                                                  ((12, 30), 2, 1), ((8, 7, 20), 3, 2), ((5, 4, 3, 16), (1, 3, 3, 3), 1)])
+def test_event_local_subm_bitexact_vs_oracle(shape, ksize, dilation):
+    rng = np.random.default_rng(11)
+    B = 9
+    idx = _sorted_by_event(rand_coords(rng, B, shape, min(1500, B * int(np.prod(shape)) // 3)))
+    t = torch.from_numpy(idx).to(DEV)
+    nbr, flags, _ = _ev_subm(t, B, shape, ksize, dilation)
+    assert flags == (0, 0, 0)
+    want = _oracle_nbr_out(idx, B, shape, ksize, dilation)
+    assert np.array_equal(nbr.cpu().numpy(), want)
+
+
+def test_event_local_subm_at_psd_scale_equals_chipwide_build():
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.spconv import ops
+    B, T = 256, 256
+    c, _f, _y = synthetic.generate(B, T, 3, seed=77)
+    idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(DEV)
+    N = idx.shape[0]
+    cap = N + 777                                     # device-count mode: capacity rows beyond the valid count
+    pad = torch.cat([idx, torch.full((cap - N, 4), 123456, dtype=torch.int32, device=DEV)])
+    nv = torch.tensor([N], dtype=torch.int64, device=DEV)
+    nbr, flags, _ = _ev_subm(pad, B, (14, 11, T), 3, 1, nv)
+    assert flags == (0, 0, 0)
+    rb = ops.build_rulebook(idx, B, [14, 11, T], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True)
+    assert torch.equal(nbr[:, :N], rb.nbr_out)
+
+
+def test_event_local_subm_flags():
+    rng = np.random.default_rng(3)
+    B, shape = 6, (14, 11, 32)
+    idx = _sorted_by_event(rand_coords(rng, B, shape, 900))
+    # batch column not sorted
+    bad = idx.copy()
+    bad[[10, 700]] = bad[[700, 10]]
+    _, flags, _ = _ev_subm(torch.from_numpy(bad).to(DEV), B, shape, 3)
+    assert flags[0] == 1
+    # duplicate coordinates: detected (the caller then takes the chip-wide build, which resolves "the last row wins")
+    dup = np.concatenate([idx[:50], idx[:1], idx[50:]])
+    dup = _sorted_by_event(dup)
+    _, flags, _ = _ev_subm(torch.from_numpy(dup).to(DEV), B, shape, 3)
+    assert flags[1] == 1 and flags[0] == 0
+    # an index outside the spatial shape
+    out = idx.copy()
+    out[5, 3] = 32
+    _, flags, _ = _ev_subm(torch.from_numpy(out).to(DEV), B, shape, 3)
+    assert flags[2] == 1
+    # more active cells in one event than the LDS sample arrays hold (64 KiB = 32 cells of 1024 samples): flagged, not wrong
+    many = np.array([(0, x, y, 0) for x in range(14) for y in range(11)], np.int32)
+    _, flags, _ = _ev_subm(torch.from_numpy(many).to(DEV), 1, (14, 11, 1024), 3)
+    assert flags[0] == 1
+
+
+def test_captured_step_identical_with_and_without_event_local_build():
+    """Same tables -> the captured step is bit-identical; check() stays silent on well-formed batches."""
+    import copy
+    import json
+    import os
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.config import DictionaryUtility
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    from waveformml_amd.psd.graph import GraphedTrainStep
+    from waveformml_amd.psd.lit import LitPSD
+    from waveformml_amd.spconv import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "config", "psd_c2_3d.json")) as f:
+        cfg = json.load(f)
+    T, B = 64, 32
+    cfg["system_config"]["n_samples"] = T
+    cfg["net_config"]["algorithm"][-1] = [32 * 10 * 7 * 4, 3]
+    batches = []
+    for seed in (5, 6, 7):
+        c, f, y = synthetic.generate(B, T, 3, seed=seed)
+        batches.append(([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV)))
+    losses, params = [], []
+    old = ops.EVENT_LOCAL
+    try:
+        for on in (False, True):
+            ops.EVENT_LOCAL = on
+            torch.manual_seed(0)
+            mod = LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg))).to(DEV)
+            red = FlatGradAllReducer(mod.model.parameters(), world_size=1)
+            mod.optimizer_parameters = red.optimizer_parameters()
+            opt = mod.configure_optimizers()[0][0]
+            step = GraphedTrainStep(mod, opt, red, batches[0])
+            ls = [float(step(bt)) for bt in batches]
+            step.check()
+            assert bool(step._event_flags) == on
+            losses.append(ls)
+            params.append(red.flat_param.detach().clone())
+    finally:
+        ops.EVENT_LOCAL = old
+    assert losses[0] == losses[1], losses
+    assert torch.equal(params[0], params[1])

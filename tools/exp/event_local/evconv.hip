@@ -1,13 +1,12 @@
-// evconv.hip -- EVENT-LOCAL sparse convolution kernels (round 3).
+// evconv.hip -- EVENT-LOCAL sparse convolution kernels (round 3 experiment; NOT part of libwfsparse: verified bit-equal to the
+// tile-parallel kernel, measured no faster inside the step -- see README.md here and profiles/r03_event_local_*).
 //
 // A sparse convolution never crosses events: the rulebook key includes the batch index, and the
 // reference's collate_fn (src/engineering/PSDDataModule.py:10-20) concatenates the items of a batch in order, so the
 // rows of one event are ONE contiguous range of every row set of the net -- the input voxels, and (first-seen numbering
 // walks the inputs in order) the outputs of every regular conv.  These kernels use that:
 //
-//   k_event_offsets   row range of every event of an index set [N, D+1] (batch column non-decreasing), plus per-block
-//                     flags that say whether the column really is non-decreasing and in range (verified on the device,
-//                     every launch: a row set that is not grouped by event takes the tile-parallel path below)
+//   (k_event_offsets, the row range of every event of an index set, lives in the product: csrc/evrulebook.hip)
 //   k_slot_table      a gather table int32 [K, R] re-encoded per event: slot k of row r = 1 + (source row - first input
 //                     row of r's event) as uint16, 0 = no neighbour; one 64-byte record per output row (32 slots)
 //   k_evconv32        32 -> 32 channel gather conv (forward, dX with the transposed filter; SubM, regular, inverse --
@@ -21,6 +20,7 @@
 // Same arithmetic as k_gconv32_bf16: v_mfma_f32_32x32x16_bf16 / _f16, fp32 accumulate, filters rounded to the row type
 // while they are staged; the order of the fp32 sum over offsets is the same (increasing k).
 #include "wfs_common.h"
+#include "event_local.h"
 
 namespace {
 
@@ -28,8 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int EV_FLAG_BLOCKS = WFS_EVENT_FLAG_WORDS;      // k_event_offsets runs this many blocks, one flag word each
 
 __device__ __forceinline__ long long valid_rows(long long R, const long long *r_dev) {
     long long v = r_dev ? *r_dev : R;
@@ -53,31 +51,6 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {
     v.z = ok ? v.z : 0u;
     v.w = ok ? v.w : 0u;
     return v;
-}
-
-// ------------------------------------------------------------------------------------------ event offsets
-// off[e] = first row of event e (e = 0 .. B; off[B] = number of valid rows); off[B + 1 + blk] = 1 if block blk saw a
-// batch index out of [0, B) or smaller than its predecessor's.  Every word is written by every launch (no clearing).
-__global__ void __launch_bounds__(256) k_event_offsets(const int *__restrict__ idx, long long N, int cols, int B,
-                                                       const long long *__restrict__ n_dev, int *__restrict__ off) {
-    const long long Nv = valid_rows(N, n_dev);
-    int bad = 0;
-    if (Nv == 0) {
-        for (int e = blockIdx.x * 256 + threadIdx.x; e <= B; e += gridDim.x * 256) off[e] = 0;
-    }
-    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < Nv; j += (long long)gridDim.x * 256) {
-        const int b = idx[j * cols];
-        const int bp = j > 0 ? idx[(j - 1) * cols] : -1;
-        const bool ok = b >= 0 && b < B && b >= bp && bp >= -1 && bp < B;
-        bad |= ok ? 0 : 1;
-        if (ok) {
-            for (int e = bp + 1; e <= b; ++e) off[e] = (int)j;
-            if (j == Nv - 1)
-                for (int e = b + 1; e <= B; ++e) off[e] = (int)Nv;
-        }
-    }
-    bad = __syncthreads_or(bad);
-    if (threadIdx.x == 0) off[B + 1 + blockIdx.x] = bad;
 }
 
 // ------------------------------------------------------------------------------------------ slot tables
@@ -126,7 +99,9 @@ constexpr int EV_WAVES = EV_THREADS / 64;
 constexpr int EV_ROWLOADS = 8;         // 16-byte row chunks per thread in flight at once: 1024 rows (larger events: more trips)
 constexpr int EV_STRIDE = 80;
 
-template <typename H, bool TRANSPOSE_W>
+// MIRROR: the slot records are in the TABLE's offset order and the table is read mirrored (SubM forward through nbr_out:
+// offset k gathers through entry 26 - k; K = 27 only, so that the entry index is a compile-time constant)
+template <typename H, bool TRANSPOSE_W, bool MIRROR>
 __global__ void __launch_bounds__(EV_THREADS) k_evconv32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                          long long R, const long long *__restrict__ r_dev,
                                                          const uint4 *__restrict__ ctab, const int *__restrict__ out_ev,
@@ -222,7 +197,7 @@ __global__ void __launch_bounds__(EV_THREADS) k_evconv32(const int *__restrict__
             // does any row of the two tiles use one of the group's three offsets?
             unsigned any = 0;
 #pragma unroll
-            for (int kk = 0; kk < 3; ++kk) any |= slot_of(ca, 3 * g + kk) | slot_of(cb, 3 * g + kk);
+            for (int kk = 0; kk < 3; ++kk) any |= slot_of(ca, MIRROR ? 26 - (3 * g + kk) : 3 * g + kk) | slot_of(cb, MIRROR ? 26 - (3 * g + kk) : 3 * g + kk);
             if ((EV_KNOCK & 1) || __ballot(any != 0u) == 0ull) continue;
             // all operands of the group's three offsets are asked for before the first MFMA
             uint4 b0[3], b1[3], alo[3], ahi[3], blo[3], bhi[3];
@@ -233,8 +208,9 @@ __global__ void __launch_bounds__(EV_THREADS) k_evconv32(const int *__restrict__
                 const uint4 *bp = sWb + kc * 128 + h * 32 + r;
                 b0[kk] = bp[0];
                 b1[kk] = bp[64];
-                const unsigned char *xa = sXb + ((EV_KNOCK & 256) ? 0u : slot_of(ca, k)) * EV_STRIDE + 32 * h;
-                const unsigned char *xb = sXb + ((EV_KNOCK & 256) ? 0u : slot_of(cb, k)) * EV_STRIDE + 32 * h;
+                const int ke = MIRROR ? 26 - k : k;
+                const unsigned char *xa = sXb + ((EV_KNOCK & 256) ? 0u : slot_of(ca, ke)) * EV_STRIDE + 32 * h;
+                const unsigned char *xb = sXb + ((EV_KNOCK & 256) ? 0u : slot_of(cb, ke)) * EV_STRIDE + 32 * h;
                 alo[kk] = *reinterpret_cast<const uint4 *>(xa);
                 ahi[kk] = *reinterpret_cast<const uint4 *>(xa + 16);
                 blo[kk] = *reinterpret_cast<const uint4 *>(xb);
@@ -390,22 +366,6 @@ __global__ void __launch_bounds__(EV_THREADS) k_evconv32(const int *__restrict__
 
 }  // namespace
 
-extern "C" size_t wfs_event_offsets_ints(int32_t batch_size) {
-    return (size_t)(batch_size > 0 ? batch_size : 0) + 1 + EV_FLAG_BLOCKS;
-}
-
-extern "C" int wfs_event_offsets(const int32_t *indices, int64_t N, int32_t ndim, int32_t batch_size,
-                                 const int64_t *n_dev, int32_t *offsets, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    WFS_REQUIRE(offsets && (indices || N == 0), WFS_EINVAL, "NULL device pointer");
-    WFS_REQUIRE(ndim >= 1 && ndim <= WFS_MAX_DIM && batch_size >= 1 && N >= 0 && N < (1ll << 31), WFS_EINVAL,
-                "bad shape");
-    k_event_offsets<<<dim3(EV_FLAG_BLOCKS), dim3(256), 0, stream>>>(indices, N, ndim + 1, batch_size,
-                                                                    (const long long *)n_dev, offsets);
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
-}
-
 extern "C" int wfs_event_conv_ok(int32_t K, int32_t Cx, int32_t Cw_in, int32_t Cw_out, int32_t dtype,
                                  int32_t batch_size) {
     return (dtype == WFS_BF16 || dtype == WFS_F16) && Cx == 32 && Cw_in == 32 && Cw_out == 32 && K >= 1 && K <= 27 &&
@@ -430,8 +390,8 @@ extern "C" int wfs_slot_table(const int32_t *table, int32_t mirror, int32_t K, i
 
 template <typename H>
 static int launch_evconv(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
-                         const uint4 *ctab, const int *out_ev, const int *in_ev, int B, const H *X, const float *W,
-                         int transpose_w, const float *bias, H *Y, hipStream_t stream) {
+                         const uint4 *ctab, int slots_mirror, const int *out_ev, const int *in_ev, int B, const H *X,
+                         const float *W, int transpose_w, const float *bias, H *Y, hipStream_t stream) {
     // LDS: filters K * 2 KiB, then as many 80-byte rows as fit under 160 KiB (+ the zero row)
     const size_t budget = 160 * 1024 - 512;
     int cap = (int)((budget - (size_t)K * 2048) / EV_STRIDE) - 1;
@@ -443,9 +403,10 @@ static int launch_evconv(const int *table, int mirror, int K, int identity_k, lo
         nblk = (R + 32 * EV_WAVES - 1) / (32 * EV_WAVES);
         if (nblk > 256) nblk = 256;
     }
-    static bool attr[2] = {false, false};
-    auto kern = transpose_w ? k_evconv32<H, true> : k_evconv32<H, false>;
-    bool *done = &attr[transpose_w ? 1 : 0];
+    static bool attr[4] = {false, false, false, false};
+    auto kern = slots_mirror ? (transpose_w ? k_evconv32<H, true, true> : k_evconv32<H, false, true>)
+                             : (transpose_w ? k_evconv32<H, true, false> : k_evconv32<H, false, false>);
+    bool *done = &attr[(transpose_w ? 1 : 0) + (slots_mirror ? 2 : 0)];
     if (!*done) {
         WFS_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
         *done = true;
@@ -457,21 +418,23 @@ static int launch_evconv(const int *table, int mirror, int K, int identity_k, lo
 }
 
 extern "C" int wfs_event_conv(const int32_t *table, int32_t mirror, int32_t K, int32_t identity_k, int64_t R,
-                              const void *slots, const int32_t *out_events, const int32_t *in_events,
-                              int32_t batch_size, const void *X, const float *W, int32_t transpose_w, const float *bias,
-                              void *Y, int32_t dtype, const int64_t *r_dev, void *stream_) {
+                              const void *slots, int32_t slots_mirror, const int32_t *out_events,
+                              const int32_t *in_events, int32_t batch_size, const void *X, const float *W,
+                              int32_t transpose_w, const float *bias, void *Y, int32_t dtype, const int64_t *r_dev,
+                              void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(wfs_event_conv_ok(K, 32, 32, 32, dtype, batch_size), WFS_EINVAL,
                 "wfs_event_conv covers 32 -> 32 channels, 16-bit rows, K <= 27");
     if (R == 0) return WFS_OK;
     WFS_REQUIRE(table && slots && out_events && in_events && X && W && Y, WFS_EINVAL, "NULL device pointer");
     WFS_REQUIRE(identity_k < K && (long long)K * R < (1ll << 31), WFS_EINVAL, "identity_k / K * R out of range");
+    WFS_REQUIRE(!slots_mirror || K == 27, WFS_EINVAL, "mirrored slot records: K = 27 only");
     WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
     if (dtype == WFS_F16)
         return launch_evconv<wfs_f16>(table, mirror, K, identity_k, R, (const long long *)r_dev, (const uint4 *)slots,
-                                      out_events, in_events, batch_size, (const wfs_f16 *)X, W, transpose_w, bias,
-                                      (wfs_f16 *)Y, stream);
+                                      slots_mirror, out_events, in_events, batch_size, (const wfs_f16 *)X, W, transpose_w,
+                                      bias, (wfs_f16 *)Y, stream);
     return launch_evconv<wfs_bf16>(table, mirror, K, identity_k, R, (const long long *)r_dev, (const uint4 *)slots,
-                                   out_events, in_events, batch_size, (const wfs_bf16 *)X, W, transpose_w, bias,
-                                   (wfs_bf16 *)Y, stream);
+                                   slots_mirror, out_events, in_events, batch_size, (const wfs_bf16 *)X, W, transpose_w,
+                                   bias, (wfs_bf16 *)Y, stream);
 }

@@ -2,7 +2,8 @@
 results compared, then each timed inside a replayed HIP graph.
 usage: python tools/microbench_evconv.py [iters] [events]"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(HERE))))
 import numpy as np, torch
 from waveformml_amd import _lib
 from waveformml_amd.psd import synthetic
@@ -13,6 +14,25 @@ NB = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 DT = torch.bfloat16
 dev = torch.device("cuda:0")
 lib = _lib.load()
+# the experiments' own library (make -C tools/exp/event_local), resolved after the product's symbols
+xlib = ctypes.CDLL(os.environ.get("WFS_EVEXP_LIB") or os.path.join(HERE, "libwfs_evexp.so"))
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+xlib.wfs_slot_table.argtypes = [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp]
+xlib.wfs_event_conv.argtypes = [_vp, _i32, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]
+xlib.wfs_event_rulebook_conv.argtypes = [ctypes.POINTER(_lib.Geometry), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]
+xlib.wfs_event_rulebook_conv_workspace_bytes.argtypes = [_i32]
+xlib.wfs_event_rulebook_conv_workspace_bytes.restype = ctypes.c_size_t
+for _n in ("wfs_slot_table", "wfs_event_conv", "wfs_event_rulebook_conv"):
+    getattr(xlib, _n).restype = ctypes.c_int
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def I64(v):
+    return ctypes.c_int64(int(v))
 c, f, y = synthetic.generate(NB, 256, 3, seed=1234)
 torch.cuda.set_stream(torch.cuda.Stream())
 idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(dev)
@@ -46,7 +66,7 @@ def slots_of(table, mirror, ident, R, ev_o, ev_i):
     key = (table.data_ptr(), mirror, ident, ev_o.data_ptr(), ev_i.data_ptr())
     if key not in _SLOTS:
         s = torch.empty((R, 32), dtype=torch.int16, device=dev)
-        _lib.check(lib.wfs_slot_table(_lib.ptr(table), mirror, 27, ident, R, _lib.ptr(ev_o), _lib.ptr(ev_i), NB, None,
+        _lib.check(xlib.wfs_slot_table(_lib.ptr(table), mirror, 27, ident, R, _lib.ptr(ev_o), _lib.ptr(ev_i), NB, None,
                                       _lib.ptr(s), _lib.stream_ptr()))
         _SLOTS[key] = s
     return _SLOTS[key]
@@ -55,7 +75,7 @@ def slots_of(table, mirror, ident, R, ev_o, ev_i):
 def evconv(table, mirror, ident, R, ev_o, ev_i, Xin, tr, b=None):
     Y = torch.empty((R, 32), dtype=DT, device=dev)
     sl = slots_of(table, mirror, ident, R, ev_o, ev_i)
-    _lib.check(lib.wfs_event_conv(_lib.ptr(table), mirror, 27, ident, R, _lib.ptr(sl), _lib.ptr(ev_o), _lib.ptr(ev_i), NB, _lib.ptr(Xin),
+    _lib.check(xlib.wfs_event_conv(_lib.ptr(table), mirror, 27, ident, R, _lib.ptr(sl), 0, _lib.ptr(ev_o), _lib.ptr(ev_i), NB, _lib.ptr(Xin),
                                   _lib.ptr(W), 1 if tr else 0, _lib.ptr(b), _lib.ptr(Y), _lib.dtype_code(Xin), None,
                                   _lib.stream_ptr()))
     return Y
@@ -117,7 +137,7 @@ timeit("event offsets (N rows)", lambda: offsets(idx, N))
 
 def mk_slots():
     s = torch.empty((N, 32), dtype=torch.int16, device=dev)
-    _lib.check(lib.wfs_slot_table(_lib.ptr(t), 1, 27, rb.centre_k, N, _lib.ptr(ev_in), _lib.ptr(ev_in), NB, None, _lib.ptr(s),
+    _lib.check(xlib.wfs_slot_table(_lib.ptr(t), 1, 27, rb.centre_k, N, _lib.ptr(ev_in), _lib.ptr(ev_in), NB, None, _lib.ptr(s),
                                   _lib.stream_ptr()))
     return s
 

@@ -71,16 +71,9 @@ SIGNATURES = {
                                        _vp, _vp, _i32, _vp, _vp]),
     "wfs_event_offsets_ints": (_sz, [_i32]),
     "wfs_event_offsets": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "wfs_event_conv_ok": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
-    "wfs_slot_table": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "wfs_event_conv": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp,
-                                      _vp]),
     "wfs_event_rulebook_ok": (ctypes.c_int, [ctypes.POINTER(Geometry)]),
+    "wfs_event_rulebook_flag_ints": (_sz, [_i32]),
     "wfs_event_rulebook_subm": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "wfs_event_rulebook_conv_ok": (ctypes.c_int, [ctypes.POINTER(Geometry)]),
-    "wfs_event_rulebook_conv_workspace_bytes": (_sz, [_i32]),
-    "wfs_event_rulebook_conv": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
-                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "wfs_conv_stats_workspace_bytes": (_sz, [_i64, _i32]),
     "wfs_gather_conv_bnstats": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp,
                                                _i32, _vp, ctypes.POINTER(BnStats), c_i32p, _vp]),

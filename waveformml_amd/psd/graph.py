@@ -118,6 +118,7 @@ class GraphedTrainStep(object):
             reducer.remove()
             self._warm_and_capture(warmup)
         self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
+        self._event_flags = _event_flags(module)
 
     def _warm_and_capture(self, warmup):
         for _ in range(warmup):
@@ -230,10 +231,30 @@ class GraphedTrainStep(object):
         flag = torch.zeros((), dtype=torch.int32, device=self.coords.device)
         if self._overflow:
             flag = torch.stack([o.reshape(()) for o in self._overflow]).any().to(torch.int32)
+        evf = torch.zeros((), dtype=torch.int32, device=self.coords.device)
+        for f in getattr(self, "_event_flags", ()):
+            evf = evf | f[: 2 * (f.numel() // 3)].any().to(torch.int32)
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            dist.all_reduce(evf, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        if bool(evf.item()):
+            raise RuntimeError("a batch was not grouped by event (or an event exceeded the LDS tables of the event-local "
+                               "rulebook build, or held duplicate coordinates); set WFS_EVENT_LOCAL=0 and re-capture")
         if self.world > 1 and dist.is_available() and dist.is_initialized():
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
         if bool(flag.item()):
             raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
+
+
+def _event_flags(module):
+    """Failure flags of the event-local rulebook builds of the module's conv layers (spconv.ops.EVENT_LOCAL)."""
+    out, seen = [], set()
+    for m in module.modules():
+        rb = getattr(m, "last_rulebook", None)
+        f = getattr(rb, "event_flags", None) if rb is not None else None
+        if f is not None and f.data_ptr() not in seen:
+            seen.add(f.data_ptr())
+            out.append(f)
+    return out
 
 
 class GraphedEvalStep(object):

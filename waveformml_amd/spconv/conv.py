@@ -116,7 +116,10 @@ class SparseConvolution(SparseModule):
                 rb = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride,
                                         self.padding, self.dilation, self.subm, known_unique=input.unique,
                                         n_dev=input.n_valid, out_capacity=getattr(self, "out_capacity", None),
-                                        transposed=self.transposed, output_padding=self.output_padding)
+                                        transposed=self.transposed, output_padding=self.output_padding,
+                                        events=getattr(input, "events", None))
+                if getattr(rb, "events_in", None) is not None:
+                    input.events = rb.events_in          # the offsets of this row set, for the layers that follow
                 self.last_rulebook = rb          # capacity calibration / overflow checks of graph-captured steps
                 input.unique = not rb.has_dup
                 input.indice_dict[self.indice_key] = IndiceData(rb, spatial_shape)
@@ -142,6 +145,8 @@ class SparseConvolution(SparseModule):
         out_tensor.unique = out_unique
         out_tensor.n_valid = out_n_valid
         out_tensor.prefetched = getattr(input, "prefetched", None)
+        if self.subm:
+            out_tensor.events = getattr(input, "events", None)          # same row set, same event offsets
         out_tensor.bn_stats = bn_request if (bn_request is not None and bn_request.stats is not None) else None
         if not self.subm and not self.inverse:
             out_tensor.cell_map = getattr(rb, "cell_map", None)      # dense() of THIS row set can use the build's map

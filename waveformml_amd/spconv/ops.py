@@ -78,6 +78,16 @@ DEFER_BATCH_NORM = os.environ.get("WFS_DEFER_BATCH_NORM", "0") != "0"
 # with those reads issued after the last gather): 0.570 vs 0.566 ms per step, same-box A/B.
 FUSE_BN_BACKWARD_SUMS = os.environ.get("WFS_FUSE_BN_BACKWARD_SUMS", "0") != "0"
 
+# Event-local SubM rulebook build (round 3; csrc/evrulebook.hip): in device-count mode -- captured steps, where the index
+# rows come from the reference's collate_fn, i.e. grouped by event -- a SubM rulebook is built by a pair of workgroups
+# per event with the event's site table in LDS: no site grid over the batch in HBM (18.5 MB cleared per build at the PSD
+# batch), no global atomics, traffic = coordinates in + table out; 12.7 vs 22 us alone, the same inside the step;
+# bit-identical tables.  The grouping is verified on the device by every build; a batch that violates it (or an event
+# beyond the LDS tables, or duplicate coordinates) raises a flag that GraphedTrainStep.check() reports like a capacity
+# overflow.  WFS_EVENT_LOCAL=0: the chip-wide build.
+EVENT_LOCAL = os.environ.get("WFS_EVENT_LOCAL", "1") != "0"
+EVENT_LOCAL_MAX_BATCH = 16384
+
 _SIDE_STREAMS = {}
 
 
@@ -145,6 +155,11 @@ class Rulebook(object):
         # regular conv built on a direct grid: (ticket ptr, slot_id ptr, workspace kept alive, out volume) -- the
         # cell -> output row map of the build, which dense() of the conv's output can use (wfs_to_dense_mapped)
         self.cell_map = None
+        # event-local build (device-count mode, see EVENT_LOCAL): offsets of the events in the row set
+        # (wfs_event_offsets) and the build's failure flags (any word != 0 in the first two thirds: the table is
+        # incomplete -- reported by the captured step's check())
+        self.events_in = None
+        self.event_flags = None
         self._pairs = None
         self._pair_num = None
 
@@ -240,8 +255,18 @@ def reused(tag, source, make):
     return hit[0]
 
 
+def event_offsets(indices, batch_size, n_dev=None):
+    """int32 [batch + 1 + flag words]: first row of every event of an index set grouped by event (wfs_event_offsets)."""
+    lib = _lib.load()
+    out = torch.empty((int(lib.wfs_event_offsets_ints(int(batch_size))),), dtype=torch.int32, device=indices.device)
+    _lib.check(lib.wfs_event_offsets(_lib.ptr(indices), indices.shape[0], indices.shape[1] - 1, int(batch_size),
+                                     _lib.ptr(n_dev), _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                   known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None):
+                   known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None,
+                   events=None):
     """Cached front of :func:`_build_rulebook` (see :class:`reuse_rulebooks`)."""
     global BUILD_COUNT
     if transposed:
@@ -251,7 +276,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     if _REUSE is None:
         BUILD_COUNT += 1
         return _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                               known_unique, n_dev, out_capacity)
+                               known_unique, n_dev, out_capacity, events=events)
     ndim = indices.shape[1] - 1
     key = (indices.data_ptr(), tuple(indices.shape), tuple(indices.stride()), int(batch_size),
            tuple(int(s) for s in spatial_shape), tuple(_listify(ksize, ndim)), tuple(_listify(stride, ndim)),
@@ -268,7 +293,8 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
 
 
 def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                    known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None):
+                    known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None,
+                    events=None):
     """Builds the device rulebook.  ``known_unique``: True if the caller knows the index rows are
     distinct sites (skips the duplicate check a regular conv would otherwise run once).
 
@@ -308,9 +334,19 @@ def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, 
             rb.M = m_cap
             rb.m_dev = torch.empty((1,), dtype=torch.int64, device=dev)        # written by the plan
             rb.overflow = torch.empty((1,), dtype=torch.int32, device=dev)     # cleared, then set, by the emit
-        _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
-                                         ws.numel(), None, _lib.ptr(n_dev), None if subm else _lib.ptr(rb.m_dev),
-                                         m_cap, stream))
+        if (subm and EVENT_LOCAL and N > 0 and 1 <= int(batch_size) <= EVENT_LOCAL_MAX_BATCH
+                and lib.wfs_event_rulebook_ok(ctypes.byref(g))):
+            # a pair of workgroups per event, site table in LDS
+            rb.events_in = events if events is not None else event_offsets(indices, batch_size, n_dev)
+            rb.event_flags = torch.empty((int(lib.wfs_event_rulebook_flag_ints(int(batch_size))),), dtype=torch.int32,
+                                         device=dev)
+            _lib.check(lib.wfs_event_rulebook_subm(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(n_dev),
+                                                   _lib.ptr(rb.events_in), _lib.ptr(rb.nbr_out), None,
+                                                   _lib.ptr(rb.event_flags), stream))
+        else:
+            _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
+                                             ws.numel(), None, _lib.ptr(n_dev), None if subm else _lib.ptr(rb.m_dev),
+                                             m_cap, stream))
         rb.has_dup = False
     elif subm and known_unique:
         _lib.check(lib.wfs_rulebook_plan(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(rb.nbr_out), _lib.ptr(ws),
