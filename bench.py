@@ -326,6 +326,30 @@ def parity(cpu_logits, cpu_loss, gpu_logits, gpu_loss):
             "loss_cpu": cpu_loss, "loss_gpu": gpu_loss, "rel_loss_diff": abs(cpu_loss - gpu_loss) / max(abs(cpu_loss), 1e-30)}
 
 
+def visible_gpus():
+    """Number of GPU agents the kernel driver exposes, read from sysfs (KFD topology: a node with SIMDs is a GPU), cut
+    to the devices ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES leave visible; None when the
+    topology cannot be read (then the children find out).  No HIP / torch.cuda call is made."""
+    import glob
+    nodes = glob.glob(os.path.join(os.environ.get("WFS_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology"), "nodes", "*", "properties"))
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            with open(path) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks here, one child process per
     GPU, BEFORE this process makes any GPU call (a process that has initialised the GPU must not exec or fork GPU work).
@@ -335,8 +359,8 @@ def launch_ranks(args):
     import subprocess
     n = args.gpus
     if not os.environ.get("WFS_REHEARSAL_ONE_GPU"):
-        have = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
-        if have < n:
+        have = visible_gpus()                     # from sysfs: this parent must not touch the GPU runtime before it forks
+        if have is not None and have < n:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (WFS_REHEARSAL_ONE_GPU=1 runs N ranks on one "
                              "card over gloo as a dry run of the N-rank code path)" % (n, have))
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:

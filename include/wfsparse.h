@@ -59,7 +59,11 @@ extern "C" {
 
 #define WFS_MAX_DIM 4
 
-/* library / device ------------------------------------------------------------------------ */
+/* library / device ------------------------------------------------------------------------
+ * WFS_ABI_VERSION changes whenever a struct layout or an exported signature does (3: round 3 -- wfs_geometry grew
+ * `transposed` / `output_padding` in round 2, the event-local build joined in round 3).  A binding compiled against
+ * another version must refuse the library: waveformml_amd/_lib.py does. */
+#define WFS_ABI_VERSION 3
 int wfs_abi_version(void);
 const char *wfs_last_error(void);
 

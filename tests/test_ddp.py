@@ -157,3 +157,41 @@ def test_two_ranks_read_disjoint_items():
             assert set(a).isdisjoint(b) and sorted(a + b) == list(range(8)), (shuffle, epoch, a, b)
     assert out[0][True][0] != out[0][True][1]                    # another permutation per epoch
     assert out[0][False][0] == out[0][False][1] == [0, 2, 4, 6]
+
+
+def _agree_worker(rank, world, port, out):
+    from waveformml_amd.psd.graph import _agree_max
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out[rank] = (_agree_max(1 if rank == 1 else 0, None), _agree_max(0, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_one_sided_capture_failure():
+    """psd/graph.py: whether the in-graph exchange could be captured is decided by ALL ranks (MAX over a host-side flag
+    on a gloo side group) -- a failure on one rank only must send every rank down the exchange-after-replay path."""
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_agree_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == (1, 0) and out[1] == (1, 0)
+
+
+def test_bench_counts_gpus_from_sysfs_without_the_runtime(tmp_path, monkeypatch):
+    """bench.py's launcher parent must not touch the GPU runtime before it starts its ranks: devices are counted from
+    the KFD topology (a node with SIMDs is a GPU; CPU nodes have none), cut by *_VISIBLE_DEVICES."""
+    import importlib
+    bench = importlib.import_module("bench")
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):
+        d = tmp_path / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    monkeypatch.setenv("WFS_KFD_TOPOLOGY", str(tmp_path))
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
+    monkeypatch.setenv("WFS_KFD_TOPOLOGY", str(tmp_path / "nowhere"))
+    assert bench.visible_gpus() is None

@@ -181,3 +181,47 @@ def test_captured_step_identical_with_and_without_event_local_build():
         ops.EVENT_LOCAL = old
     assert losses[0] == losses[1], losses
     assert torch.equal(params[0], params[1])
+
+
+def test_resume_from_checkpoint_keeps_the_momentum_under_capture(tmp_path):
+    """Trainer(resume_from_checkpoint=, capture=True): the capture's calibration / warm-up steps must not be folded
+    into the checkpointed momentum.  One epoch eager -> checkpoint -> one more epoch, eager and captured:
+    same parameters and momentum (1e-5 of scale: a replayed step sums some reductions in another order)."""
+    import copy
+    import json
+    import os
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.config import DictionaryUtility
+    from waveformml_amd.psd.lit import LitPSD
+    from waveformml_amd.psd.trainer import Trainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "config", "psd_c2_3d.json")) as f:
+        cfg = json.load(f)
+    T, B = 64, 16
+    cfg["system_config"]["n_samples"] = T
+    cfg["net_config"]["algorithm"][-1] = [32 * 10 * 7 * 4, 3]
+    cfg["optimize_config"].pop("scheduler_class", None)
+    batches = []
+    for seed in (21, 22, 23):
+        c, f, y = synthetic.generate(B, T, 3, seed=seed)
+        batches.append(([torch.from_numpy(c), torch.from_numpy(f)], torch.from_numpy(y)))
+
+    def module():
+        torch.manual_seed(3)
+        return LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg)))
+
+    # one epoch, then a checkpoint with the optimizer's momentum in it
+    t_save = Trainer(max_epochs=1, device=DEV, default_root_dir=str(tmp_path))
+    m1 = module()
+    t_save.fit(m1, batches, val_loader=batches)
+    ck = t_save.last_checkpoint
+    assert ck is not None
+    res = {}
+    for capture in (False, True):
+        m = module()
+        tr = Trainer(max_epochs=2, device=DEV, capture=capture, resume_from_checkpoint=ck)
+        hist = tr.fit(m, batches)
+        assert [h["epoch"] for h in hist] == [1]
+        res[capture] = torch.cat([p.detach().flatten().float().cpu() for p in m.model.parameters()])
+    scale = float(res[False].abs().max())
+    assert float((res[False] - res[True]).abs().max()) <= 2e-5 * scale

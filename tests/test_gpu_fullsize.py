@@ -208,10 +208,15 @@ import numpy as np
 import torch
 import torch.distributed as dist
 rank, world, mode, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1], sys.argv[2]
-torch.cuda.set_device(0)
-dev = torch.device("cuda", 0)
+backend = os.environ.get("WFS_TEST_BACKEND", "gloo")
+local = rank if backend == "nccl" else 0          # nccl: one device per rank; gloo: the ranks share the card
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
 torch.cuda.set_stream(torch.cuda.Stream(dev))
-dist.init_process_group("gloo", rank=rank, world_size=world)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 from test_gpu_fullsize import _rank_run
 res = _rank_run(rank, world, mode, dev)
 torch.save(res, out + ".rank%d" % rank)
@@ -304,9 +309,11 @@ def _rank_run(rank, world, mode, dev):
             step(b)
             grads.append(red.flat_grad.detach().cpu().clone())
         step.check()
+        in_graph = bool(step.in_graph_exchange)
     torch.cuda.synchronize()
     return {"grads": grads, "params": red.flat_param.detach().cpu().clone(),
-            "bn": [t.detach().float().cpu().clone() for t in mod.buffers()]}
+            "bn": [t.detach().float().cpu().clone() for t in mod.buffers()],
+            "in_graph_exchange": in_graph if mode != "eager" else False}
 
 
 @pytest.mark.parametrize("mode", ["eager", "graph"])
@@ -348,7 +355,7 @@ def test_two_ranks_step_the_hip_net_on_one_card(mode, tmp_path):
     _assert_close(r0["grads"][0].numpy(), want.numpy(), 1e-5 if mode == "eager" else 1e-4, "averaged gradient, step 1")
 
 
-def _launch_two_ranks(tmp_path, mode):
+def _launch_two_ranks(tmp_path, mode, backend="gloo"):
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT.format(root=ROOT))
     with socket.socket() as s:
@@ -359,6 +366,9 @@ def _launch_two_ranks(tmp_path, mode):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", WFS_REHEARSAL_ONE_GPU="1")
+        if backend == "nccl":
+            env.update(LOCAL_RANK=str(r), WFS_TEST_BACKEND="nccl")
+            env.pop("WFS_REHEARSAL_ONE_GPU")
         procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, cwd=ROOT))
     try:
         for p in procs:
@@ -368,6 +378,38 @@ def _launch_two_ranks(tmp_path, mode):
             if p.poll() is None:
                 p.kill()
     return [torch.load(out + ".rank%d" % r, weights_only=True) for r in range(2)]
+
+
+def _two_devices():
+    """Counting devices does not initialise the GPU on this image; the children each take their own."""
+    return torch.cuda.device_count() >= 2
+
+
+@pytest.mark.skipif(not _two_devices(), reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_ranks_over_rccl_on_two_devices(mode, tmp_path):
+    """The N-rank path over RCCL itself (runs wherever the driver has a multi-GPU lease): two ranks, one device each,
+    "nccl" backend -- the bucketed all-reduce from the gradient hooks (eager) and the exchange captured INSIDE the
+    step's HIP graph (graph).  Replicas bit-identical, step-1 gradient = mean of the two shards' own gradients, and the
+    captured step really holds the collectives (reference: Lightning DDP, src/utils/util.py:228-239)."""
+    r0, r1 = _launch_two_ranks(tmp_path, mode, backend="nccl")
+    assert torch.equal(r0["params"], r1["params"])
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)
+    if mode == "graph":
+        assert r0["in_graph_exchange"] and r1["in_graph_exchange"]
+    dev = torch.device(DEV)
+    g = [_rank_run(r, 1, "eager", dev)["grads"][0] for r in range(2)]
+    _assert_close(r0["grads"][0].numpy(), ((g[0] + g[1]) / 2).numpy(), 1e-5 if mode == "eager" else 1e-4,
+                  "averaged gradient, step 1")
+
+
+@pytest.mark.skipif(not _two_devices(), reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_rank_trainer_misfit_over_rccl_on_two_devices(tmp_path):
+    """Trainer(capture=True) over RCCL: one rank's oversized batch sends BOTH ranks through the eager step together."""
+    r0, r1 = _launch_two_ranks(tmp_path, "trainer_misfit", backend="nccl")
+    assert r0["eager_fallbacks"] == 1 and r1["eager_fallbacks"] == 1
+    assert torch.equal(r0["params"], r1["params"])
 
 
 def test_two_rank_trainer_takes_the_eager_step_together_when_one_rank_misfits(tmp_path):

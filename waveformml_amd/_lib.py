@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("WFS_LIB") or os.path.join(_HERE, "lib", "libwfsparse.
 WFS_OK, WFS_EINVAL, WFS_EOVERFLOW, WFS_EHIP, WFS_EWORKSPACE = 0, 1, 2, 3, 4
 WFS_F32, WFS_BF16, WFS_F16 = 0, 1, 2
 WFS_MAX_DIM = 4
+WFS_ABI_VERSION = 3         # include/wfsparse.h: this binding's struct layouts and signatures
 TIMER_GATHER_CONV, TIMER_GATHER_DW, TIMER_RULEBOOK = 0, 1, 2
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -148,6 +149,10 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        got = lib.wfs_abi_version()
+        if got != WFS_ABI_VERSION:
+            raise ImportError("%s has ABI version %d, this binding was written for %d (struct layouts / signatures "
+                              "differ): rebuild with `make -C waveformml_amd/csrc`" % (LIB_PATH, got, WFS_ABI_VERSION))
         _LIB = lib
     return _LIB
 

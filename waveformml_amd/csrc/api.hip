@@ -16,7 +16,7 @@ void wfs_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int wfs_abi_version(void) { return 1; }
+extern "C" int wfs_abi_version(void) { return WFS_ABI_VERSION; }
 extern "C" const char *wfs_last_error(void) { return g_err; }
 
 // Replaces the Python front door of spconv.ops.get_indice_pairs.

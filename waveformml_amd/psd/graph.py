@@ -104,15 +104,21 @@ class GraphedTrainStep(object):
         if self.indices is not None:
             net.batch_first_indices = (self.coords, self.indices)
         self._load(example_batch)
+        failed, err = 0, None
         try:
             self._warm_and_capture(warmup)
         except Exception as e:            # noqa: BLE001
             if not self.in_graph_exchange:
                 raise
-            # a collective library that cannot be captured: every rank fails here alike (same software, same call),
-            # so every rank falls back to the exchange after the replay
-            print("[waveformml_amd] in-graph gradient exchange could not be captured (%s: %s); exchanging after the "
-                  "replay" % (type(e).__name__, e), file=sys.stderr, flush=True)
+            failed, err = 1, e
+        if self.in_graph_exchange and self.world > 1:
+            # a collective library that cannot be captured: ranks must not assume they all failed alike -- they AGREE
+            # (MAX over a CPU-side flag on a gloo side group, which needs nothing from the communicator in doubt)
+            failed = _agree_max(failed, reducer.group)
+        if failed:
+            print("[waveformml_amd] in-graph gradient exchange could not be captured on some rank (%s); exchanging "
+                  "after the replay" % (("%s: %s" % (type(err).__name__, err)) if err is not None else "another rank"),
+                  file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             self.in_graph_exchange, self.exchange_after, self.in_graph_optimizer = False, True, False
             reducer.remove()
@@ -164,7 +170,17 @@ class GraphedTrainStep(object):
         """The same step on an exact-size batch without the graph (a batch that does not fit the capture), with the
         SAME sequence of collectives as a replay, so that ranks replaying and ranks stepping eagerly could even mix."""
         self.reducer.reset()
-        loss = self.module.training_step(batch, 0)
+        net = getattr(self.module, "model", None)
+        hint = getattr(net, "batch_size_hint", None)
+        if self.per_row and hint is not None:
+            # the captured step's hint is its ROW capacity as a bound on the events; this batch is exactly the one that
+            # exceeds it: let the net read the event count off the batch, as it does outside captured steps
+            net.batch_size_hint = None
+        try:
+            loss = self.module.training_step(batch, 0)
+        finally:
+            if self.per_row and hint is not None:
+                net.batch_size_hint = hint
         loss.backward()
         if self.exchange_after:
             self.reducer.pack_all()
@@ -243,6 +259,23 @@ class GraphedTrainStep(object):
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
         if bool(flag.item()):
             raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
+
+
+_GLOO_SIDE = {}
+
+
+def _agree_max(flag, group):
+    """MAX of a host-side integer over the ranks of ``group``, over a gloo group of the same ranks (created once): used
+    to agree on things that must not depend on the device communicator being healthy."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flag
+    key = id(group)
+    if key not in _GLOO_SIDE:
+        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+        _GLOO_SIDE[key] = dist.new_group(ranks=ranks, backend="gloo")
+    t = torch.tensor([int(flag)], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_GLOO_SIDE[key])
+    return int(t.item())
 
 
 def _event_flags(module):

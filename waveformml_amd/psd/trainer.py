@@ -76,8 +76,11 @@ class Trainer(object):
         params = reducer.flat_param.detach().clone() if reducer.flat_param is not None else \
             [p.detach().clone() for p in reducer.params]
         buffers = [b.detach().clone() for b in module.buffers()]
-        had_state = {id(p): (p in optimizer.state and len(optimizer.state[p]) > 0)
-                     for g in optimizer.param_groups for p in g["params"]}
+        # optimizer state that exists already (a resumed checkpoint's momentum): kept aside and copied back IN PLACE after
+        # the capture -- its calibration and warm-up steps would otherwise be folded into it.  State the capture creates
+        # is zeroed (zero momentum == no history).
+        kept = {id(p): {k: v.detach().clone() for k, v in optimizer.state[p].items() if torch.is_tensor(v)}
+                for g in optimizer.param_groups for p in g["params"] if p in optimizer.state and len(optimizer.state[p]) > 0}
         graph = GraphedTrainStep(module, optimizer, reducer, batch)
         with torch.no_grad():
             if reducer.flat_param is not None:
@@ -89,11 +92,14 @@ class Trainer(object):
                 b.copy_(q)
             for g in optimizer.param_groups:
                 for p in g["params"]:
-                    if not had_state[id(p)]:
-                        for v in optimizer.state.get(p, {}).values():
-                            if torch.is_tensor(v):
-                                v.zero_()      # in place: the graph holds these addresses (zero momentum == no history)
-        if hasattr(optimizer, "mark_fresh"):
+                    old = kept.get(id(p))
+                    for k, v in optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):           # in place: the graph holds these addresses
+                            if old is not None and k in old and old[k].shape == v.shape:
+                                v.copy_(old[k])
+                            else:
+                                v.zero_()
+        if hasattr(optimizer, "mark_fresh") and not kept:
             optimizer.mark_fresh()             # dampening != 0: the first real step must be torch's "buf = g" (eager)
         return graph
 
