@@ -278,16 +278,6 @@ int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_
  * gamma / beta may be NULL (affine=False).  C <= 1024.                                           */
 size_t wfs_bn_workspace_bytes(int64_t N, int32_t C);
 
-/* OPTIONAL single-launch form (off by default; wfs_bn_set_single_launch(1) or WFS_BN_SINGLE_LAUNCH=1): batches whose
- * rows fit the register files of <= 256 workgroups take ONE launch per direction -- the reduction and the elementwise
- * pass share the loaded rows and are separated by a grid-wide barrier (all workgroups resident: one per compute unit);
- * same partial sums folded in the same order, so the results are bit-identical to the two-launch path.  On MI355X the
- * barrier (device-scope atomics + L2 write-back / invalidate across 8 XCDs) costs more than the kernel boundary it
- * replaces (measured dead ends), hence the default.  The barrier's wait is bounded;
- * wfs_bn_barrier_timeouts() returns how many waits gave up since the library was loaded (0 in a healthy run; it
- * synchronises with the device).                                                                                      */
-void wfs_bn_set_single_launch(int32_t on);
-int64_t wfs_bn_barrier_timeouts(void);
 
 int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, int64_t *num_batches_tracked,
@@ -322,104 +312,6 @@ int wfs_bn_apply_fwd_fold(const void *X, int64_t N, int32_t C, const float *gamm
  * long as the workspace is kept. */
 int wfs_rulebook_cell_map(const wfs_geometry *g, int64_t N, void *workspace, const uint32_t **ticket,
                           const int32_t **slot_id, int64_t *cells);
-
-/* BatchNorm1d (+ ReLU) applied by the CONSUMER of the rows ------------------------------------------------------
- * The reference's stacks are conv -> nn.BatchNorm1d -> nn.ReLU -> conv ... -> ToDense on `.features`
- * (src/models/SPConvBlocks.py:498-516).  In training mode the producing conv takes the batch statistics in its
- * epilogue (wfs_gather_conv_bnstats), and instead of a separate normalisation pass that reads and re-writes every row,
- * the kernel that reads the rows next applies  y = [relu](gamma * (x - mean) * invstd + beta)  to each row as it
- * gathers it: the normalised tensor is never materialised.  wfs_row_affine describes that map (device pointers to [C]
- * floats; gamma / beta may be NULL).  These kernels evaluate it as x * sc + sh with sc = gamma * invstd, sh = beta -
- * mean * sc (one fused multiply-add per gathered value); wfs_bn_apply_fwd subtracts the mean first, so the two agree to
- * rounding, not bit for bit.
- *   wfs_gather_conv_affine    wfs_gather_conv (forward product) / wfs_gather_conv_bnstats (when `stats` is given) with
- *                             the gathered rows of X read through `in_affine`.  32 -> 32 channels.
- *   wfs_gather_dw_affine      wfs_gather_dw with the STATIONARY rows S read through `s_affine`.  32 x 32 channels.
- *   wfs_to_dense_mapped_affine  wfs_to_dense_mapped with the rows read through `in_affine`. */
-typedef struct wfs_row_affine {
-    const float *mean;
-    const float *invstd;
-    const float *gamma;
-    const float *beta;
-    int32_t relu;
-} wfs_row_affine;
-
-int wfs_gather_conv_affine(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
-                           const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in, int32_t Cw_out,
-                           const float *bias, void *Y, int32_t dtype, const int64_t *r_dev,
-                           const wfs_row_affine *in_affine, const wfs_bn_stats *stats, void *stream);
-
-int wfs_gather_dw_affine(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
-                         const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
-                         int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev,
-                         const wfs_row_affine *s_affine, wfs_dw_job *defer, void *stream);
-
-int wfs_to_dense_mapped_affine(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
-                               const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y, int32_t dtype,
-                               const wfs_row_affine *in_affine, void *stream);
-
-/* BatchNorm backward sums taken by the launch that produces dL/dy --------------------------------------------
- * Backward of conv -> BatchNorm1d (+ ReLU) -> conv: the second conv's dX launch writes dL/dy of the BatchNorm; the
- * BatchNorm backward then needs sum(g) and sum(g * xhat) over the rows (g = dL/dy masked by the ReLU) before its
- * elementwise pass.  wfs_gather_conv_bnbwd is the dX product of a 32 -> 32 layer (wfs_gather_conv with transpose_w = 1,
- * no bias) whose epilogue takes those sums from the tile it holds in registers and the BatchNorm's input rows `bn_x`
- * (same row set as Y; `bn` = its statistics / parameters / relu flag), leaving *nblk per-block partials [nblk][2][32]
- * in `partial` (wfs_gather_conv_bnbwd_partial_bytes() bytes).  wfs_bn_relu_bwd_sums is the elementwise half of
- * wfs_bn_relu_bwd fed with such partials: one launch and one read of both tensors less per BatchNorm. */
-size_t wfs_gather_conv_bnbwd_partial_bytes(void);
-
-int wfs_gather_conv_bnbwd(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
-                          const void *X, int64_t X_rows, const float *W, void *Y, int32_t dtype, const int64_t *r_dev,
-                          const wfs_row_affine *bn, const void *bn_x, float *partial, size_t partial_bytes,
-                          int32_t *nblk, void *stream);
-
-int wfs_bn_relu_bwd_sums(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma, const float *beta,
-                         const float *save_mean, const float *save_invstd, int32_t training, int32_t relu, void *dX,
-                         float *dgamma, float *dbeta, const float *partial, int32_t nblk, int32_t dtype,
-                         const int64_t *n_dev, void *stream);
-
-/* rulebook chain ----------------------------------------------------------------------------
- * The rulebooks of a whole stack of conv layers (what SparseSequential hands spconv one
- * torch.ops.spconv.get_indice_pairs call per layer for: reference src/models/SPConvBlocks.py:75,134,498,
- * config "algorithm" lists such as config/psd_c2_3d.json) in TWO launches, one workgroup per EVENT with the
- * event's site tables in LDS (rulebook_chain.hip).  layers[l].geo.spatial must equal layers[l-1].geo.out_shape;
- * a SubM layer keeps the site set, a regular layer's outputs (first-seen order, A.3) are the next layer's inputs.
- * Requirements, verified on the device: the batch column of `indices` is non-decreasing (events contiguous and in
- * order, as the reference's collate_fn delivers them), no event has more than 2048 rows in any of its site sets,
- * K <= 32.  A violation sets the error word returned by wfs_rulebook_chain_count(host_flags) (bit 0: rows not
- * grouped by event or an index out of range; bit 1: event too large) and every regular layer's *overflow_dev; the
- * caller then builds the layers one by one (wfs_rulebook_plan / _emit).
- *   wfs_rulebook_chain_count  per event: row range and number of output sites per regular layer -> workspace.
- *                             host_counts (optional, [nlayers], synchronises): total outputs per layer (0 for SubM).
- *   wfs_rulebook_chain_build  per event: everything else.  Per layer: nbr_out [K, N_cap] (N_cap = rows of the
- *                             layer's input set = the previous regular layer's M_cap), and for a regular layer
- *                             nbr_in [K, M_cap], out_indices [M_cap, ndim+1], *m_dev = min(M, M_cap),
- *                             *overflow_dev = (M > M_cap or chain error), optionally the cell -> row map
- *                             cell_ticket / cell_row [batch * out_volume] in the format of wfs_rulebook_cell_map.
- * Both take the same layers / indices / workspace (wfs_rulebook_chain_workspace_bytes(batch_size) bytes, kept
- * untouched between the two calls). */
-#define WFS_CHAIN_MAX_LAYERS 4
-typedef struct wfs_chain_layer {
-    wfs_geometry geo;
-    int32_t *nbr_out;
-    int32_t *nbr_in;
-    int32_t *out_indices;
-    int64_t N_cap;
-    int64_t M_cap;
-    int64_t *m_dev;
-    int32_t *overflow_dev;
-    uint32_t *cell_ticket;
-    int32_t *cell_row;
-} wfs_chain_layer;
-
-size_t wfs_rulebook_chain_workspace_bytes(int32_t batch_size);
-
-int wfs_rulebook_chain_count(const wfs_chain_layer *layers, int32_t nlayers, const int32_t *indices, int64_t N,
-                             const int64_t *n_dev, void *workspace, size_t workspace_bytes, int64_t *host_counts,
-                             int32_t *host_flags, void *stream);
-
-int wfs_rulebook_chain_build(const wfs_chain_layer *layers, int32_t nlayers, const int32_t *indices, int64_t N,
-                             const int64_t *n_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 /* SparseConvTensor.dense() -------------------------------------------------------------------
  * Y is [B, C, *spatial] (channels first, contiguous) and must be zero-filled by the caller;
@@ -464,20 +356,6 @@ int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I, const floa
                  void *dX, float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes,
                  wfs_dw_job *defer, void *stream);
 
-/* ToDense + flatten + Linear without the dense tensor ---------------------------------------------------
- * What the reference computes at src/models/SPConvNet.py:65-68 for the last sparse layer's rows X [M, C] (dtype) with
- * DISTINCT sites indices [M, ndim+1] (batch first, rows of one event contiguous and events in increasing order, as
- * every conv of this library emits them): Y [batch, O] = bias + flatten(dense(X)) . W^T with W [O, C * V] fp32
- * (nn.Linear.weight over the [C, *spatial] flattening), V = prod(spatial) <= 16384, C % 8 == 0, O <= 8.
- * forward also fills grid [batch, V] int32 (row of each cell or -1; may be NULL when no dW will be asked for).
- * backward: G [batch, O] fp32 -> dX [M, C] (dtype), dW [O, C * V], dB [O] (each may be NULL).  No atomics. */
-int wfs_sparse_head_fwd(const void *X, const int32_t *indices, int64_t M, int32_t ndim, const int32_t *spatial,
-                        int32_t batch, int32_t C, const float *W, const float *bias, int32_t O, float *Y,
-                        int32_t *grid, int32_t dtype, const int64_t *m_dev, void *stream);
-
-int wfs_sparse_head_bwd(const void *X, const int32_t *indices, int64_t M, int32_t ndim, const int32_t *spatial,
-                        int32_t batch, int32_t C, const float *W, int32_t O, const float *G, void *dX, float *dW,
-                        float *dB, const int32_t *grid, int32_t dtype, const int64_t *m_dev, void *stream);
 
 /* hybrid front end -----------------------------------------------------------------------------------
  * TemporalConvNet(1, [1] * levels, kernel_size = k) as the reference's SPConvNet applies it to the waveform rows

@@ -1008,81 +1008,8 @@ def test_batch_hand_over_kernel_copies_and_permutes(cols, perm, C, dtype):
     assert torch.equal(ldst, labels) and int(nv) == n
 
 
-@pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.float32, 8), (torch.bfloat16, 2), (torch.float16, 3)],
-                         ids=["f32_o3", "f32_o8", "bf16_o2", "f16_o3"])
-def test_sparse_head_equals_todense_view_linear(dtype, O):
-    """wfs_sparse_head_fwd / _bwd (ToDense + view + nn.Linear on the sparse rows, no dense tensor) against the literal
-    composition the reference runs (src/models/SPConvNet.py:65-68) on the CPU in fp32: logits, dX, dW, db.  Events with
-    no rows, a non-multiple-of-32 cell count and device-side row counts are covered."""
-    from waveformml_amd.spconv import functional as Fsp
-    sp = _sp()
-    rng = np.random.default_rng(23)
-    B, C, shape = 7, 32, [5, 3, 6]
-    V = int(np.prod(shape))
-    rows = []
-    for b in (0, 1, 3, 4, 6):                               # events 2 and 5 have no active site
-        cells = rng.choice(V, size=int(rng.integers(1, 40)), replace=False)
-        for cell in cells:
-            rows.append([b, cell // 18, (cell // 6) % 3, cell % 6])
-    idx = np.asarray(rows, np.int32)
-    M = len(idx)
-    feat = rng.standard_normal((M, C)).astype(np.float32)
-    lin_ref = torch.nn.Linear(C * V, O)
-    lin = torch.nn.Linear(C * V, O).to(DEV)
-    lin.load_state_dict(lin_ref.state_dict())
-    fin = torch.from_numpy(feat).to(dtype).float()
-    fr = fin.clone().requires_grad_(True)
-    dense = torch.zeros((B, C, V))
-    cell_id = torch.from_numpy((idx[:, 1] * 18 + idx[:, 2] * 6 + idx[:, 3]).astype(np.int64))
-    dense = dense.index_put((torch.from_numpy(idx[:, 0].astype(np.int64))[:, None], torch.arange(C)[None, :], cell_id[:, None]), fr)
-    yr = lin_ref(dense.view(B, -1))
-    g = rng.standard_normal((B, O)).astype(np.float32)
-    yr.backward(torch.from_numpy(g))
-    pad = 13                                               # capacity rows beyond the valid count hold garbage
-    idx_cap = np.concatenate([idx, np.full((pad, 4), 9999, np.int32)])
-    feat_cap = torch.cat([fin, torch.full((pad, C), float("nan"))]).to(DEV).to(dtype).requires_grad_(True)
-    st = sp.SparseConvTensor(feat_cap, torch.from_numpy(idx_cap).to(DEV), shape, B)
-    st.unique = True
-    st.n_valid = torch.tensor([M], dtype=torch.int64, device=DEV)
-    assert Fsp.can_use_sparse_head(lin, st)
-    yg = Fsp.sparse_head(st, lin)
-    yg.backward(torch.from_numpy(g).to(DEV))
-    tol = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
-    _assert_close(yg.detach().cpu().numpy(), yr.detach().numpy(), tol, "logits")
-    _assert_close(feat_cap.grad[:M].float().cpu().numpy(), fr.grad.numpy(), tol, "dX")
-    _assert_close(lin.weight.grad.cpu().numpy(), lin_ref.weight.grad.numpy(), tol, "dW")
-    _assert_close(lin.bias.grad.cpu().numpy(), lin_ref.bias.grad.numpy(), 1e-5, "db")
-    st.unique = None
-    assert not Fsp.can_use_sparse_head(lin, st)           # duplicates possible: dense()'s "last wins" must decide
 
 
-def test_net_with_sparse_head_matches_dense_route():
-    """SPConvNet with ``sparse_head = True`` (ToDense + view + Linear taken from the sparse rows) gives the same logits
-    and gradients as the default dense route, on the C2-shaped net."""
-    import copy
-    from waveformml_amd.psd import synthetic
-    from waveformml_amd.psd.config import DictionaryUtility
-    from waveformml_amd.psd.lit import LitPSD
-    with open(os.path.join(HERE, "..", "config", "psd_c2_3d.json")) as f:
-        cfg = json.load(f)
-    T, B = 64, 12
-    cfg["system_config"]["n_samples"] = T
-    cfg["net_config"]["algorithm"][-1] = [32 * 10 * 7 * 4, 3]
-    torch.manual_seed(3)
-    a = LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg))).to(DEV)
-    b = LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg))).to(DEV)
-    b.load_state_dict(a.state_dict())
-    b.model.sparse_head = True
-    c, f, y = synthetic.generate(B, T, 3, seed=17)
-    batch = lambda: ([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV))   # noqa: E731
-    la, lb = a.training_step(batch(), 0), b.training_step(batch(), 0)
-    la.backward()
-    lb.backward()
-    assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
-    for (name, pa), pb in zip(a.model.named_parameters(), b.model.parameters()):
-        if float(pa.grad.abs().max()) < 1e-6:
-            continue
-        _assert_close(pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), 1e-4, name)
 
 
 def _random_geometry(rng):
@@ -1458,149 +1385,6 @@ def test_gradient_slots_with_a_shared_module_and_with_accumulation():
                       "%s, two backward passes" % n)
     with pytest.raises(TypeError):
         FlatGradAllReducer(torch.nn.Linear(4, 4).half().to(DEV).parameters(), world_size=1)
-
-
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)],
-                         ids=["f32", "bf16", "f16"])
-def test_batchnorm_deferred_to_the_next_reader(dtype, tol, monkeypatch):
-    """ops.DEFER_BATCH_NORM: conv -> BatchNorm1d -> ReLU -> conv ... -> ToDense with every BatchNorm (+ ReLU) applied
-    by the NEXT reader of the raw rows while it gathers them (functional.RowAffine; wfs_gather_conv_affine,
-    wfs_gather_dw_affine, wfs_to_dense_mapped_affine), the statistics taken by the producing conv's epilogue -- against
-    the same stack with the stand-alone BatchNorm kernels: dense output, input gradient, every parameter gradient and
-    the running statistics (fp32: 1e-5 of scale -- the statistics are summed in another order; 16-bit rows: the
-    rounding of one stored tensor).  A reader that cannot apply the map (here: user code asking for ``.features``)
-    gets the normalised rows."""
-    sp = _sp()
-    rng = np.random.default_rng(41)
-    B, T = 6, 48
-    idx = _waveform_like(rng, B, T)
-    feat = rng.standard_normal((len(idx), 2)).astype(np.float32)
-
-    def build():
-        torch.manual_seed(5)
-        return sp.SparseSequential(
-            sp.SubMConv3d(2, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
-            sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
-            sp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
-            sp.ToDense()).to(DEV)
-
-    res = []
-    for on in (False, True):
-        monkeypatch.setattr(sp.ops, "DEFER_BATCH_NORM", on)
-        net = build()
-        f = torch.from_numpy(feat).to(DEV).to(dtype).requires_grad_(True)
-        y = net(sp.SparseConvTensor(f, torch.from_numpy(idx).to(DEV), [14, 11, T], B))
-        w = torch.linspace(-1, 1, y.numel(), device=DEV).reshape(y.shape)
-        (y.float() * w).sum().backward()
-        res.append((y.detach().float().cpu().numpy(), f.grad.float().cpu().numpy(),
-                    [p.grad.float().cpu().numpy() for p in net.parameters()],
-                    [b.float().cpu().numpy() for b in net.buffers()]))
-    (y0, g0, p0, b0), (y1, g1, p1, b1) = res
-    _assert_close(y1, y0, tol, "dense output")
-    _assert_close(g1, g0, tol * 10, "input gradient")
-    for a, b in zip(p1, p0):
-        _assert_close(a, b, tol * 10, "parameter gradient")
-    for a, b in zip(b1, b0):
-        _assert_close(a, b, max(tol, 1e-5), "running statistics")
-    # a reader that cannot apply the map gets the normalised rows
-    monkeypatch.setattr(sp.ops, "DEFER_BATCH_NORM", True)
-    head = sp.SparseSequential(sp.SubMConv3d(2, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU()).to(DEV)
-    out = head(sp.SparseConvTensor(torch.from_numpy(feat).to(DEV).to(dtype), torch.from_numpy(idx).to(DEV), [14, 11, T], B))
-    assert out._pending is not None
-    rows = out.features
-    assert out._pending is None and float(rows.float().min()) >= 0.0 and rows.shape == (len(idx), 32)
-
-
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-5), (torch.float16, 1e-5)],
-                         ids=["f32", "bf16", "f16"])
-def test_batchnorm_backward_sums_taken_by_the_dx_launch(dtype, tol, monkeypatch):
-    """ops.FUSE_BN_BACKWARD_SUMS: in conv -> BatchNorm1d -> ReLU -> conv the second conv's dX launch takes sum(g) and
-    sum(g * xhat) of the BatchNorm backward in its epilogue (wfs_gather_conv_bnbwd + wfs_bn_relu_bwd_sums, functional
-    .BnLink) instead of a separate reduction launch.  Same values as the two-launch backward: the sums are taken from the
-    same stored gradients with the same mask expression, only the fp32 summation order differs (2e-6 of scale in fp32;
-    16-bit rows: the elementwise pass rounds identical fp32 results, so nearly every element is bit-equal).  SubM and
-    strided consumers, odd row counts, capacity-padded rows with a device-side count."""
-    sp = _sp()
-    rng = np.random.default_rng(77)
-    B, T = 5, 40
-    idx = _waveform_like(rng, B, T)
-    n = len(idx)
-    feat = rng.standard_normal((n, 32)).astype(np.float32)
-
-    def build():
-        torch.manual_seed(9)
-        return sp.SparseSequential(
-            sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
-            sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, False, "k0"), torch.nn.BatchNorm1d(32), torch.nn.ReLU(),
-            sp.SparseConv3d(32, 32, 3, (1, 1, 4), 0, 1, 1, False), torch.nn.BatchNorm1d(32),
-            sp.SparseConv3d(32, 32, 3, (1, 1, 2), 0, 1, 1, False)).to(DEV)
-
-    for padded in (False, True):
-        res = []
-        for on in (False, True):
-            monkeypatch.setattr(sp.ops, "FUSE_BN_BACKWARD_SUMS", on)
-            net = build()
-            f = torch.from_numpy(feat).to(DEV).to(dtype)
-            if padded:
-                cap = n + 45
-                pf = torch.full((cap, 32), float("nan"), dtype=dtype, device=DEV)
-                pi = torch.zeros((cap, 4), dtype=torch.int32, device=DEV)
-                pf[:n], pi[:n] = f, torch.from_numpy(idx).to(DEV)
-                f = pf.requires_grad_(True)
-                x = sp.SparseConvTensor(f, pi, [14, 11, T], B)
-                x.n_valid = torch.tensor([n], dtype=torch.int64, device=DEV)
-                x.unique = True
-            else:
-                f = f.requires_grad_(True)
-                x = sp.SparseConvTensor(f, torch.from_numpy(idx).to(DEV), [14, 11, T], B)
-            y = net(x)
-            m = int(y.n_valid) if y.n_valid is not None else y.features.shape[0]
-            w = torch.linspace(-1, 1, m * 32, device=DEV).reshape(m, 32)
-            (y.features[:m].float() * w).sum().backward()
-            res.append((f.grad[:n].float().cpu().numpy(), [p.grad.float().cpu().numpy() for p in net.parameters()]))
-        (g0, p0), (g1, p1) = res
-        assert np.isfinite(g1).all()
-        _assert_close(g1, g0, tol, "input gradient (padded=%s)" % padded)
-        for a, b in zip(p1, p0):
-            _assert_close(a, b, tol * 5, "parameter gradient (padded=%s)" % padded)
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("N,C,padded", [(1, 32, False), (300, 32, False), (30011, 32, True), (70000, 32, False),
-                                         (110000, 32, True), (9000, 64, False), (5000, 252, True), (40000, 8, False)])
-def test_batchnorm_single_launch_equals_the_two_launch_path(N, C, padded, dtype):
-    """The optional one-launch-per-direction form (reduction | grid barrier | elementwise pass from the same registers,
-    include/wfsparse.h wfs_bn_set_single_launch; off by default, slower on this GPU) against the two-launch path: same partial sums folded in the same order,
-    so outputs, statistics, running statistics and all gradients are BIT-identical; no barrier wait gave up."""
-    from waveformml_amd import _lib
-    from waveformml_amd.spconv import functional as Fsp
-    lib = _lib.load()
-    rng = np.random.default_rng(77)
-    cap = N + 513 if padded else N
-    x = torch.from_numpy((rng.standard_normal((cap, C)) * 2 + 5).astype(np.float32)).to(DEV).to(dtype)
-    g = torch.from_numpy(rng.standard_normal((cap, C)).astype(np.float32)).to(DEV).to(dtype)
-    n_dev = torch.tensor([N], dtype=torch.int64, device=DEV) if padded else None
-    outs = []
-    try:
-        for single in (0, 1):
-            lib.wfs_bn_set_single_launch(single)
-            torch.manual_seed(1)
-            bn = torch.nn.BatchNorm1d(C).to(DEV)
-            with torch.no_grad():
-                bn.weight.uniform_(0.5, 1.5)
-                bn.bias.uniform_(-0.5, 0.5)
-            xin = x.clone().requires_grad_(True)
-            y = Fsp.batch_norm_relu(xin, bn, True, n_dev=n_dev)
-            y.backward(g)
-            torch.cuda.synchronize()
-            outs.append([y.detach()[:N].clone(), xin.grad[:N].clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
-                         bn.running_mean.clone(), bn.running_var.clone()])
-    finally:
-        lib.wfs_bn_set_single_launch(0)
-    for a, b, what in zip(outs[0], outs[1], ["y", "dx", "dgamma", "dbeta", "running_mean", "running_var"]):
-        assert torch.equal(a, b), what
-    assert float(outs[1][0].abs().sum()) > 0
-    assert lib.wfs_bn_barrier_timeouts() == 0
 
 
 @pytest.mark.parametrize("R,C,dtype,padded", [(1, 5, torch.float32, False), (777, 32, torch.float32, True),

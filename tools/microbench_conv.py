@@ -59,17 +59,6 @@ timeit("subm dW 32x32", lambda: Fsp.gather_dw(rb.nbr_out, 27, rb.centre_k, N, X,
 bns = torch.nn.BatchNorm1d(32).to(dev)
 timeit("subm fwd 32->32 + BN stats", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None, None, Fsp.BatchNormRequest(bns)), by)
 timeit("subm fwd 2->32 + BN stats", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X2, W2, False, None, None, Fsp.BatchNormRequest(bns)), N * 136 + P * 8)
-if DT != torch.float32 or True:
-    mean, invstd = torch.randn(32, device=dev) * 0.1, torch.rand(32, device=dev) + 0.5
-    spec = Fsp.RowAffine(bns, True, mean, invstd)
-    aff = spec.struct()
-    timeit("subm fwd 32->32, rows through BN+ReLU", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None, None, None, aff), by)
-    timeit("subm fwd 32->32, through BN+ReLU + stats", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None, None, Fsp.BatchNormRequest(bns, False), aff), by)
-    timeit("subm fwd 32->32 + BN stats (folded now)", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None, None, Fsp.BatchNormRequest(bns, False)), by)
-    timeit("subm dW 32x32, S through BN+ReLU", lambda: Fsp.gather_dw(rb.nbr_out, 27, rb.centre_k, N, X, dY, False, s_affine=aff), by)
-link = Fsp.BnLink()
-link.x, link.weight, link.bias, link.save_mean, link.save_invstd, link.relu = X, bns.weight, bns.bias, mean, invstd, True
-timeit("subm dX 32->32 + BN backward sums", lambda: Fsp.gather_conv(rb.nbr_out, None, 27, rb.centre_k, N, dY, W, True, None, None, None, None, link), by)
 by1 = N * 32 * ES + M1 * 32 * ES + P1 * 8 + 27 * 4096
 timeit("conv s4 fwd 32->32", lambda: Fsp.gather_conv(rb1.nbr_in, None, 27, -1, M1, X, W, False, None), by1)
 timeit("conv s4 dX", lambda: Fsp.gather_conv(rb1.nbr_out, None, 27, -1, N, dY1, W, True, None), by1)

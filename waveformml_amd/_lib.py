@@ -42,17 +42,6 @@ class DwJob(ctypes.Structure):
                 ("transpose", _i32), ("dW", _vp)]
 
 
-class RowAffine(ctypes.Structure):
-    """struct wfs_row_affine"""
-    _fields_ = [("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp), ("relu", _i32)]
-
-
-class ChainLayer(ctypes.Structure):
-    """struct wfs_chain_layer"""
-    _fields_ = [("geo", Geometry), ("nbr_out", _vp), ("nbr_in", _vp), ("out_indices", _vp), ("N_cap", _i64),
-                ("M_cap", _i64), ("m_dev", _vp), ("overflow_dev", _vp), ("cell_ticket", _vp), ("cell_row", _vp)]
-
-
 # name -> (restype, argtypes); mirrors include/wfsparse.h one to one
 SIGNATURES = {
     "wfs_abi_version": (ctypes.c_int, []),
@@ -63,10 +52,6 @@ SIGNATURES = {
                                          _vp]),
     "wfs_rulebook_emit": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _sz, _vp, _vp, _vp]),
-    "wfs_rulebook_chain_workspace_bytes": (_sz, [_i32]),
-    "wfs_rulebook_chain_count": (ctypes.c_int, [ctypes.POINTER(ChainLayer), _i32, _vp, _i64, _vp, _vp, _sz, c_i64p, c_i32p,
-                                                _vp]),
-    "wfs_rulebook_chain_build": (ctypes.c_int, [ctypes.POINTER(ChainLayer), _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "wfs_indices_check": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _sz, c_i64p, _vp]),
     "wfs_gather_conv": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _i32,
                                        _vp, _vp, _i32, _vp, _vp]),
@@ -78,17 +63,6 @@ SIGNATURES = {
     "wfs_conv_stats_workspace_bytes": (_sz, [_i64, _i32]),
     "wfs_gather_conv_bnstats": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp,
                                                _i32, _vp, ctypes.POINTER(BnStats), c_i32p, _vp]),
-    "wfs_gather_conv_affine": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i32,
-                                              _vp, ctypes.POINTER(RowAffine), ctypes.POINTER(BnStats), _vp]),
-    "wfs_gather_dw_affine": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
-                                            _sz, _vp, ctypes.POINTER(RowAffine), ctypes.POINTER(DwJob), _vp]),
-    "wfs_to_dense_mapped_affine": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i32,
-                                                  ctypes.POINTER(RowAffine), _vp]),
-    "wfs_gather_conv_bnbwd_partial_bytes": (_sz, []),
-    "wfs_gather_conv_bnbwd": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _vp, _vp, _i32, _vp,
-                                             ctypes.POINTER(RowAffine), _vp, _vp, _sz, c_i32p, _vp]),
-    "wfs_bn_relu_bwd_sums": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
-                                            _i32, _vp, _vp]),
     "wfs_bn_apply_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "wfs_bn_apply_fwd_fold": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, ctypes.POINTER(BnStats), _i32, _i32, _vp, _i32,
                                              _vp, _vp]),
@@ -100,8 +74,6 @@ SIGNATURES = {
     "wfs_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "wfs_column_sum_workspace_bytes": (_sz, [_i32]),
     "wfs_column_sum": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _sz, _i32, _vp, _vp]),
-    "wfs_bn_set_single_launch": (None, [_i32]),
-    "wfs_bn_barrier_timeouts": (_i64, []),
     "wfs_bn_relu_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32,
                                        _i32, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp]),
     "wfs_bn_relu_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
@@ -116,10 +88,6 @@ SIGNATURES = {
     "wfs_head_fwd": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp]),
     "wfs_head_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _sz, ctypes.POINTER(DwJob),
                                     _vp]),
-    "wfs_sparse_head_fwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp,
-                                           _vp]),
-    "wfs_sparse_head_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
-                                           _i32, _vp, _vp]),
     "wfs_tcn_lds_bytes": (_sz, [_i32, _i32, _i32]),
     "wfs_tcn_taps_fwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "wfs_tcn_taps_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),

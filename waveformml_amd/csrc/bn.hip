@@ -740,244 +740,6 @@ __global__ void __launch_bounds__(TB) k_bn_bwd_apply_rr(const T *__restrict__ X,
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// One launch per direction.  The two register-resident kernels of a direction load the SAME rows; with <= 256 blocks
-// (one per compute unit, all resident) the column reduction and the elementwise pass can share one launch and one load
-// of the rows, separated by a grid-wide barrier: every block writes its partial sums, arrives, waits until all blocks
-// have arrived, folds the partials (same order as before: bit-identical results) and finishes from its registers.
-// That saves a kernel boundary (~1.7 us launch + ~1.5 us drain), the second round trip for the rows and their second
-// read -- and costs MORE than it saves on this GPU: OFF by default (WFS_BN_SINGLE_LAUNCH=1 / wfs_bn_set_single_launch).
-// With 8 XCDs, each behind its own L2, a device-wide barrier needs device-scope atomics (~2 us each way) and two
-// __threadfence() (L2 write-back + invalidate, ~5 us each): tools/exp/grid_barrier.hip measures +15 us per barrier
-// against +3 us for a kernel boundary (profiles/r02_grid_barrier_microbench.txt), and the PSD step went from 0.565 to
-// 0.726 ms with its 10 BatchNorm launch pairs fused this way.  Kept because it is bit-identical and tested, for parts
-// with one L2.
-//
-// The barrier is two words of device memory that are zero between launches (the last block to leave resets them).  The
-// wait is BOUNDED: a block that does not see everyone arrive within ~1 s counts a timeout and goes on (its results are
-// then wrong; wfs_bn_barrier_timeouts() reports it) -- a grid that cannot become resident must not hang the device.
-constexpr unsigned int BAR_SPIN_LIMIT = 1u << 22;
-
-__device__ __forceinline__ void grid_barrier(unsigned int *bar, unsigned int nblocks, unsigned int *timeouts) {
-    __syncthreads();                                            // this block's partial stores are issued
-    if (threadIdx.x == 0) {
-        __threadfence();                                        // release them device-wide (all XCDs)
-        atomicAdd(&bar[0], 1u);
-        unsigned int tries = 0;
-        while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
-            if (++tries > BAR_SPIN_LIMIT) {
-                atomicAdd(timeouts, 1u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __threadfence();                                        // acquire the other blocks' partials
-        if (atomicAdd(&bar[1], 1u) == nblocks - 1) {            // everyone is past the wait: zero for the next launch
-            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-}
-
-template <typename T, int PER>
-__global__ void __launch_bounds__(TB) k_bn_fwd_one(const T *__restrict__ X, long long Ncap,
-                                                   const long long *__restrict__ n_dev, int C,
-                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                   float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                   long long *__restrict__ batches_tracked, float momentum, float eps,
-                                                   int relu, T *__restrict__ Y, float *__restrict__ save_mean,
-                                                   float *__restrict__ save_invstd, float *__restrict__ partial,
-                                                   unsigned int *__restrict__ bar, unsigned int *__restrict__ timeouts) {
-    constexpr int VEC = 4;
-    __shared__ float red[2][TB][VEC];
-    __shared__ float sSlice[2 * TB];
-    __shared__ float sA[MAXC], sB[MAXC];
-    const int groups = C / VEC, slots = TB / groups;
-    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
-    const bool active = slot < slots;
-    const int c0 = grp * VEC;
-    const long long stride = (long long)gridDim.x * slots, first = (long long)blockIdx.x * slots + slot;
-    Raw4<T> x[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const long long r = first + i * stride;
-        x[i].load(X + ((active && r < Ncap) ? r : 0) * C + c0);
-    }
-    const long long N = valid_rows(Ncap, n_dev);
-    float sh[VEC], ga[VEC], be[VEC], sa[VEC], sb[VEC];
-    load_vec<T, VEC>(X + c0, sh);                               // the shift: row 0
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        ga[i] = (gamma && active) ? gamma[c0 + i] : 1.f;
-        be[i] = (beta && active) ? beta[c0 + i] : 0.f;
-        sa[i] = sb[i] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const long long r = first + i * stride;
-        if (active && r < N) {
-            float xv[VEC];
-            x[i].get(xv);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const float d = xv[q] - sh[q];
-                sa[q] += d;
-                sb[q] = fmaf(d, d, sb[q]);
-            }
-        }
-    }
-    if (rr_block_sums<VEC>(sa, sb, red, groups, active)) {
-        float *p = partial + (long long)blockIdx.x * 2 * C;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            p[c0 + i] = sa[i];
-            p[C + c0 + i] = sb[i];
-        }
-    }
-    grid_barrier(bar, gridDim.x, timeouts);
-    fold_partials(partial, (int)gridDim.x, C, sSlice, sA, sB);
-    const float n = N > 0 ? (float)N : 1.f;
-    for (int c = threadIdx.x; c < C; c += TB) {
-        const float shift = wfs_ld(X + c);
-        const float md = sA[c] / n;
-        float var = sB[c] / n - md * md;
-        const float mean = shift + md;
-        var = var > 0.f ? var : 0.f;
-        const float inv = rsqrtf(var + eps);
-        sA[c] = mean;
-        sB[c] = inv;
-        if (blockIdx.x == 0) {
-            save_mean[c] = mean;
-            save_invstd[c] = inv;
-            if (running_mean) {
-                const float unbiased = N > 1 ? var * (n / (n - 1.f)) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-            }
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && batches_tracked) *batches_tracked += 1;
-    __syncthreads();
-    if (!active) return;
-    float m[VEC], is[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        m[i] = sA[c0 + i];
-        is[i] = sB[c0 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const long long r = first + i * stride;
-        if (r < N) {
-            float v[VEC], y[VEC];
-            x[i].get(v);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const float t = fmaf(ga[q], (v[q] - m[q]) * is[q], be[q]);
-                y[q] = (relu && !(t > 0.f)) ? 0.f : t;
-            }
-            store_vec<T, VEC>(Y + r * C + c0, y);
-        }
-    }
-}
-
-template <typename T, int PER>
-__global__ void __launch_bounds__(TB) k_bn_bwd_one(const T *__restrict__ X, const T *__restrict__ dY, long long Ncap,
-                                                   const long long *__restrict__ n_dev, int C,
-                                                   const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                   int training, int relu, T *__restrict__ dX,
-                                                   float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                   float *__restrict__ partial, unsigned int *__restrict__ bar,
-                                                   unsigned int *__restrict__ timeouts) {
-    constexpr int VEC = 4;
-    __shared__ float red[2][TB][VEC];
-    __shared__ float sSlice[2 * TB];
-    __shared__ float sA[MAXC], sB[MAXC];
-    const int groups = C / VEC, slots = TB / groups;
-    const int grp = threadIdx.x % groups, slot = threadIdx.x / groups;
-    const bool active = slot < slots;
-    const int c0 = grp * VEC;
-    const long long stride = (long long)gridDim.x * slots, first = (long long)blockIdx.x * slots + slot;
-    Raw4<T> x[PER], g[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const long long r = first + i * stride;
-        const long long rc = (active && r < Ncap) ? r : 0;
-        x[i].load(X + rc * C + c0);
-        g[i].load(dY + rc * C + c0);
-    }
-    const long long N = valid_rows(Ncap, n_dev);
-    float m[VEC], is[VEC], ga[VEC], be[VEC], sa[VEC], sb[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        m[i] = active ? mean[c0 + i] : 0.f;
-        is[i] = active ? invstd[c0 + i] : 0.f;
-        ga[i] = (gamma && active) ? gamma[c0 + i] : 1.f;
-        be[i] = (beta && active) ? beta[c0 + i] : 0.f;
-        sa[i] = sb[i] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const long long r = first + i * stride;
-        if (active && r < N) {
-            float xv[VEC], gv[VEC];
-            x[i].get(xv);
-            g[i].get(gv);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const float xh = (xv[q] - m[q]) * is[q];
-                float gi = gv[q];
-                if (relu && !(fmaf(ga[q], xh, be[q]) > 0.f)) gi = 0.f;
-                sa[q] += gi;
-                sb[q] = fmaf(gi, xh, sb[q]);
-            }
-        }
-    }
-    if (rr_block_sums<VEC>(sa, sb, red, groups, active)) {
-        float *p = partial + (long long)blockIdx.x * 2 * C;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            p[c0 + i] = sa[i];
-            p[C + c0 + i] = sb[i];
-        }
-    }
-    grid_barrier(bar, gridDim.x, timeouts);
-    fold_partials(partial, (int)gridDim.x, C, sSlice, sA, sB);
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < C; c += TB) {
-            if (dbeta) dbeta[c] = sA[c];
-            if (dgamma) dgamma[c] = sB[c];
-        }
-    }
-    if (!active) return;
-    const float invN = N > 0 ? 1.f / (float)N : 0.f;
-    float k1[VEC], k2[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        k1[i] = training ? sA[c0 + i] * invN : 0.f;
-        k2[i] = training ? sB[c0 + i] * invN : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const long long r = first + i * stride;
-        if (r < N) {
-            float xv[VEC], gv[VEC], o[VEC];
-            x[i].get(xv);                                    // the raw rows stayed in registers across the barrier
-            g[i].get(gv);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const float xh = (xv[q] - m[q]) * is[q];
-                float gi = gv[q];
-                if (relu && !(fmaf(ga[q], xh, be[q]) > 0.f)) gi = 0.f;
-                o[q] = ga[q] * is[q] * (gi - k1[q] - xh * k2[q]);
-            }
-            store_vec<T, VEC>(dX + r * C + c0, o);
-        }
-    }
-}
-
 // blocks and rows per thread of the register-resident kernels; 0 = the batch does not fit (use the loop kernels)
 int rr_plan(long long N, int C, int max_per, long long *blocks) {
     if (C % 4 != 0 || C / 4 > TB) return 0;
@@ -1009,60 +771,8 @@ long long bn_apply_blocks(long long N) {
     return b;
 }
 
-// Barrier words of the single-launch kernels: a per-device pool, zero-filled once; every launch takes the next slot
-// (a captured graph keeps the slots of its nodes), so launches on different streams do not share one unless more than
-// BAR_SLOTS of them are in flight together.  Word 2 * BAR_SLOTS counts timed-out waits.
-constexpr int BAR_SLOTS = 2048, BAR_DEVICES = 16;
-unsigned int *g_bar_pool[BAR_DEVICES];
-std::atomic<unsigned int> g_bar_next{0};
-std::atomic<int> g_single_launch{-1};           // -1: not read yet (WFS_BN_SINGLE_LAUNCH, default off)
-
-bool single_launch_enabled() {
-    int v = g_single_launch.load();
-    if (v < 0) {
-        const char *e = getenv("WFS_BN_SINGLE_LAUNCH");
-        v = (e && e[0] != '0' && e[0] != 0) ? 1 : 0;
-        g_single_launch.store(v);
-    }
-    return v != 0;
-}
-
-// nullptr when the pool cannot be set up now (another device error, or the first use falls inside a stream capture,
-// where allocations are not allowed): the caller then takes the two-launch path
-unsigned int *barrier_pool(hipStream_t stream) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BAR_DEVICES) return nullptr;
-    if (!g_bar_pool[dev]) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-        static std::mutex mu;
-        std::lock_guard<std::mutex> lock(mu);
-        if (!g_bar_pool[dev]) {
-            unsigned int *p = nullptr;
-            const size_t bytes = (2 * BAR_SLOTS + 1) * sizeof(unsigned int);
-            if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
-            if (hipMemset(p, 0, bytes) != hipSuccess) {
-                (void)hipFree(p);
-                return nullptr;
-            }
-            g_bar_pool[dev] = p;
-        }
-    }
-    return g_bar_pool[dev];
-}
-
 }  // namespace
 
-extern "C" void wfs_bn_set_single_launch(int32_t on) { g_single_launch.store(on ? 1 : 0); }
-
-// waits of the single-launch BatchNorm kernels that gave up (0 in a healthy run); synchronises with the device
-extern "C" int64_t wfs_bn_barrier_timeouts(void) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BAR_DEVICES || !g_bar_pool[dev]) return 0;
-    unsigned int v = 0;
-    if (hipMemcpy(&v, g_bar_pool[dev] + 2 * BAR_SLOTS, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int64_t)v;
-}
 
 extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
     size_t nb = (size_t)bn_reduce_blocks(N, C);
@@ -1090,23 +800,6 @@ static int bn_fwd_slice(const void *X, int64_t N, int32_t C, long long ld, const
     if (training && ld == C) {
         long long rb = 0;
         const int per = rr_plan(N, C, 16, &rb);
-        unsigned int *pool = (per && single_launch_enabled()) ? barrier_pool(stream) : nullptr;
-        if (pool) {
-            const dim3 g2((unsigned)rb);
-            unsigned int *bar = pool + 2 * (g_bar_next.fetch_add(1) % BAR_SLOTS), *tmo = pool + 2 * BAR_SLOTS;
-#define WFS_BN_FWD_ONE(T, PER)                                                                                         \
-    k_bn_fwd_one<T, PER><<<g2, block, 0, stream>>>((const T *)X, N, n_dev, C, gamma, beta, running_mean, running_var,   \
-                                                   (long long *)num_batches_tracked, momentum, eps, relu, (T *)Y,      \
-                                                   save_mean, save_invstd, partial, bar, tmo)
-#define WFS_BN_FWD_ONE_T(T)                                                                                            \
-    if (per == 2) WFS_BN_FWD_ONE(T, 2); else if (per == 4) WFS_BN_FWD_ONE(T, 4); else if (per == 8) WFS_BN_FWD_ONE(T, 8); \
-    else WFS_BN_FWD_ONE(T, 16)
-            if (dtype == WFS_F32) { WFS_BN_FWD_ONE_T(float); } else if (dtype == WFS_BF16) { WFS_BN_FWD_ONE_T(wfs_bf16); } else { WFS_BN_FWD_ONE_T(wfs_f16); }
-#undef WFS_BN_FWD_ONE_T
-#undef WFS_BN_FWD_ONE
-            WFS_LAUNCH_CHECK();
-            return WFS_OK;
-        }
         if (per) {
             const dim3 g2((unsigned)rb);
 #define WFS_BN_FWD_RR(T, PER)                                                                                          \
@@ -1253,22 +946,6 @@ static int bn_bwd_slice(const void *X, const void *dY, int64_t N, int32_t C, lon
     if (ld == C) {
         long long rb = 0;
         const int per = rr_plan(N, C, dtype == WFS_F32 ? 8 : 16, &rb);
-        unsigned int *pool = (per && single_launch_enabled()) ? barrier_pool(stream) : nullptr;
-        if (pool) {
-            const dim3 g2((unsigned)rb);
-            unsigned int *bar = pool + 2 * (g_bar_next.fetch_add(1) % BAR_SLOTS), *tmo = pool + 2 * BAR_SLOTS;
-#define WFS_BN_BWD_ONE(T, PER)                                                                                         \
-    k_bn_bwd_one<T, PER><<<g2, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, save_mean, save_invstd,    \
-                                                   gamma, beta, training, relu, (T *)dX, dgamma, dbeta, partial, bar, tmo)
-#define WFS_BN_BWD_ONE_T(T)                                                                                            \
-    if (per == 2) WFS_BN_BWD_ONE(T, 2); else if (per == 4) WFS_BN_BWD_ONE(T, 4); else if (per == 8) WFS_BN_BWD_ONE(T, 8); \
-    else WFS_BN_BWD_ONE(T, 16)
-            if (dtype == WFS_F32) { WFS_BN_BWD_ONE_T(float); } else if (dtype == WFS_BF16) { WFS_BN_BWD_ONE_T(wfs_bf16); } else { WFS_BN_BWD_ONE_T(wfs_f16); }
-#undef WFS_BN_BWD_ONE_T
-#undef WFS_BN_BWD_ONE
-            WFS_LAUNCH_CHECK();
-            return WFS_OK;
-        }
         if (per) {
             const dim3 g2((unsigned)rb);
 #define WFS_BN_BWD_RR(T, PER)                                                                                          \
@@ -1305,52 +982,6 @@ static int bn_bwd_slice(const void *X, const void *dY, int64_t N, int32_t C, lon
         if (vec4) WFS_BN_BWD(wfs_f16, 4); else WFS_BN_BWD(wfs_f16, 1);
     }
 #undef WFS_BN_BWD
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
-}
-
-// The elementwise half of wfs_bn_relu_bwd alone: the two sums arrive as `nblk` per-block partials [nblk][2][C] left
-// by the launch that produced dY (wfs_gather_conv_bnbwd).  C == 32, nblk <= 256.
-extern "C" int wfs_bn_relu_bwd_sums(const void *X, const void *dY, int64_t N, int32_t C, const float *gamma,
-                                    const float *beta, const float *save_mean, const float *save_invstd, int32_t training,
-                                    int32_t relu, void *dX, float *dgamma, float *dbeta, const float *partial,
-                                    int32_t nblk, int32_t dtype, const int64_t *n_dev_, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long *n_dev = (const long long *)n_dev_;
-    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
-    WFS_REQUIRE(C == 32 && nblk >= 1 && nblk <= 256, WFS_EINVAL, "C == 32 and 1 .. 256 partials (C %d, %d partials)", C, nblk);
-    WFS_REQUIRE(N > 0 && X && dY && dX && save_mean && save_invstd && partial, WFS_EINVAL, "NULL device pointer / no rows");
-    const dim3 block(TB);
-    long long rb = 0;
-    const int per = rr_plan(N, C, dtype == WFS_F32 ? 8 : 16, &rb);
-    if (per) {
-        const dim3 g2((unsigned)rb);
-#define WFS_BN_SUMS_RR(T, PER)                                                                                       \
-    k_bn_bwd_apply_rr<T, PER><<<g2, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, partial, (int)nblk, \
-                                                        save_mean, save_invstd, gamma, beta, training, relu, (T *)dX, \
-                                                        dgamma, dbeta)
-#define WFS_BN_SUMS_RR_T(T)                                                                                          \
-    if (per == 2) WFS_BN_SUMS_RR(T, 2); else if (per == 4) WFS_BN_SUMS_RR(T, 4); else if (per == 8) WFS_BN_SUMS_RR(T, 8); \
-    else WFS_BN_SUMS_RR(T, 16)
-        if (dtype == WFS_F32) { WFS_BN_SUMS_RR_T(float); } else if (dtype == WFS_BF16) { WFS_BN_SUMS_RR_T(wfs_bf16); } else { WFS_BN_SUMS_RR_T(wfs_f16); }
-#undef WFS_BN_SUMS_RR_T
-#undef WFS_BN_SUMS_RR
-    } else {
-        const long long nblk_a = bn_apply_blocks(N), rpb_a = wfs_cdiv(N, nblk_a);
-        const dim3 grid_a((unsigned)nblk_a);
-        if (dtype == WFS_F32)
-            k_bn_bwd_apply<float, 4><<<grid_a, block, 0, stream>>>((const float *)X, (const float *)dY, N, n_dev, C, C, rpb_a,
-                                                                   partial, (int)nblk, save_mean, save_invstd, gamma, beta,
-                                                                   training, relu, (float *)dX, dgamma, dbeta);
-        else if (dtype == WFS_BF16)
-            k_bn_bwd_apply<wfs_bf16, 4><<<grid_a, block, 0, stream>>>((const wfs_bf16 *)X, (const wfs_bf16 *)dY, N, n_dev, C, C,
-                                                                      rpb_a, partial, (int)nblk, save_mean, save_invstd, gamma,
-                                                                      beta, training, relu, (wfs_bf16 *)dX, dgamma, dbeta);
-        else
-            k_bn_bwd_apply<wfs_f16, 4><<<grid_a, block, 0, stream>>>((const wfs_f16 *)X, (const wfs_f16 *)dY, N, n_dev, C, C,
-                                                                     rpb_a, partial, (int)nblk, save_mean, save_invstd, gamma,
-                                                                     beta, training, relu, (wfs_f16 *)dX, dgamma, dbeta);
-    }
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

@@ -35,39 +35,17 @@ __device__ __forceinline__ long long valid_rows(long long R, const long long *r_
 // ------------------------------------------------------------------------------------------ 32 -> 32
 // LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
 // (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
-// AFFINE: the gathered rows are the RAW output of the producing conv; each is read as [relu](x * sc + sh) (the
-// BatchNorm1d + ReLU between the two layers, include/wfsparse.h wfs_row_affine), sc / sh per channel in LDS.
-template <bool TRANSPOSE_W, bool STATS, bool AFFINE, bool BNBWD = false>
+template <bool TRANSPOSE_W, bool STATS>
 __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                       long long R, const long long *__restrict__ r_dev,
                                                       const float *__restrict__ X,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                       float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
-                                                      WfsStatsArgs sa, WfsAffine aff, const float *__restrict__ bn_x,
-                                                      float *__restrict__ bn_partial) {
+                                                      WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float sW[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
-    __shared__ float sBn[BNBWD ? 16 * 64 : 1];          // BNBWD: see k_gconv32_bf16
-    float bm = 0.f, bis = 0.f, bga = 1.f, bbe = 0.f, bsa = 0.f, bsb = 0.f;
-    if constexpr (BNBWD) {
-        const int ch = threadIdx.x & 31;
-        bm = aff.mean[ch];
-        bis = aff.invstd[ch];
-        bga = aff.gamma ? aff.gamma[ch] : 1.f;
-        bbe = aff.beta ? aff.beta[ch] : 0.f;
-    }
-    __shared__ __attribute__((aligned(16))) float sAff[AFFINE ? 64 : 4];          // sc[32] | sh[32]
     WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     const int nthreads = blockDim.x;
-    if constexpr (AFFINE) {
-        if (threadIdx.x < 32) {
-            float sc, sh;
-            wfs_bn_scale_shift(aff.gamma ? aff.gamma[threadIdx.x] : 1.f, aff.beta ? aff.beta[threadIdx.x] : 0.f,
-                               aff.mean[threadIdx.x], aff.invstd[threadIdx.x], sc, sh);
-            sAff[threadIdx.x] = sc;
-            sAff[32 + threadIdx.x] = sh;
-        }
-    }
     if (!TRANSPOSE_W) {
         for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
             int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;
@@ -145,29 +123,6 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
                 unsigned m2 = mask & (mask - 1);
                 int k_nn = m2 ? __builtin_ctz(m2) : k_next;
                 int nb_nn = entry(k_nn);
-                if constexpr (AFFINE) {
-                    const f32x4 *scp = (const f32x4 *)(sAff + h * 16), *shp = (const f32x4 *)(sAff + 32 + h * 16);
-                    const bool rl = aff.relu != 0;
-#define WFS_AFF4(a, q)                                                    \
-    {                                                                     \
-        const f32x4 sc = scp[q], sh = shp[q];                             \
-        a.x = fmaf(a.x, sc.x, sh.x);                                      \
-        a.y = fmaf(a.y, sc.y, sh.y);                                      \
-        a.z = fmaf(a.z, sc.z, sh.z);                                      \
-        a.w = fmaf(a.w, sc.w, sh.w);                                      \
-        if (rl) {                                                         \
-            a.x = a.x > 0.f ? a.x : 0.f;                                  \
-            a.y = a.y > 0.f ? a.y : 0.f;                                  \
-            a.z = a.z > 0.f ? a.z : 0.f;                                  \
-            a.w = a.w > 0.f ? a.w : 0.f;                                  \
-        }                                                                 \
-    }
-                    WFS_AFF4(a0, 0)
-                    WFS_AFF4(a1, 1)
-                    WFS_AFF4(a2, 2)
-                    WFS_AFF4(a3, 3)
-#undef WFS_AFF4
-                }
                 if (nb_cur < 0) a0 = a1 = a2 = a3 = zero4;
                 const f32x4 *bp = (const f32x4 *)(sW + (((k_cur * 2 + h) * 4) * 32 + r) * 4);
                 f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
@@ -206,41 +161,8 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
             const long long left = Rv - tile * 32;
             wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
-        if constexpr (BNBWD) {
-            const int left = (int)(Rv - tile * 32 < 32 ? Rv - tile * 32 : 32);
-            float bx[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                bx[i] = bn_x[(orow < Rv ? orow : 0) * 32 + r];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float xh = (bx[i] - bm) * bis;
-                const bool pass = !aff.relu || fmaf(bga, xh, bbe) > 0.f;
-                const float gm = (rr < left && pass) ? acc[i] : 0.f;
-                bsa += gm;
-                bsb = fmaf(gm, xh, bsb);
-            }
-        }
     }
     if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
-    if constexpr (BNBWD) {
-        bsa += __shfl_xor(bsa, 32, 64);
-        bsb += __shfl_xor(bsb, 32, 64);
-        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = blockDim.x >> 6;
-        if (ln < 32) {
-            sBn[wv * 64 + ln] = bsa;
-            sBn[wv * 64 + 32 + ln] = bsb;
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            float t = 0.f;
-            for (int w = 0; w < nwv; ++w) t += sBn[w * 64 + threadIdx.x];
-            bn_partial[(long long)blockIdx.x * 64 + threadIdx.x] = t;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------ 32 -> 32, bf16
@@ -287,66 +209,17 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 #ifndef WFS_KNOCK
 #define WFS_KNOCK 0
 #endif
-// [relu](x * sc + sh) on the 8 packed 16-bit values of v (channels c0 .. c0 + 7 of a gathered row): per dword two
-// unpacks, one v_pk_fma_f32, two v_max_f32 (against `floor` = 0 with ReLU, -inf without: no branch), one packed convert.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-template <typename H>
-__device__ __forceinline__ unsigned affine2(unsigned w, f32x2 sc, f32x2 sh, float floor) {
-    f32x2 x;
-    if constexpr (__is_same(H, wfs_f16)) {
-        x = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2);
-    } else {
-        x = f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
-    }
-    f32x2 y = __builtin_elementwise_fma(x, sc, sh);
-    y = __builtin_elementwise_max(y, f32x2{floor, floor});
-    if constexpr (__is_same(H, wfs_f16))
-        return __builtin_bit_cast(unsigned, __builtin_convertvector(y, f16x2_t));
-    else
-        return __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2_t));
-}
-template <typename H>
-__device__ __forceinline__ uint4 affine8(uint4 v, const float *sc, const float *sh, float floor) {
-    v.x = affine2<H>(v.x, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]}, floor);
-    v.y = affine2<H>(v.y, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]}, floor);
-    v.z = affine2<H>(v.z, f32x2{sc[4], sc[5]}, f32x2{sh[4], sh[5]}, floor);
-    v.w = affine2<H>(v.w, f32x2{sc[6], sc[7]}, f32x2{sh[6], sh[7]}, floor);
-    return v;
-}
-__device__ __forceinline__ float relu_floor(int relu) { return relu ? 0.f : -__builtin_inff(); }
-
-// AFFINE: see k_gconv32_f32; here sc / sh of the lane's 16 channels live in registers (blocks of at most 768 threads)
-// BNBWD (dX launches): the rows this launch produces are dL/dA of a BatchNorm1d (+ ReLU) whose INPUT rows are bn_x
-// (same row set, 32 channels; `aff` holds its statistics and parameters).  The epilogue takes the two sums the BatchNorm
-// backward needs -- sum(g) and sum(g * xhat) over the rows, g masked by the ReLU -- from the output tile it holds in
-// registers and the tile's own bn_x rows, and leaves them as per-block partials [gridDim.x][2][32] in the layout of the
-// stand-alone reduction (bn.hip k_bn_reduce*), so wfs_bn_relu_bwd_sums skips that launch and its read of both tensors.
-template <typename H, bool TRANSPOSE_W, bool STATS, bool AFFINE, bool BNBWD = false>
-__global__ void __launch_bounds__((AFFINE || BNBWD) ? 768 : 1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
+template <typename H, bool TRANSPOSE_W, bool STATS>
+__global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
                                                        int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
                                                        const H *__restrict__ X,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                        H *__restrict__ Y, long long ntiles,
-                                                       long long tiles_per_xcd, WfsStatsArgs sa, WfsAffine aff,
-                                                       const H *__restrict__ bn_x, float *__restrict__ bn_partial) {
+                                                       long long tiles_per_xcd, WfsStatsArgs sa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float sStat[STATS ? 16 * 65 : 1];
-    __shared__ float sBn[BNBWD ? 16 * 64 : 1];
     WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
-    float bm = 0.f, bis = 0.f, bga = 1.f, bbe = 0.f, bsa = 0.f, bsb = 0.f;
-    if constexpr (BNBWD) {
-        const int ch = threadIdx.x & 31;
-        bm = aff.mean[ch];
-        bis = aff.invstd[ch];
-        bga = aff.gamma ? aff.gamma[ch] : 1.f;
-        bbe = aff.beta ? aff.beta[ch] : 0.f;
-    }
-    float asc[AFFINE ? 16 : 1], ash[AFFINE ? 16 : 1];
-    if constexpr (AFFINE) wfs_affine_load<16>(aff, ((threadIdx.x & 63) >> 5) * 16, asc, ash);
-    const float afloor = relu_floor(aff.relu);
     uint4 *sWb = reinterpret_cast<uint4 *>(smem);                           // K * 128 fragments of 16 B
     int *sNb = reinterpret_cast<int *>(smem + (size_t)K * 2048);            // [waves][K][32]
     const int nthreads = blockDim.x;
@@ -399,7 +272,6 @@ __global__ void __launch_bounds__((AFFINE || BNBWD) ? 768 : 1024) k_gconv32_bf16
         const long long row = tile * 32 + r;
         const bool live = row < Rv;
         const long long rowc = live ? row : 0;
-        H bx[BNBWD ? 16 : 1];
         // ---- phase 1
         int v[32];
 #pragma unroll
@@ -442,10 +314,6 @@ __global__ void __launch_bounds__((AFFINE || BNBWD) ? 768 : 1024) k_gconv32_bf16
             for (int g = 0; g < BF_GROUP; ++g)
                 if (ks[g] >= 0) {
                     uint4 lo = a_lo[g], hi = a_hi[g];
-                    if constexpr (AFFINE) {
-                        lo = affine8<H>(lo, asc, ash, afloor);
-                        hi = affine8<H>(hi, asc + 8, ash + 8, afloor);
-                    }
                     lo = keep_if(lo, nbs[g] >= 0);
                     hi = keep_if(hi, nbs[g] >= 0);
                     const uint4 *bp = sWb + (size_t)ks[g] * 128 + h * 32 + r;
@@ -453,16 +321,6 @@ __global__ void __launch_bounds__((AFFINE || BNBWD) ? 768 : 1024) k_gconv32_bf16
                     acc = mfma16<H>(lo, b0, acc);
                     acc = mfma16<H>(hi, b1, acc);
                 }
-        }
-        if constexpr (BNBWD) {
-            // the BatchNorm input at (row of register i, column r).  Asked for AFTER the last gather: these rows were
-            // written a whole forward pass ago (HBM), and loads return in order -- issued at the top of the tile they
-            // held up the table reads and gathers behind them (30 vs 22 us per launch inside the step)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                bx[i] = bn_x[(orow < Rv ? orow : 0) * 32 + r];
-            }
         }
         // ---- epilogue: reg i holds (row (i&3) + 8(i>>2) + 4h, col r).  Neighbouring columns are paired with one
         // lane exchange so that every lane stores one packed dword: even lanes row(i), odd lanes row(i+1).
@@ -485,37 +343,8 @@ __global__ void __launch_bounds__((AFFINE || BNBWD) ? 768 : 1024) k_gconv32_bf16
             const long long left = Rv - tile * 32;
             wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
         }
-        if constexpr (BNBWD) {
-            const int left = (int)(Rv - tile * 32 < 32 ? Rv - tile * 32 : 32);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float g = wfs_round_to<H>(acc[i]);                         // the gradient as stored
-                const float xh = (wfs_ld(&bx[i]) - bm) * bis;
-                const bool pass = !aff.relu || fmaf(bga, xh, bbe) > 0.f;        // the mask expression of bn.hip
-                const float gm = (rr < left && pass) ? g : 0.f;
-                bsa += gm;
-                bsb = fmaf(gm, xh, bsb);
-            }
-        }
     }
     if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
-    if constexpr (BNBWD) {
-        // lanes (r, 0) and (r, 1) hold the two row halves of column r; waves are added in wave order
-        bsa += __shfl_xor(bsa, 32, 64);
-        bsb += __shfl_xor(bsb, 32, 64);
-        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = blockDim.x >> 6;
-        if (ln < 32) {
-            sBn[wv * 64 + ln] = bsa;
-            sBn[wv * 64 + 32 + ln] = bsb;
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            float t = 0.f;
-            for (int w = 0; w < nwv; ++w) t += sBn[w * 64 + threadIdx.x];
-            bn_partial[(long long)blockIdx.x * 64 + threadIdx.x] = t;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------ 2 -> 32
@@ -570,18 +399,14 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
 constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator registers)
 constexpr int DW_WAVES = 8;
 
-// AFFINE: the stationary rows S are raw conv outputs read as [relu](x * sc + sh) (wfs_row_affine)
-template <typename T, bool AFFINE>
+template <typename T>
 __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
                                                   const long long *__restrict__ r_dev, const T *__restrict__ S,
                                                   const T *__restrict__ G,
-                                                  float *__restrict__ part, int ngroups, long long tiles_per_block,
-                                                  WfsAffine aff) {
+                                                  float *__restrict__ part, int ngroups, long long tiles_per_block) {
     __shared__ float sRed[DW_WAVES * 1024];                           // block reduction staging, 32 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    float asc[1], ash[1];
-    if constexpr (AFFINE) wfs_affine_load<1>(aff, j, asc, ash);
     const int g = blockIdx.y;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
@@ -609,10 +434,6 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
         for (int s = 0; s < 16; ++s) {
             long long row = row0 + 2 * s + h;
             float t = wfs_ld(S + (row < R ? row : R - 1) * 32 + j);
-            if constexpr (AFFINE) {
-                t = fmaf(t, asc[0], ash[0]);
-                if (aff.relu) t = t > 0.f ? t : 0.f;
-            }
             a[s] = row < R ? t : 0.f;
         }
         bool any = false;
@@ -849,20 +670,15 @@ __device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename H, bool AFFINE>
+template <typename H>
 __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int K, int identity_k,
                                                      long long Rcap, const long long *__restrict__ r_dev,
                                                      const H *__restrict__ S, const H *__restrict__ G,
-                                                     float *__restrict__ part, int ngroups, long long tiles_per_block,
-                                                     WfsAffine aff) {
+                                                     float *__restrict__ part, int ngroups, long long tiles_per_block) {
     __shared__ __attribute__((aligned(16))) unsigned short sTiles[DWB_WAVES][2][32 * 32];   // per wave: S tile, G tile
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;          // fragment coordinates
     const int grow = lane >> 2, gchunk = lane & 3;   // staging coordinates: rows grow and grow+16, 16-B chunk gchunk
-    // AFFINE is applied to the S FRAGMENTS: after the transposed LDS read a lane holds 16 rows of ONE channel (c), so it
-    // needs a single (sc, sh) pair (at staging time a lane holds 8 channels: 16 more registers, and the kernel spilled)
-    float asc[1] = {1.f}, ash[1] = {0.f};
-    if constexpr (AFFINE) wfs_affine_load<1>(aff, c, asc, ash);
     unsigned short *sS = sTiles[wid][0], *sG = sTiles[wid][1];
     const int g = blockIdx.y;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
@@ -907,32 +723,6 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
         *(uint4 *)(sS + (grow + 16) * 32 + gchunk * 8) = keep_if(s1, lb);
         __builtin_amdgcn_wave_barrier();
         bf16x8 a0, a1;
-        if constexpr (AFFINE) {
-            // the S fragments first (their ~60 conversion instructions need registers the gathers would hold)
-            a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
-        {
-            // element j of k-step s is row 16 s + 8 h + j of the tile; rows beyond the valid count stay zero
-            const int left = (int)(R - row0 < 32 ? R - row0 : 32);          // 32-bit: 64-bit row compares spilled
-            const f32x2 sc2 = {asc[0], asc[0]}, sh2 = {ash[0], ash[0]};
-            const float fl = relu_floor(aff.relu);
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                uint4 v = __builtin_bit_cast(uint4, st ? a1 : a0);
-                unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int rr = 16 * st + 8 * h + 2 * m;
-                    unsigned o = affine2<H>(w[m], sc2, sh2, fl);
-                    o = rr < left ? o : 0u;                              // rows beyond the valid count stay zero
-                    o = rr + 1 < left ? o : (o & 0xFFFFu);
-                    w[m] = o;
-                }
-                const uint4 o4 = {w[0], w[1], w[2], w[3]};
-                if (st) a1 = __builtin_bit_cast(bf16x8, o4); else a0 = __builtin_bit_cast(bf16x8, o4);
-            }
-        }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         // the gathers of ALL the block's offsets are issued together and unconditionally (clamped rows): one memory
         // round trip per tile; a load under the per-offset branch would cost one per offset (hipcc waits vmcnt(0))
         uint4 g0[DWB_KG], g1[DWB_KG];
@@ -941,7 +731,7 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
             g0[q] = *(const uint4 *)(G + (long long)(ta[q] >= 0 ? ta[q] : 0) * 32 + gchunk * 8);
             g1[q] = *(const uint4 *)(G + (long long)(tb[q] >= 0 ? tb[q] : 0) * 32 + gchunk * 8);
         }
-        if constexpr (!AFFINE) a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
+        a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
 #pragma unroll
         for (int q = 0; q < DWB_KG; ++q) {
             if (act[q] == 0ull) continue;
@@ -1331,115 +1121,57 @@ static WfsStatsArgs stats_args(const wfs_bn_stats *st, long long nblk) {
 
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
     gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
     const size_t lds = (size_t)K * 4096;
-    static bool attr[5] = {false, false, false, false, false};
+    static bool attr[3] = {false, false, false};
     const WfsStatsArgs sa = stats_args(stats, nblk);
-    const WfsAffine aff = affine ? *affine : WfsAffine{nullptr, nullptr, nullptr, nullptr, 0};
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
-        return launch_big_lds(k_gconv32_f32<true, false, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
-    int rc;
+        return launch_big_lds(k_gconv32_f32<true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
     if (stats) {
-        if (affine)
-            rc = launch_big_lds(k_gconv32_f32<false, true, true>, &attr[3], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
-        else
-            rc = launch_big_lds(k_gconv32_f32<false, true, false>, &attr[1], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
+        const int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
+                                      identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
-    if (affine)
-        return launch_big_lds(k_gconv32_f32<false, false, true>, &attr[4], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
-    return launch_big_lds(k_gconv32_f32<false, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
-                          identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa, aff, nullptr, nullptr);
+    return launch_big_lds(k_gconv32_f32<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
+                          identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
 }
 
 template <typename H>
 static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                               const H *Xb, const float *W, int transpose_w, const float *bias, H *Yb,
-                              const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream) {
+                              const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
-    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, affine ? 12 : 16);     // the AFFINE kernels: <= 768 threads
+    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
     const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
-    static bool attr[5] = {false, false, false, false, false};          // per instantiation of this template, i.e. per H
+    static bool attr[3] = {false, false, false};          // per instantiation of this template, i.e. per H
     const WfsStatsArgs sa = stats_args(stats, nblk);
-    const WfsAffine aff = affine ? *affine : WfsAffine{nullptr, nullptr, nullptr, nullptr, 0};
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
-        return launch_big_lds(k_gconv32_bf16<H, true, false, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
-    int rc;
+        return launch_big_lds(k_gconv32_bf16<H, true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
     if (stats) {
-        if (affine)
-            rc = launch_big_lds(k_gconv32_bf16<H, false, true, true>, &attr[3], grid, block, lds, stream, table, mirror, K,
-                                identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
-        else
-            rc = launch_big_lds(k_gconv32_bf16<H, false, true, false>, &attr[1], grid, block, lds, stream, table, mirror,
-                                K, identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
+        const int rc = launch_big_lds(k_gconv32_bf16<H, false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
+                                      identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
         return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
     }
-    if (affine)
-        return launch_big_lds(k_gconv32_bf16<H, false, false, true>, &attr[4], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
-    return launch_big_lds(k_gconv32_bf16<H, false, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
-                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa, aff, (const H *)nullptr, (float *)nullptr);
+    return launch_big_lds(k_gconv32_bf16<H, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
+                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
 }
 
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
     if (dtype == WFS_F16)
         return launch_gconv32_h16<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, transpose_w,
-                                           bias, (wfs_f16 *)Y, stats, pending, affine, stream);
+                                           bias, (wfs_f16 *)Y, stats, pending, stream);
     return launch_gconv32_h16<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, transpose_w, bias,
-                                        (wfs_bf16 *)Y, stats, pending, affine, stream);
-}
-
-// dX (transposed filters) of a 32 -> 32 layer whose epilogue takes the sums of the BatchNorm backward in front of it
-// (BNBWD above): partial [*nblk][2][32] floats, *nblk <= 256
-size_t wfs_conv_bnbwd_partial_bytes(void) { return (size_t)256 * 64 * sizeof(float); }
-
-template <typename H>
-static int launch_gconv32_h16_bnbwd(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
-                                    const H *Xb, const float *W, H *Yb, const WfsAffine &bn, const H *bn_x, float *partial,
-                                    int *nblk_out, hipStream_t stream) {
-    long long ntiles, nblk, tiles_per_xcd;
-    int wpb;
-    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, 12);
-    const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
-    static bool attr = false;
-    const WfsStatsArgs sa = stats_args(nullptr, nblk);
-    *nblk_out = (int)nblk;
-    return launch_big_lds(k_gconv32_bf16<H, true, false, false, true>, &attr, dim3((unsigned)nblk), dim3(wpb * 64), lds, stream,
-                          table, mirror, K, identity_k, R, r_dev, Xb, W, (const float *)nullptr, Yb, ntiles, tiles_per_xcd, sa,
-                          bn, bn_x, partial);
-}
-
-int wfs_launch_gconv32_bnbwd(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
-                             const void *X, const float *W, void *Y, int dtype, const WfsAffine *bn, const void *bn_x,
-                             float *partial, int *nblk_out, hipStream_t stream) {
-    if (dtype == WFS_F16)
-        return launch_gconv32_h16_bnbwd<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, (wfs_f16 *)Y,
-                                                 *bn, (const wfs_f16 *)bn_x, partial, nblk_out, stream);
-    if (dtype == WFS_BF16)
-        return launch_gconv32_h16_bnbwd<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W,
-                                                  (wfs_bf16 *)Y, *bn, (const wfs_bf16 *)bn_x, partial, nblk_out, stream);
-    long long ntiles, nblk, tiles_per_xcd;
-    int wpb;
-    gconv32_grid(R, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
-    static bool attr = false;
-    const WfsStatsArgs sa = stats_args(nullptr, nblk);
-    *nblk_out = (int)nblk;
-    return launch_big_lds(k_gconv32_f32<true, false, false, true>, &attr, dim3((unsigned)nblk), dim3(wpb * 64),
-                          (size_t)K * 4096, stream, table, mirror, K, identity_k, R, r_dev, (const float *)X, W,
-                          (const float *)nullptr, (float *)Y, ntiles, tiles_per_xcd, sa, *bn, (const float *)bn_x, partial);
+                                        (wfs_bf16 *)Y, stats, pending, stream);
 }
 
 // 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.
@@ -1523,23 +1255,15 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
 }
 
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
-                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer,
-                     const WfsAffine *s_affine, hipStream_t stream) {
+                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream) {
     const long long nblk = dw32_blocks(R);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
-    const WfsAffine aff = s_affine ? *s_affine : WfsAffine{nullptr, nullptr, nullptr, nullptr, 0};
     const dim3 grid((unsigned)nblk, (unsigned)ngroups);
 #define WFS_DW32(KERNEL, T, THREADS)                                                                                  \
-    {                                                                                                                 \
-        if (s_affine)                                                                                                 \
-            KERNEL<T, true><<<grid, dim3(THREADS), 0, stream>>>(table, K, identity_k, R, r_dev, (const T *)S,          \
-                                                                (const T *)G, part, ngroups, tiles_per_block, aff);    \
-        else                                                                                                          \
-            KERNEL<T, false><<<grid, dim3(THREADS), 0, stream>>>(table, K, identity_k, R, r_dev, (const T *)S,         \
-                                                                 (const T *)G, part, ngroups, tiles_per_block, aff);   \
-    }
+    KERNEL<T><<<grid, dim3(THREADS), 0, stream>>>(table, K, identity_k, R, r_dev, (const T *)S, (const T *)G, part,    \
+                                                  ngroups, tiles_per_block);
     if (dtype == WFS_F32) WFS_DW32(k_gdw32, float, 512)
     else if (dtype == WFS_BF16) WFS_DW32(k_gdw32_bf16, wfs_bf16, 1024)
     else WFS_DW32(k_gdw32_bf16, wfs_f16, 1024)

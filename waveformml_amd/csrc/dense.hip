@@ -80,48 +80,15 @@ __device__ __forceinline__ int mapped_row(const unsigned *ticket, const int *slo
     return (id >= 0 && id < Mv) ? id : -1;
 }
 
-// raw element (16 or 32 bits in the low end of `raw`) -> [relu](x * sc + sh) -> raw element
-template <typename T>
-__device__ __forceinline__ unsigned affine_raw(unsigned raw, float sc, float sh, bool relu) {
-    float v;
-    if constexpr (sizeof(T) == 4) {
-        v = __uint_as_float(raw);
-    } else {
-        T t;
-        *reinterpret_cast<unsigned short *>(&t) = (unsigned short)raw;
-        v = wfs_ld(&t);
-    }
-    v = fmaf(v, sc, sh);
-    if (relu) v = v > 0.f ? v : 0.f;
-    if constexpr (sizeof(T) == 4) {
-        return __float_as_uint(v);
-    } else {
-        T t;
-        wfs_st(&t, v);
-        return (unsigned)*reinterpret_cast<unsigned short *>(&t);
-    }
-}
 
-// AFFINE: the rows are the raw output of the last conv, read as [relu](x * sc + sh) (its BatchNorm1d + ReLU,
-// include/wfsparse.h wfs_row_affine); empty cells stay zero
-template <typename T, bool AFFINE>
+template <typename T>
 __global__ void __launch_bounds__(TB) k_to_dense_mapped(const T *__restrict__ X, const unsigned *__restrict__ ticket,
                                                         const int *__restrict__ slot_id, long long M,
-                                                        const long long *m_dev, long long V, int C, T *__restrict__ Y,
-                                                        WfsAffine aff) {
+                                                        const long long *m_dev, long long V, int C, T *__restrict__ Y) {
     constexpr int PACK = 4 / (int)sizeof(T);              // cells per 32-bit word: 2 (16-bit rows) or 1 (fp32)
     constexpr int WORDS = DM_CELLS / PACK;                // words per channel and tile
     extern __shared__ unsigned sT[];                      // [C][WORDS + 1]
     __shared__ int sRow[DM_CELLS];
-    __shared__ float sAff[AFFINE ? 256 : 2];              // sc[C] | sh[C], C <= 128
-    if constexpr (AFFINE) {
-        for (int c = threadIdx.x; c < C; c += TB) {
-            float sc, sh;
-            wfs_bn_scale_shift(aff.gamma ? aff.gamma[c] : 1.f, aff.beta ? aff.beta[c] : 0.f, aff.mean[c], aff.invstd[c], sc, sh);
-            sAff[c] = sc;
-            sAff[128 + c] = sh;
-        }
-    }
     const long long Mv = valid_rows(M, m_dev);
     const long long b = blockIdx.y, p0 = (long long)blockIdx.x * DM_CELLS;
     if (threadIdx.x < DM_CELLS) {
@@ -143,21 +110,11 @@ __global__ void __launch_bounds__(TB) k_to_dense_mapped(const T *__restrict__ X,
                 if constexpr (sizeof(T) == 4) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(src);
                     unsigned e[4] = {v.x, v.y, v.z, v.w};
-                    if constexpr (AFFINE) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            e[j] = affine_raw<T>(e[j], sAff[4 * q + j], sAff[128 + 4 * q + j], aff.relu != 0);
-                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) word[j] = ok ? e[j] : 0u;
                 } else {
                     const uint2 v = *reinterpret_cast<const uint2 *>(src);          // 4 x 16 bit
                     unsigned e[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
-                    if constexpr (AFFINE) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            e[j] = affine_raw<T>(e[j], sAff[4 * q + j], sAff[128 + 4 * q + j], aff.relu != 0);
-                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) word[j] |= ok ? e[j] << (16 * h) : 0u;
                 }
@@ -288,9 +245,9 @@ static int mapped_ok(int64_t V, int32_t C, int32_t dtype, int32_t batch) {
     return V > 0 && V % pack == 0 && C >= 4 && C % 4 == 0 && C <= 128 && batch >= 1 && batch <= 65535;
 }
 
-static int to_dense_mapped_impl(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
-                                const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y, int32_t dtype,
-                                const WfsAffine *affine, void *stream_) {
+extern "C" int wfs_to_dense_mapped(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
+                                   const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y,
+                                   int32_t dtype, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(mapped_ok(V, C, dtype, batch_size), WFS_EINVAL, "unsupported shape for the mapped dense(): V=%lld C=%d",
@@ -300,40 +257,13 @@ static int to_dense_mapped_impl(const void *X, const uint32_t *ticket, const int
     const int words = DM_CELLS / (dtype == WFS_F32 ? 1 : 2);
     const size_t lds = (size_t)C * (words + 1) * sizeof(unsigned);
     const long long *md = (const long long *)m_dev;
-    const WfsAffine aff = affine ? *affine : WfsAffine{nullptr, nullptr, nullptr, nullptr, 0};
-    if (affine) {
-        if (dtype == WFS_F32)
-            k_to_dense_mapped<float, true><<<grid, block, lds, stream>>>((const float *)X, ticket, slot_id, M, md, V, C,
-                                                                         (float *)Y, aff);
-        else if (dtype == WFS_BF16)
-            k_to_dense_mapped<wfs_bf16, true><<<grid, block, lds, stream>>>((const wfs_bf16 *)X, ticket, slot_id, M, md, V,
-                                                                            C, (wfs_bf16 *)Y, aff);
-        else
-            k_to_dense_mapped<wfs_f16, true><<<grid, block, lds, stream>>>((const wfs_f16 *)X, ticket, slot_id, M, md, V,
-                                                                           C, (wfs_f16 *)Y, aff);
-    } else if (dtype == WFS_F32) {
-        k_to_dense_mapped<float, false><<<grid, block, lds, stream>>>((const float *)X, ticket, slot_id, M, md, V, C,
-                                                                      (float *)Y, aff);
-    } else {        // bf16 and fp16 alike: 2-byte elements, copied as they are
-        k_to_dense_mapped<wfs_bf16, false><<<grid, block, lds, stream>>>((const wfs_bf16 *)X, ticket, slot_id, M, md, V, C,
-                                                                         (wfs_bf16 *)Y, aff);
-    }
+    if (dtype == WFS_F32)
+        k_to_dense_mapped<float><<<grid, block, lds, stream>>>((const float *)X, ticket, slot_id, M, md, V, C, (float *)Y);
+    else        // bf16 and fp16 alike: 2-byte elements, copied as they are
+        k_to_dense_mapped<wfs_bf16><<<grid, block, lds, stream>>>((const wfs_bf16 *)X, ticket, slot_id, M, md, V, C,
+                                                                  (wfs_bf16 *)Y);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
-}
-
-extern "C" int wfs_to_dense_mapped(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
-                                   const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y,
-                                   int32_t dtype, void *stream) {
-    return to_dense_mapped_impl(X, ticket, slot_id, M, m_dev, batch_size, V, C, Y, dtype, nullptr, stream);
-}
-
-extern "C" int wfs_to_dense_mapped_affine(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
-                                          const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *Y,
-                                          int32_t dtype, const wfs_row_affine *in_affine, void *stream) {
-    WFS_REQUIRE(in_affine && in_affine->mean && in_affine->invstd, WFS_EINVAL, "incomplete wfs_row_affine");
-    const WfsAffine aff = wfs_affine_from(in_affine);
-    return to_dense_mapped_impl(X, ticket, slot_id, M, m_dev, batch_size, V, C, Y, dtype, &aff, stream);
 }
 
 extern "C" int wfs_to_dense_bwd_mapped(const void *dY, const uint32_t *ticket, const int32_t *slot_id, int64_t M,

@@ -407,7 +407,7 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
                             int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
                             int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
                             const int64_t *r_dev_, const wfs_bn_stats *stats, bool *stats_done, int *pending,
-                            void *stream_, const WfsAffine *affine = nullptr) {
+                            void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     *stats_done = false;
     const long long *r_dev = (const long long *)r_dev_;
@@ -434,14 +434,13 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
     if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
-                                      bias, (float *)Y, stats, pending, affine, stream);
+                                      bias, (float *)Y, stats, pending, stream);
     }
     if (dtype != WFS_F32 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_h16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
-                                      dtype, stats, pending, affine, stream);
+                                      dtype, stats, pending, stream);
     }
-    WFS_REQUIRE(!affine, WFS_EINVAL, "rows read through a BatchNorm affine: 32 -> 32 channels, K <= 27, identity or mirror map");
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
         return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stats, stats_done,
                                       pending, stream);
@@ -516,56 +515,6 @@ extern "C" int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap
     return wfs_launch_bn_stats(Y, R, Cw_out, dtype, (const long long *)r_dev, stats, (hipStream_t)stream);
 }
 
-extern "C" int wfs_gather_conv_affine(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
-                                      int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
-                                      int32_t Cw_out, const float *bias, void *Y, int32_t dtype, const int64_t *r_dev,
-                                      const wfs_row_affine *in_affine, const wfs_bn_stats *stats, void *stream) {
-    WFS_REQUIRE(in_affine && in_affine->mean && in_affine->invstd, WFS_EINVAL, "incomplete wfs_row_affine");
-    WFS_REQUIRE(Cx == 32 && Cw_in == 32 && Cw_out == 32, WFS_EINVAL, "wfs_gather_conv_affine covers 32 -> 32 channels");
-    if (stats) {
-        WFS_REQUIRE(stats->save_mean && stats->save_invstd && stats->workspace, WFS_EINVAL, "incomplete wfs_bn_stats");
-        WFS_REQUIRE(stats->workspace_bytes >= wfs_conv_stats_workspace_bytes(R, Cw_out), WFS_EWORKSPACE,
-                    "statistics workspace %zu < %zu", stats->workspace_bytes, wfs_conv_stats_workspace_bytes(R, Cw_out));
-        WFS_REQUIRE(R > 0, WFS_EINVAL, "batch statistics of zero rows");
-    }
-    const WfsAffine aff = wfs_affine_from(in_affine);
-    bool done = false;
-    int rc = gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, 0, bias, Y, dtype, r_dev,
-                              stats, &done, nullptr, stream, &aff);
-    if (rc != WFS_OK || !stats || done) return rc;
-    return wfs_launch_bn_stats(Y, R, Cw_out, dtype, (const long long *)r_dev, stats, (hipStream_t)stream);
-}
-
-extern "C" size_t wfs_gather_conv_bnbwd_partial_bytes(void) { return wfs_conv_bnbwd_partial_bytes(); }
-
-extern "C" int wfs_gather_conv_bnbwd(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
-                                     int64_t R, const void *X, int64_t X_rows, const float *W, void *Y, int32_t dtype,
-                                     const int64_t *r_dev, const wfs_row_affine *bn, const void *bn_x, float *partial,
-                                     size_t partial_bytes, int32_t *nblk, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    (void)X_rows;
-    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
-    WFS_REQUIRE(bn && bn->mean && bn->invstd && bn_x && partial && nblk, WFS_EINVAL, "incomplete BatchNorm description");
-    WFS_REQUIRE(partial_bytes >= wfs_conv_bnbwd_partial_bytes(), WFS_EWORKSPACE, "partial buffer %zu < %zu", partial_bytes,
-                wfs_conv_bnbwd_partial_bytes());
-    WFS_REQUIRE(R > 0 && table && X && W && Y, WFS_EINVAL, "NULL device pointer / no rows");
-    WFS_REQUIRE(K >= 1 && (dtype == WFS_F32 ? wfs_mfma_gconv32_ok(K) : K <= 27), WFS_EINVAL, "kernel volume %d not covered", K);
-    bool is_ident = true, is_mirror = true;
-    for (int k = 0; k < K; ++k) {
-        const int v = kmap_host ? kmap_host[k] : k;
-        is_ident = is_ident && v == k;
-        is_mirror = is_mirror && v == K - 1 - k;
-    }
-    WFS_REQUIRE(is_ident || is_mirror, WFS_EINVAL, "column map must be the identity or the SubM mirror");
-    WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
-    const WfsAffine a = wfs_affine_from(bn);
-    int nb = 0;
-    int rc = wfs_launch_gconv32_bnbwd(table, is_ident ? 0 : 1, K, identity_k, R, (const long long *)r_dev, X, W, Y, dtype, &a,
-                                      bn_x, partial, &nb, stream);
-    *nblk = nb;
-    return rc;
-}
-
 extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X,
                                 int32_t Cx, const float *W, int32_t Cw_in, int32_t Cw_out, int32_t transpose_w,
                                 float *Y_accum, int32_t dtype, void *stream_) {
@@ -601,7 +550,7 @@ extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs
 static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
                           const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
                           int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev_,
-                          wfs_dw_job *defer, void *stream_, const WfsAffine *s_affine) {
+                          wfs_dw_job *defer, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long *r_dev = (const long long *)r_dev_;
     (void)G_rows;
@@ -618,9 +567,7 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
     if (Cs == 32 && Cg == 32 && table && !kmap_host)
-        return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, defer, s_affine,
-                                stream);
-    WFS_REQUIRE(!s_affine, WFS_EINVAL, "stationary rows read through a BatchNorm affine: 32 x 32 channels, no column map");
+        return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, defer, stream);
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K && kmap_host; ++k) {
         is_ident = is_ident && kmap_host[k] == k;
@@ -671,18 +618,7 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
                              int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev,
                              wfs_dw_job *defer, void *stream) {
     return gather_dw_impl(table, kmap_host, K, identity_k, R, S, Cs, G, G_rows, Cg, swap, dW, dtype, workspace,
-                          workspace_bytes, r_dev, defer, stream, nullptr);
-}
-
-extern "C" int wfs_gather_dw_affine(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
-                                    const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap,
-                                    float *dW, int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev,
-                                    const wfs_row_affine *s_affine, wfs_dw_job *defer, void *stream) {
-    WFS_REQUIRE(s_affine && s_affine->mean && s_affine->invstd, WFS_EINVAL, "incomplete wfs_row_affine");
-    WFS_REQUIRE(R > 0, WFS_EINVAL, "no rows");
-    const WfsAffine aff = wfs_affine_from(s_affine);
-    return gather_dw_impl(table, kmap_host, K, identity_k, R, S, Cs, G, G_rows, Cg, swap, dW, dtype, workspace,
-                          workspace_bytes, r_dev, defer, stream, &aff);
+                          workspace_bytes, r_dev, defer, stream);
 }
 
 extern "C" int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream) {

@@ -270,219 +270,6 @@ __global__ void __launch_bounds__(XE_TB) k_xent_mean(const float *__restrict__ Z
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// ToDense + flatten + Linear without the dense tensor.  The reference densifies the last sparse layer's [M, C] rows
-// into [B, C, *spatial] (18 MB of mostly zeros at the PSD shapes), flattens and multiplies with W [O, C V]
-// (src/models/SPConvNet.py:65-68).  With distinct output sites that is
-//     Y[b][o] = bias[o] + sum_{rows r of event b} sum_c X[r][c] W[o][c V + cell(r)],       V = prod(spatial)
-// Rows of one event are contiguous (a conv numbers its outputs in first-seen order over inputs sorted by event, and
-// collate_fn sorts the inputs): block b finds its row range by a two-level counting search on the batch column.
-//   forward  one block per event; also writes grid[b][cell] = row or -1 (every cell) for the dW pass
-//   dX       row-parallel:  dX[r][c] = sum_o g[b][o] W[o][c V + cell]
-//   dW       dW[o][c V + cell] = sum_b g[b][o] X[grid[b][cell]][c]: thread = (cell, 8-channel chunk, slice of events),
-//            slices combined by a wave butterfly; dB by block 0.  No float atomics anywhere: results are reproducible.
-struct HShape {
-    int ndim;
-    int spatial[4];
-};
-__device__ __forceinline__ int cell_of(const HShape &sh, const int *row) {
-    int lin = 0;
-    for (int d = 0; d < sh.ndim; ++d) lin = lin * sh.spatial[d] + row[1 + d];
-    return lin;
-}
-template <typename T, int O>
-__global__ void __launch_bounds__(TB) k_sparse_head_fwd(const T *__restrict__ X, const int *__restrict__ idx, long long Mcap,
-                                                        const long long *__restrict__ m_dev, HShape sh, int V, int C,
-                                                        const float *__restrict__ W, const float *__restrict__ bias,
-                                                        float *__restrict__ Y, int *__restrict__ grid) {
-    extern __shared__ int sgrid[];                     // [V]
-    __shared__ float red[TB / 64][O];
-    __shared__ long long srange[2];
-    const int b = blockIdx.x;
-    const int stride = sh.ndim + 1;
-    const long long M = m_dev ? (*m_dev < Mcap ? *m_dev : Mcap) : Mcap;
-    // row range [r0, r1) of event b = number of rows with batch < b and < b + 1.  Two-level counting search, all
-    // threads: TB equidistant samples bracket both bounds (one memory round trip), the two brackets are then counted
-    // exactly (one more) -- a plain binary search would be ~17 dependent loads per block.
-    for (int v = threadIdx.x; v < V; v += TB) sgrid[v] = -1;
-    const long long step = (M + TB - 1) / TB > 0 ? (M + TB - 1) / TB : 1;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ int swc[2][TB / 64];
-    {
-        const long long pos = (long long)threadIdx.x * step;           // first row of this thread's segment
-        const int vb = pos < M ? idx[pos * stride] : 0x7FFFFFFF;
-        // segments whose FIRST row is below the bound: ballots + a 4-entry LDS sum (LDS atomics on one address
-        // would serialise all 256 threads)
-        const int c0 = __popcll(__ballot(vb < b)), c1 = __popcll(__ballot(vb < b + 1));
-        if (lane == 0) {
-            swc[0][wv] = c0;
-            swc[1][wv] = c1;
-        }
-    }
-    __syncthreads();
-    int n0 = 0, n1 = 0;
-#pragma unroll
-    for (int w = 0; w < TB / 64; ++w) {
-        n0 += swc[0][w];
-        n1 += swc[1][w];
-    }
-    const int seg0 = n0 > 0 ? n0 - 1 : 0, seg1 = n1 > 0 ? n1 - 1 : 0;       // the segments holding the two bounds
-    __syncthreads();
-    {
-        int c0 = 0, c1 = 0;
-        for (long long i = threadIdx.x; i < step; i += TB) {
-            const long long p0 = (long long)seg0 * step + i, p1 = (long long)seg1 * step + i;
-            const int v0 = p0 < M ? idx[p0 * stride] : 0x7FFFFFFF, v1 = p1 < M ? idx[p1 * stride] : 0x7FFFFFFF;
-            c0 += v0 < b ? 1 : 0;
-            c1 += v1 < b + 1 ? 1 : 0;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            c0 += __shfl_xor(c0, off, 64);
-            c1 += __shfl_xor(c1, off, 64);
-        }
-        if (lane == 0) {
-            swc[0][wv] = c0;
-            swc[1][wv] = c1;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t0 = 0, t1 = 0;
-        for (int w = 0; w < TB / 64; ++w) {
-            t0 += swc[0][w];
-            t1 += swc[1][w];
-        }
-        srange[0] = (long long)seg0 * step + t0;
-        srange[1] = (long long)seg1 * step + t1;
-    }
-    __syncthreads();
-    const long long r0 = srange[0], r1 = srange[1];
-    for (long long r = r0 + threadIdx.x; r < r1; r += TB) sgrid[cell_of(sh, idx + r * stride)] = (int)r;
-    __syncthreads();
-    if (grid)
-        for (int v = threadIdx.x; v < V; v += TB) grid[(long long)b * V + v] = sgrid[v];
-    // thread = (row slot, 8-channel chunk): chunks = C / 8
-    const int chunks = C >> 3, slots = TB / chunks;
-    const int ch = threadIdx.x % chunks, slot = threadIdx.x / chunks;
-    float acc[O];
-#pragma unroll
-    for (int o = 0; o < O; ++o) acc[o] = 0.f;
-    const long long CV = (long long)C * V;
-    if (slot < slots)
-        for (long long r = r0 + slot; r < r1; r += slots) {
-            const int cell = cell_of(sh, idx + r * stride);
-            float xv[8];
-            load8<T>(X + r * C + ch * 8, xv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float *w = W + (long long)(ch * 8 + i) * V + cell;
-#pragma unroll
-                for (int o = 0; o < O; ++o) acc[o] = fmaf(xv[i], w[o * CV], acc[o]);
-            }
-        }
-    // fixed-order reduction: butterfly inside the wave, waves in wave order
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off, 64);
-    }
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int o = 0; o < O; ++o) red[threadIdx.x >> 6][o] = acc[o];
-    __syncthreads();
-    if (threadIdx.x < O) {
-        float v = bias ? bias[threadIdx.x] : 0.f;
-        for (int w = 0; w < TB / 64; ++w) v += red[w][threadIdx.x];
-        Y[(long long)b * O + threadIdx.x] = v;
-    }
-}
-
-template <typename T, int O>
-__global__ void __launch_bounds__(TB) k_sparse_head_dx(const int *__restrict__ idx, long long Mcap,
-                                                       const long long *__restrict__ m_dev, HShape sh, int V, int C,
-                                                       const float *__restrict__ W, const float *__restrict__ G,
-                                                       T *__restrict__ dX) {
-    const long long M = m_dev ? (*m_dev < Mcap ? *m_dev : Mcap) : Mcap;
-    const int chunks = C >> 3, stride = sh.ndim + 1;
-    const long long CV = (long long)C * V;
-    for (long long u = (long long)blockIdx.x * TB + threadIdx.x; u < M * chunks; u += (long long)gridDim.x * TB) {
-        const long long r = u / chunks;
-        const int ch = (int)(u - r * chunks);
-        const int *row = idx + r * stride;
-        const int b = row[0], cell = cell_of(sh, row);
-        float g[O];
-#pragma unroll
-        for (int o = 0; o < O; ++o) g[o] = G[(long long)b * O + o];
-        float out[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float *w = W + (long long)(ch * 8 + i) * V + cell;
-            float a = 0.f;
-#pragma unroll
-            for (int o = 0; o < O; ++o) a = fmaf(g[o], w[o * CV], a);
-            out[i] = a;
-        }
-        store8<T>(dX + r * C + ch * 8, out);
-    }
-}
-
-// dW: wave = 2 cells x 32 event slices (lane & 31 = slice, lane >> 5 = cell of the pair), block = 4 waves = 8 cells,
-// blockIdx.y = 8-channel chunk.  A thread takes events slice, slice + 32, ... eight at a time (all grid entries, then
-// all feature rows, unconditional and clamped: two memory round trips per batch); the 32 slices of a cell are summed by
-// a butterfly inside the wave (fixed order), lane 0 of each half stores.
-template <typename T, int O>
-__global__ void __launch_bounds__(TB) k_sparse_head_dw(const T *__restrict__ X, const int *__restrict__ grid, int B, int V,
-                                                       int C, const float *__restrict__ G, float *__restrict__ dW,
-                                                       float *__restrict__ dB) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int sl = lane & 31;
-    const int cell = (blockIdx.x * 4 + wid) * 2 + (lane >> 5), ch = blockIdx.y;
-    const int cellc = cell < V ? cell : V - 1;
-    float acc[O][8];
-#pragma unroll
-    for (int o = 0; o < O; ++o)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
-    for (int b0 = sl; b0 < B; b0 += 32 * 8) {
-        int rr[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = b0 + u * 32;
-            rr[u] = grid[(long long)(b < B ? b : 0) * V + cellc];
-            if (b >= B || cell >= V) rr[u] = -1;
-        }
-        float xv[8][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) load8<T>(X + (long long)(rr[u] >= 0 ? rr[u] : 0) * C + ch * 8, xv[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = b0 + u * 32;
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const float g = rr[u] >= 0 ? G[(long long)(b < B ? b : 0) * O + o] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[o][i] = fmaf(g, xv[u][i], acc[o][i]);
-            }
-        }
-    }
-    const long long CV = (long long)C * V;
-#pragma unroll
-    for (int o = 0; o < O; ++o)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v = acc[o][i];
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (sl == 0 && cell < V) dW[o * CV + (long long)(ch * 8 + i) * V + cell] = v;
-        }
-    if (dB && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < O) {
-        float v = 0.f;
-        for (int b = 0; b < B; ++b) v += G[(long long)b * O + threadIdx.x];
-        dB[threadIdx.x] = v;
-    }
-}
-
 }  // namespace
 
 extern "C" size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O) {
@@ -596,107 +383,5 @@ extern "C" int wfs_xent_mean_fwd_bwd(const float *logits, const int64_t *target,
     WFS_REQUIRE(logits && target && loss, WFS_EINVAL, "NULL device pointer");
     k_xent_mean<<<dim3(1), dim3(XE_TB), 0, stream>>>(logits, (const long long *)target, B, C, ignore_index, loss, dlogits);
     WFS_LAUNCH_CHECK();
-    return WFS_OK;
-}
-
-static int make_hshape(HShape *sh, int32_t ndim, const int32_t *spatial, long long *V) {
-    WFS_REQUIRE(ndim >= 1 && ndim <= 4 && spatial, WFS_EINVAL, "ndim %d not in [1,4]", ndim);
-    sh->ndim = ndim;
-    *V = 1;
-    for (int d = 0; d < 4; ++d) {
-        sh->spatial[d] = d < ndim ? spatial[d] : 1;
-        *V *= sh->spatial[d];
-    }
-    return WFS_OK;
-}
-
-#define WFS_HEAD_O(CALL)            \
-    switch (O) {                    \
-        case 1: CALL(1); break;     \
-        case 2: CALL(2); break;     \
-        case 3: CALL(3); break;     \
-        case 4: CALL(4); break;     \
-        case 5: CALL(5); break;     \
-        case 6: CALL(6); break;     \
-        case 7: CALL(7); break;     \
-        default: CALL(8); break;    \
-    }
-
-extern "C" int wfs_sparse_head_fwd(const void *X, const int32_t *indices, int64_t M, int32_t ndim,
-                                   const int32_t *spatial, int32_t batch, int32_t C, const float *W, const float *bias,
-                                   int32_t O, float *Y, int32_t *grid, int32_t dtype, const int64_t *m_dev_,
-                                   void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long *m_dev = (const long long *)m_dev_;
-    HShape sh;
-    long long V;
-    int rc = make_hshape(&sh, ndim, spatial, &V);
-    if (rc != WFS_OK) return rc;
-    WFS_REQUIRE(O >= 1 && O <= MAXO && C >= 8 && C % 8 == 0 && C / 8 <= TB, WFS_EINVAL, "unsupported head shape C=%d O=%d", C, O);
-    WFS_REQUIRE(V >= 1 && V * 4 <= 64 * 1024, WFS_EINVAL, "%lld cells per event do not fit the LDS grid", V);
-    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
-    if (batch == 0) return WFS_OK;
-    WFS_REQUIRE((M == 0 || (X && indices)) && W && Y, WFS_EINVAL, "NULL device pointer");
-    const dim3 grd((unsigned)batch), block(TB);
-    const size_t lds = (size_t)V * sizeof(int);
-#define WFS_CALL(OO)                                                                                                   \
-    if (dtype == WFS_F32)                                                                                              \
-        k_sparse_head_fwd<float, OO><<<grd, block, lds, stream>>>((const float *)X, indices, M, m_dev, sh, (int)V, C, W, \
-                                                                   bias, Y, grid);                                     \
-    else if (dtype == WFS_BF16) \
-        k_sparse_head_fwd<wfs_bf16, OO><<<grd, block, lds, stream>>>((const wfs_bf16 *)X, indices, M, m_dev, sh, (int)V, \
-                                                                      C, W, bias, Y, grid); \
-    else \
-        k_sparse_head_fwd<wfs_f16, OO><<<grd, block, lds, stream>>>((const wfs_f16 *)X, indices, M, m_dev, sh, (int)V, \
-                                                                      C, W, bias, Y, grid)
-    WFS_HEAD_O(WFS_CALL)
-#undef WFS_CALL
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
-}
-
-extern "C" int wfs_sparse_head_bwd(const void *X, const int32_t *indices, int64_t M, int32_t ndim,
-                                   const int32_t *spatial, int32_t batch, int32_t C, const float *W, int32_t O,
-                                   const float *G, void *dX, float *dW, float *dB, const int32_t *grid, int32_t dtype,
-                                   const int64_t *m_dev_, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long *m_dev = (const long long *)m_dev_;
-    HShape sh;
-    long long V;
-    int rc = make_hshape(&sh, ndim, spatial, &V);
-    if (rc != WFS_OK) return rc;
-    WFS_REQUIRE(O >= 1 && O <= MAXO && C >= 8 && C % 8 == 0, WFS_EINVAL, "unsupported head shape C=%d O=%d", C, O);
-    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
-    WFS_REQUIRE(W && G, WFS_EINVAL, "NULL device pointer");
-    if (dX && M > 0) {
-        WFS_REQUIRE(indices, WFS_EINVAL, "NULL indices");
-        long long blocks = wfs_cdiv(M * (C / 8), TB);
-        if (blocks > 4096) blocks = 4096;
-        const dim3 grd((unsigned)blocks), block(TB);
-#define WFS_CALL(OO)                                                                                                  \
-    if (dtype == WFS_F32)                                                                                             \
-        k_sparse_head_dx<float, OO><<<grd, block, 0, stream>>>(indices, M, m_dev, sh, (int)V, C, W, G, (float *)dX);   \
-    else if (dtype == WFS_BF16)                                                                                       \
-        k_sparse_head_dx<wfs_bf16, OO><<<grd, block, 0, stream>>>(indices, M, m_dev, sh, (int)V, C, W, G, (wfs_bf16 *)dX); \
-    else                                                                                                              \
-        k_sparse_head_dx<wfs_f16, OO><<<grd, block, 0, stream>>>(indices, M, m_dev, sh, (int)V, C, W, G, (wfs_f16 *)dX)
-        WFS_HEAD_O(WFS_CALL)
-#undef WFS_CALL
-        WFS_LAUNCH_CHECK();
-    }
-    if (dW) {
-        WFS_REQUIRE(grid && (X || M == 0), WFS_EINVAL, "dW needs the forward's grid and the features");
-        const dim3 grd((unsigned)wfs_cdiv(V, 8), (unsigned)(C / 8)), block(TB);
-#define WFS_CALL(OO)                                                                                                  \
-    if (dtype == WFS_F32)                                                                                             \
-        k_sparse_head_dw<float, OO><<<grd, block, 0, stream>>>((const float *)X, grid, batch, (int)V, C, G, dW, dB);   \
-    else if (dtype == WFS_BF16)                                                                                       \
-        k_sparse_head_dw<wfs_bf16, OO><<<grd, block, 0, stream>>>((const wfs_bf16 *)X, grid, batch, (int)V, C, G, dW, dB); \
-    else                                                                                                              \
-        k_sparse_head_dw<wfs_f16, OO><<<grd, block, 0, stream>>>((const wfs_f16 *)X, grid, batch, (int)V, C, G, dW, dB)
-        WFS_HEAD_O(WFS_CALL)
-#undef WFS_CALL
-        WFS_LAUNCH_CHECK();
-    }
     return WFS_OK;
 }

@@ -146,26 +146,6 @@ __global__ void k_site_insert(Geo g, int batch, const int *idx, long long N, con
     if (old >= 0) info[1] = 1;
 }
 
-__global__ void k_subm_lookup(Geo g, int batch, const int *idx, long long N, const long long *n_dev, Table t,
-                              const int *vals, int *nbr_out) {
-    long long j = (long long)blockIdx.x * TB + threadIdx.x;
-    if (j >= valid_rows(N, n_dev)) return;
-    int x[4], b;
-    bool ok = load_row(g, idx, j, x, b, batch);
-    Walker w;
-    w.reset();
-    for (int k = 0; k < g.K; ++k) {
-        int res = -1;
-        int key = ok ? w.key(g, x, b) : -1;
-        if (key >= 0) {
-            unsigned s = tbl_find(t, key);
-            if (s != 0xFFFFFFFFu) res = vals[s];
-        }
-        nbr_out[(long long)k * N + j] = res;
-        w.next(g);
-    }
-}
-
 // ---------------------------------------------------------------- (row, offset)-parallel forms
 // grid = (rows / 64, ceil(K / 4)), block = 256: lane = row, wave = offset -> every thread does ONE site lookup /
 // insert, writes of nbr_out[k][j] are coalesced over j, and the per-offset arithmetic is wave-uniform (scalar).

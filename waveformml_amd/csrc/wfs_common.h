@@ -91,42 +91,6 @@ __device__ __forceinline__ float wfs_round_to(float v) {
     wfs_st(&t, v);
     return wfs_ld(&t);
 }
-// BatchNorm's affine map as the kernels that apply it WHILE THEY GATHER evaluate it (wfs_row_affine):
-//     y = x * sc + sh,   sc = gamma * invstd,   sh = beta - mean * sc      (one fused multiply-add per value)
-// The stand-alone BatchNorm kernels (bn.hip) keep  gamma * ((x - mean) * invstd) + beta : subtracting the mean first is
-// exact for values near it, whereas x * sc and sh cancel when |mean| >> std (measured: replacing the expression in
-// bn.hip moved a six-step fp32 training trajectory by 1e-3 instead of 1e-4).  The two forms differ by rounding only;
-// a value within an ulp of zero may therefore pass the ReLU in one and not in the other.
-__device__ __forceinline__ void wfs_bn_scale_shift(float gamma, float beta, float mean, float invstd, float &sc, float &sh) {
-    sc = gamma * invstd;
-    sh = fmaf(-mean, sc, beta);
-}
-// "read these rows as [relu](BatchNorm(row))": the statistics and parameters of the BatchNorm1d (+ ReLU) that sits
-// between the kernel that produced the rows and the one that reads them (include/wfsparse.h, wfs_row_affine)
-struct WfsAffine {
-    const float *mean, *invstd, *gamma, *beta;      // [C]; gamma / beta may be NULL (affine=False)
-    int relu;
-};
-static inline WfsAffine wfs_affine_from(const wfs_row_affine *a) {
-    WfsAffine w = {nullptr, nullptr, nullptr, nullptr, 0};
-    if (a) {
-        w.mean = a->mean;
-        w.invstd = a->invstd;
-        w.gamma = a->gamma;
-        w.beta = a->beta;
-        w.relu = a->relu;
-    }
-    return w;
-}
-// sc / sh of channels [c0, c0 + n) into a thread's registers
-template <int NCH>
-__device__ __forceinline__ void wfs_affine_load(const WfsAffine &a, int c0, float (&sc)[NCH], float (&sh)[NCH]) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-        wfs_bn_scale_shift(a.gamma ? a.gamma[c0 + i] : 1.f, a.beta ? a.beta[c0 + i] : 0.f, a.mean[c0 + i], a.invstd[c0 + i],
-                           sc[i], sh[i]);
-}
-
 static inline bool wfs_dtype_ok(int dtype) { return dtype == WFS_F32 || dtype == WFS_BF16 || dtype == WFS_F16; }
 
 // event timing (opt-in; see wfs_timing_enable)
@@ -145,15 +109,11 @@ bool wfs_mfma_gconv32_ok(int K);
 bool wfs_bn_fold_ok(long long N, int C);          // bn.hip: can the apply kernel fold conv partials for this batch?
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream);
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream);
 // 16-bit rows (dtype WFS_BF16 or WFS_F16)
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, int *pending, const WfsAffine *affine, hipStream_t stream);
-size_t wfs_conv_bnbwd_partial_bytes(void);
-int wfs_launch_gconv32_bnbwd(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
-                             const void *X, const float *W, void *Y, int dtype, const WfsAffine *bn, const void *bn_x,
-                             float *partial, int *nblk_out, hipStream_t stream);
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
                            const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream);
@@ -163,8 +123,7 @@ int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long
                         hipStream_t stream);
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg);
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
-                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer,
-                     const WfsAffine *s_affine, hipStream_t stream);
+                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream);
 int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                          const void *S, const void *G, int swap, float *dW, float *part, int dtype,
                          wfs_dw_job *defer, hipStream_t stream);

@@ -104,20 +104,7 @@ class SPConvNet(nn.Module):
         if len(x) > 2 and x[2] is not None:       # [coords, feats, n_valid]: rows beyond n_valid[0] are padding
             st.n_valid = x[2]
         fsp = getattr(self.spconv, "functional", None)
-        mods = list(self.sparseModel._modules.values()) if hasattr(self.sparseModel, "run") else []
-        if (len(self.linear) == 1 and mods and type(mods[-1]).__name__ == "ToDense" and fsp is not None
-                and hasattr(fsp, "can_use_sparse_head") and getattr(self, "sparse_head", False)):
-            # ToDense -> view -> Linear with a handful of outputs: the head can read the sparse rows directly, so that the
-            # dense [B, C, *spatial] tensor (mostly zeros) is never built (set ``net.sparse_head = True``).  OFF by default:
-            # at the PSD shapes it only ties with the dense route (65 us vs 68 us per step for forward + backward): the
-            # weight reads W[o][c V + cell] are fully scattered 4-byte loads, 7.7 M of them, bound by L2 request rate.
-            # It wins when B * V is large against the number of active rows.
-            last = self.sparseModel.run(st, mods[:-1])
-            if hasattr(last, "features") and fsp.can_use_sparse_head(self.linear[0], last):
-                return fsp.sparse_head(last, self.linear[0])
-            out = mods[-1](last)
-        else:
-            out = self.sparseModel(st)
+        out = self.sparseModel(st)
         out = out.view(-1, self.n_linear)
         if (len(self.linear) == 1 and fsp is not None and hasattr(fsp, "can_use_skinny_linear")
                 and fsp.can_use_skinny_linear(self.linear[0], out)):

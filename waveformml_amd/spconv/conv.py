@@ -53,19 +53,9 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             init.uniform_(self.bias, -bound, bound)
 
-    def _reads_through_affine(self, input):
-        """Can this layer apply a deferred BatchNorm (+ ReLU) of its input while it gathers the raw rows?  (the 32 -> 32
-        channel MFMA kernels, include/wfsparse.h wfs_gather_conv_affine / wfs_gather_dw_affine)"""
-        f = input._features
-        return (input._pending is not None and not self.conv1x1 and not self.inverse and not self.transposed
-                and self.in_channels == 32 and self.out_channels == 32 and int(np.prod(self.kernel_size)) <= 27
-                and f.is_cuda and f.shape[0] > 0 and f.dtype in (torch.float32, torch.bfloat16, torch.float16)
-                and (not self.subm or all(k % 2 == 1 and d == 1 for k, d in zip(self.kernel_size, self.dilation))))
-
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
-        through_affine = self._reads_through_affine(input)
-        features = input._features if through_affine else input.features
+        features = input.features
         indices = input.indices
         spatial_shape = input.spatial_shape
         batch_size = input.batch_size
@@ -124,19 +114,11 @@ class SparseConvolution(SparseModule):
                 input.unique = not rb.has_dup
                 input.indice_dict[self.indice_key] = IndiceData(rb, spatial_shape)
             out_indices = rb.out_indices
-            if through_affine and rb.has_dup:
-                features = input.features          # duplicate sites take the scatter form: normalised rows needed
-                through_affine = False
-            if through_affine:
-                raw, spec = input.take_pending()
-                out_features = Fsp.affine_indice_conv(raw, self.weight, self.bias, rb, self.subm, spec, bn_request)
-                input._features, input._pending = raw, spec      # the input still stands for its normalised rows
-                out_unique = input.unique if self.subm else True
-            elif self.subm:
-                out_features = Fsp.indice_subm_conv(features, self.weight, self.bias, rb, bn_request, input.bn_link)
+            if self.subm:
+                out_features = Fsp.indice_subm_conv(features, self.weight, self.bias, rb, bn_request)
                 out_unique = input.unique
             else:
-                out_features = Fsp.indice_conv(features, self.weight, self.bias, rb, bn_request, input.bn_link)
+                out_features = Fsp.indice_conv(features, self.weight, self.bias, rb, bn_request)
                 out_unique = True      # a regular conv numbers DISTINCT output sites
             out_n_valid = rb.m_dev
         out_tensor = SparseConvTensor(out_features, out_indices, out_spatial_shape, batch_size)

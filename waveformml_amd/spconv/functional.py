@@ -67,45 +67,8 @@ class BatchNormRequest(object):
     def __init__(self, bn, allow_pending=True):
         self.bn = bn
         self.stats = None          # (save_mean, save_invstd, pending partials or None)
-        # allow_pending: the per-block partials may stay unfolded for the BatchNorm apply kernel to fold; False when
-        # the statistics are consumed by a kernel that expects save_mean / save_invstd (a deferred BatchNorm, RowAffine)
+        # allow_pending: the per-block partials may stay unfolded for the BatchNorm apply kernel to fold
         self.allow_pending = allow_pending
-
-
-class RowAffine(object):
-    """"Read these raw rows as [relu](BatchNorm(row))": the training-mode nn.BatchNorm1d (+ nn.ReLU) that sits between
-    the conv that produced the rows -- whose epilogue took the batch statistics -- and whoever reads them next
-    (include/wfsparse.h, wfs_row_affine).  The reader applies the map while it gathers; the normalised tensor is never
-    written.  ``save_mean`` / ``save_invstd``: fp32 [C] tensors filled by the producing launch."""
-
-    def __init__(self, bn, relu, save_mean, save_invstd):
-        self.bn, self.relu, self.save_mean, self.save_invstd = bn, bool(relu), save_mean, save_invstd
-
-    def struct(self, weight=None, bias=None):
-        w = self.bn.weight if weight is None else weight
-        b = self.bn.bias if bias is None else bias
-        return _lib.RowAffine(_lib.ptr(self.save_mean), _lib.ptr(self.save_invstd), _lib.ptr(w), _lib.ptr(b),
-                              1 if self.relu else 0)
-
-
-class BnLink(object):
-    """Hand-over between the backward of a fused BatchNorm1d (+ ReLU) and the dX launch of the conv that consumed its
-    output (SparseSequential: conv -> BatchNorm1d -> ReLU -> conv).  The BatchNorm's forward fills in what describes it
-    (its raw input rows, parameters, statistics); the next conv's backward, which produces dL/dy of that BatchNorm, takes
-    the two sums the BatchNorm backward needs in its epilogue (wfs_gather_conv_bnbwd) and leaves them here; the
-    BatchNorm's backward, which runs right after, then skips its reduction launch (wfs_bn_relu_bwd_sums).  Nothing
-    changes if either side does not take part: without partials the BatchNorm reduces as before."""
-
-    def __init__(self):
-        self.x = self.weight = self.bias = self.save_mean = self.save_invstd = None
-        self.relu = False
-        self.partial = None        # float32 buffer with `nblk` per-block partials, set by the dX launch
-        self.nblk = 0
-        self.dy_ptr = None         # address of the dL/dy tensor the partials belong to
-
-
-def _affine_struct(mean, invstd, weight, bias, relu):
-    return _lib.RowAffine(_lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), 1 if relu else 0)
 
 
 def can_take_batch_norm_stats(bn, features):
@@ -184,14 +147,12 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, affine=None,
-                bn_link=None):
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
-    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only).
-    ``affine`` (a wfs_row_affine struct): the rows of X are raw conv outputs read through a BatchNorm (+ ReLU)."""
+    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
-    if transpose_w and bn_link is None and not _fast_shape(Cw_out, Cw_in):
+    if transpose_w and not _fast_shape(Cw_out, Cw_in):
         # the shape-generic MFMA kernel reads the filter with the OUTPUT channel on the lanes: for dX that is a strided
         # walk over W[k] (a new 128-B line per lane and step; 47 vs 26 us measured at 64 channels) -- hand it W[k]^T
         # instead (one small transpose launch: the filters are at most a few MB)
@@ -203,38 +164,6 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
-    if bn_link is not None:
-        assert transpose_w and bias is None and R > 0 and bn_link.x.shape[0] == R
-        st = _affine_struct(bn_link.save_mean, bn_link.save_invstd, bn_link.weight, bn_link.bias, bn_link.relu)
-        part = torch.empty((int(lib.wfs_gather_conv_bnbwd_partial_bytes()) // 4,), dtype=torch.float32, device=X.device)
-        nblk = ctypes.c_int32(0)
-        _lib.check(lib.wfs_gather_conv_bnbwd(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], _lib.ptr(W),
-                                             _lib.ptr(Y), _lib.dtype_code(X), _lib.ptr(r_dev), ctypes.byref(st),
-                                             _lib.ptr(bn_link.x), _lib.ptr(part), part.numel() * 4, ctypes.byref(nblk),
-                                             _lib.stream_ptr()))
-        bn_link.partial, bn_link.nblk, bn_link.dy_ptr = part, int(nblk.value), Y.data_ptr()
-        _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
-        return Y
-    if affine is not None:
-        assert not transpose_w and R > 0
-        st = None
-        if bn_request is not None:
-            bn = bn_request.bn
-            track = bn.track_running_stats and bn.running_mean is not None
-            save_mean = torch.empty((Cy,), dtype=torch.float32, device=X.device)
-            save_invstd = torch.empty((Cy,), dtype=torch.float32, device=X.device)
-            ws = torch.empty((int(lib.wfs_conv_stats_workspace_bytes(R, Cy)),), dtype=torch.uint8, device=X.device)
-            st = _lib.BnStats(_lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(bn.running_mean) if track else None,
-                              _lib.ptr(bn.running_var) if track else None,
-                              _lib.ptr(bn.num_batches_tracked) if (track and bn.training) else None,
-                              float(bn.momentum), float(bn.eps), _lib.ptr(ws), ws.numel())
-            bn_request.stats = (save_mean, save_invstd, None)
-        _lib.check(lib.wfs_gather_conv_affine(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
-                                              _lib.ptr(W), Cw_in, Cw_out, _lib.ptr(bias), _lib.ptr(Y), _lib.dtype_code(X),
-                                              _lib.ptr(r_dev), ctypes.byref(affine),
-                                              ctypes.byref(st) if st is not None else None, _lib.stream_ptr()))
-        _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
-        return Y
     if _gemm_route(X.shape[1], Cy, K, R, r_dev, table) and bn_request is None:
         G = _gathered(table, kmap, K, identity_k, R, X, r_dev)                       # [R, K * Cx]
         Wk = (W.transpose(1, 2) if transpose_w else W).reshape(K * X.shape[1], Cy)   # [K * Cx, Cy]
@@ -388,7 +317,7 @@ def join_side_streams():
         del _PENDING_SIDE[:]
 
 
-def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False, like=None, s_affine=None):
+def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False, like=None):
     """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a]).
     overlap=True launches on the side stream (see ops.OVERLAP_DW): memory is allocated on the calling stream
     and every operand is kept alive until join_side_streams().  ``like``: the parameter this is the gradient of
@@ -404,7 +333,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
         dW = torch.empty(shape, dtype=torch.float32, device=S.device)
     assert S.dtype == G.dtype and S.shape[0] == R
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
-    if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap and s_affine is None:
+    if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap:
         Gk = _gathered(table, kmap, K, identity_k, R, G, r_dev)                      # [R, K * Cg]
         ok = _row_ok(R, r_dev, S.device)
         Sv = S if ok is None else torch.where(ok.unsqueeze(1), S, S.new_zeros(()))
@@ -416,15 +345,9 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
     def launch():
         defer = _DEFERRED_DW is not None and in_slot and not overlap
         job = _lib.DwJob() if defer else None
-        if s_affine is not None:
-            _lib.check(lib.wfs_gather_dw_affine(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G),
-                                                G.shape[0], Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S),
-                                                _lib.ptr(ws), ws.numel(), _lib.ptr(r_dev), ctypes.byref(s_affine),
-                                                ctypes.byref(job) if defer else None, _lib.stream_ptr()))
-        else:
-            _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0],
-                                         Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
-                                         _lib.ptr(r_dev), ctypes.byref(job) if defer else None, _lib.stream_ptr()))
+        _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0],
+                                     Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(r_dev), ctypes.byref(job) if defer else None, _lib.stream_ptr()))
         if defer and job.nslabs > 0:
             _DEFERRED_DW.append((job, ws))          # second stage pending: flush_deferred_dw()
 
@@ -451,10 +374,9 @@ class SparseConvFunction(Function):
     """features [n_in, Cin], filters [*k, Cin, Cout] fp32, bias [Cout] or None -> [n_out, Cout]."""
 
     @staticmethod
-    def forward(ctx, features, filters, bias, rulebook, mode, bn_request=None, bn_link=None):
+    def forward(ctx, features, filters, bias, rulebook, mode, bn_request=None):
         rb = rulebook
         features = _features_ok(features)
-        ctx.bn_link = bn_link
         K = rb.K
         W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
@@ -503,118 +425,13 @@ class SparseConvFunction(Function):
                 else:
                     dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov, filters)
             if ctx.needs_input_grad[0]:
-                link = ctx.bn_link
-                if (link is not None and link.x is not None and features.shape[1] == 32 and dY.shape[1] == 32
-                        and not rb.has_dup and K <= 27 and link.x.shape[0] == rb.N and link.x.dtype == dY.dtype):
-                    # `features` is the output of a fused BatchNorm1d (+ ReLU): this launch produces its dL/dy and
-                    # takes the sums its backward needs (BnLink)
-                    dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev, bn_link=link)
-                else:
-                    dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
+                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
             # dY has one row per OUTPUT of this product: rb.N rows for an inverse conv, rb.M otherwise
             db = _masked_column_sum(dY, rb.n_dev if mode == INVERSE else rb.m_dev).to(bias.dtype)
-        return dX, dW, db, None, None, None, None
-
-
-class AffineSparseConvFunction(Function):
-    """conv([relu](BatchNorm1d(features))) with the BatchNorm (+ ReLU) applied while the conv GATHERS the raw rows
-    (RowAffine; reference: the plain nn.BatchNorm1d / nn.ReLU modules between two spconv layers of a SparseSequential,
-    src/models/SPConvBlocks.py:498-516).  features: the producing conv's raw output [N, 32]; the batch statistics were
-    taken by that conv's epilogue.  Backward: dA through the transposed filters, dW with the stationary rows read
-    through the same map, then the BatchNorm backward on (features, dA) -> d features, d gamma, d beta."""
-
-    @staticmethod
-    def forward(ctx, features, filters, bias, bn_weight, bn_bias, rulebook, mode, spec, bn_request):
-        rb = rulebook
-        features = _features_ok(features)
-        assert mode in (CONV, SUBM) and not rb.has_dup and features.shape[0] == rb.N
-        K = rb.K
-        W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
-        b = None if bias is None else bias.detach().float().contiguous()
-        ident = rb.centre_k if rb.subm else -1
-        aff = _affine_struct(spec.save_mean, spec.save_invstd, bn_weight, bn_bias, spec.relu)
-        table, kmap = rb.table_by_out()
-        out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev, bn_request, affine=aff)
-        ctx.save_for_backward(features, filters, bias, bn_weight, bn_bias, spec.save_mean, spec.save_invstd)
-        ctx.rb, ctx.relu = rb, spec.relu
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        features, filters, bias, bn_weight, bn_bias, save_mean, save_invstd = ctx.saved_tensors
-        rb, relu = ctx.rb, ctx.relu
-        K = rb.K
-        dY = grad_output.contiguous()
-        if dY.dtype != features.dtype:
-            dY = dY.to(features.dtype)
-        W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
-        ident = rb.centre_k if rb.subm else -1
-        dX = dW = db = dgamma = dbeta = None
-        if ctx.needs_input_grad[1]:
-            aff = _affine_struct(save_mean, save_invstd, bn_weight, bn_bias, relu)
-            dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, False, filters, s_affine=aff)
-            dW = dW.reshape(filters.shape).to(filters.dtype)
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-            dA = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
-            dX, dgamma, dbeta = bn_relu_backward(features, dA, bn_weight, bn_bias, save_mean, save_invstd, True, relu,
-                                                 rb.n_dev)
-        if bias is not None and ctx.needs_input_grad[2]:
-            db = _masked_column_sum(dY, rb.m_dev).to(bias.dtype)
-        return dX, dW, db, dgamma, dbeta, None, None, None, None
-
-
-def affine_indice_conv(features, filters, bias, rulebook, subm, spec, bn_request=None):
-    return AffineSparseConvFunction.apply(features, filters, bias, spec.bn.weight, spec.bn.bias, rulebook,
-                                          SUBM if subm else CONV, spec, bn_request)
-
-
-class AffineToDenseFunction(Function):
-    """dense([relu](BatchNorm1d(features))) through the producing conv's cell -> row map, the BatchNorm (+ ReLU) applied
-    while the rows are read (RowAffine); empty cells are zero, as SparseConvTensor.dense() leaves them."""
-
-    @staticmethod
-    def forward(ctx, features, bn_weight, bn_bias, spec, cell_map, spatial_shape, batch_size, m_dev):
-        lib = _lib.load()
-        features = _features_ok(features)
-        M, C = features.shape
-        spatial = [int(s_) for s_ in spatial_shape]
-        ticket, slot, _keep, V = cell_map
-        aff = _affine_struct(spec.save_mean, spec.save_invstd, bn_weight, bn_bias, spec.relu)
-        out = torch.empty([int(batch_size), C] + spatial, dtype=features.dtype, device=features.device)
-        _lib.check(lib.wfs_to_dense_mapped_affine(_lib.ptr(features), ticket, slot, M, _lib.ptr(m_dev), int(batch_size), V,
-                                                  C, _lib.ptr(out), _lib.dtype_code(features), ctypes.byref(aff),
-                                                  _lib.stream_ptr()))
-        ctx.save_for_backward(features, bn_weight, bn_bias, spec.save_mean, spec.save_invstd)
-        ctx.meta = (cell_map, int(batch_size), M, C, m_dev, spec.relu)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        lib = _lib.load()
-        features, bn_weight, bn_bias, save_mean, save_invstd = ctx.saved_tensors
-        cell_map, batch_size, M, C, m_dev, relu = ctx.meta
-        ticket, slot, _keep, V = cell_map
-        dY = grad_output.contiguous()
-        if dY.dtype != features.dtype:
-            dY = dY.to(features.dtype)
-        dA = torch.empty((M, C), dtype=features.dtype, device=features.device)
-        _lib.check(lib.wfs_to_dense_bwd_mapped(_lib.ptr(dY), ticket, slot, M, _lib.ptr(m_dev), batch_size, V, C,
-                                               _lib.ptr(dA), _lib.dtype_code(dA), _lib.stream_ptr()))
-        dX, dgamma, dbeta = bn_relu_backward(features, dA, bn_weight, bn_bias, save_mean, save_invstd, True, relu, m_dev)
-        return dX, dgamma, dbeta, None, None, None, None, None
-
-
-def affine_to_dense(features, spec, cell_map, spatial_shape, batch_size, m_dev):
-    return AffineToDenseFunction.apply(features, spec.bn.weight, spec.bn.bias, spec, cell_map, spatial_shape, batch_size,
-                                       m_dev)
-
-
-def materialize_affine(features, spec, n_dev=None):
-    """The normalised rows themselves (a reader that cannot apply the map while it reads)."""
-    return batch_norm_relu(features, spec.bn, spec.relu, n_dev, (spec.save_mean, spec.save_invstd, None))
+        return dX, dW, db, None, None, None
 
 
 def _dense_map_ok(cell_map, spatial, batch_size, C, features):
@@ -694,11 +511,10 @@ class BatchNormReLUFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, n_dev=None,
-                batches_tracked=None, stats=None, link=None):
+                batches_tracked=None, stats=None):
         lib = _lib.load()
         x = _features_ok(x)
         N, C = x.shape
-        ctx.link = link
         y = _rows(tuple(x.shape), x, n_dev)
         for t in (weight, bias, running_mean, running_var):
             assert t is None or (t.dtype == torch.float32 and t.numel() == C and t.is_contiguous())
@@ -721,7 +537,6 @@ class BatchNormReLUFunction(Function):
             ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
             ctx.flags = (True, bool(relu))
             ctx.n_dev = n_dev
-            _fill_link(link, x, weight, bias, save_mean, save_invstd, relu, True)
             return y
         save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
@@ -735,49 +550,27 @@ class BatchNormReLUFunction(Function):
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.flags = (bool(training), bool(relu))
         ctx.n_dev = n_dev
-        _fill_link(link, x, weight, bias, save_mean, save_invstd, relu, training)
         return y
 
     @staticmethod
     def backward(ctx, grad_output):
         x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         training, relu = ctx.flags
-        link, sums = ctx.link, None
-        if link is not None:
-            if link.partial is not None and link.dy_ptr == grad_output.data_ptr() and grad_output.is_contiguous():
-                sums = (link.partial, link.nblk)      # taken by the launch that produced grad_output
-            link.partial = link.x = None              # one backward pass, one hand-over
-        dx, dgamma, dbeta = bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, ctx.n_dev,
-                                             sums)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        dx, dgamma, dbeta = bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, ctx.n_dev)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def _fill_link(link, x, weight, bias, save_mean, save_invstd, relu, training):
-    if link is not None and training and x.shape[1] == 32:
-        link.x, link.weight, link.bias = x.detach(), weight, bias
-        link.save_mean, link.save_invstd, link.relu = save_mean, save_invstd, bool(relu)
-
-
-def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, n_dev, sums=None):
+def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, n_dev):
     """(dx, dgamma, dbeta) of y = [relu](BatchNorm1d(x)) over the active rows, given dL/dy (two launches: the sums
-    sum(g), sum(g * xhat) with the ReLU mask recomputed from x, then the elementwise pass).  ``sums`` = (partials,
-    count) when the launch that produced dL/dy already took the sums (BnLink): the elementwise pass alone."""
+    sum(g), sum(g * xhat) with the ReLU mask recomputed from x, then the elementwise pass)."""
     lib = _lib.load()
     N, C = x.shape
     dy = grad_output.contiguous()
     if dy.dtype != x.dtype:
-        dy, sums = dy.to(x.dtype), None
+        dy = dy.to(x.dtype)
     dx = _rows(tuple(x.shape), x, n_dev)
     dgamma = grad_like(weight) if weight is not None else None
     dbeta = grad_like(bias) if bias is not None else None
-    if sums is not None and C == 32 and N > 0:
-        part, nblk = sums
-        _lib.check(lib.wfs_bn_relu_bwd_sums(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
-                                            _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
-                                            1 if relu else 0, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                            _lib.ptr(part), int(nblk), _lib.dtype_code(x), _lib.ptr(n_dev),
-                                            _lib.stream_ptr()))
-        return dx, dgamma, dbeta
     ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
     _lib.check(lib.wfs_bn_relu_bwd(_lib.ptr(x), _lib.ptr(dy), N, C, _lib.ptr(weight), _lib.ptr(bias),
                                    _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if training else 0,
@@ -786,7 +579,7 @@ def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, train
     return dx, dgamma, dbeta
 
 
-def batch_norm_relu(features, bn, relu, n_dev=None, stats=None, link=None):
+def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
     """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features
     (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts";
     ``stats``: (save_mean, save_invstd) already taken by the producing convolution)."""
@@ -794,8 +587,7 @@ def batch_norm_relu(features, bn, relu, n_dev=None, stats=None, link=None):
     tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # bumped by the kernel
     return BatchNormReLUFunction.apply(
         features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats,
-        link)
+        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats)
 
 
 def can_fuse_batch_norm(bn, features):
@@ -863,72 +655,6 @@ def skinny_linear(x, linear):
     return SkinnyLinearFunction.apply(x, linear.weight, linear.bias)
 
 
-class SparseHeadFunction(Function):
-    """ToDense + flatten + nn.Linear on the sparse rows themselves (reference src/models/SPConvNet.py:65-68):
-    features [M, C] at distinct sites -> logits [B, O]; the dense [B, C, *spatial] tensor is never built."""
-
-    @staticmethod
-    def forward(ctx, features, weight, bias, indices, spatial_shape, batch_size, m_dev):
-        lib = _lib.load()
-        features = _features_ok(features)
-        indices = indices.contiguous()
-        M, C = features.shape
-        O = weight.shape[0]
-        spatial = [int(s) for s in spatial_shape]
-        V = 1
-        for s_ in spatial:
-            V *= s_
-        B = int(batch_size)
-        w = weight.detach().float().contiguous()
-        b = None if bias is None else bias.detach().float().contiguous()
-        y = torch.empty((B, O), dtype=torch.float32, device=features.device)
-        grid = torch.empty((B, V), dtype=torch.int32, device=features.device) if ctx.needs_input_grad[1] else None
-        _lib.check(lib.wfs_sparse_head_fwd(_lib.ptr(features), _lib.ptr(indices), M, len(spatial), _lib.i32_array(spatial),
-                                           B, C, _lib.ptr(w), _lib.ptr(b), O, _lib.ptr(y), _lib.ptr(grid),
-                                           _lib.dtype_code(features), _lib.ptr(m_dev), _lib.stream_ptr()))
-        ctx.save_for_backward(features, weight, bias, indices)
-        ctx.meta = (spatial, B, grid, m_dev)
-        return y
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        lib = _lib.load()
-        features, weight, bias, indices = ctx.saved_tensors
-        spatial, B, grid, m_dev = ctx.meta
-        M, C = features.shape
-        O = weight.shape[0]
-        g = grad_output.float().contiguous()
-        w = weight.detach().float().contiguous()
-        dx = _rows(tuple(features.shape), features, m_dev) if ctx.needs_input_grad[0] else None
-        dw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=features.device) if ctx.needs_input_grad[1] else None
-        db = (torch.empty((O,), dtype=torch.float32, device=features.device)
-              if (bias is not None and ctx.needs_input_grad[2] and dw is not None) else None)
-        _lib.check(lib.wfs_sparse_head_bwd(_lib.ptr(features), _lib.ptr(indices), M, len(spatial), _lib.i32_array(spatial),
-                                           B, C, _lib.ptr(w), O, _lib.ptr(g), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
-                                           _lib.ptr(grid), _lib.dtype_code(features), _lib.ptr(m_dev), _lib.stream_ptr()))
-        if bias is not None and ctx.needs_input_grad[2] and db is None:
-            db = g.sum(0)
-        return (dx, dw.to(weight.dtype) if dw is not None else None, db.to(bias.dtype) if db is not None else None,
-                None, None, None, None)
-
-
-def can_use_sparse_head(linear, st):
-    """``st``: the SparseConvTensor that would go into ToDense.  Needs distinct sites (then dense() has no "last row
-    wins" to reproduce) and the shapes the kernels cover."""
-    f = st.features
-    v = 1
-    for s_ in st.spatial_shape:
-        v *= int(s_)
-    return (type(linear) is torch.nn.Linear and linear.out_features <= 8 and linear.weight.dtype == torch.float32
-            and f.is_cuda and f.dim() == 2 and f.dtype in (torch.float32, torch.bfloat16, torch.float16) and f.shape[1] % 8 == 0
-            and f.shape[1] // 8 <= 256 and v <= 16384 and linear.in_features == f.shape[1] * v
-            and getattr(st, "unique", None) is True and len(st.spatial_shape) <= 4 and int(st.batch_size) >= 1)
-
-
-def sparse_head(st, linear):
-    return SparseHeadFunction.apply(st.features, linear.weight, linear.bias, st.indices, st.spatial_shape, st.batch_size, st.n_valid)
-
-
 class CrossEntropyMeanFunction(Function):
     """nn.CrossEntropyLoss(reduction='mean') on [B, C] fp32 logits: loss and d loss / d logits from one launch
     (reference criterion: src/engineering/LitBase.py:38-43, applied at LitPSD.py:102)."""
@@ -983,12 +709,12 @@ def cross_entropy_mean(logits, target, ignore_index=-100):
 
 # 16-bit storage: bf16, and fp16 for the reference's ``half_precision`` / ``use_half`` (float16 features,
 # src/datasets/HDF5Dataset.py:227-228).  Both have native kernels (fp32 accumulate, fp32 master filters).
-def indice_conv(features, filters, bias, rulebook, bn_request=None, bn_link=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request, bn_link)
+def indice_conv(features, filters, bias, rulebook, bn_request=None):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request)
 
 
-def indice_subm_conv(features, filters, bias, rulebook, bn_request=None, bn_link=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request, bn_link)
+def indice_subm_conv(features, filters, bias, rulebook, bn_request=None):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request)
 
 
 def indice_inverse_conv(features, filters, bias, rulebook, bn_request=None):

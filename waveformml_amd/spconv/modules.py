@@ -91,61 +91,6 @@ class SparseSequential(SparseModule):
                     break                           # ToDense or an unknown sparse module ends the sparse stack
         x.prefetched = plan
 
-    @staticmethod
-    def _chain_rulebooks(mods, x):
-        """The rulebooks of every conv layer of the stack from ONE event-parallel build (ops.build_rulebook_chain) on
-        the current stream; None when the stack or the input is outside what the chain build covers (the layers then
-        build their own)."""
-        from . import ops
-        from .conv import SparseConvolution
-        if x.indice_dict:
-            return None                             # rulebooks from an earlier pass: leave everything to the layers
-        ndim = x.indices.shape[1] - 1
-        specs, owners, flags = [], [], []           # owners[i]: conv modules served by chain entry i
-        site, keys = 0, {}                          # current site-set generation; (site, key / geometry) -> entry
-        last_regular = None
-        for m in mods:
-            if isinstance(m, SparseConvolution):
-                if m.conv1x1:
-                    continue
-                if m.inverse or m.transposed or not ops.chain_spec_ok(ndim, m.kernel_size, m.dilation, m.subm):
-                    break
-                if m.subm:
-                    geo = (site, "subm", tuple(m.kernel_size), tuple(m.dilation))
-                    key = (site, "key", m.indice_key) if m.indice_key is not None else geo
-                    if key in keys:
-                        owners[keys[key]].append(m)
-                        continue
-                    if len(specs) == ops.CHAIN_MAX_LAYERS:
-                        break
-                    keys[key] = len(specs)
-                    specs.append((m.kernel_size, m.stride, m.padding, m.dilation, True))
-                    owners.append([m])
-                    flags.append(False)
-                else:
-                    if len(specs) == ops.CHAIN_MAX_LAYERS:
-                        break
-                    if m.indice_key is not None:
-                        keys[(site, "key", m.indice_key)] = len(specs)
-                    specs.append((m.kernel_size, m.stride, m.padding, m.dilation, False))
-                    owners.append([m])
-                    flags.append(False)
-                    last_regular = len(specs) - 1
-                    site += 1
-            elif isinstance(m, ToDense):
-                if last_regular is not None and last_regular == len(specs) - 1:
-                    flags[last_regular] = True      # dense() of this layer's output can use the build's cell map
-                break
-            elif isinstance(m, SparseModule):
-                break
-        if not specs:
-            return None
-        caps = [getattr(o[0], "out_capacity", None) for o in owners]
-        rbs = ops.build_rulebook_chain(x.indices, x.batch_size, x.spatial_shape, specs, x.n_valid, caps, flags)
-        if rbs is None:
-            return None
-        return {id(m): rb for rb, ms in zip(rbs, owners) for m in ms}
-
     def forward(self, input):
         return self.run(input, list(self._modules.values()))
 
@@ -154,24 +99,18 @@ class SparseSequential(SparseModule):
         trailing ToDense when the head can consume the sparse rows directly)."""
         from . import functional as Fsp
         from . import ops
-        if (ops.EVENT_LOCAL_RULEBOOKS and _is_sparse_tensor(input) and input.features.is_cuda
-                and getattr(input, "prefetched", None) is None and input.indices.shape[0] > 0
-                and (input.n_valid is not None or input.unique is True or ops.ASSUME_VALID_UNIQUE_INDICES)):
-            plan = self._chain_rulebooks(mods, input)
-            if plan:
-                input.prefetched = plan
         want_prefetch = (ops.PREFETCH_RULEBOOKS and _is_sparse_tensor(input) and input.n_valid is not None
                          and getattr(input, "prefetched", None) is None and input.features.is_cuda)
         i = 0
         while i < len(mods):
             module = mods[i]
             if isinstance(module, SparseModule):
-                if ((ops.FUSE_CONV_BN_STATS or ops.DEFER_BATCH_NORM) and _is_sparse_tensor(input) and i + 1 < len(mods)
+                if (ops.FUSE_CONV_BN_STATS and _is_sparse_tensor(input) and i + 1 < len(mods)
                         and isinstance(mods[i + 1], nn.BatchNorm1d)
                         and getattr(module, "weight", None) is not None
-                        and Fsp.can_take_batch_norm_stats(mods[i + 1], input._features)):
+                        and Fsp.can_take_batch_norm_stats(mods[i + 1], input.features)):
                     # conv -> BatchNorm1d (training): the conv's epilogue takes the batch statistics
-                    input.bn_request = Fsp.BatchNormRequest(mods[i + 1], allow_pending=not ops.DEFER_BATCH_NORM)
+                    input.bn_request = Fsp.BatchNormRequest(mods[i + 1])
                 input = module(input)
                 if want_prefetch and _is_sparse_tensor(input):
                     # the first layer has built its own rulebook and launched its conv on this stream; the
@@ -186,18 +125,7 @@ class SparseSequential(SparseModule):
                         req = getattr(input, "bn_stats", None)
                         stats = req.stats if (req is not None and req.bn is module) else None
                         input.bn_stats = None
-                        if (ops.DEFER_BATCH_NORM and stats is not None and stats[2] is None and module.training
-                                and module.num_features == 32 and module.weight is not None):
-                            # the producing conv took the statistics: leave the rows raw, the next reader (conv, dense())
-                            # applies the normalisation while it gathers them (functional.RowAffine)
-                            input.defer_affine(Fsp.RowAffine(module, relu, stats[0], stats[1]))
-                        else:
-                            # training mode: the conv that reads these rows next can take the sums of this BatchNorm's
-                            # backward in its dX launch (functional.BnLink)
-                            link = Fsp.BnLink() if (ops.FUSE_BN_BACKWARD_SUMS and module.training
-                                                    and module.num_features == 32) else None
-                            input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats, link)
-                            input.bn_link = link
+                        input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats)
                         if relu:
                             i += 1
                     else:

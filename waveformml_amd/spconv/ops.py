@@ -40,44 +40,6 @@ OVERLAP_DW = False
 # "measured dead ends"); it should pay when the rows no longer fit the L2s.
 FUSE_CONV_BN_STATS = os.environ.get("WFS_FUSE_CONV_BN_STATS", "0") != "0"
 
-# The rulebooks of ALL conv layers of a SparseSequential in two launches, one workgroup per event with its site tables
-# in LDS (csrc/rulebook_chain.hip, include/wfsparse.h "rulebook chain"), instead of 3 / 6 chip-wide launches per layer.
-# Needs the batch column to be non-decreasing (events contiguous, in order: the reference's collate_fn output) and
-# events of at most 2048 rows; both are verified on the device.  Exact-size mode falls back to the per-layer builds by
-# itself when the check fails; in device-count mode (no host read-back) a failure sets every layer's overflow flag,
-# which the captured step's check() reports.
-# OFF by default (WFS_EVENT_LOCAL_RULEBOOKS=1 switches it on): bit-exact, but at the PSD batch (256 events on 256 CUs)
-# the largest event (~3x the mean) runs its ~7 passes on ONE compute unit, so the two launches take 35 + 109 us
-# against ~165 us of kernel time for the 15 chip-wide launches, most of which hide beside the first layers on the side
-# stream: measured 0.73 vs 0.57 ms per step (profiles/r02_rulebook_chain_stages.txt).  It pays when there are many more
-# events than compute units (e.g. 2048-event batches).
-EVENT_LOCAL_RULEBOOKS = os.environ.get("WFS_EVENT_LOCAL_RULEBOOKS", "0") != "0"
-CHAIN_MAX_LAYERS = 4
-CHAIN_BUILD_COUNT = 0      # chains actually built (tests / diagnostics)
-
-# conv -> nn.BatchNorm1d (training) -> nn.ReLU -> next reader inside a SparseSequential: the conv's epilogue takes the
-# batch statistics and the normalisation is DEFERRED to whoever reads the rows next -- the next 32 -> 32 conv (forward
-# gathers and the stationary rows of its dW) or dense() apply  [relu](x * sc + sh)  on the fly (functional.RowAffine,
-# include/wfsparse.h wfs_row_affine), so the normalised tensor is never written.  A reader that cannot do it (1 x 1 convs,
-# other channel counts, duplicate sites, user code touching ``.features``) gets the rows materialised as before.
-# OFF by default (WFS_DEFER_BATCH_NORM=1 switches it on): same results, but at the PSD batch a row is gathered by ~10
-# (tile, offset) pairs, so normalising on the fly does ~10x the arithmetic of the separate pass it removes -- isolated
-# launches (profiles/r02_microbench_conv_bf16.txt): forward 16.2 us plain, +1.8 statistics epilogue, +6.0 gathered rows
-# through the map, +6.3 for the launch that folds the block partials = 30.3 us against 16.2 + 5.9 + 8.7 = 30.8 us for
-# conv + reduce + apply; the dW kernel, already at its register limit, spills with the map (36.8 vs 17.1 us).  Whole
-# step 0.65 vs 0.57 ms.  It should pay where rows are gathered by few offsets (1 x 1 / strided stacks) or no longer fit
-# the caches.
-DEFER_BATCH_NORM = os.environ.get("WFS_DEFER_BATCH_NORM", "0") != "0"
-
-# Backward of conv -> BatchNorm1d (+ ReLU) -> conv: the second conv's dX launch, which produces dL/dy of the BatchNorm,
-# also takes the two sums the BatchNorm backward needs (sum g, sum g * xhat) from the tile it holds in registers
-# (functional.BnLink, include/wfsparse.h wfs_gather_conv_bnbwd), so the BatchNorm backward is one launch instead of two.
-# Same numbers up to the order of the fp32 sums.  OFF by default (WFS_FUSE_BN_BACKWARD_SUMS=1: on): isolated the dX
-# launch grows 17.9 -> 20.1 us and a 7.7 us reduction launch goes away, but inside the step the BatchNorm's input rows
-# it has to read were written a whole forward pass earlier (HBM, 2-byte strided reads) and the launch takes 30 us (22 us
-# with those reads issued after the last gather): 0.570 vs 0.566 ms per step, same-box A/B.
-FUSE_BN_BACKWARD_SUMS = os.environ.get("WFS_FUSE_BN_BACKWARD_SUMS", "0") != "0"
-
 # Event-local SubM rulebook build (round 3; csrc/evrulebook.hip): in device-count mode -- captured steps, where the index
 # rows come from the reference's collate_fn, i.e. grouped by event -- a SubM rulebook is built by a pair of workgroups
 # per event with the event's site table in LDS: no site grid over the batch in HBM (18.5 MB cleared per build at the PSD
@@ -396,96 +358,6 @@ def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, 
                                          ctypes.byref(cells)):
                 rb.cell_map = (ticket.value, slot.value, ws, int(np.prod(rb.out_spatial_shape)))
     return rb
-
-
-def chain_spec_ok(ndim, ksize, dilation, subm):
-    """Layer shapes the event-local chain build covers: K <= 32, and for SubM the mirrored-table form (odd kernel,
-    dilation 1) the compute kernels use without a stored nbr_in."""
-    K = int(np.prod(ksize))
-    if K < 1 or K > 32 or ndim > _lib.WFS_MAX_DIM:
-        return False
-    if subm and not all(int(k) % 2 == 1 and int(d) == 1 for k, d in zip(ksize, dilation)):
-        return False
-    return True
-
-
-def build_rulebook_chain(indices, batch_size, spatial_shape, specs, n_dev=None, capacities=None, cell_maps=None):
-    """Rulebooks of a stack of conv layers from one event-parallel build.
-
-    ``specs``: [(ksize, stride, padding, dilation, subm)] in layer order (per-dim lists); a SubM layer keeps the row
-    set, a regular layer's outputs are the next layer's inputs.  ``capacities``: per layer, rows to reserve for a
-    regular layer's outputs in device-count mode (``n_dev`` given; default: default_out_capacity).  ``cell_maps``: per
-    layer, whether to emit the cell -> row map dense() can use.  Returns [Rulebook] (one per spec), or None when the
-    inputs are not grouped by event / an event is too large (exact-size mode only: device-count mode cannot know and
-    reports through the rulebooks' overflow flags)."""
-    global CHAIN_BUILD_COUNT
-    if not indices.is_cuda or indices.dtype != torch.int32:
-        raise RuntimeError("waveformml_amd.spconv: indices must be int32 on the GPU")
-    indices = indices.contiguous()
-    lib = _lib.load()
-    dev = indices.device
-    ndim = indices.shape[1] - 1
-    L = len(specs)
-    assert 1 <= L <= CHAIN_MAX_LAYERS
-    capacities = list(capacities) if capacities is not None else [None] * L
-    cell_maps = list(cell_maps) if cell_maps is not None else [False] * L
-    layers = (_lib.ChainLayer * L)()
-    geos, shape = [], [int(s_) for s_ in spatial_shape]
-    for l, (ksize, stride, padding, dilation, subm) in enumerate(specs):
-        g = _lib.make_geometry(ndim, batch_size, shape, ksize, stride, padding, dilation, subm)
-        geos.append(g)
-        ctypes.memmove(ctypes.byref(layers[l].geo), ctypes.byref(g), ctypes.sizeof(g))
-        shape = [int(g.out_shape[i]) for i in range(ndim)]
-    N = int(indices.shape[0])
-    if N == 0:
-        return None
-    stream = _lib.stream_ptr()
-    ws = torch.empty((int(lib.wfs_rulebook_chain_workspace_bytes(int(batch_size))),), dtype=torch.uint8, device=dev)
-    exact = n_dev is None
-    counts = (ctypes.c_int64 * L)()
-    flags = ctypes.c_int32(0)
-    _lib.check(lib.wfs_rulebook_chain_count(layers, L, _lib.ptr(indices), N, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
-                                            counts if exact else None, ctypes.byref(flags) if exact else None, stream))
-    if exact and flags.value != 0:
-        return None
-    rbs, keep = [], []
-    cur_idx, cur_n, cur_ndev = indices, N, n_dev
-    for l, g in enumerate(geos):
-        rb = Rulebook()
-        rb.geometry, rb.N, rb.K, rb.subm, rb.indices = g, cur_n, int(g.K), bool(g.subm), cur_idx
-        rb.out_spatial_shape = [int(g.out_shape[i]) for i in range(ndim)]
-        rb.n_dev, rb.has_dup = cur_ndev, False
-        rb.nbr_out = torch.empty((rb.K, cur_n), dtype=torch.int32, device=dev)
-        layers[l].nbr_out = _lib.ptr(rb.nbr_out)
-        layers[l].N_cap = cur_n
-        if g.subm:
-            rb.M, rb.m_dev, rb.out_indices = cur_n, cur_ndev, cur_idx
-            rb.kmap_in = _lib.i32_array([rb.K - 1 - k for k in range(rb.K)])
-            rb.centre_k = rb.K // 2
-        else:
-            cells = int(batch_size) * int(np.prod(rb.out_spatial_shape))
-            M = int(counts[l]) if exact else int(capacities[l] or default_out_capacity(cur_n, rb.K, cells))
-            rb.M = M
-            rb.out_indices = torch.empty((M, ndim + 1), dtype=torch.int32, device=dev)
-            rb.nbr_in = torch.empty((rb.K, M), dtype=torch.int32, device=dev)
-            layers[l].nbr_in, layers[l].out_indices, layers[l].M_cap = _lib.ptr(rb.nbr_in), _lib.ptr(rb.out_indices), M
-            if not exact:
-                rb.m_dev = torch.empty((1,), dtype=torch.int64, device=dev)
-                rb.overflow = torch.empty((1,), dtype=torch.int32, device=dev)
-                layers[l].m_dev, layers[l].overflow_dev = _lib.ptr(rb.m_dev), _lib.ptr(rb.overflow)
-            if cell_maps[l] and M > 0:
-                ticket = torch.empty((cells,), dtype=torch.int32, device=dev)
-                slot = torch.empty((cells,), dtype=torch.int32, device=dev)
-                layers[l].cell_ticket, layers[l].cell_row = _lib.ptr(ticket), _lib.ptr(slot)
-                rb.cell_map = (ticket.data_ptr(), slot.data_ptr(), (ticket, slot), int(np.prod(rb.out_spatial_shape)))
-            cur_idx, cur_n, cur_ndev = rb.out_indices, M, rb.m_dev
-        rbs.append(rb)
-    _lib.check(lib.wfs_rulebook_chain_build(layers, L, _lib.ptr(indices), N, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
-                                            stream))
-    for rb in rbs:
-        rb._chain_ws = ws          # the counts / flags live here until every kernel of the chain has run
-    CHAIN_BUILD_COUNT += 1
-    return rbs
 
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,

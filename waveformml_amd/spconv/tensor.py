@@ -53,9 +53,7 @@ class SparseConvTensor(object):
             batch_size: int (the reference hands in a 0-dim tensor, src/models/SPConvNet.py:63)
             grid: unused, kept for signature compatibility
         """
-        self._features = features
-        self._pending = None        # functional.RowAffine: BatchNorm (+ ReLU) still to be applied to the raw rows
-        self.bn_link = None         # functional.BnLink of the fused BatchNorm that produced `features`, if any
+        self.features = features
         self.indices = indices
         if self.indices.dtype != torch.int32:
             self.indices = self.indices.int()
@@ -67,32 +65,6 @@ class SparseConvTensor(object):
         # device-count mode: `features`/`indices` hold a CAPACITY of rows, the first n_valid[0] are real
         # (int64 [1] device tensor).  None = every row is valid (spconv's normal contract).
         self.n_valid = None
-
-    # ``features`` is what spconv exposes.  Inside a SparseSequential a training-mode BatchNorm1d (+ ReLU) that follows
-    # a conv may be DEFERRED to the next reader of the rows (functional.RowAffine: the next conv / dense() applies it
-    # while gathering); whoever asks for ``.features`` gets the normalised rows (materialised on first access).
-    @property
-    def features(self):
-        if self._pending is not None:
-            spec, self._pending = self._pending, None
-            self._features = Fsp.materialize_affine(self._features, spec, self.n_valid)
-        return self._features
-
-    @features.setter
-    def features(self, value):
-        self._features = value
-        self._pending = None
-        self.bn_link = None         # whoever assigns new rows says if a BatchNorm produced them (SparseSequential)
-
-    def defer_affine(self, spec):
-        """Keep the raw rows and remember the BatchNorm (+ ReLU) the next reader has to apply."""
-        assert self._pending is None
-        self._pending = spec
-
-    def take_pending(self):
-        """(raw rows, RowAffine or None) for a reader that applies the map itself; clears the deferral."""
-        spec, self._pending = self._pending, None
-        return self._features, spec
 
     @property
     def spatial_size(self):
@@ -107,16 +79,8 @@ class SparseConvTensor(object):
 
     def dense(self, channels_first=True):
         cell_map = getattr(self, "cell_map", None)
-        if (self._pending is not None and cell_map is not None and self._features.shape[0] > 0
-                and (self.unique is True or self.n_valid is not None)
-                and Fsp._dense_map_ok(cell_map, self.spatial_shape, int(self.batch_size), self._features.shape[1],
-                                      self._features)):
-            raw, spec = self.take_pending()
-            out = Fsp.affine_to_dense(raw, spec, cell_map, self.spatial_shape, self.batch_size, self.n_valid)
-            self._features, self._pending = raw, spec          # the tensor itself still stands for the normalised rows
-        else:
-            out = Fsp.to_dense(self.features, self.indices, self.spatial_shape, self.batch_size,
-                               self.unique is True or self.n_valid is not None, self.n_valid, cell_map)
+        out = Fsp.to_dense(self.features, self.indices, self.spatial_shape, self.batch_size,
+                           self.unique is True or self.n_valid is not None, self.n_valid, cell_map)
         if channels_first:
             return out
         ndim = len(self.spatial_shape)
