@@ -50,6 +50,12 @@ typedef struct wfh5_info {
 const char *wfh5_last_error(void);
 
 int wfh5_open(const char *path, const char *table, wfh5_file **out);
+/* The same with the names of the coordinate and feature members / datasets (the reference's datasets bind several:
+ * "coord" / "waveform", "coord" / "pulse", "det" / "pulse", src/datasets/PulseDataset.py:700-1160).  Both names ""
+ * opens a table for wfh5_read_member alone -- a label file (reference `label_file_pattern`,
+ * src/datasets/HDF5Dataset.py:404-427), whose table need not hold coordinates at all. */
+int wfh5_open_named(const char *path, const char *table, const char *coord_name, const char *feat_name,
+                    wfh5_file **out);
 void wfh5_close(wfh5_file *f);
 int wfh5_get_info(const wfh5_file *f, wfh5_info *info);
 
@@ -64,6 +70,15 @@ int wfh5_set_threads(int n);
 
 /* labels [e0, e1) widened to int64 (reference :319-327) */
 int wfh5_read_labels(wfh5_file *f, int64_t e0, int64_t e1, int64_t *labels);
+
+/* ANY member of a compound table / dataset of a group table by name -- the reference's per-row label columns
+ * (`label_name: "PID"`, `"phys"`, `"EZ"`: config/examples/IoniClassifierCNN.json:75-89, SegQuantifier.json:70-78) and
+ * `additional_fields` (src/datasets/HDF5Dataset.py:486-520): name NULL / "" = the FIRST member (what the reference
+ * takes from a label file, :483).  wfh5_member_info: rows, array length per row, float or integer, stored element
+ * size.  wfh5_read_member: rows [row0, row1) widened to float32 (as_float != 0) or int64, [n, cols] row-major. */
+int wfh5_member_info(wfh5_file *f, const char *name, int64_t *rows, int32_t *cols, int32_t *is_float,
+                     int32_t *elem_bytes);
+int wfh5_read_member(wfh5_file *f, const char *name, int64_t row0, int64_t row1, int32_t as_float, void *out);
 
 /* Row range of the events [e0, e1] (inclusive, as the reference's event_range): first row whose event id
  * (column event_col of coord) equals e0, and first row whose event id equals e1 + 1 (n_rows if e1 is the

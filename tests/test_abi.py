@@ -34,7 +34,7 @@ def test_ctypes_table_mirrors_header():
 def test_h5_reader_library_exports_and_ctypes_table_mirror_its_header():
     from waveformml_amd.psd import h5data
     names = _header_functions("wfh5.h", "wfh5_")
-    assert len(names) == 8 and sorted(h5data.SIGNATURES) == names
+    assert len(names) == 11 and sorted(h5data.SIGNATURES) == names
     lib = ctypes.CDLL(h5data.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libwfh5.so does not export %s" % n

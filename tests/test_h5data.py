@@ -267,3 +267,88 @@ def test_packed_loader_exposes_its_sampler_for_per_epoch_reshuffling():
         assert sum(1 for _ in loader) == 4
         seen.append(set(e1))
     assert seen[0].isdisjoint(seen[1]) and seen[0] | seen[1] == set(range(8))
+
+
+# ---- round 3: the sibling tasks' files (reference src/datasets/HDF5Dataset.py:186-217, 250-347, 404-427) ------------
+R3 = os.path.join(H5, "r3")
+EXP3 = np.load(os.path.join(os.path.dirname(H5), "expected_r3.npz"))
+PID_MAP = {"1": 0, "4": 1, "6": 2, "256": 3, "258": 2, "512": 4}          # config/examples/IoniClassifierCNN.json:67-74
+
+
+def _ioni(**kw):
+    return h5data.HDF5Dataset([os.path.join(R3, "ioni")], "*WaveformPairSim.h5", "WaveformPairs", "coord", "waveform", 12, **kw)
+
+
+def test_per_row_label_column_by_member_name_through_the_label_map():
+    """`label_name: "PID"` (IoniClassifierCNN.json:75-76): one label per ROW of the compound table, mapped to class
+    indices in place, int64 -- the item of a partly used file is cut at the event boundary like the features."""
+    ds = _ioni(label_name="PID", label_map=PID_MAP)
+    assert len(ds) == 2                                     # 9 events of run_1, 3 of run_2's 7 (budget 12)
+    lut = {int(k): v for k, v in PID_MAP.items()}
+    (c, f), y = ds[0]
+    want = np.vectorize(lut.get)(EXP3["ioni/run_1/PID"])
+    assert y.dtype == torch.int64 and np.array_equal(y.numpy(), want) and len(y) == len(c)
+    assert np.array_equal(c.numpy(), EXP3["ioni/run_1/coord"])
+    assert np.array_equal(f.numpy(), EXP3["ioni/run_1/waveform"].astype(np.float32))
+    (c, f), y = ds[1]
+    n = int(np.searchsorted(EXP3["ioni/run_2/coord"][:, 2], 3))          # rows of events 0..2
+    assert len(c) == n and np.array_equal(y.numpy(), np.vectorize(lut.get)(EXP3["ioni/run_2/PID"][:n]))
+    # a float member as the label: regression targets, float32, [n, len] (SegQuantifier.json:70 "phys")
+    (c, f), y = _ioni(label_name="phys")[0]
+    assert y.dtype == torch.float32 and np.array_equal(y.numpy(), EXP3["ioni/run_1/phys"])
+    (c, f), y = _ioni(label_name="EZ", normalize=True)[0]
+    assert np.array_equal(y.numpy(), EXP3["ioni/run_1/EZ"])
+    np.testing.assert_allclose(f.numpy(), EXP3["ioni/run_1/waveform"].astype(np.float32) / (2 ** 14 - 1), rtol=1e-6)
+
+
+def test_additional_fields_come_back_as_the_reference_list():
+    """`additional_fields: ["phys"]` (IoniClassifierCNN.json:88-89): vals = [feats, *fields], the fields in their stored
+    type, every entry cut to the item's rows."""
+    ds = _ioni(label_name="PID", label_map=PID_MAP, additional_fields=["phys", "PID"], use_half=True)
+    (c, vals), y = ds[1]
+    n = len(c)
+    assert isinstance(vals, list) and len(vals) == 3 and vals[0].dtype == torch.float16
+    assert vals[1].dtype == torch.float32 and np.array_equal(vals[1].numpy(), EXP3["ioni/run_2/phys"][:n])
+    assert vals[2].dtype == torch.int32 and np.array_equal(vals[2].numpy(), EXP3["ioni/run_2/PID"][:n])      # unmapped
+
+
+def test_label_file_pattern_reads_the_first_member_per_event():
+    """`label_file_pattern` (reference :404-427, :483): labels live in the sibling file named by the pattern swap, in
+    the `label_name` table, first member, one entry per EVENT of the item's range."""
+    ds = _ioni(label_name="EventLabels", label_file_pattern="*Label.h5", label_map={"3": 0})
+    (c, f), y = ds[0]
+    want = EXP3["ioni/run_1/label"].astype(np.int64)
+    want[want == 3] = 0
+    assert y.dtype == torch.int64 and np.array_equal(y.numpy(), want)
+    (c, f), y = ds[1]
+    want = EXP3["ioni/run_2/label"][:3].astype(np.int64)
+    want[want == 3] = 0
+    assert np.array_equal(y.numpy(), want)
+    with pytest.raises(RuntimeError, match="No corresponding label file"):
+        _ioni(label_name="EventLabels", label_file_pattern="*Nothing.h5")[0]
+
+
+def test_other_member_names_and_length_based_ranges():
+    """"det" / "pulse" tables without an `nevents` attribute (reference PulseDatasetWaveformNorm, `event_based=False`):
+    an item's range counts ROWS."""
+    ds = h5data.HDF5Dataset([os.path.join(R3, "pulses")], "*PulseNorm.h5", "WaveformNorm", "det", "pulse", 17,
+                            label_name="phys", event_based=False, additional_fields=["PID"])
+    assert len(ds) == 1 and ds.info["data_info"][0]["event_range"] == [0, 16] and ds.info["data_info"][0]["n_events"] == 23
+    (c, vals), y = ds[0]
+    assert c.shape == (17, 1) and np.array_equal(c.numpy()[:, 0], EXP3["pulses/p_1/det"][:17])
+    assert np.array_equal(vals[0].numpy(), EXP3["pulses/p_1/pulse"][:17]) and np.array_equal(vals[1].numpy(), EXP3["pulses/p_1/PID"][:17])
+    assert y.dtype == torch.float32 and np.array_equal(y.numpy(), EXP3["pulses/p_1/phys"][:17])
+
+
+def test_member_reads_through_the_c_abi():
+    with h5data.H5Table(os.path.join(R3, "ioni", "run_1_WaveformPairSim.h5"), "WaveformPairs") as t:
+        rows, cols, fl, es = t.member_info("phys")
+        assert (rows, cols, fl, es) == (len(EXP3["ioni/run_1/PID"]), 8, True, 4)
+        assert t.member_info("PID")[1:] == (1, False, 4) and t.member_info(None)[1:] == (1, False, 8)        # first member: evt
+        assert np.array_equal(t.read_member("PID", 2, 7).numpy(), EXP3["ioni/run_1/PID"][2:7])
+        with pytest.raises(h5data.H5Error):
+            t.read_member("nope", 0, 1)
+        with pytest.raises(h5data.H5Error):
+            t.read_member("PID", 0, rows + 1)
+    with h5data.H5Table(os.path.join(R3, "ioni", "run_1_Label.h5"), "EventLabels", "", "") as t:
+        assert t.n_events == 9 and np.array_equal(t.read_member(None, 0, 9).numpy(), EXP3["ioni/run_1/label"])

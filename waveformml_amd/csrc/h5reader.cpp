@@ -40,6 +40,8 @@ struct wfh5_file {
     // compound layout
     hid_t d_table = -1;
     bool labels_member = false;
+    std::string coord_name = "coord", feat_name = "waveform";      // member / dataset names bound at open
+    hid_t group = -1;               // group layout: the table's group, for wfh5_read_member
     wfh5_info info{};
     std::vector<int32_t> event_col_cache;     // the event-id column, loaded once for the linear event search
     int cached_event_col = -1;
@@ -130,6 +132,7 @@ static bool dims2(hid_t dset, hsize_t *d0, hsize_t *d1) {
 
 extern "C" void wfh5_close(wfh5_file *f) {
     if (!f) return;
+    if (f->group >= 0) H5Gclose(f->group);
     if (f->d_coord >= 0) H5Dclose(f->d_coord);
     if (f->d_feat >= 0) H5Dclose(f->d_feat);
     if (f->d_labels >= 0) H5Dclose(f->d_labels);
@@ -150,13 +153,17 @@ static hsize_t member_len(hid_t mtype) {
     return n;
 }
 
-extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
+extern "C" int wfh5_open_named(const char *path, const char *table, const char *coord_name, const char *feat_name,
+                               wfh5_file **out) {
     if (!path || !table || !out) {
         set_err("NULL argument");
         return WFH5_EINVAL;
     }
     H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);          // errors are reported through return codes
     wfh5_file *f = new wfh5_file;
+    if (coord_name) f->coord_name = coord_name;
+    if (feat_name) f->feat_name = feat_name;
+    const bool members_only = f->coord_name.empty() && f->feat_name.empty();      // e.g. a label file: wfh5_read_member only
     f->file = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
     if (f->file < 0) {
         set_err("cannot open %s", path);
@@ -174,13 +181,19 @@ extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
         f->layout = WFH5_GROUP;
         hid_t g = H5Gopen2(f->file, table, H5P_DEFAULT);
         f->info.n_events = read_nevents(g);
-        f->d_coord = H5Lexists(g, "coord", H5P_DEFAULT) > 0 ? H5Dopen2(g, "coord", H5P_DEFAULT) : -1;
-        f->d_feat = H5Lexists(g, "waveform", H5P_DEFAULT) > 0 ? H5Dopen2(g, "waveform", H5P_DEFAULT) : -1;
+        const char *cn = f->coord_name.c_str(), *fn = f->feat_name.c_str();
+        f->d_coord = (!members_only && H5Lexists(g, cn, H5P_DEFAULT) > 0) ? H5Dopen2(g, cn, H5P_DEFAULT) : -1;
+        f->d_feat = (!members_only && H5Lexists(g, fn, H5P_DEFAULT) > 0) ? H5Dopen2(g, fn, H5P_DEFAULT) : -1;
         f->d_labels = H5Lexists(g, "labels", H5P_DEFAULT) > 0 ? H5Dopen2(g, "labels", H5P_DEFAULT) : -1;
-        H5Gclose(g);
+        f->group = g;
+        if (members_only) {
+            f->info.layout = f->layout;
+            *out = f;
+            return WFH5_OK;
+        }
         hsize_t n0, c0, n1, c1;
         if (f->d_coord < 0 || f->d_feat < 0 || !dims2(f->d_coord, &n0, &c0) || !dims2(f->d_feat, &n1, &c1) || n0 != n1) {
-            set_err("%s:%s is a group without matching coord / waveform datasets", path, table);
+            set_err("%s:%s is a group without matching %s / %s datasets", path, table, cn, fn);
             wfh5_close(f);
             return WFH5_EFORMAT;
         }
@@ -233,9 +246,17 @@ extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
             wfh5_close(f);
             return WFH5_EFORMAT;
         }
-        int ic = H5Tget_member_index(t, "coord"), iw = H5Tget_member_index(t, "waveform");
+        if (members_only) {
+            H5Tclose(t);
+            f->info.n_rows = (int64_t)n0;
+            f->info.n_events = read_nevents(f->d_table);
+            f->info.layout = f->layout;
+            *out = f;
+            return WFH5_OK;
+        }
+        int ic = H5Tget_member_index(t, f->coord_name.c_str()), iw = H5Tget_member_index(t, f->feat_name.c_str());
         if (ic < 0 || iw < 0) {
-            set_err("%s:%s has no coord / waveform members", path, table);
+            set_err("%s:%s has no %s / %s members", path, table, f->coord_name.c_str(), f->feat_name.c_str());
             H5Tclose(t);
             wfh5_close(f);
             return WFH5_EFORMAT;
@@ -422,8 +443,9 @@ extern "C" int wfh5_read_rows(wfh5_file *f, int64_t row0, int64_t row1, int32_t 
         if (coords) rc = read_slab(f->d_coord, r0, r1, f->info.coord_cols, true, H5T_NATIVE_INT32, coords);
         if (rc == WFH5_OK && feats) rc = read_slab(f->d_feat, r0, r1, f->info.feat_cols, true, H5T_NATIVE_FLOAT, feats);
     } else {
-        if (coords) rc = read_member(f, "coord", f->info.coord_cols, H5T_NATIVE_INT32, 4, r0, r1, coords);
-        if (rc == WFH5_OK && feats) rc = read_member(f, "waveform", f->info.feat_cols, H5T_NATIVE_FLOAT, 4, r0, r1, feats);
+        if (coords) rc = read_member(f, f->coord_name.c_str(), f->info.coord_cols, H5T_NATIVE_INT32, 4, r0, r1, coords);
+        if (rc == WFH5_OK && feats)
+            rc = read_member(f, f->feat_name.c_str(), f->info.feat_cols, H5T_NATIVE_FLOAT, 4, r0, r1, feats);
     }
     if (rc != WFH5_OK) {
         set_err("HDF5 read failed for rows [%lld, %lld)", (long long)row0, (long long)row1);
@@ -520,4 +542,121 @@ extern "C" int wfh5_event_rows(wfh5_file *f, int32_t event_col, int64_t e0, int6
     *row0 = a;
     *row1 = b < 0 ? n : b;
     return WFH5_OK;
+}
+
+extern "C" int wfh5_open(const char *path, const char *table, wfh5_file **out) {
+    return wfh5_open_named(path, table, "coord", "waveform", out);
+}
+
+// the member (compound layout) or dataset (group layout) called `name`; NULL / "" = the first member of a compound
+static int find_member(wfh5_file *f, const char *name, std::string *resolved, hid_t *dset, hsize_t *rows, hsize_t *cols,
+                       bool *is_float, size_t *elem) {
+    *dset = -1;
+    if (f->layout == WFH5_COMPOUND) {
+        hid_t t = H5Dget_type(f->d_table);
+        int idx = (name && name[0]) ? H5Tget_member_index(t, name) : 0;
+        if (idx < 0 || idx >= H5Tget_nmembers(t)) {
+            H5Tclose(t);
+            set_err("no member named %s", name ? name : "(first)");
+            return WFH5_EFORMAT;
+        }
+        char *mn = H5Tget_member_name(t, (unsigned)idx);
+        *resolved = mn;
+        H5free_memory(mn);
+        hid_t mt = H5Tget_member_type(t, (unsigned)idx);
+        *cols = member_len(mt);
+        hid_t base = H5Tget_class(mt) == H5T_ARRAY ? H5Tget_super(mt) : H5Tcopy(mt);
+        const H5T_class_t cls = H5Tget_class(base);
+        *is_float = cls == H5T_FLOAT;
+        *elem = H5Tget_size(base);
+        H5Tclose(base);
+        H5Tclose(mt);
+        H5Tclose(t);
+        if (cls != H5T_FLOAT && cls != H5T_INTEGER) {
+            set_err("member %s is neither integer nor float", resolved->c_str());
+            return WFH5_EFORMAT;
+        }
+        hsize_t n0 = 0, c0 = 0;
+        dims2(f->d_table, &n0, &c0);
+        *rows = n0;
+        return WFH5_OK;
+    }
+    if (!name || !name[0] || f->group < 0 || H5Lexists(f->group, name, H5P_DEFAULT) <= 0) {
+        set_err("no dataset named %s in the group", name ? name : "(none)");
+        return WFH5_EFORMAT;
+    }
+    *resolved = name;
+    *dset = H5Dopen2(f->group, name, H5P_DEFAULT);
+    hsize_t n0 = 0, c0 = 0;
+    if (*dset < 0 || !dims2(*dset, &n0, &c0)) {
+        set_err("dataset %s cannot be read as [n] / [n, c]", name);
+        if (*dset >= 0) H5Dclose(*dset);
+        return WFH5_EFORMAT;
+    }
+    hid_t t = H5Dget_type(*dset);
+    *is_float = H5Tget_class(t) == H5T_FLOAT;
+    *elem = H5Tget_size(t);
+    H5Tclose(t);
+    *rows = n0;
+    *cols = c0;
+    return WFH5_OK;
+}
+
+extern "C" int wfh5_member_info(wfh5_file *f, const char *name, int64_t *rows, int32_t *cols, int32_t *is_float,
+                                int32_t *elem_bytes) {
+    if (!f) {
+        set_err("NULL handle");
+        return WFH5_EINVAL;
+    }
+    std::string rn;
+    hid_t d;
+    hsize_t n, c;
+    bool fl;
+    size_t es;
+    int rc = find_member(f, name, &rn, &d, &n, &c, &fl, &es);
+    if (rc != WFH5_OK) return rc;
+    if (d >= 0) H5Dclose(d);
+    if (rows) *rows = (int64_t)n;
+    if (cols) *cols = (int32_t)c;
+    if (is_float) *is_float = fl ? 1 : 0;
+    if (elem_bytes) *elem_bytes = (int32_t)es;
+    return WFH5_OK;
+}
+
+extern "C" int wfh5_read_member(wfh5_file *f, const char *name, int64_t row0, int64_t row1, int32_t as_float, void *out) {
+    if (!f || !out || row0 < 0 || row1 < row0) {
+        set_err("bad argument");
+        return WFH5_EINVAL;
+    }
+    std::string rn;
+    hid_t d;
+    hsize_t n, c;
+    bool fl;
+    size_t es;
+    int rc = find_member(f, name, &rn, &d, &n, &c, &fl, &es);
+    if (rc != WFH5_OK) return rc;
+    if ((hsize_t)row1 > n) {
+        if (d >= 0) H5Dclose(d);
+        set_err("rows [%lld, %lld) of %s beyond %lld", (long long)row0, (long long)row1, rn.c_str(), (long long)n);
+        return WFH5_EINVAL;
+    }
+    if (row1 == row0) {
+        if (d >= 0) H5Dclose(d);
+        return WFH5_OK;
+    }
+    const hid_t base = as_float ? H5T_NATIVE_FLOAT : H5T_NATIVE_INT64;
+    const size_t bs = as_float ? 4 : 8;
+    if (f->layout == WFH5_COMPOUND) {
+        rc = read_member(f, rn.c_str(), c, base, bs, (hsize_t)row0, (hsize_t)row1, out);
+    } else {
+        hsize_t n0 = 0, c0 = 0;
+        dims2(d, &n0, &c0);
+        hid_t sp = H5Dget_space(d);
+        const bool two_d = H5Sget_simple_extent_ndims(sp) == 2;
+        H5Sclose(sp);
+        rc = read_slab(d, (hsize_t)row0, (hsize_t)row1, c, two_d, base, out);
+        H5Dclose(d);
+    }
+    if (rc != WFH5_OK) set_err("HDF5 read of %s failed", rn.c_str());
+    return rc;
 }

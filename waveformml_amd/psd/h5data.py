@@ -16,7 +16,14 @@ What differs from the reference, on purpose:
   * the event column of the range search is ``batch_index`` (3 for the 3-D table); the reference searches column 2 for
     every 2-D coord array (:231-248), which for (x, y, t, evt) rows is the time sample.  Identical results whenever an
     item is a whole file, which is every file but the last one of a directory's budget;
-  * no data cache: items are decoded straight into (optionally pinned) tensors.
+  * no data cache: items are decoded straight into (optionally pinned) tensors;
+  * ``normalize`` scales the features only (with ``additional_fields`` the reference multiplies the Python LIST of
+    tensors by a float, :345-346, which raises).
+
+Served since round 3 (reference :186-217, :250-347, :404-427): per-row label columns by member name
+(``label_name: "PID"`` with ``label_map``, ``"phys"``, ``"EZ"``), ``additional_fields`` (returned as the reference's
+``[feats, *fields]`` list), ``label_file_pattern`` files (first member of the ``label_name`` table, one entry per event),
+length-based ranges (``event_based=False``) and any coordinate / feature member names.
 """
 import ctypes
 import os
@@ -49,6 +56,11 @@ class Info(ctypes.Structure):
 SIGNATURES = {
     "wfh5_last_error": (ctypes.c_char_p, []),
     "wfh5_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    "wfh5_open_named": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                       ctypes.POINTER(_vp)]),
+    "wfh5_member_info": (ctypes.c_int, [_vp, ctypes.c_char_p, c_i64p, ctypes.POINTER(_i32), ctypes.POINTER(_i32),
+                                        ctypes.POINTER(_i32)]),
+    "wfh5_read_member": (ctypes.c_int, [_vp, ctypes.c_char_p, _i64, _i64, _i32, _vp]),
     "wfh5_close": (None, [_vp]),
     "wfh5_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(Info)]),
     "wfh5_read_rows": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, ctypes.c_float]),
@@ -90,10 +102,11 @@ def _check(rc):
 class H5Table:
     """One open table of one file (a handle is not shared between DataLoader workers: open per use)."""
 
-    def __init__(self, path, table):
+    def __init__(self, path, table, coord_name="coord", feat_name="waveform"):
         self._lib = load()
         self._h = _vp()
-        _check(self._lib.wfh5_open(str(path).encode(), table.encode(), ctypes.byref(self._h)))
+        _check(self._lib.wfh5_open_named(str(path).encode(), table.encode(), (coord_name or "").encode(),
+                                         (feat_name or "").encode(), ctypes.byref(self._h)))
         info = Info()
         _check(self._lib.wfh5_get_info(self._h, ctypes.byref(info)))
         self.n_rows, self.n_events, self.n_labels = info.n_rows, info.n_events, info.n_labels
@@ -132,6 +145,25 @@ class H5Table:
         _check(self._lib.wfh5_read_rows(self._h, row0, row1, coords.data_ptr(), feats.data_ptr(), scale))
         return coords, feats
 
+    def member_info(self, name=None):
+        """(rows, array length per row, is_float, stored element bytes) of a member / dataset; None: the first member."""
+        rows, cols, fl, es = _i64(), _i32(), _i32(), _i32()
+        _check(self._lib.wfh5_member_info(self._h, name.encode() if name else None, ctypes.byref(rows), ctypes.byref(cols),
+                                          ctypes.byref(fl), ctypes.byref(es)))
+        return rows.value, cols.value, bool(fl.value), es.value
+
+    def read_member(self, name, row0, row1):
+        """Rows [row0, row1) of any member: float members as float32, integer members as int64 (int32 when stored in at
+        most 4 bytes, as numpy would hand them to torch); [n] for scalars, [n, len] for array members."""
+        _rows, cols, fl, es = self.member_info(name)
+        n = row1 - row0
+        out = torch.empty((n, cols), dtype=torch.float32 if fl else torch.int64)
+        _check(self._lib.wfh5_read_member(self._h, name.encode() if name else None, row0, row1, 1 if fl else 0,
+                                          out.data_ptr()))
+        if not fl and es <= 4:
+            out = out.to(torch.int32)
+        return out[:, 0].contiguous() if cols == 1 else out
+
     def read_labels(self, e0, e1):
         y = torch.empty((e1 - e0,), dtype=torch.int64)
         _check(self._lib.wfh5_read_labels(self._h, e0, e1, y.data_ptr()))
@@ -162,13 +194,6 @@ class HDF5Dataset(Dataset):
                  label_file_pattern=None, data_cache_size=1, normalize=False, use_half=False, event_based=True,
                  additional_fields=None, label_map=None, batch_index=2, pin_memory=False):
         super().__init__()
-        if (coordinate_name, feature_name) != ("coord", "waveform"):
-            raise NotImplementedError("the native reader binds the PSD tables' coord / waveform columns")
-        if label_file_pattern is not None or additional_fields is not None or not event_based:
-            raise NotImplementedError("separate label files / additional fields / length-based ranges are not on "
-                                      "the PSD classification path")
-        if label_name not in (None, "labels"):
-            raise NotImplementedError("labels come from the directory index or a `labels` dataset")
         self.num_dirs = len(file_paths)
         self.normalize = normalize
         self.half_precision = use_half
@@ -217,11 +242,41 @@ class HDF5Dataset(Dataset):
             self.ordered_file_set.append(str(f.resolve()))
             self._add_data_infos(str(f.resolve()), dir_index)
 
+    def _table(self, file_path):
+        return H5Table(file_path, self.info["data_name"], self.info["coord_name"], self.info["feat_name"])
+
     def _get_event_num(self, file_path):
-        with H5Table(file_path, self.info["data_name"]) as t:
+        with self._table(file_path) as t:
+            if not self.info["event_based"]:
+                return t.n_rows                    # ranges count ROWS (reference :381-384)
             if t.n_events < 0:
                 raise H5Error("%s:%s has no nevents attribute" % (file_path, self.info["data_name"]))
             return t.n_events
+
+    def _label_file(self, file_path):
+        """The label file that goes with a data file (reference :404-411, src/utils/util.py:527-537)."""
+        fdir, fname = os.path.split(file_path)
+        p1, p2 = self.info["file_pattern"].split("*"), self.info["label_file_pattern"].split("*")
+        if len(p1) != len(p2):
+            raise ValueError("incompatible patterns: {0} and {1}".format(p1, p2))
+        for a, b in zip(p1, p2):
+            if a == b == "":
+                continue
+            fname = fname.replace(a, b, 1)
+        path = os.path.join(fdir, fname)
+        if not os.path.exists(path):
+            raise RuntimeError("No corresponding label file found for file {0}, tried {1}".format(file_path, path))
+        return path
+
+    def _convert_label(self, y):
+        """label_map applied in place on integer labels, then the reference's tensor type: int32 labels become int64
+        class indices, everything else float32 regression targets (reference :331-341, :582-585)."""
+        if self.info["label_map"] and not y.is_floating_point():
+            m = {int(k): int(v) for k, v in self.info["label_map"].items()}
+            src = y.clone()
+            for k, v in m.items():
+                y[src == k] = v
+        return y.to(torch.int64) if not y.is_floating_point() else y.to(torch.float32)
 
     def _add_data_infos(self, file_path, dir_index):
         n_file_events = self._get_event_num(file_path)
@@ -238,21 +293,33 @@ class HDF5Dataset(Dataset):
         di = self.info["data_info"][index]
         e0, e1 = di["event_range"]
         scale = MAX_RANGE_INV if self.normalize else 1.0
-        with H5Table(di["file_path"], self.info["data_name"]) as t:
-            if e0 == 0 and e1 + 1 >= di["n_events"]:
+        label_name, label_file = self.info["label_name"], self.info["label_file_pattern"]
+        with self._table(di["file_path"]) as t:
+            if not self.info["event_based"]:
+                r0, r1 = e0, e1 + 1                                    # the range IS the row range (reference :232-246)
+            elif e0 == 0 and e1 + 1 >= di["n_events"]:
                 r0, r1 = 0, t.n_rows
             else:
                 r0, r1 = t.event_rows(e0, e1, min(self.batch_index, t.coord_cols - 1))
             coords, feats = t.read_rows(r0, r1, scale, self.pin_memory)
-            if self.info["label_name"] is None:
+            extra = [t.read_member(f, r0, r1) for f in (self.info["additional_fields"] or [])]
+            if label_name is None:
                 y = torch.full((e1 + 1 - e0,), di["dir_index"], dtype=torch.int64)
+            elif label_file is not None:
+                y = None                                               # from the label file, below
+            elif t.layout == WFH5_GROUP:
+                y = self._convert_label(t.read_labels(e0, e1 + 1) if label_name == "labels"
+                                        else t.read_member(label_name, e0, e1 + 1))      # one label per EVENT (:319-327)
             else:
-                y = t.read_labels(e0, e1 + 1)
-                if self.info["label_map"]:
-                    m = {int(k): int(v) for k, v in self.info["label_map"].items()}
-                    y = torch.from_numpy(np.vectorize(lambda v: m.get(int(v), int(v)), otypes=[np.int64])(y.numpy()))
+                y = self._convert_label(t.read_member(label_name, r0, r1))               # one label per ROW (:331-341)
+        if y is None:
+            # a separate label file: the FIRST member of its `label_name` table, one entry per event (:483, :319-327)
+            with H5Table(self._label_file(di["file_path"]), label_name, "", "") as lt:
+                y = self._convert_label(lt.read_member(None, e0, e1 + 1))
         if self.half_precision:
             feats = feats.half()
+        if self.info["additional_fields"] is not None:
+            return [coords, [feats] + extra], y                        # the reference's [feats, *fields] list (:250-262)
         return [coords, feats], y
 
 
