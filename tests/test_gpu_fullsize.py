@@ -35,8 +35,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 DEV = "cuda:0"
 
-# per-tensor relative L2 error of a parameter gradient, 16-bit rows vs the fp32 oracle (measured: see DESIGN.md 3)
-GRAD_REL_L2 = {torch.bfloat16: 0.35, torch.float16: 0.15}
+# per-tensor relative L2 error of a parameter gradient, 16-bit rows vs the fp32 oracle: 1.5 x the largest value measured
+# per tensor against the fp64 oracle (tools/grad_error_by_tensor.py -> profiles/r03_grad_error_by_tensor.json: C2 bf16
+# 0.138 at sparseModel.1.bias, C4 fp16 0.104 at sparseModel.7.weight; C4 bf16 0.240, C2 fp16 0.052 are not run here)
+GRAD_REL_L2 = {torch.bfloat16: 0.21, torch.float16: 0.16}
 
 
 def _assert_close(got, want, rtol, what):

@@ -241,11 +241,13 @@ def test_packed_loader_hands_over_the_same_batches():
     for layout, fn in (("3d", data.collate_fn_3d), ("2d", data.collate_fn)):
         ds = data.SyntheticPulseDataset(5, 4, 24, layout=layout)
         plain = list(DataLoader(ds, batch_size=2, collate_fn=fn))
-        packed = list(data.PackedLoader(ds, fn, batch_size=2, num_workers=2))
-        assert len(plain) == len(packed) == 3
-        for a, b in zip(plain, packed):
-            for x, y in ((a[0][0], b[0][0]), (a[0][1], b[0][1]), (a[1], b[1])):
-                assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
+        for group in (1, 2, 4):                     # batches per worker -> trainer message
+            loader = data.PackedLoader(ds, fn, group=group, batch_size=2, num_workers=2)
+            packed = list(loader)
+            assert len(plain) == len(packed) == len(loader) == 3
+            for a, b in zip(plain, packed):
+                for x, y in ((a[0][0], b[0][0]), (a[0][1], b[0][1]), (a[1], b[1])):
+                    assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
 
 
 def test_packed_loader_exposes_its_sampler_for_per_epoch_reshuffling():

@@ -4,7 +4,8 @@ reference's converters write them) -> libwfh5 reader inside DataLoader workers -
 DevicePrefetcher -> Trainer(capture=True): bf16 rows, HIP-graph step.  Prints one JSON object with
   * loader: events/s of the DataLoader alone for several worker counts (the per-rank loader budget),
   * train: steps, events/s including loading, eager fallbacks, overflow checks, loss per epoch.
-The three classes differ in their pulse decay constant, so the loss has something to learn.
+The files hold the BENCH'S events (psd/synthetic.generate, ~330 voxels per event; one class per directory), so loader
+and training rates are comparable with bench.py's in events/s AND voxels/s.
 
 usage: python tools/soak_from_files.py [files_per_class] [events_per_file] [epochs] [workers]
 """
@@ -28,27 +29,20 @@ T = 256
 CLASSES = ["Gamma", "Electron", "Positron"]
 
 WRITER = r'''
-import sys, os, numpy as np, h5py
-root, files, events, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+# one class directory per event class, every event drawn by psd/synthetic.generate -- THE BENCH'S EVENTS (1 + Poisson(2)
+# hit segments, ~110 active samples each: ~330 voxels per event), not lighter stand-ins (round 2's files had 159)
+import importlib.util, sys, os, numpy as np, h5py
+root, files, events, T, synth = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+spec = importlib.util.spec_from_file_location("wfs_synthetic", synth)
+synthetic = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(synthetic)
 dt = np.dtype([("evt", "<i8"), ("t", "<f8"), ("dt", "<f4"), ("z", "<f4"), ("E", "<f4"), ("PSD", "<f4"), ("PE", "<f4", (2,)),
                ("coord", "<i4", (4,)), ("waveform", "<f4", (2,)), ("EZ", "<f4", (2,)), ("PID", "<i4")])
 rows = 0
 for ci, name in enumerate(["Gamma", "Electron", "Positron"]):
     os.makedirs(os.path.join(root, name), exist_ok=True)
-    tau = (12.0, 20.0, 32.0)[ci]
     for fi in range(files):
-        rng = np.random.default_rng(1000 * ci + fi)
-        coords, wf = [], []
-        for e in range(events):
-            for _ in range(int(rng.integers(1, 4))):
-                x, y, t0 = int(rng.integers(0, 14)), int(rng.integers(0, 11)), int(rng.integers(0, T // 4))
-                n = int(rng.integers(T // 8, T // 2))
-                c = np.empty((n, 4), np.int32); c[:, 0] = x; c[:, 1] = y; c[:, 2] = np.arange(t0, t0 + n); c[:, 3] = e
-                amp = rng.uniform(2000, 12000)
-                s = amp * np.exp(-np.arange(n) / tau)
-                w = np.stack([s * rng.uniform(0.7, 1.0), s * rng.uniform(0.7, 1.0)], 1) + rng.normal(0, 30, (n, 2))
-                coords.append(c); wf.append(w.astype(np.float32))
-        coords = np.concatenate(coords); wf = np.concatenate(wf)
+        coords, wf, _y = synthetic.generate(events, T, 3, seed=100000 * ci + fi, label=ci)
         rec = np.zeros(len(coords), dt)
         rec["coord"] = coords; rec["evt"] = coords[:, 3]; rec["waveform"] = wf
         with h5py.File(os.path.join(root, name, "%03d_Waveform3DPairSim.h5" % fi), "w") as f:
@@ -70,10 +64,12 @@ def main():
     out = {"files_per_class": files_per_class, "events_per_file": events_per_file, "classes": len(CLASSES), "T": T}
     try:
         t0 = time.perf_counter()
-        rows = int(subprocess.run([CONDA, "-c", WRITER, tmp, str(files_per_class), str(events_per_file), str(T)],
+        rows = int(subprocess.run([CONDA, "-c", WRITER, tmp, str(files_per_class), str(events_per_file), str(T),
+                                   os.path.join(ROOT, "waveformml_amd", "psd", "synthetic.py")],
                                   check=True, capture_output=True, text=True).stdout.strip())
         size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmp) for f in fs)
-        out["files"] = {"rows": rows, "bytes_on_disk": size, "write_seconds": round(time.perf_counter() - t0, 1)}
+        out["files"] = {"rows": rows, "bytes_on_disk": size, "write_seconds": round(time.perf_counter() - t0, 1),
+                        "voxels_per_event": round(rows / (len(CLASSES) * files_per_class * events_per_file), 1)}
         print("wrote %d files, %d rows, %.1f MB" % (files_per_class * len(CLASSES), rows, size / 1e6), flush=True)
         cfg = json.load(open(os.path.join(ROOT, "config", "psd_c2_3d.json")))
         n_events = files_per_class * events_per_file
@@ -94,22 +90,25 @@ def main():
             dm.setup("fit")
             return conf, dm.train_dataloader()
 
-        # ---- loader alone: the budget one rank's workers deliver
+        # ---- loader alone: the budget one rank's workers deliver, per hand-over group (batches per worker message)
         out["loader"] = []
-        for nw in sorted({1, 4, workers, 2 * workers}):
-            _, loader = module_and_loader(nw)
-            for _ in loader:                       # first pass: worker start-up, page cache
-                pass
-            t0 = time.perf_counter()
-            ev = vox = 0
-            for (c, f), y in loader:
-                ev += int(y.shape[0])
-                vox += int(c.shape[0])
-            dt = time.perf_counter() - t0
-            out["loader"].append({"workers": nw, "events_per_s": round(ev / dt), "voxels_per_s": round(vox / dt),
-                                  "batches": len(loader), "seconds": round(dt, 2), "handover": "one buffer per batch"})
-            print("loader", out["loader"][-1], flush=True)
-            del loader
+        for group in (1, 4):
+            os.environ["WFS_LOADER_GROUP"] = str(group)
+            for nw in sorted({1, 4, workers, 2 * workers}):
+                _, loader = module_and_loader(nw)
+                for _ in loader:                       # first pass: worker start-up, page cache
+                    pass
+                t0 = time.perf_counter()
+                ev = vox = 0
+                for (c, f), y in loader:
+                    ev += int(y.shape[0])
+                    vox += int(c.shape[0])
+                dt = time.perf_counter() - t0
+                out["loader"].append({"workers": nw, "batches_per_message": group, "events_per_s": round(ev / dt),
+                                      "voxels_per_s": round(vox / dt), "batches": len(loader), "seconds": round(dt, 2)})
+                print("loader", out["loader"][-1], flush=True)
+                del loader
+        os.environ["WFS_LOADER_GROUP"] = os.environ.get("WFS_SOAK_TRAIN_GROUP", "4")
         _, loader = module_and_loader(workers, pack=False)
         for _ in loader:
             pass
@@ -138,7 +137,9 @@ def main():
                         "events_per_s_incl_loading_and_capture": round(steps * len(CLASSES) * events_per_file / dt),
                         "events_per_s_per_epoch": [round(h["steps"] * len(CLASSES) * events_per_file / h["train_seconds"])
                                                    for h in hist],
+                        "voxels_per_s_per_epoch": [round(rows / h["train_seconds"]) for h in hist],
                         "n_cap": tr._graph.n_cap if tr._graph is not None else None, "eager_fallbacks": tr.eager_fallbacks,
+                        "recaptures": tr.recaptures, "loader_group": int(os.environ.get("WFS_LOADER_GROUP", "1")),
                         "history": hist}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

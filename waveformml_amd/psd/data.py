@@ -74,54 +74,81 @@ def rank_sampler(dataset, shuffle, seed=0):
 class _PackedCollate(object):
     """Collate in the worker, then pack the batch's tensors into ONE byte buffer (each at a 16-byte boundary): a batch
     then crosses the worker -> trainer process boundary as one shared-memory segment instead of three (or more), and is
-    pinned with one copy.  ``unpack`` rebuilds the tensors as views of the buffer."""
+    pinned with one copy.  ``unpack`` rebuilds the tensors as views of the buffer.
 
-    def __init__(self, collate):
-        self.collate = collate
+    ``group`` > 1: one message carries ``group`` consecutive batches (the worker is handed group x items and collates
+    them ``items_per_batch`` at a time): the per-message cost of the DataLoader machinery (queue hand-over, pinning
+    thread; ~1 ms, i.e. a ceiling of ~1000 batches/s per trainer process whatever the number of workers) is paid once
+    per group."""
+
+    def __init__(self, collate, items_per_batch=None, group=1):
+        self.collate, self.items_per_batch, self.group = collate, items_per_batch, int(group)
 
     def __call__(self, items):
-        (coords, feats), labels = self.collate(items)
-        feats_list = feats if isinstance(feats, list) else [feats]
-        tensors = [coords] + feats_list + [labels]
-        meta, off = [], 0
-        for t in tensors:
-            nbytes = t.numel() * t.element_size()
-            meta.append((off, nbytes, t.dtype, tuple(t.shape)))
-            off += (nbytes + 15) // 16 * 16
+        if self.group <= 1 or not self.items_per_batch:
+            chunks = [items]
+        else:
+            chunks = [items[i:i + self.items_per_batch] for i in range(0, len(items), self.items_per_batch)]
+        batches, off = [], 0
+        for chunk in chunks:
+            (coords, feats), labels = self.collate(chunk)
+            feats_list = feats if isinstance(feats, list) else [feats]
+            tensors = [coords] + feats_list + [labels]
+            meta = []
+            for t in tensors:
+                nbytes = t.numel() * t.element_size()
+                meta.append((off, nbytes, t.dtype, tuple(t.shape)))
+                off += (nbytes + 15) // 16 * 16
+            batches.append((tensors, meta, isinstance(feats, list)))
         buf = torch.empty(max(off, 16), dtype=torch.uint8)
-        for t, (o, nbytes, _, _) in zip(tensors, meta):
-            if nbytes:
-                buf[o:o + nbytes].view(t.dtype).view(t.shape).copy_(t)
-        return buf, meta, isinstance(feats, list)
+        for tensors, meta, _ in batches:
+            for t, (o, nbytes, _, _) in zip(tensors, meta):
+                if nbytes:
+                    buf[o:o + nbytes].view(t.dtype).view(t.shape).copy_(t)
+        return buf, [(meta, is_list) for _t, meta, is_list in batches]
 
     @staticmethod
     def unpack(packed):
-        buf, meta, feats_is_list = packed
-        ts = [buf[o:o + nbytes].view(dtype).view(shape) if nbytes else torch.empty(shape, dtype=dtype)
-              for (o, nbytes, dtype, shape) in meta]
-        feats = ts[1:-1] if feats_is_list else ts[1]
-        return [ts[0], feats], ts[-1]
+        """The batches of one message, in order."""
+        buf, metas = packed
+        out = []
+        for meta, feats_is_list in metas:
+            ts = [buf[o:o + nbytes].view(dtype).view(shape) if nbytes else torch.empty(shape, dtype=dtype)
+                  for (o, nbytes, dtype, shape) in meta]
+            feats = ts[1:-1] if feats_is_list else ts[1]
+            out.append(([ts[0], feats], ts[-1]))
+        return out
 
 
 class PackedLoader(object):
     """A ``DataLoader`` whose worker processes hand over each batch as one buffer (see _PackedCollate); iterating yields
-    the same ``[[coords, feats], labels]`` batches as the plain loader.  Measured on the MI355X box's host
-    (tools/soak_from_files.py, 255-event batches out of 3 files each): 330 k events/s -> see profiles/r02_soak_from_files.json."""
+    the same ``[[coords, feats], labels]`` batches as the plain loader.  ``group``: batches per message (default
+    $WFS_LOADER_GROUP or 1).  Measured on the MI355X box's host, 255-event batches of the bench's events out of 3 files
+    each (tools/soak_from_files.py -> profiles/r03_soak_from_files.json)."""
 
-    def __init__(self, dataset, collate_fn, **loader_kwargs):
-        self.loader = DataLoader(dataset, collate_fn=_PackedCollate(collate_fn), **loader_kwargs)
+    def __init__(self, dataset, collate_fn, group=None, **loader_kwargs):
+        import os
+        self.group = int(group if group is not None else os.environ.get("WFS_LOADER_GROUP", "1"))
+        self.items_per_batch = int(loader_kwargs.get("batch_size", 1) or 1)
+        if self.group > 1:
+            loader_kwargs["batch_size"] = self.items_per_batch * self.group
+        self.loader = DataLoader(dataset, collate_fn=_PackedCollate(collate_fn, self.items_per_batch, self.group),
+                                 **loader_kwargs)
         self.dataset = dataset
+        self.drop_last = bool(loader_kwargs.get("drop_last", False))
 
     @property
     def sampler(self):
         return self.loader.sampler
 
     def __len__(self):
-        return len(self.loader)
+        n = len(self.loader.sampler) if self.loader.sampler is not None else len(self.dataset)
+        return n // self.items_per_batch if self.drop_last else (n + self.items_per_batch - 1) // self.items_per_batch
 
     def __iter__(self):
         for packed in self.loader:
-            yield _PackedCollate.unpack(packed)
+            for batch in _PackedCollate.unpack(packed):
+                yield batch
 
 
 def make_loader(dataset, items_per_batch, num_workers=0, shuffle=False, pin_memory=True):

@@ -23,7 +23,7 @@ def _round_up(v, m):
 
 
 class GraphedTrainStep(object):
-    def __init__(self, module, optimizer, reducer, example_batch, headroom=None, granule=None, warmup=2):
+    def __init__(self, module, optimizer, reducer, example_batch, headroom=None, granule=None, warmup=2, min_rows=0):
         # headroom: row capacities = headroom x the example batch's row counts.  Capacity is not free (the
         # register-resident BatchNorm kernels and the rulebook grids are sized by it: 1.25 -> 1.12 measured -4 % per
         # step).  The voxel count of an E-event PSD batch varies by sigma ~ 0.5 / sqrt(E) of its mean (3.1 % at 256
@@ -40,7 +40,7 @@ class GraphedTrainStep(object):
         assert coords.is_cuda and feats.is_cuda and labels.is_cuda
         self.module, self.optimizer, self.reducer = module, optimizer, reducer
         dev = coords.device
-        self.n_cap = _round_up(headroom * coords.shape[0], granule)
+        self.n_cap = max(_round_up(headroom * coords.shape[0], granule), _round_up(min_rows, granule))
         self.coords = torch.zeros((self.n_cap, coords.shape[1]), dtype=coords.dtype, device=dev)
         self.feats = torch.zeros((self.n_cap, feats.shape[1]), dtype=feats.dtype, device=dev)
         # targets: one per EVENT (LitPSD: a fixed number per batch), or one per ROW (per-segment modules with

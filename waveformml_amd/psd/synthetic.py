@@ -31,12 +31,14 @@ def _cluster(rng, m):
     return cells
 
 
-def generate(n_events, n_samples, n_type=3, seed=1234, rank=0, layout="3d"):
-    """Returns (coords int32, feats float32, labels int64) in the reference's dataset layout."""
+def generate(n_events, n_samples, n_type=3, seed=1234, rank=0, layout="3d", label=None):
+    """Returns (coords int32, feats float32, labels int64) in the reference's dataset layout.  ``label``: every event of
+    this class (the files of one class directory, tools/soak_from_files.py) instead of a random class per event."""
     rng = np.random.default_rng(seed + rank)
     T = int(n_samples)
     t = np.arange(T, dtype=np.float64)
-    labels = rng.integers(0, n_type, size=n_events).astype(np.int64)
+    labels = (rng.integers(0, n_type, size=n_events).astype(np.int64) if label is None
+              else np.full((n_events,), int(label), np.int64))
     coords, feats = [], []
     for e in range(n_events):
         m = int(np.clip(1 + rng.poisson(2), 1, 10))

@@ -57,7 +57,7 @@ def load_from_checkpoint(path, config, module_class=None, map_location="cpu", st
 
 class Trainer(object):
     def __init__(self, max_epochs=1, device="cuda:0", default_root_dir=None, feature_dtype=None, log_every=0,
-                 capture=False, check_every=100, resume_from_checkpoint=None):
+                 capture=False, check_every=100, resume_from_checkpoint=None, recapture_after=4):
         self.max_epochs, self.device = max_epochs, torch.device(device)
         self.root = default_root_dir
         self.feature_dtype = feature_dtype
@@ -66,11 +66,17 @@ class Trainer(object):
         self.resume_from_checkpoint = resume_from_checkpoint
         self.history = []
         self._graph = None
+        # a captured step sizes its row capacities on its first batch + a few sigma of an event-level mix; batches whose
+        # files differ systematically (one class per file, classes with different pulse lengths) can exceed them often:
+        # after `recapture_after` misfits by SIZE the step is captured again on the batch that did not fit
+        self.recapture_after = int(recapture_after)
+        self.recaptures = 0
+        self._size_misfits = 0
         self.eager_fallbacks = 0
         self.global_step = 0
         self.last_checkpoint = None
 
-    def _capture(self, module, reducer, optimizer, batch):
+    def _capture(self, module, reducer, optimizer, batch, min_rows=0):
         """Capture the step on ``batch`` without letting the capture's calibration / warm-up steps train the model."""
         from .graph import GraphedTrainStep
         params = reducer.flat_param.detach().clone() if reducer.flat_param is not None else \
@@ -81,7 +87,7 @@ class Trainer(object):
         # is zeroed (zero momentum == no history).
         kept = {id(p): {k: v.detach().clone() for k, v in optimizer.state[p].items() if torch.is_tensor(v)}
                 for g in optimizer.param_groups for p in g["params"] if p in optimizer.state and len(optimizer.state[p]) > 0}
-        graph = GraphedTrainStep(module, optimizer, reducer, batch)
+        graph = GraphedTrainStep(module, optimizer, reducer, batch, min_rows=min_rows)
         with torch.no_grad():
             if reducer.flat_param is not None:
                 reducer.flat_param.copy_(params)
@@ -115,6 +121,21 @@ class Trainer(object):
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=reducer.group)
             misfit = bool(flag.item())
         if misfit:
+            too_big = batch[0][0].shape[0] > self._graph.n_cap
+            if reducer.world > 1 and reducer.exchange:
+                flag = torch.tensor([1 if too_big else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=reducer.group)
+                too_big = bool(flag.item())
+            self._size_misfits += 1 if too_big else 0
+            if too_big and self.recapture_after > 0 and self._size_misfits >= self.recapture_after:
+                # the capacity is too small for this data: capture again, sized on this batch (never smaller than before)
+                old = self._graph
+                self._graph = None
+                self._graph = self._capture(module, reducer, optimizer, batch, min_rows=old.n_cap)
+                del old
+                self._size_misfits = 0
+                self.recaptures += 1
+                return self._graph(batch)
             self.eager_fallbacks += 1
             return self._graph.eager_step(batch)
         loss = self._graph(batch)
