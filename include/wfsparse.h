@@ -60,10 +60,10 @@ extern "C" {
 #define WFS_MAX_DIM 4
 
 /* library / device ------------------------------------------------------------------------
- * WFS_ABI_VERSION changes whenever a struct layout or an exported signature does (3: round 3 -- wfs_geometry grew
- * `transposed` / `output_padding` in round 2, the event-local build joined in round 3).  A binding compiled against
+ * WFS_ABI_VERSION changes whenever a struct layout or an exported signature does (3: wfs_geometry grew
+ * `transposed` / `output_padding` in round 2, the event-local build joined in round 3; 4: the wide-layer entry points).  A binding compiled against
  * another version must refuse the library: waveformml_amd/_lib.py does. */
-#define WFS_ABI_VERSION 3
+#define WFS_ABI_VERSION 4
 int wfs_abi_version(void);
 const char *wfs_last_error(void);
 
@@ -159,6 +159,28 @@ int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, i
                     int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
                     int32_t dtype, const int64_t *r_dev, void *stream);
+
+/* Wide layers on the 16-bit matrix cores (round 3; csrc/wide.hip).
+ * Same contract as wfs_gather_conv -- replaces torch.ops.spconv.indice_conv / the dX half of
+ * indice_conv_backward (spconv 1.2.1 ops.py; the reference reaches them from src/models/SPConvBlocks.py:450-516
+ * with 1697 / 1021 / 345 channels, BASELINE configs[4]) and, with K == 1 && table == NULL, the torch.mm of a
+ * 1 x 1 SparseConv2d (spconv conv.py: `features = torch.mm(input.features, weight.view(in, out))`) -- for
+ * 16-bit rows (WFS_BF16 / WFS_F16) when a side of the filter has >= 256 channels: the layer runs as ONE dense
+ * v_mfma_f32_32x32x16 product over whichever side (X_rows source rows, R destination rows) is shorter, fp32
+ * accumulate, ordered fp32 sum over the kernel offsets, every output row written once (no atomics).
+ * wfs_wide_conv_ok: does this path take the shape?  The workspace holds the 16-bit filters, the padded /
+ * gathered rows and the per-offset products; 16-byte aligned. */
+int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy, int32_t dtype);
+/* A/B switch for benchmarks (tools/microbench_generic.py): 0 sends every layer back to the 32 x 32-tile kernels
+ * (wfs_gather_conv / the narrow arm of wfs_gather_dw).  Returns the previous setting; default on. */
+int wfs_wide_enable(int32_t on);
+size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy,
+                                     int32_t has_table);
+int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
+                         int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
+                         int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
+                         int32_t dtype, const int64_t *r_dev, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* Event-local rulebook build (round 3; csrc/evrulebook.hip).
  * A sparse convolution never crosses events (the rulebook key includes the batch index) and the

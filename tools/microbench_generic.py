@@ -37,13 +37,38 @@ def timeit(name, fn, reps=10, iters=20):
     print("%-46s %8.1f us" % (name, a.elapsed_time(b) / (iters * reps) * 1e3), flush=True)
 
 
-SHAPES = ((1697, 1021), (1021, 345)) if (len(sys.argv) > 3 and sys.argv[3] == "wide") else ((252, 158), (158, 64), (64, 64), (130, 138))
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
+SHAPES = ((1697, 1021), (1021, 345), (300, 252)) if WIDE else ((252, 158), (158, 64), (64, 64), (130, 138))
+from waveformml_amd import _lib
+lib = _lib.load()
+# the hybrid net's second 3 x 3 layer works on the OUTPUT set of the first one
+rb2 = ops.build_rulebook(rb.out_indices, NB, [12, 9], [3, 3], [1, 1], [0, 0], [1, 1], False, known_unique=True)
+print("second layer: rows in %d out %d pairs %d" % (rb2.N, rb2.M, int((rb2.nbr_out >= 0).sum())))
 for (ci, co) in SHAPES:
-    X = torch.randn(N, ci, device=dev).to(DT)
-    dY = torch.randn(M, co, device=dev).to(DT)
+    r = rb2 if (ci, co) == (1021, 345) else rb
+    X = torch.randn(r.N, ci, device=dev).to(DT)
+    dY = torch.randn(r.M, co, device=dev).to(DT)
     W = torch.randn(K, ci, co, device=dev) * 0.05
-    for route, lim in (("libwfsparse MFMA", 1 << 30), ("torch gather + library GEMM", 8)):
+    routes = [("libwfsparse wide (16-bit MFMA, 128 x 128 tiles)", 1, 1 << 30)] if DT != torch.float32 else []
+    routes += [("libwfsparse 32 x 32-tile MFMA", 0, 1 << 30), ("torch gather + library GEMM", 0, 8)]
+    for route, wide, lim in routes:
+        lib.wfs_wide_enable(wide)
         Fsp.GEMM_ROUTE_MIN_CHANNELS = lim
-        timeit("%d->%d fwd  %s" % (ci, co, route), lambda: Fsp.gather_conv(rb.nbr_in, None, K, -1, M, X, W, False, None))
-        timeit("%d->%d dX   %s" % (ci, co, route), lambda: Fsp.gather_conv(rb.nbr_out, None, K, -1, N, dY, W, True, None))
-        timeit("%d->%d dW   %s" % (ci, co, route), lambda: Fsp.gather_dw(rb.nbr_out, K, -1, N, X, dY, False))
+        Fsp.GEMM_ROUTE_ANY_DTYPE = True
+        timeit("%d->%d fwd  %s" % (ci, co, route), lambda: Fsp.gather_conv(r.nbr_in, None, K, -1, r.M, X, W, False, None))
+        timeit("%d->%d dX   %s" % (ci, co, route), lambda: Fsp.gather_conv(r.nbr_out, None, K, -1, r.N, dY, W, True, None))
+        timeit("%d->%d dW   %s" % (ci, co, route), lambda: Fsp.gather_dw(r.nbr_out, K, -1, r.N, X, dY, False))
+    lib.wfs_wide_enable(1)
+if WIDE and DT != torch.float32:
+    # the hybrid net's 1 x 1 layer (2048 -> 1697): spconv's torch.mm against the wide path
+    R = rb.N
+    X = torch.randn(R, 2048, device=dev).to(DT)
+    dY = torch.randn(R, 1697, device=dev).to(DT)
+    W = torch.randn(1, 2048, 1697, device=dev) * 0.02
+    Wh = W[0].to(DT)
+    timeit("2048->1697 1x1 fwd  libwfsparse wide", lambda: Fsp.gather_conv(None, None, 1, 0, R, X, W, False, None))
+    timeit("2048->1697 1x1 dX   libwfsparse wide", lambda: Fsp.gather_conv(None, None, 1, 0, R, dY, W, True, None))
+    timeit("2048->1697 1x1 dW   libwfsparse wide", lambda: Fsp.gather_dw(None, 1, 0, R, X, dY, False))
+    timeit("2048->1697 1x1 fwd  torch.mm (+ filter cast)", lambda: torch.mm(X, W[0].to(DT)))
+    timeit("2048->1697 1x1 dX   torch.mm (+ filter cast)", lambda: torch.mm(dY, W[0].to(DT).t()))
+    timeit("2048->1697 1x1 dW   torch.mm", lambda: torch.mm(X.t(), dY).float())

@@ -544,6 +544,10 @@ extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identit
 extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg) {
     size_t generic = (size_t)(gm_shape(Cs, Cg) ? dw_chunks_mfma(R, K, Cs, Cg) : dw_chunks(R)) * K * Cs * Cg * sizeof(float);
     size_t fast = wfs_dw_fast_workspace(K, R, Cs, Cg);
+    if (wfs_wide_dw_ok(K, R, Cs, Cg, WFS_BF16)) {
+        size_t wide = wfs_wide_dw_workspace(K, R, Cs, Cg);
+        generic = generic > wide ? generic : wide;
+    }
     return generic > fast ? generic : fast;
 }
 
@@ -566,6 +570,12 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
     size_t need = wfs_gather_dw_workspace_bytes(K, R, Cs, Cg);
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
+    if (wfs_wide_dw_ok(K, R, Cs, Cg, dtype) && K <= 128 && ((uintptr_t)workspace & 15) == 0) {
+        for (int k = 0; k < K && kmap_host; ++k)
+            WFS_REQUIRE(kmap_host[k] >= 0 && kmap_host[k] < K, WFS_EINVAL, "kmap[%d] out of range", k);
+        return wfs_launch_wide_dw(table, kmap_host, K, identity_k, R, r_dev, S, Cs, G, G_rows, Cg, swap, dW, dtype, workspace,
+                                  workspace_bytes, stream);
+    }
     if (Cs == 32 && Cg == 32 && table && !kmap_host)
         return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, defer, stream);
     bool is_ident = true, is_mirror = true;

@@ -68,9 +68,13 @@ class SparseConvolution(SparseModule):
         else:
             out_spatial_shape = spatial_shape
         if self.conv1x1:
-            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels).to(features.dtype))
-            if self.bias is not None:
-                features = features + self.bias.to(features.dtype)
+            if (features.dtype in (torch.bfloat16, torch.float16)
+                    and Fsp.can_use_pointwise_conv(features, self.in_channels, self.out_channels)):
+                features = Fsp.pointwise_conv(features, self.weight, self.bias, input.n_valid)
+            else:
+                features = torch.mm(features, self.weight.view(self.in_channels, self.out_channels).to(features.dtype))
+                if self.bias is not None:
+                    features = features + self.bias.to(features.dtype)
             out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
             out_tensor.indice_dict = input.indice_dict
             out_tensor.grid = input.grid

@@ -81,14 +81,16 @@ def can_take_batch_norm_stats(bn, features):
             and (bn.training or bn.running_mean is None))
 
 
-# Layers wider than 512 channels (the hybrid net's 2048 -> 1821 -> ... stack, BASELINE configs[4]) are GEMMs of tens of
-# GFLOP per launch: they go to the library GEMM (rocBLAS / hipBLASLt) on rows gathered through the SAME tables -- still
-# output-stationary, no atomics, deterministic.  Everything up to 512 channels, whatever the channel counts, runs in
-# libwfsparse: the 32- and 2-channel MFMA kernels of conv_mfma.hip, the shape-generic MFMA kernels of gather_conv.hip
-# (k_gconv_mfma / k_gdw_mfma: the reference's GEP.json 252 -> 158 -> 64 stack, SparseConv2DPreserve's 130 ... 154
-# channels, 16 / 24 / 64-channel 3-D layers).
+# 16-bit rows: every layer runs in libwfsparse -- the 32- and 2-channel MFMA kernels of conv_mfma.hip, the shape-generic
+# MFMA kernels of gather_conv.hip (k_gconv_mfma / k_gdw_mfma: the reference's GEP.json 252 -> 158 -> 64 stack,
+# SparseConv2DPreserve's 130 ... 154 channels, 16 / 24 / 64-channel 3-D layers) and, from 256 channels on a side, the
+# dense 128 x 128-tile matrix-core products of wide.hip (the hybrid net's 2048 -> 1697 -> 1021 -> 345 stack, BASELINE
+# configs[4]).  fp32 rows wider than 512 channels still take the library's fp32 GEMM on rows gathered through the SAME
+# tables (output-stationary, no atomics, deterministic): the exact-fp32 matrix-core kernels tile 32 x 32 and re-read
+# the filters per row tile, which loses to the library there (profiles/r02_microbench_generic_mfma.txt).
 GEMM_ROUTE_MIN_CHANNELS = 513
 GEMM_ROUTE_MAX_ELEMENTS = 1 << 27
+GEMM_ROUTE_ANY_DTYPE = False        # benchmarks only (tools/microbench_generic.py): the library route for 16-bit rows too
 
 
 def _fast_shape(Cx, Cy):
@@ -96,9 +98,9 @@ def _fast_shape(Cx, Cy):
     return (Cx == 32 and Cy == 32) or (Cx == 2 and Cy == 32) or (Cx == 32 and Cy == 2)
 
 
-def _gemm_route(Cx, Cy, K, R, r_dev, table):
+def _gemm_route(Cx, Cy, K, R, r_dev, table, dtype=torch.float32):
     fast = _fast_shape(Cx, Cy)
-    return (not fast and table is not None and R > 0 and max(Cx, Cy) >= GEMM_ROUTE_MIN_CHANNELS
+    return (not fast and (dtype == torch.float32 or GEMM_ROUTE_ANY_DTYPE) and table is not None and R > 0 and max(Cx, Cy) >= GEMM_ROUTE_MIN_CHANNELS
             and K * R * max(Cx, Cy) <= GEMM_ROUTE_MAX_ELEMENTS and ACCOUNT is None)
 
 
@@ -147,11 +149,33 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
+def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev):
+    """16-bit rows, >= 256 channels on a side: one dense matrix-core product over the shorter side of the layer
+    (csrc/wide.hip; include/wfsparse.h wfs_wide_gather_conv).  The BatchNorm statistics, when a BatchNorm1d follows,
+    are taken by its own kernel (bn_request stays unanswered)."""
+    Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
+    Cx, Cy = int(X.shape[1]), (Cw_in if transpose_w else Cw_out)
+    assert W.dtype == torch.float32 and W.is_contiguous() and X.is_contiguous()
+    assert Cx == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
+    assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
+    Y = _rows((R, Cy), X, r_dev)
+    nbytes = lib.wfs_wide_conv_workspace_bytes(K, R, X.shape[0], Cx, Cy, 0 if table is None else 1)
+    ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=X.device)
+    _lib.check(lib.wfs_wide_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], Cx, _lib.ptr(W),
+                                        Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
+                                        _lib.dtype_code(X), _lib.ptr(r_dev), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+    _account("gather_conv", table, R, X.shape[0], Cx, R, Cy, K, Cw_in, Cw_out, X.element_size())
+    return Y
+
+
 def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
     With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
+    if X.is_cuda and lib.wfs_wide_conv_ok(K, R, X.shape[0], int(X.shape[1]), Cw_in if transpose_w else Cw_out, _lib.dtype_code(X)):
+        return _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev)
     if transpose_w and not _fast_shape(Cw_out, Cw_in):
         # the shape-generic MFMA kernel reads the filter with the OUTPUT channel on the lanes: for dX that is a strided
         # walk over W[k] (a new 128-B line per lane and step; 47 vs 26 us measured at 64 channels) -- hand it W[k]^T
@@ -164,7 +188,7 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
-    if _gemm_route(X.shape[1], Cy, K, R, r_dev, table) and bn_request is None:
+    if _gemm_route(X.shape[1], Cy, K, R, r_dev, table, X.dtype) and bn_request is None:
         G = _gathered(table, kmap, K, identity_k, R, X, r_dev)                       # [R, K * Cx]
         Wk = (W.transpose(1, 2) if transpose_w else W).reshape(K * X.shape[1], Cy)   # [K * Cx, Cy]
         out = _mm_f32(G, Wk.to(X.dtype))
@@ -333,7 +357,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
         dW = torch.empty(shape, dtype=torch.float32, device=S.device)
     assert S.dtype == G.dtype and S.shape[0] == R
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
-    if _gemm_route(Cs, Cg, K, R, r_dev, table) and not overlap:
+    if _gemm_route(Cs, Cg, K, R, r_dev, table, S.dtype) and not overlap:
         Gk = _gathered(table, kmap, K, identity_k, R, G, r_dev)                      # [R, K * Cg]
         ok = _row_ok(R, r_dev, S.device)
         Sv = S if ok is None else torch.where(ok.unsqueeze(1), S, S.new_zeros(()))
@@ -432,6 +456,51 @@ class SparseConvFunction(Function):
             # dY has one row per OUTPUT of this product: rb.N rows for an inverse conv, rb.M otherwise
             db = _masked_column_sum(dY, rb.n_dev if mode == INVERSE else rb.m_dev).to(bias.dtype)
         return dX, dW, db, None, None, None
+
+
+class PointwiseConvFunction(Function):
+    """1 x 1 convolution of 16-bit rows with >= 256 channels on a side: Y = X . W (+ bias) on the matrix cores of
+    csrc/wide.hip instead of spconv's ``torch.mm(features, weight.view(in, out))`` (spconv 1.2.1 conv.py; the hybrid
+    net's 2048 -> 1697 layer, reference src/models/SPConvBlocks.py:498)."""
+
+    @staticmethod
+    def forward(ctx, features, filters, bias, n_dev):
+        features = _features_ok(features)
+        R = int(features.shape[0])
+        W = filters.detach().reshape(1, filters.shape[-2], filters.shape[-1]).float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        out = gather_conv(None, None, 1, 0, R, features, W, False, b, n_dev)
+        ctx.save_for_backward(features, filters, bias)
+        ctx.n_dev = n_dev
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, filters, bias = ctx.saved_tensors
+        n_dev = ctx.n_dev
+        R = int(features.shape[0])
+        dY = grad_output.contiguous()
+        if dY.dtype != features.dtype:
+            dY = dY.to(features.dtype)
+        W = filters.detach().reshape(1, filters.shape[-2], filters.shape[-1]).float().contiguous()
+        dX = dW = db = None
+        if ctx.needs_input_grad[1]:
+            dW = gather_dw(None, 1, 0, R, features, dY, False, None, n_dev, False, filters)
+            dW = dW.reshape(filters.shape).to(filters.dtype)
+        if ctx.needs_input_grad[0]:
+            dX = gather_conv(None, None, 1, 0, R, dY, W, True, None, n_dev)
+        if bias is not None and ctx.needs_input_grad[2]:
+            db = _masked_column_sum(dY, n_dev).to(bias.dtype)
+        return dX, dW, db, None
+
+
+def can_use_pointwise_conv(features, c_in, c_out):
+    return bool(features.is_cuda and features.dim() == 2 and features.shape[0] > 0 and _lib.load().wfs_wide_conv_ok(
+        1, features.shape[0], features.shape[0], int(c_in), int(c_out), _lib.dtype_code(features)))
+
+
+def pointwise_conv(features, filters, bias, n_dev=None):
+    return PointwiseConvFunction.apply(features, filters, bias, n_dev)
 
 
 def _dense_map_ok(cell_map, spatial, batch_size, C, features):
