@@ -201,3 +201,40 @@ def test_wide_layers_forward_backward_against_the_cpu_oracle(dtype, tol):
             close(a.grad, b.grad, name, 2 * tol)       # behind the ReLU: element-wise
         else:
             close_l2(a.grad, b.grad, name, l2)
+
+
+@pytest.mark.parametrize("C,dtype", [(345, torch.bfloat16), (1697, torch.float32), (252, torch.float16)],
+                         ids=["c345_bf16", "c1697_f32", "c252_f16"])
+def test_wide_batchnorm_with_a_device_side_row_count(C, dtype):
+    """The column-block BatchNorm kernels (csrc/bn.hip k_bnw_*) under a captured step's conditions: capacity rows
+    beyond the device-side count hold NaN and must neither enter the statistics nor be touched; the valid rows must
+    equal the same call on exactly the valid rows (bit for bit: same chunking is not required, so compare to 1e-6 of
+    scale for fp32 and exactly-rounded 16-bit values within one unit in the last place)."""
+    from waveformml_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(C)
+    N, cap = 700, 900
+    x = (rng.standard_normal((N, C)) * 2 + 3).astype(np.float32)
+    g = rng.standard_normal((N, C)).astype(np.float32)
+    outs = []
+    for padded in (False, True):
+        torch.manual_seed(1)
+        bn = torch.nn.BatchNorm1d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+        xs = torch.from_numpy(x).to(DEV).to(dtype)
+        gs = torch.from_numpy(g).to(DEV).to(dtype)
+        n_dev = None
+        if padded:
+            xs = torch.cat([xs, torch.full((cap - N, C), float("nan"), device=DEV, dtype=dtype)])
+            gs = torch.cat([gs, torch.full((cap - N, C), float("nan"), device=DEV, dtype=dtype)])
+            n_dev = torch.tensor([N], dtype=torch.int64, device=DEV)
+        xs.requires_grad_(True)
+        y = Fsp.batch_norm_relu(xs, bn, True, n_dev)
+        y.backward(gs)
+        outs.append((y.detach()[:N].float().cpu().numpy(), xs.grad[:N].float().cpu().numpy(),
+                     bn.weight.grad.cpu().numpy(), bn.bias.grad.cpu().numpy(), bn.running_var.cpu().numpy()))
+    ulp = {torch.float32: 1e-6, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    for a, b in zip(outs[0], outs[1]):
+        assert np.isfinite(b).all()
+        assert np.abs(a - b).max() <= ulp * max(np.abs(a).max(), 1e-30)

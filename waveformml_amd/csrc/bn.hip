@@ -774,6 +774,231 @@ long long bn_apply_blocks(long long N) {
 }  // namespace
 
 
+// ------------------------------------------------------------------------------------------------------------------
+// Column-block variants for WIDE layers with few rows (the hybrid net, BASELINE configs[4]: 776 ... 4105 rows of 1697 /
+// 1021 / 345 channels behind SPConvBlocks.py:505-508).  The row-block kernels above give such a layer one block per
+// 256-channel slice and row range -- a handful of blocks walking their rows one dependent load after the other
+// (9 - 12 us per launch, 13 launches per pass at 1697 + 1021 + 345 channels).  Here the grid is 2-D: a block owns 64
+// channels (one per lane: 128-B row pieces of 16-bit data, any channel count, any alignment) and one chunk of rows on
+// 4 row slots, so the layer is a few hundred blocks of <= 8 row steps.  Same arithmetic and the same fixed-order
+// sums (per-chunk partials, folded in chunk order by every elementwise block): deterministic, no atomics.
+constexpr int BW_COLS = 64, BW_SLOTS = TB / BW_COLS, BW_MAX_CHUNKS = 256;
+
+static inline long long bw_chunks(long long N) {
+    long long n = wfs_cdiv(N, 32);
+    return n < 1 ? 1 : (n > BW_MAX_CHUNKS ? BW_MAX_CHUNKS : n);
+}
+static inline bool bw_ok(long long N, int C) { return C >= 128 && (C > MAXC || C % 4 != 0 || N * (long long)C <= (1ll << 23)); }
+
+// block sums over the row slots, slot order fixed; the result lands in the slot-0 threads
+__device__ __forceinline__ void bw_slot_sum(float &a, float &b, float (&red)[2][TB]) {
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < BW_COLS) {
+#pragma unroll
+        for (int q = 1; q < BW_SLOTS; ++q) {
+            a += red[0][q * BW_COLS + threadIdx.x];
+            b += red[1][q * BW_COLS + threadIdx.x];
+        }
+    }
+}
+
+// partial[chunk][2][C], MODE as k_bn_reduce
+template <typename T, int MODE>
+__global__ void __launch_bounds__(TB) k_bnw_reduce(const T *__restrict__ X, const T *__restrict__ dY, long long Ncap,
+                                                   const long long *__restrict__ n_dev, int C, long long rows_per_chunk,
+                                                   const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   int relu, float *__restrict__ partial) {
+    __shared__ float red[2][TB];
+    const long long N = valid_rows(Ncap, n_dev);
+    const int lane = threadIdx.x & (BW_COLS - 1), slot = threadIdx.x / BW_COLS;
+    const int c = blockIdx.x * BW_COLS + lane;
+    const bool ok = c < C;
+    const int cc = ok ? c : 0;
+    float m = 0.f, is = 0.f, ga = 1.f, be = 0.f;
+    if (MODE == 0) {
+        m = wfs_ld(X + cc);                                   // the shift: row 0
+    } else {
+        m = mean[cc];
+        is = invstd[cc];
+        ga = gamma ? gamma[cc] : 1.f;
+        be = beta ? beta[cc] : 0.f;
+    }
+    const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < N ? r_begin + rows_per_chunk : N;
+    float sa = 0.f, sb = 0.f;
+#pragma unroll 4
+    for (long long r = r_begin + slot; r < r_end; r += BW_SLOTS) {
+        const float x = wfs_ld(X + r * C + cc);
+        if (MODE == 0) {
+            const float d = x - m;
+            sa += d;
+            sb = fmaf(d, d, sb);
+        } else {
+            const float xh = (x - m) * is;
+            float gi = wfs_ld(dY + r * C + cc);
+            if (relu && !(fmaf(ga, xh, be) > 0.f)) gi = 0.f;
+            sa += gi;
+            sb = fmaf(gi, xh, sb);
+        }
+    }
+    bw_slot_sum(sa, sb, red);
+    if (threadIdx.x < BW_COLS && ok) {
+        float *p = partial + (long long)blockIdx.y * 2 * C;
+        p[c] = sa;
+        p[C + c] = sb;
+    }
+}
+
+// sums of the chunk partials of this block's 64 channels, chunk order fixed (slot s adds chunks s, s + 4, ...; the
+// slots are added in slot order); valid in the slot-0 threads, broadcast to the others through `out`
+__device__ __forceinline__ void bw_fold(const float *__restrict__ partial, int nch, int C, int c, bool ok,
+                                        float (&red)[2][TB], float (&out)[2][BW_COLS], float &a, float &b) {
+    const int lane = threadIdx.x & (BW_COLS - 1), slot = threadIdx.x / BW_COLS;
+    a = 0.f;
+    b = 0.f;
+    if (ok)
+        for (int p = slot; p < nch; p += BW_SLOTS) {
+            a += partial[(long long)p * 2 * C + c];
+            b += partial[(long long)p * 2 * C + C + c];
+        }
+    bw_slot_sum(a, b, red);
+    if (threadIdx.x < BW_COLS) {
+        out[0][lane] = a;
+        out[1][lane] = b;
+    }
+    __syncthreads();
+    a = out[0][lane];
+    b = out[1][lane];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(TB) k_bnw_apply(const T *__restrict__ X, long long Ncap,
+                                                  const long long *__restrict__ n_dev, int C, long long rows_per_chunk,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                  long long *__restrict__ batches_tracked, float momentum, float eps,
+                                                  int training, int relu, T *__restrict__ Y,
+                                                  float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                  const float *__restrict__ partial, int nch) {
+    __shared__ float red[2][TB];
+    __shared__ float tot[2][BW_COLS];
+    const long long N = valid_rows(Ncap, n_dev);
+    const int lane = threadIdx.x & (BW_COLS - 1), slot = threadIdx.x / BW_COLS;
+    const int c = blockIdx.x * BW_COLS + lane;
+    const bool ok = c < C;
+    const int cc = ok ? c : 0;
+    const bool publish = blockIdx.y == 0 && slot == 0 && ok;
+    float m, is;
+    if (training) {
+        float a, b;
+        bw_fold(partial, nch, C, c, ok, red, tot, a, b);
+        const float n = N > 0 ? (float)N : 1.f;
+        const float shift = wfs_ld(X + cc);
+        const float md = a / n;                               // mean of (x - shift)
+        float var = b / n - md * md;                          // biased, what torch normalises with
+        var = var > 0.f ? var : 0.f;
+        m = shift + md;
+        is = rsqrtf(var + eps);
+        if (publish) {
+            save_mean[c] = m;
+            save_invstd[c] = is;
+            if (running_mean) {
+                const float unbiased = N > 1 ? var * (n / (n - 1.f)) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && batches_tracked) *batches_tracked += 1;
+    } else {
+        m = running_mean[cc];
+        is = rsqrtf(running_var[cc] + eps);
+        if (publish) {
+            save_mean[c] = m;
+            save_invstd[c] = is;
+        }
+    }
+    const float ga = gamma ? gamma[cc] : 1.f, be = beta ? beta[cc] : 0.f;
+    const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < N ? r_begin + rows_per_chunk : N;
+    if (!ok) return;
+#pragma unroll 4
+    for (long long r = r_begin + slot; r < r_end; r += BW_SLOTS) {
+        const float v = fmaf(ga, (wfs_ld(X + r * C + c) - m) * is, be);      // same expression as the backward's mask
+        wfs_st(Y + r * C + c, (relu && !(v > 0.f)) ? 0.f : v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(TB) k_bnw_bwd_apply(const T *__restrict__ X, const T *__restrict__ dY, long long Ncap,
+                                                      const long long *__restrict__ n_dev, int C,
+                                                      long long rows_per_chunk, const float *__restrict__ partial,
+                                                      int nch, const float *__restrict__ mean,
+                                                      const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, int training, int relu,
+                                                      T *__restrict__ dX, float *__restrict__ dgamma,
+                                                      float *__restrict__ dbeta) {
+    __shared__ float red[2][TB];
+    __shared__ float tot[2][BW_COLS];
+    const long long N = valid_rows(Ncap, n_dev);
+    const int lane = threadIdx.x & (BW_COLS - 1), slot = threadIdx.x / BW_COLS;
+    const int c = blockIdx.x * BW_COLS + lane;
+    const bool ok = c < C;
+    float a, b;
+    bw_fold(partial, nch, C, c, ok, red, tot, a, b);
+    if (blockIdx.y == 0 && slot == 0 && ok) {
+        if (dbeta) dbeta[c] = a;
+        if (dgamma) dgamma[c] = b;
+    }
+    if (!ok) return;
+    const float invN = N > 0 ? 1.f / (float)N : 0.f;
+    const float m = mean[c], is = invstd[c], ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float k1 = training ? a * invN : 0.f, k2 = training ? b * invN : 0.f;
+    const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < N ? r_begin + rows_per_chunk : N;
+#pragma unroll 4
+    for (long long r = r_begin + slot; r < r_end; r += BW_SLOTS) {
+        const float xh = (wfs_ld(X + r * C + c) - m) * is;
+        float gi = wfs_ld(dY + r * C + c);
+        if (relu && !(fmaf(ga, xh, be) > 0.f)) gi = 0.f;
+        wfs_st(dX + r * C + c, ga * is * (gi - k1 - xh * k2));
+    }
+}
+
+template <typename T>
+static int bw_fwd(const void *X, long long N, int C, const float *gamma, const float *beta, float *running_mean,
+                  float *running_var, int64_t *num_batches_tracked, float momentum, float eps, int training, int relu,
+                  void *Y, float *save_mean, float *save_invstd, float *partial, const long long *n_dev,
+                  hipStream_t stream) {
+    const long long nch = bw_chunks(N), rpc = wfs_cdiv(wfs_cdiv(N, nch), BW_SLOTS) * BW_SLOTS;
+    const dim3 grid((unsigned)wfs_cdiv(C, BW_COLS), (unsigned)nch), block(TB);
+    if (training)
+        k_bnw_reduce<T, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, rpc, nullptr, nullptr, nullptr,
+                                                       nullptr, 0, partial);
+    k_bnw_apply<T><<<grid, block, 0, stream>>>((const T *)X, N, n_dev, C, rpc, gamma, beta, running_mean, running_var,
+                                               (long long *)num_batches_tracked, momentum, eps, training, relu, (T *)Y,
+                                               save_mean, save_invstd, partial, (int)nch);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+template <typename T>
+static int bw_bwd(const void *X, const void *dY, long long N, int C, const float *gamma, const float *beta,
+                  const float *save_mean, const float *save_invstd, int training, int relu, void *dX, float *dgamma,
+                  float *dbeta, float *partial, const long long *n_dev, hipStream_t stream) {
+    const long long nch = bw_chunks(N), rpc = wfs_cdiv(wfs_cdiv(N, nch), BW_SLOTS) * BW_SLOTS;
+    const dim3 grid((unsigned)wfs_cdiv(C, BW_COLS), (unsigned)nch), block(TB);
+    k_bnw_reduce<T, 1><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpc, save_mean, save_invstd,
+                                                   gamma, beta, relu, partial);
+    k_bnw_bwd_apply<T><<<grid, block, 0, stream>>>((const T *)X, (const T *)dY, N, n_dev, C, rpc, partial, (int)nch,
+                                                   save_mean, save_invstd, gamma, beta, training, relu, (T *)dX, dgamma,
+                                                   dbeta);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
 extern "C" size_t wfs_bn_workspace_bytes(int64_t N, int32_t C) {
     size_t nb = (size_t)bn_reduce_blocks(N, C);
     if (nb < (size_t)RR_BLOCKS) nb = RR_BLOCKS;
@@ -852,6 +1077,20 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
                                const int64_t *n_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long *n_dev = (const long long *)n_dev_;
+    if (bw_ok(N, C) && N > 0 && wfs_dtype_ok(dtype)) {
+        WFS_REQUIRE(training || (running_mean && running_var), WFS_EINVAL, "eval mode needs running statistics");
+        WFS_REQUIRE(X && Y && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
+        WFS_REQUIRE(workspace_bytes >= wfs_bn_workspace_bytes(N, C), WFS_EWORKSPACE, "workspace too small");
+        float *partial = (float *)workspace;
+        if (dtype == WFS_F32)
+            return bw_fwd<float>(X, N, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                 training, relu, Y, save_mean, save_invstd, partial, n_dev, stream);
+        if (dtype == WFS_BF16)
+            return bw_fwd<wfs_bf16>(X, N, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                    training, relu, Y, save_mean, save_invstd, partial, n_dev, stream);
+        return bw_fwd<wfs_f16>(X, N, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                               training, relu, Y, save_mean, save_invstd, partial, n_dev, stream);
+    }
     if (C <= (C % 4 == 0 ? MAXC : TB))
         return bn_fwd_slice(X, N, C, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                             training, relu, Y, save_mean, save_invstd, workspace, workspace_bytes, dtype, n_dev, stream);
@@ -992,6 +1231,19 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
                                size_t workspace_bytes, int32_t dtype, const int64_t *n_dev_, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long *n_dev = (const long long *)n_dev_;
+    if (bw_ok(N, C) && N > 0 && wfs_dtype_ok(dtype)) {
+        WFS_REQUIRE(X && dY && dX && save_mean && save_invstd && workspace, WFS_EINVAL, "NULL device pointer");
+        WFS_REQUIRE(workspace_bytes >= wfs_bn_workspace_bytes(N, C), WFS_EWORKSPACE, "workspace too small");
+        float *partial = (float *)workspace;
+        if (dtype == WFS_F32)
+            return bw_bwd<float>(X, dY, N, C, gamma, beta, save_mean, save_invstd, training, relu, dX, dgamma, dbeta,
+                                 partial, n_dev, stream);
+        if (dtype == WFS_BF16)
+            return bw_bwd<wfs_bf16>(X, dY, N, C, gamma, beta, save_mean, save_invstd, training, relu, dX, dgamma, dbeta,
+                                    partial, n_dev, stream);
+        return bw_bwd<wfs_f16>(X, dY, N, C, gamma, beta, save_mean, save_invstd, training, relu, dX, dgamma, dbeta,
+                               partial, n_dev, stream);
+    }
     if (C <= (C % 4 == 0 ? MAXC : TB))
         return bn_bwd_slice(X, dY, N, C, C, gamma, beta, save_mean, save_invstd, training, relu, dX, dgamma, dbeta,
                             workspace, workspace_bytes, dtype, n_dev, stream);
