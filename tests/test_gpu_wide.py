@@ -238,3 +238,34 @@ def test_wide_batchnorm_with_a_device_side_row_count(C, dtype):
     for a, b in zip(outs[0], outs[1]):
         assert np.isfinite(b).all()
         assert np.abs(a - b).max() <= ulp * max(np.abs(a).max(), 1e-30)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,I,O", [(256, 24150, 269), (37, 1000, 33), (300, 515, 700)])
+def test_wide_linear_against_fp64_on_rounded_operands(B, I, O, dtype):
+    """wfs_linear16_fwd / _bwd (the hybrid net's Linear(24150, 269)): y, dX, dW, db against numpy fp64 on the operands
+    as the kernels see them (x, W and dY rounded to the row type): fp32 results within 1e-4 of scale, dX within one unit
+    in the last place of the row type."""
+    from waveformml_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(B + I)
+    x = rng.standard_normal((B, I)).astype(np.float32)
+    lin = torch.nn.Linear(I, O).to(DEV)
+    g = rng.standard_normal((B, O)).astype(np.float32)
+    xg = torch.from_numpy(x).to(DEV).to(dtype).requires_grad_(True)
+    assert Fsp.can_use_wide_linear(lin, xg)
+    y = Fsp.wide_linear(xg, lin)
+    assert y.dtype == torch.float32
+    y.backward(torch.from_numpy(g).to(DEV))
+    torch.cuda.synchronize()
+    xr, wr, gr = _round(x, dtype), _round(lin.weight.detach().cpu().numpy(), dtype), _round(g, dtype)
+    b = lin.bias.detach().cpu().numpy().astype(np.float64)
+
+    def close(got, want, what, ulp=0.0):
+        got = got.detach().float().cpu().numpy().astype(np.float64)
+        err = np.abs(got - want) - ulp * np.abs(want)
+        assert err.max() <= 1e-4 * np.abs(want).max(), (what, err.max(), np.abs(want).max())
+
+    close(y, xr @ wr.T + b, "y")
+    close(xg.grad, gr @ wr, "dX", ULP[dtype])
+    close(lin.weight.grad, gr.T @ xr, "dW")
+    close(lin.bias.grad, g.astype(np.float64).sum(0), "db")

@@ -38,8 +38,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int GT = 128;           // output tile edge
 constexpr int GK = 64;            // contraction depth of one step
 constexpr int GTHREADS = 256;     // 4 waves: 2 (rows) x 2 (columns) of 64 x 64
-constexpr int G_TILE_BYTES = GT * GK * 2;            // one operand tile in LDS: 16 KiB
-constexpr int G_LDS_BYTES = 4 * G_TILE_BYTES;        // 2 operands x 2 buffers
+// Timing knock-outs (tools/exp/knock_gemm.sh): -DWFS_GEMM_KNOCK=bits builds a library whose k_gemm16 skips a phase --
+// 1 the global loads after the first two tiles, 2 the MFMAs, 4 the LDS stores after the first two tiles.  Results are
+// wrong by construction; 0 = nothing.
+#ifndef WFS_GEMM_KNOCK
+#define WFS_GEMM_KNOCK 0
+#endif
 
 struct GemmArgs {
     const unsigned short *A, *B;
@@ -47,13 +51,14 @@ struct GemmArgs {
     const float *bias;            // [N] or NULL (16-bit output only)
     long long lda, ldb, ldc;      // row pitches in elements (lda, ldb: multiples of 8)
     long long sA, sB;             // element offset of segment s: A + s * sA, B + s * sB
-    long long zC;                 // element offset of batch z in C
+    long long zC, pC;             // element offsets in C of segment batch zs and of contraction part `part`
     int M, N, Ks;                 // Ks: contraction length of ONE segment
-    int nseg_total, nseg;         // segments in all / per batch: batch z takes segments z * nseg ...
-    int nz;
+    int nseg_total, nseg;         // segments in all / per batch: batch zs takes segments zs * nseg ...
+    int nz;                       // segment batches
+    int ksplit, kchunk;           // every segment's contraction is cut into ksplit parts of kchunk (multiple of 64):
+                                  // block z = zs * ksplit + part writes its own slab of C (summed by k_sum_rows)
     const long long *k_dev;       // optional device-side contraction length (<= Ks): rows of a dW product
     int out_h;                    // 1: C holds 16-bit elements (bias added), 0: fp32
-    int accumulate;               // fp32 output: C += product
 };
 
 template <typename H>
@@ -74,62 +79,65 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
     return v;
 }
 
-// One operand tile (128 rows of the output dimension x 64 of the contraction) from global memory into 4 x 16 bytes per
-// thread.  KM == false: stored [row][k]: a thread takes piece (t & 7) of rows (t >> 3) + 32 i -- 8 lanes read one full
-// 128-B line.  KM == true: stored [k][row]: chunk (t & 15) of contraction rows (t >> 4) + 16 i -- 16 lanes read 256 B.
-// Rows / columns beyond the matrix edge are read from a clamped address (their products are never stored); contraction
-// indices beyond the segment give zeros.
-template <bool KM>
-__device__ __forceinline__ void g_load(uint4 (&r)[4], const unsigned short *__restrict__ base, long long ld, int o0,
+// One operand tile (BO rows of the output dimension x 64 of the contraction) from global memory into BO / 32 x 16 bytes
+// per thread.  KM == false: stored [row][k]: a thread takes piece (t & 7) of rows (t >> 3) + 32 i -- 8 lanes read one
+// full 128-B line.  KM == true: stored [k][row]: chunk t % (BO / 8) of contraction rows t / (BO / 8) + (2048 / BO) i --
+// BO / 8 lanes read 2 BO contiguous bytes.  Rows / columns beyond the matrix edge are read from a clamped address (their
+// products are never stored); contraction indices beyond the segment give zeros.
+template <bool KM, int BO>
+__device__ __forceinline__ void g_load(uint4 (&r)[BO / 32], const unsigned short *__restrict__ base, long long ld, int o0,
                                        int lim, int kk0, int Ks, int t) {
     if constexpr (!KM) {
         const int p = t & 7, rr = t >> 3;
         const bool kok = kk0 + p * 8 < Ks;
         const int kk = kok ? kk0 + p * 8 : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < BO / 32; ++i) {
             int row = o0 + rr + 32 * i;
             row = row < lim ? row : lim - 1;
-            const uint4 v = *reinterpret_cast<const uint4 *>(base + (long long)row * ld + kk);
-            r[i] = keep_if(v, kok);
+            r[i] = *reinterpret_cast<const uint4 *>(base + (long long)row * ld + kk);
         }
     } else {
-        const int ch = t & 15, rr = t >> 4;
+        constexpr int CH = BO / 8, RP = GTHREADS / CH;      // chunks per contraction row, rows per pass
+        const int ch = t % CH, rr = t / CH;
         int col = o0 + ch * 8;
         col = col < lim ? col : o0;                  // whole chunks beyond the edge: any valid address
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kk = kk0 + rr + 16 * i;
+        for (int i = 0; i < BO / 32; ++i) {
+            const int kk = kk0 + rr + RP * i;
             const bool ok = kk < Ks;
-            const uint4 v = *reinterpret_cast<const uint4 *>(base + (long long)(ok ? kk : 0) * ld + col);
-            r[i] = keep_if(v, ok);
+            r[i] = *reinterpret_cast<const uint4 *>(base + (long long)(ok ? kk : 0) * ld + col);
         }
     }
 }
 
-// LDS images (byte offsets inside one 16-KiB tile):
+// LDS images (byte offsets inside one operand tile of BO x 64 elements):
 //   [row][k]: 128-B rows, 16-B piece p of row r at r * 128 + ((p ^ ((r >> 1) & 7)) << 4): the 16-lane groups of
 //             ds_read_b128 ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md "LDS") land on 16 distinct 16-B bank groups
-//   [k][row]: 256-B rows, 16-B chunk c of contraction row k at k * 256 + ((c ^ ((k & 3) << 2)) << 4): the 4 rows x 32
-//             columns one half-wave takes with ds_read_b64_tr_b16 cover all 64 banks once
-template <bool KM>
-__device__ __forceinline__ void s_store(unsigned char *tile, const uint4 (&r)[4], int t) {
+//   [k][row]: 2 BO-byte rows, 16-B chunk c of contraction row k at k * 2 BO + ((c ^ ((k & 3) << 2)) << 4): the 4 rows x
+//             32 columns one half-wave takes with ds_read_b64_tr_b16 cover all 64 banks once
+template <bool KM, int BO>
+__device__ __forceinline__ void s_store(unsigned char *tile, const uint4 (&r)[BO / 32], int kk0, int Ks, int t) {
     if constexpr (!KM) {
         const int p = t & 7, rr = t >> 3;
+        const bool kok = kk0 + p * 8 < Ks;
         unsigned char *d = tile + rr * 128 + ((p ^ ((rr >> 1) & 7)) << 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(d + i * 32 * 128) = r[i];
+        for (int i = 0; i < BO / 32; ++i) *reinterpret_cast<uint4 *>(d + i * 32 * 128) = keep_if(r[i], kok);
     } else {
-        const int ch = t & 15, rr = t >> 4;
-        unsigned char *d = tile + rr * 256 + ((ch ^ ((rr & 3) << 2)) << 4);
+        constexpr int CH = BO / 8, RP = GTHREADS / CH;
+        static_assert(RP % 4 == 0, "the row swizzle must not change from pass to pass");
+        const int ch = t % CH, rr = t / CH;
+        unsigned char *d = tile + rr * (2 * BO) + ((ch ^ ((rr & 3) << 2)) << 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(d + i * 16 * 256) = r[i];
+        for (int i = 0; i < BO / 32; ++i)
+            *reinterpret_cast<uint4 *>(d + i * RP * (2 * BO)) = keep_if(r[i], kk0 + rr + RP * i < Ks);
     }
 }
 
 // MFMA operand (32 rows of the output dimension starting at o, contraction sub-step s of 16) of lane (i = lane & 31,
 // h = lane >> 5): elements k = 16 s + 8 h .. + 7 of row o + i.
-template <bool KM>
+template <bool KM, int BO>
 __device__ __forceinline__ s16x8 frag(const unsigned char *tile, int o, int s, int lane) {
     if constexpr (!KM) {
         const int row = o + (lane & 31), p = 2 * s + (lane >> 5);
@@ -140,96 +148,142 @@ __device__ __forceinline__ s16x8 frag(const unsigned char *tile, int o, int s, i
         const int g = lane >> 4, l = lane & 15, q = l >> 2, p = l & 3;
         const int kk = 16 * s + 8 * (g >> 1) + q;
         const int col = o + 16 * (g & 1) + 4 * p;
-        const unsigned char *a = tile + kk * 256 + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + 8 * ((col >> 2) & 1);
+        const unsigned char *a = tile + kk * (2 * BO) + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + 8 * ((col >> 2) & 1);
         typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * 256));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * (2 * BO)));
         return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 }
 
-template <typename H, bool A_KM, bool B_KM>
+// BM x BN output tile, 4 waves as 2 (rows) x 2 (columns), each BM / 2 x BN / 2.  Two LDS buffers; DEPTH register
+// stages: with DEPTH == 2 the global loads of tile t + 2 are issued before the MFMAs of tile t and written to LDS
+// after those of tile t + 1 -- two compute phases to arrive in (the 256 x 128 form: one block per CU, one wave per
+// SIMD, 1024 MFMA cycles per step against a load round trip of more than that under load).
+template <typename H, bool A_KM, bool B_KM, int BM, int BN, int DEPTH>
 __global__ void __launch_bounds__(GTHREADS) k_gemm16(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int TM = BM / 64, TN = BN / 64;                   // 32 x 32 MFMA tiles of a wave
+    constexpr int A_BYTES = BM * GK * 2, STAGE = (BM + BN) * GK * 2;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w & 1, wn = w >> 1;
     // consecutive block ids go round the 8 XCDs: give every XCD one contiguous range of tiles, rows fastest, so that
     // the blocks sharing a B panel (the large operand: filters / gathered rows) sit behind one L2
-    const int tiles_m = (g.M + GT - 1) / GT, tiles_n = (g.N + GT - 1) / GT;
-    const long long nblk = (long long)tiles_m * tiles_n * g.nz;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const long long nblk = (long long)tiles_m * tiles_n * g.nz * g.ksplit;
     const long long per = (nblk + 7) >> 3;
     const long long id = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (id >= nblk) return;
     const int tm = (int)(id % tiles_m);
     const int tn = (int)((id / tiles_m) % tiles_n);
     const int z = (int)(id / ((long long)tiles_m * tiles_n));
-    const int m0 = tm * GT, n0 = tn * GT;
+    const int zs = z / g.ksplit, part = z % g.ksplit;
+    const int m0 = tm * BM, n0 = tn * BN;
     int Ks = g.Ks;
     if (g.k_dev) {
         const long long kd = *g.k_dev;
         Ks = kd < Ks ? (int)(kd < 0 ? 0 : kd) : Ks;
     }
-    const int seg0 = z * g.nseg;
+    const int k_lo = part * g.kchunk;
+    const int k_hi = k_lo + g.kchunk < Ks ? k_lo + g.kchunk : Ks;
+    const int seg0 = zs * g.nseg;
     const int nseg = g.nseg_total - seg0 < g.nseg ? g.nseg_total - seg0 : g.nseg;
-    const int per_seg = (Ks + GK - 1) / GK;
+    const int per_seg = k_hi > k_lo ? (k_hi - k_lo + GK - 1) / GK : 0;
     const int nsteps = nseg * per_seg;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    uint4 ra[4], rb[4];
-    auto fetch = [&](int st) {
-        const int seg = seg0 + st / per_seg, kk0 = (st % per_seg) * GK;
-        g_load<A_KM>(ra, g.A + seg * g.sA, g.lda, m0, g.M, kk0, Ks, t);
-        g_load<B_KM>(rb, g.B + seg * g.sB, g.ldb, n0, g.N, kk0, Ks, t);
+    uint4 ra[DEPTH][BM / 32], rb[DEPTH][BN / 32];
+    auto fetch = [&](int st, uint4 (&xa)[BM / 32], uint4 (&xb)[BN / 32]) {
+        if ((WFS_GEMM_KNOCK & 1) && st > 1) return;
+        const int seg = seg0 + st / per_seg, kk0 = k_lo + (st % per_seg) * GK;
+        g_load<A_KM, BM>(xa, g.A + seg * g.sA, g.lda, m0, g.M, kk0, k_hi, t);
+        g_load<B_KM, BN>(xb, g.B + seg * g.sB, g.ldb, n0, g.N, kk0, k_hi, t);
     };
-    auto park = [&](int buf) {
-        s_store<A_KM>(lds + buf * 2 * G_TILE_BYTES, ra, t);
-        s_store<B_KM>(lds + buf * 2 * G_TILE_BYTES + G_TILE_BYTES, rb, t);
+    auto park = [&](int st, const uint4 (&xa)[BM / 32], const uint4 (&xb)[BN / 32]) {      // tile st -> buffer st & 1
+        if ((WFS_GEMM_KNOCK & 4) && st > 1) return;
+        const int kk0 = k_lo + (st % per_seg) * GK;
+        s_store<A_KM, BM>(lds + (st & 1) * STAGE, xa, kk0, k_hi, t);
+        s_store<B_KM, BN>(lds + (st & 1) * STAGE + A_BYTES, xb, kk0, k_hi, t);
     };
-    if (nsteps > 0) {
-        fetch(0);
-        park(0);
-    }
-    __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const bool more = st + 1 < nsteps;
-        if (more) fetch(st + 1);                       // in flight under the MFMAs below
-        const unsigned char *ta = lds + (st & 1) * 2 * G_TILE_BYTES, *tb = ta + G_TILE_BYTES;
+    auto compute = [&](int buf) {
+        const unsigned char *ta = lds + buf * STAGE, *tb = ta + A_BYTES;
 #pragma unroll
         for (int s = 0; s < GK / 16; ++s) {
-            const s16x8 a0 = frag<A_KM>(ta, wm * 64, s, lane), a1 = frag<A_KM>(ta, wm * 64 + 32, s, lane);
-            const s16x8 b0 = frag<B_KM>(tb, wn * 64, s, lane), b1 = frag<B_KM>(tb, wn * 64 + 32, s, lane);
-            acc[0][0] = mfma16<H>(a0, b0, acc[0][0]);
-            acc[0][1] = mfma16<H>(a0, b1, acc[0][1]);
-            acc[1][0] = mfma16<H>(a1, b0, acc[1][0]);
-            acc[1][1] = mfma16<H>(a1, b1, acc[1][1]);
+            s16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = frag<A_KM, BM>(ta, wm * (BM / 2) + a * 32, s, lane);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = frag<B_KM, BN>(tb, wn * (BN / 2) + b * 32, s, lane);
+            if (WFS_GEMM_KNOCK & 2) {          // no MFMA: keep the fragment reads alive
+#pragma unroll
+                for (int a = 0; a < TM; ++a) asm volatile("" ::"v"(af[a]));
+#pragma unroll
+                for (int b = 0; b < TN; ++b) asm volatile("" ::"v"(bf[b]));
+                continue;
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<H>(af[a], bf[b], acc[a][b]);
         }
-        if (more) park((st + 1) & 1);                  // the other buffer: its readers passed the last barrier
+    };
+    if constexpr (DEPTH == 1) {
+        if (nsteps > 0) {
+            fetch(0, ra[0], rb[0]);
+            park(0, ra[0], rb[0]);
+        }
         __syncthreads();
+        for (int st = 0; st < nsteps; ++st) {
+            const bool more = st + 1 < nsteps;
+            if (more) fetch(st + 1, ra[0], rb[0]);        // in flight under the MFMAs below
+            compute(st & 1);
+            if (more) park(st + 1, ra[0], rb[0]);         // the other buffer: its readers passed the last barrier
+            __syncthreads();
+        }
+    } else {
+        // invariant at the top of step st: tile st is in LDS buffer st & 1, tile st + 1 is on its way into register
+        // stage (st + 1) & 1; stage st & 1 is free (its tile was parked) and takes tile st + 2
+        if (nsteps > 0) {
+            fetch(0, ra[0], rb[0]);
+            park(0, ra[0], rb[0]);
+        }
+        if (nsteps > 1) fetch(1, ra[1], rb[1]);
+        __syncthreads();
+        auto step = [&](int st, uint4 (&ia)[BM / 32], uint4 (&ib)[BN / 32], uint4 (&pa)[BM / 32], uint4 (&pb)[BN / 32]) {
+            if (st + 2 < nsteps) fetch(st + 2, ia, ib);
+            compute(st & 1);
+            if (st + 1 < nsteps) park(st + 1, pa, pb);
+            __syncthreads();
+        };
+        int st = 0;
+        for (; st + 1 < nsteps; st += 2) {
+            step(st, ra[0], rb[0], ra[1], rb[1]);
+            step(st + 1, ra[1], rb[1], ra[0], rb[0]);
+        }
+        if (st < nsteps) step(st, ra[0], rb[0], ra[1], rb[1]);
     }
     // C/D map of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int h = lane >> 5;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int n = n0 + wn * 64 + b * 32 + (lane & 31);
+        for (int b = 0; b < TN; ++b) {
+            const int n = n0 + wn * (BN / 2) + b * 32 + (lane & 31);
             if (n >= g.N) continue;
             const float bv = (g.out_h && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int m = m0 + wm * (BM / 2) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (m >= g.M) continue;
-                const long long e = g.zC * z + (long long)m * g.ldc + n;
+                const long long e = g.zC * zs + g.pC * part + (long long)m * g.ldc + n;
                 if (g.out_h)
                     wfs_st(reinterpret_cast<H *>(g.C) + e, acc[a][b][i] + bv);
-                else if (g.accumulate)
-                    reinterpret_cast<float *>(g.C)[e] += acc[a][b][i];
                 else
                     reinterpret_cast<float *>(g.C)[e] = acc[a][b][i];
             }
@@ -291,42 +345,39 @@ __global__ void __launch_bounds__(256) k_pad_rows(const int *__restrict__ table,
     *reinterpret_cast<uint4 *>(dst + (r * K + k) * (long long)Cp + pc * 8) = out;
 }
 
-// fp32 [rows, C] -> 16-bit [rows, Cp], zero padded (the filters: rows = K * Cw_in, C = Cw_out)
+// fp32 [rows, C] -> 16-bit [rows, Cp], zero padded (the filters: rows = K * Cw_in, C = Cw_out).  One thread = one output
+// dword (two neighbouring values): consecutive lanes read consecutive 8 bytes and write consecutive 4.
 template <typename H>
 __global__ void __launch_bounds__(256) k_pad_f32(const float *__restrict__ src, long long rows, int C, int Cp,
                                                  H *__restrict__ dst) {
-    const int pieces = Cp >> 3;
+    const int half = Cp >> 1;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= rows * pieces) return;
-    const int pc = (int)(e % pieces);
-    const long long r = e / pieces;
-    const float *s = src + r * C + pc * 8;
-    const int n = C - pc * 8;
-    unsigned o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float lo = 2 * j < n ? s[2 * j] : 0.f, hi = 2 * j + 1 < n ? s[2 * j + 1] : 0.f;
-        o[j] = wfs_pack2<H>(lo, hi);
-    }
-    *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(dst) + r * Cp + pc * 8) = uint4{o[0], o[1], o[2], o[3]};
+    if (e >= rows * half) return;
+    const int j = (int)(e % half);
+    const long long r = e / half;
+    const int c = 2 * j;
+    const float *s = src + r * C + c;
+    const float lo = c < C ? s[0] : 0.f, hi = c + 1 < C ? s[1] : 0.f;
+    reinterpret_cast<unsigned *>(dst)[e] = wfs_pack2<H>(lo, hi);
 }
 
-// Y[r, c] = bias[c] + sum_k T[row(k, r) * row_pitch + k * k_pitch + c]  in the fixed order k = 0 .. K - 1 (fp32), stored
-// as H.  row(k, r) as in k_pad_rows (a missing neighbour contributes nothing).  One block per output row.
+// Y[r, c] = bias[c] + sum_k sum_p T[row(k, r) * row_pitch + k * k_pitch + p * p_pitch + c]  in the fixed order k = 0 ..
+// K - 1, p = 0 .. P - 1 (fp32), stored as H.  row(k, r) as in k_pad_rows (a missing neighbour contributes nothing).
+// One block per output row.  K <= 256.
 template <typename H>
 __global__ void __launch_bounds__(256) k_sum_rows(const int *__restrict__ table, KMapW kmap, int K, int identity_k,
                                                   long long R, const long long *__restrict__ r_dev,
                                                   const float *__restrict__ T, long long t_rows, long long row_pitch,
-                                                  long long k_pitch, const float *__restrict__ bias, int C,
-                                                  H *__restrict__ Y) {
-    __shared__ long long sSrc[128];
+                                                  long long k_pitch, int P, long long p_pitch,
+                                                  const float *__restrict__ bias, int C, H *__restrict__ Y) {
+    __shared__ long long sSrc[256];
     const long long r = blockIdx.x;
     long long Rv = r_dev ? *r_dev : R;
     Rv = Rv < R ? Rv : R;
     if (threadIdx.x < K) {
         const int k = threadIdx.x;
         long long s = -1;
-        if (r < Rv) s = (!table || k == identity_k) ? r : (long long)table[(long long)kmap.v[k] * R + r];
+        if (r < Rv) s = (!table || k == identity_k) ? r : (long long)table[(long long)kmap.v[k < 128 ? k : 0] * R + r];
         sSrc[k] = (s >= 0 && s < t_rows) ? s : -1;
     }
     __syncthreads();
@@ -334,7 +385,19 @@ __global__ void __launch_bounds__(256) k_sum_rows(const int *__restrict__ table,
         float v = bias ? bias[c] : 0.f;
         for (int k = 0; k < K; ++k) {
             const long long s = sSrc[k];
-            if (s >= 0) v += T[s * row_pitch + k * k_pitch + c];
+            if (s < 0) continue;
+            const float *q = T + s * row_pitch + k * k_pitch + c;
+            if (P == 1) {
+                v += q[0];
+            } else {
+                int pp = 0;
+                for (; pp + 4 <= P; pp += 4) {          // four loads in flight, added in order
+                    const float a0 = q[pp * p_pitch], a1 = q[(pp + 1) * p_pitch], a2 = q[(pp + 2) * p_pitch],
+                                a3 = q[(pp + 3) * p_pitch];
+                    v = (((v + a0) + a1) + a2) + a3;
+                }
+                for (; pp < P; ++pp) v += q[pp * p_pitch];
+            }
         }
         wfs_st(Y + r * C + c, v);
     }
@@ -342,9 +405,10 @@ __global__ void __launch_bounds__(256) k_sum_rows(const int *__restrict__ table,
 
 inline int pad8(int c) { return (c + 7) & ~7; }
 
-template <typename H>
-int launch_gemm(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) {
-    const long long nblk = (long long)wfs_cdiv(g.M, GT) * wfs_cdiv(g.N, GT) * g.nz;
+template <typename H, int BM, int BN, int DEPTH>
+int launch_gemm_tile(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) {
+    constexpr int LDS = 2 * (BM + BN) * GK * 2;
+    const long long nblk = (long long)wfs_cdiv(g.M, BM) * wfs_cdiv(g.N, BN) * g.nz * g.ksplit;
     if (nblk == 0) return WFS_OK;
     WFS_REQUIRE(nblk < (1ll << 30), WFS_EINVAL, "product of %d x %d x %d tiles is too large", g.M, g.N, g.nz);
     const dim3 grid((unsigned)(wfs_cdiv(nblk, 8) * 8)), block(GTHREADS);
@@ -352,11 +416,11 @@ int launch_gemm(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) {
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            WFS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm16<H, AK, BK>),                \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));          \
+            WFS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm16<H, AK, BK, BM, BN, DEPTH>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS));                  \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        k_gemm16<H, AK, BK><<<grid, block, G_LDS_BYTES, stream>>>(g);                                             \
+        k_gemm16<H, AK, BK, BM, BN, DEPTH><<<grid, block, LDS, stream>>>(g);                                      \
     } while (0)
     if (!a_km && !b_km) WFS_GEMM(false, false);
     else if (!a_km && b_km) WFS_GEMM(false, true);
@@ -365,6 +429,15 @@ int launch_gemm(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) {
 #undef WFS_GEMM
     WFS_LAUNCH_CHECK();
     return WFS_OK;
+}
+
+// The product form: 128 x 128 tiles (two blocks per CU), two register stages.  A 256 x 128 tile (one block per CU) and
+// a single register stage were measured and lose: profiles/r03_gemm16_tile_and_pipeline_experiments.txt.
+template <typename H>
+int launch_gemm(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) {
+    WFS_REQUIRE(g.ksplit >= 1 && g.kchunk % GK == 0 && (long long)g.ksplit * g.kchunk >= g.Ks, WFS_EINVAL,
+                "bad contraction split %d x %d for %d", g.ksplit, g.kchunk, g.Ks);
+    return launch_gemm_tile<H, GT, GT, 2>(g, a_km, b_km, stream);
 }
 
 int gemm(const GemmArgs &g, int a_km, int b_km, int dtype, hipStream_t stream) {
@@ -388,10 +461,59 @@ struct Carver {
 constexpr long long WIDE_MAX_WORKSPACE = 3ll << 30;
 bool g_wide_on = true;
 
+// A launch wants a block per CU: products with fewer output tiles than half the CUs cut the contraction into `ksplit`
+// parts of `kchunk` (each at least 128 deep), one fp32 slab per part, summed in part order afterwards (a split that
+// does not shorten the launch only adds the pass over the slabs: measured, 1.61 -> 1.80 ms per C5 step).
+int plan_ksplit(long long blocks, int Ks, int *kchunk) {
+    int ks = 1;
+    if (blocks * 2 <= 256) {              // fewer 128 x 128 tiles than half the CUs: cut the contraction
+        const long long want = 256 / blocks, deep = wfs_cdiv(Ks, 128);
+        ks = (int)(want < deep ? want : deep);
+        if (ks < 1) ks = 1;
+    }
+    const int chunk = (int)(wfs_cdiv(wfs_cdiv(Ks, ks), GK) * GK);
+    *kchunk = chunk > 0 ? chunk : GK;
+    return (int)wfs_cdiv(Ks > 0 ? Ks : 1, *kchunk);
+}
+
+template <typename H>
+int launch_sum_rows(const int *table, const KMapW &km, int K, int identity_k, long long R, const long long *r_dev,
+                    const float *T, long long t_rows, long long row_pitch, long long k_pitch, int P, long long p_pitch,
+                    const float *bias, int C, H *Y, hipStream_t stream) {
+    WFS_REQUIRE(K <= 256, WFS_EINVAL, "%d slabs to sum (at most 256)", K);
+    k_sum_rows<H><<<dim3((unsigned)R), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev, T, t_rows, row_pitch, k_pitch,
+                                                        P, p_pitch, bias, C, Y);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+int pad_f32(const float *src, long long rows, int C, int Cp, void *dst, int dtype, hipStream_t stream) {
+    const long long n = rows * (Cp >> 1);
+    if (n == 0) return WFS_OK;
+    if (dtype == WFS_F16)
+        k_pad_f32<wfs_f16><<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(src, rows, C, Cp, (wfs_f16 *)dst);
+    else
+        k_pad_f32<wfs_bf16><<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(src, rows, C, Cp, (wfs_bf16 *)dst);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+int pad_rows(const int *table, const KMapW &km, int K, int identity_k, long long R, const long long *r_dev,
+             const void *src, long long src_rows, int C, int Cp, void *dst, hipStream_t stream) {
+    const long long n = R * K * (Cp >> 3);
+    if (n == 0) return WFS_OK;
+    k_pad_rows<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev,
+                                                                   (const unsigned short *)src, src_rows, C, Cp,
+                                                                   (unsigned short *)dst);
+    WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
 // workspace of one wide product: padded filters + (gathered rows | padded rows + per-offset products) + split partials
 struct WidePlan {
     bool dense_first;       // source side shorter: dense product over the source rows, then the ordered sum
     int nz, nseg;           // gather-first: the K offsets split over nz batches of nseg segments
+    int ksplit, kchunk;     // contraction split of every segment
     size_t w_bytes, rows_bytes, t_bytes;
 };
 
@@ -402,8 +524,9 @@ WidePlan conv_plan(int K, long long R, long long X_rows, int Cx, int Cy, int Cw_
     if (p.dense_first) {
         p.nz = K;
         p.nseg = 1;
+        p.ksplit = plan_ksplit(wfs_cdiv(X_rows, GT) * wfs_cdiv(Cy, GT) * K, Cx, &p.kchunk);
         p.rows_bytes = wfs_align_up((size_t)X_rows * pad8(Cx) * 2, 256);
-        p.t_bytes = wfs_align_up((size_t)X_rows * K * pad8(Cy) * 4, 256);
+        p.t_bytes = wfs_align_up((size_t)p.ksplit * X_rows * K * pad8(Cy) * 4, 256);
     } else {
         // enough blocks for the chip: split the offsets over batches while the tiles alone leave CUs idle
         const long long tiles = wfs_cdiv(R, GT) * wfs_cdiv(Cy, GT);
@@ -411,31 +534,14 @@ WidePlan conv_plan(int K, long long R, long long X_rows, int Cx, int Cy, int Cw_
         while (nz < K && tiles * nz < 384) ++nz;
         p.nseg = (int)wfs_cdiv(K, nz);
         p.nz = (int)wfs_cdiv(K, p.nseg);
+        p.ksplit = plan_ksplit(tiles * p.nz, Cx, &p.kchunk);
         p.rows_bytes = wfs_align_up((size_t)R * K * pad8(Cx) * 2, 256);
-        p.t_bytes = p.nz > 1 ? wfs_align_up((size_t)p.nz * R * pad8(Cy) * 4, 256) : 0;
+        p.t_bytes = p.nz * p.ksplit > 1 ? wfs_align_up((size_t)p.nz * p.ksplit * R * pad8(Cy) * 4, 256) : 0;
     }
     return p;
 }
 
 }  // namespace
-
-// which layers take this path: 16-bit rows, one side of the filter at least 256 channels wide (measured against the
-// 32 x 32-tile kernels of gather_conv.hip: profiles/r03_microbench_wide.txt), workspace within bounds
-extern "C" size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy,
-                                                int32_t has_table);
-
-extern "C" int wfs_wide_enable(int32_t on) {
-    const int was = g_wide_on ? 1 : 0;
-    g_wide_on = on != 0;
-    return was;
-}
-
-extern "C" int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy, int32_t dtype) {
-    if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return 0;
-    if (K < 1 || K > 128 || R < 1 || X_rows < 1 || Cx < 8 || Cy < 8) return 0;
-    if ((Cx > Cy ? Cx : Cy) < 256) return 0;
-    return (long long)wfs_wide_conv_workspace_bytes(K, R, X_rows, Cx, Cy, 1) <= WIDE_MAX_WORKSPACE;
-}
 
 extern "C" size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy,
                                                 int32_t has_table) {
@@ -445,8 +551,37 @@ extern "C" size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_
     return (p.w_bytes > q.w_bytes ? p.w_bytes : q.w_bytes) + p.rows_bytes + p.t_bytes + 1024;
 }
 
+extern "C" int wfs_wide_enable(int32_t on) {
+    const int was = g_wide_on ? 1 : 0;
+    g_wide_on = on != 0;
+    return was;
+}
+
+// which layers take this path: 16-bit rows, one side of the filter at least 256 channels wide (measured against the
+// 32 x 32-tile kernels of gather_conv.hip: profiles/r03_microbench_wide.txt), workspace within bounds
+extern "C" int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy, int32_t dtype) {
+    if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return 0;
+    if (K < 1 || K > 128 || R < 1 || X_rows < 1 || Cx < 8 || Cy < 8) return 0;
+    if (R >= (1ll << 31) || X_rows >= (1ll << 31)) return 0;
+    if ((Cx > Cy ? Cx : Cy) < 256) return 0;
+    return (long long)wfs_wide_conv_workspace_bytes(K, R, X_rows, Cx, Cy, 1) <= WIDE_MAX_WORKSPACE;
+}
+
+extern "C" size_t wfs_wide_filters16_bytes(int32_t K, int32_t Cw_in, int32_t Cw_out) {
+    return wfs_align_up((size_t)K * Cw_in * pad8(Cw_out) * 2, 256);
+}
+
+extern "C" int wfs_wide_filters16(const float *W, int32_t K, int32_t Cw_in, int32_t Cw_out, int32_t dtype, void *W16,
+                                  void *stream) {
+    WFS_REQUIRE(dtype == WFS_BF16 || dtype == WFS_F16, WFS_EINVAL, "16-bit filters only (dtype %d)", dtype);
+    WFS_REQUIRE(K >= 1 && Cw_in >= 1 && Cw_out >= 1 && W && W16, WFS_EINVAL, "bad filter block");
+    WFS_REQUIRE(((uintptr_t)W16 & 15) == 0, WFS_EINVAL, "W16 must be 16-byte aligned");
+    return pad_f32(W, (long long)K * Cw_in, Cw_out, pad8(Cw_out), W16, dtype, (hipStream_t)stream);
+}
+
 extern "C" int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
-                                    int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
+                                    int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
+                                    const void *W16, int32_t Cw_in,
                                     int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
                                     const int64_t *r_dev_, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -457,7 +592,9 @@ extern "C" int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_ho
     WFS_REQUIRE(Cx == (transpose_w ? Cw_out : Cw_in), WFS_EINVAL, "channel mismatch: X has %d, filter wants %d", Cx,
                 transpose_w ? Cw_out : Cw_in);
     if (R == 0) return WFS_OK;
-    WFS_REQUIRE((table || (K == 1 && identity_k == 0)) && X && W && Y && workspace, WFS_EINVAL, "NULL device pointer");
+    WFS_REQUIRE((table || (K == 1 && identity_k == 0)) && X && (W || W16) && Y && workspace, WFS_EINVAL,
+                "NULL device pointer");
+    WFS_REQUIRE(((uintptr_t)W16 & 15) == 0, WFS_EINVAL, "W16 must be 16-byte aligned");
     WFS_REQUIRE(X_rows >= 1, WFS_EINVAL, "no source rows");
     WFS_REQUIRE(table || X_rows == R, WFS_EINVAL, "a product without a table maps row r to row r (%lld vs %lld rows)",
                 (long long)X_rows, (long long)R);
@@ -477,95 +614,96 @@ extern "C" int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_ho
     unsigned short *rows = (unsigned short *)cv.take(p.rows_bytes);
     float *T = p.t_bytes ? (float *)cv.take(p.t_bytes) : nullptr;
     const int Cxp = pad8(Cx), Cyp = pad8(Cy), Cwp = pad8(Cw_out);
-    const unsigned short *Xs = (const unsigned short *)X;
-    {   // filters -> 16 bit, [K][Cw_in][Cwp]
-        const long long wrows = (long long)K * Cw_in, n = wrows * (Cwp >> 3);
-        if (dtype == WFS_F16)
-            k_pad_f32<wfs_f16><<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(W, wrows, Cw_out, Cwp, (wfs_f16 *)Wh);
-        else
-            k_pad_f32<wfs_bf16><<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(W, wrows, Cw_out, Cwp, Wh);
-        WFS_LAUNCH_CHECK();
-    }
+    int rc = WFS_OK;
+    if (!W16) rc = pad_f32(W, (long long)K * Cw_in, Cw_out, Cwp, Wh, dtype, stream);   // filters -> 16 bit, [K][Cw_in][Cwp]
+    if (rc != WFS_OK) return rc;
     GemmArgs g{};
-    g.B = Wh;
+    g.B = W16 ? (const unsigned short *)W16 : Wh;
     g.ldb = Cwp;
     g.sB = (long long)Cw_in * Cwp;
     g.Ks = Cx;
     g.nseg_total = K;
+    g.ksplit = p.ksplit;
+    g.kchunk = p.kchunk;
     // filter operand: forward W[k] is [contraction Cx][Cy] -> contraction-major; dX W[k] is [Cy][contraction Cx]
     const int b_km = transpose_w ? 0 : 1;
     if (p.dense_first) {
-        // rows -> aligned, padded (no gather: identity)
-        const long long n = X_rows * (Cxp >> 3);
-        k_pad_rows<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(nullptr, km, 1, 0, X_rows, nullptr, Xs, X_rows, Cx,
-                                                                       Cxp, rows);
-        WFS_LAUNCH_CHECK();
-        g.A = rows;
-        g.lda = Cxp;
-        g.sA = 0;
-        g.C = T;
-        g.ldc = (long long)K * Cyp;
-        g.zC = Cyp;
-        g.M = (int)X_rows;
-        g.N = Cy;
-        g.nseg = 1;
-        g.nz = K;
-        int rc = gemm(g, 0, b_km, dtype, stream);
+        rc = pad_rows(nullptr, km, 1, 0, X_rows, nullptr, X, X_rows, Cx, Cxp, rows, stream);   // aligned, padded rows
+        if (rc != WFS_OK) return rc;
+        const long long slab = X_rows * (long long)K * Cyp;
+        g.A = rows, g.lda = Cxp, g.sA = 0;
+        g.C = T, g.ldc = (long long)K * Cyp, g.zC = Cyp, g.pC = slab;
+        g.M = (int)X_rows, g.N = Cy, g.nseg = 1, g.nz = K;
+        rc = gemm(g, 0, b_km, dtype, stream);
         if (rc != WFS_OK) return rc;
         if (dtype == WFS_F16)
-            k_sum_rows<wfs_f16><<<dim3((unsigned)R), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev, T, X_rows,
-                                                                      (long long)K * Cyp, Cyp, bias, Cy, (wfs_f16 *)Y);
-        else
-            k_sum_rows<wfs_bf16><<<dim3((unsigned)R), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev, T, X_rows,
-                                                                       (long long)K * Cyp, Cyp, bias, Cy, (wfs_bf16 *)Y);
-        WFS_LAUNCH_CHECK();
-        return WFS_OK;
+            return launch_sum_rows<wfs_f16>(table, km, K, identity_k, R, r_dev, T, X_rows, (long long)K * Cyp, Cyp,
+                                            p.ksplit, slab, bias, Cy, (wfs_f16 *)Y, stream);
+        return launch_sum_rows<wfs_bf16>(table, km, K, identity_k, R, r_dev, T, X_rows, (long long)K * Cyp, Cyp, p.ksplit,
+                                         slab, bias, Cy, (wfs_bf16 *)Y, stream);
     }
-    {   // gathered rows G[r, (k, c)]
-        const long long n = R * K * (Cxp >> 3);
-        k_pad_rows<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev, Xs, X_rows, Cx,
-                                                                       Cxp, rows);
-        WFS_LAUNCH_CHECK();
-    }
-    g.A = rows;
-    g.lda = (long long)K * Cxp;
-    g.sA = Cxp;
-    g.M = (int)R;
-    g.N = Cy;
-    g.nseg = p.nseg;
-    g.nz = p.nz;
-    if (p.nz == 1) {
-        g.C = Y;
-        g.ldc = Cy;
-        g.zC = 0;
-        g.out_h = 1;
-        g.bias = bias;
+    rc = pad_rows(table, km, K, identity_k, R, r_dev, X, X_rows, Cx, Cxp, rows, stream);      // gathered rows G[r, (k, c)]
+    if (rc != WFS_OK) return rc;
+    g.A = rows, g.lda = (long long)K * Cxp, g.sA = Cxp;
+    g.M = (int)R, g.N = Cy, g.nseg = p.nseg, g.nz = p.nz;
+    if (p.nz * p.ksplit == 1) {
+        g.C = Y, g.ldc = Cy, g.out_h = 1, g.bias = bias;
         return gemm(g, 0, b_km, dtype, stream);
     }
-    g.C = T;
-    g.ldc = Cyp;
-    g.zC = R * (long long)Cyp;
-    int rc = gemm(g, 0, b_km, dtype, stream);
+    const long long slab = R * (long long)Cyp;
+    g.C = T, g.ldc = Cyp, g.zC = p.ksplit * slab, g.pC = slab;
+    rc = gemm(g, 0, b_km, dtype, stream);
     if (rc != WFS_OK) return rc;
     if (dtype == WFS_F16)
-        k_sum_rows<wfs_f16><<<dim3((unsigned)R), 256, 0, stream>>>(nullptr, km, p.nz, -1, R, r_dev, T, R, Cyp,
-                                                                  R * (long long)Cyp, bias, Cy, (wfs_f16 *)Y);
-    else
-        k_sum_rows<wfs_bf16><<<dim3((unsigned)R), 256, 0, stream>>>(nullptr, km, p.nz, -1, R, r_dev, T, R, Cyp,
-                                                                   R * (long long)Cyp, bias, Cy, (wfs_bf16 *)Y);
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
+        return launch_sum_rows<wfs_f16>(nullptr, km, p.nz * p.ksplit, -1, R, r_dev, T, R, Cyp, slab, 1, 0, bias, Cy,
+                                        (wfs_f16 *)Y, stream);
+    return launch_sum_rows<wfs_bf16>(nullptr, km, p.nz * p.ksplit, -1, R, r_dev, T, R, Cyp, slab, 1, 0, bias, Cy,
+                                     (wfs_bf16 *)Y, stream);
 }
 
 // dW of a wide layer (called from wfs_gather_dw): dW[k][a][b] (swap: dW[k][b][a]) = sum_r S[r][a] G[table[k][r]][b]
+static int dw_split(int K, long long R, int Cs, int Cg, int *kchunk) {
+    return plan_ksplit(wfs_cdiv(Cs, GT) * wfs_cdiv(Cg, GT) * K, (int)R, kchunk);
+}
+
 size_t wfs_wide_dw_workspace(int K, long long R, int Cs, int Cg) {
-    return wfs_align_up((size_t)R * pad8(Cs) * 2, 256) + wfs_align_up((size_t)R * K * pad8(Cg) * 2, 256) + 1024;
+    int kchunk;
+    const int ks = dw_split(K, R, Cs, Cg, &kchunk);
+    return wfs_align_up((size_t)R * pad8(Cs) * 2, 256) + wfs_align_up((size_t)R * K * pad8(Cg) * 2, 256) +
+           (ks > 1 ? wfs_align_up((size_t)ks * K * Cs * Cg * 4, 256) : 0) + 1024;
 }
 
 bool wfs_wide_dw_ok(int K, long long R, int Cs, int Cg, int dtype) {
     if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return false;
     if (K < 1 || K > 128 || R < 1 || R >= (1ll << 31) || Cs < 8 || Cg < 8 || (Cs > Cg ? Cs : Cg) < 256) return false;
     return (long long)wfs_wide_dw_workspace(K, R, Cs, Cg) <= WIDE_MAX_WORKSPACE;
+}
+
+// A^T . B over the rows of two contraction-major operands: C[z][m][n] = sum_r A[r][z sA + m] B[r][z sB + n]
+static int rows_product(const unsigned short *A, long long lda, long long sA, int M, const unsigned short *B, long long ldb,
+                        long long sB, int N, long long R, const long long *r_dev, int nz, float *C, float *slabs,
+                        int dtype, hipStream_t stream) {
+    GemmArgs g{};
+    g.A = A, g.lda = lda, g.sA = sA, g.M = M;
+    g.B = B, g.ldb = ldb, g.sB = sB, g.N = N;
+    g.Ks = (int)R;
+    g.k_dev = r_dev;
+    g.nseg_total = nz, g.nseg = 1, g.nz = nz;
+    g.ksplit = plan_ksplit(wfs_cdiv(M, GT) * wfs_cdiv(N, GT) * nz, (int)R, &g.kchunk);
+    g.ldc = N;
+    g.zC = (long long)M * N;
+    if (g.ksplit == 1) {
+        g.C = C;
+        return gemm(g, 1, 1, dtype, stream);
+    }
+    WFS_REQUIRE(slabs, WFS_EWORKSPACE, "no room for the split partials");
+    g.C = slabs;
+    g.pC = (long long)nz * M * N;
+    int rc = gemm(g, 1, 1, dtype, stream);
+    if (rc != WFS_OK) return rc;
+    KMapW km{};
+    return launch_sum_rows<float>(nullptr, km, 1, -1, (long long)nz * M, nullptr, slabs, (long long)nz * M, N, 0, g.ksplit,
+                                  g.pC, nullptr, N, C, stream);
 }
 
 int wfs_launch_wide_dw(const int *table, const int *kmap_host, int K, int identity_k, long long R, const long long *r_dev,
@@ -578,33 +716,122 @@ int wfs_launch_wide_dw(const int *table, const int *kmap_host, int K, int identi
     for (int k = 0; k < K; ++k) km.v[k] = kmap_host ? kmap_host[k] : k;
     Carver cv{(unsigned char *)workspace, workspace_bytes};
     const int Csp = pad8(Cs), Cgp = pad8(Cg);
+    int kchunk;
+    const int ks = dw_split(K, R, Cs, Cg, &kchunk);
     unsigned short *Sp = (unsigned short *)cv.take((size_t)R * Csp * 2);
     unsigned short *Gg = (unsigned short *)cv.take((size_t)R * K * Cgp * 2);
-    WFS_REQUIRE(Sp && Gg, WFS_EWORKSPACE, "workspace too small");
-    long long n = R * (Csp >> 3);
-    k_pad_rows<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(nullptr, km, 1, 0, R, r_dev, (const unsigned short *)S,
-                                                                   R, Cs, Csp, Sp);
-    WFS_LAUNCH_CHECK();
-    n = R * K * (Cgp >> 3);
-    k_pad_rows<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev,
-                                                                   (const unsigned short *)G, G_rows, Cg, Cgp, Gg);
-    WFS_LAUNCH_CHECK();
+    float *slabs = ks > 1 ? (float *)cv.take((size_t)ks * K * Cs * Cg * 4) : nullptr;
+    WFS_REQUIRE(Sp && Gg && (ks == 1 || slabs), WFS_EWORKSPACE, "workspace too small");
+    int rc = pad_rows(nullptr, km, 1, 0, R, r_dev, S, R, Cs, Csp, Sp, stream);
+    if (rc != WFS_OK) return rc;
+    rc = pad_rows(table, km, K, identity_k, R, r_dev, G, G_rows, Cg, Cgp, Gg, stream);
+    if (rc != WFS_OK) return rc;
+    if (!swap)
+        return rows_product(Sp, Csp, 0, Cs, Gg, (long long)K * Cgp, Cgp, Cg, R, r_dev, K, dW, slabs, dtype, stream);
+    return rows_product(Gg, (long long)K * Cgp, Cgp, Cg, Sp, Csp, 0, Cs, R, r_dev, K, dW, slabs, dtype, stream);
+}
+
+// ------------------------------------------------------------------------------------------ dense linear layer
+// y = x W^T + b with 16-bit x [B, I], fp32 W [O, I] (torch.nn.Linear's layout), fp32 y: the hybrid net's head
+// (Linear(24150, 269), reference src/models/SPConvNet.py:40-52 through LinearBlock) is a 3.3-GFLOP product that streams
+// 26 MB of weights: 2 x 3 output tiles, so the contraction is cut into parts (plan_ksplit) and summed in order.
+static int lin_split(long long B, int I, int O, int *kchunk) {
+    return plan_ksplit(wfs_cdiv(B, GT) * wfs_cdiv(O, GT), I, kchunk);
+}
+
+extern "C" size_t wfs_linear16_workspace_bytes(int64_t B, int32_t I, int32_t O) {
+    int kchunk;
+    const int ks = lin_split(B, I, O, &kchunk);
+    const size_t x = wfs_align_up((size_t)B * pad8(I) * 2, 256), w = wfs_align_up((size_t)O * pad8(I) * 2, 256);
+    const size_t g = wfs_align_up((size_t)B * pad8(O) * 2, 256), part = wfs_align_up((size_t)ks * B * pad8(O) * 4, 256);
+    int kc2;
+    const int ks2 = plan_ksplit(wfs_cdiv(O, GT) * wfs_cdiv(I, GT), (int)B, &kc2);
+    const size_t part2 = ks2 > 1 ? wfs_align_up((size_t)ks2 * O * I * 4, 256) : 0;
+    return x + w + g + (part > part2 ? part : part2) + 1024;
+}
+
+extern "C" int wfs_linear16_ok(int64_t B, int32_t I, int32_t O, int32_t dtype) {
+    if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return 0;
+    if (B < 1 || B >= (1ll << 31) || I < 256 || O < 9) return 0;
+    return (long long)wfs_linear16_workspace_bytes(B, I, O) <= WIDE_MAX_WORKSPACE;
+}
+
+extern "C" int wfs_linear16_fwd(const void *X, int64_t B, int32_t I, const float *W, const float *bias, int32_t O,
+                                float *Y, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(dtype == WFS_BF16 || dtype == WFS_F16, WFS_EINVAL, "16-bit rows only (dtype %d)", dtype);
+    WFS_REQUIRE(B >= 1 && B < (1ll << 31) && I >= 8 && O >= 1, WFS_EINVAL, "bad shape %lld x %d -> %d", (long long)B, I, O);
+    WFS_REQUIRE(X && W && Y && workspace, WFS_EINVAL, "NULL device pointer");
+    WFS_REQUIRE(workspace_bytes >= wfs_linear16_workspace_bytes(B, I, O), WFS_EWORKSPACE, "workspace %zu < %zu",
+                workspace_bytes, wfs_linear16_workspace_bytes(B, I, O));
+    WFS_REQUIRE(((uintptr_t)workspace & 15) == 0, WFS_EINVAL, "workspace must be 16-byte aligned");
+    const int Ip = pad8(I), Op = pad8(O);
+    Carver cv{(unsigned char *)workspace, workspace_bytes};
+    unsigned short *Xp = (unsigned short *)cv.take((size_t)B * Ip * 2);
+    unsigned short *Wh = (unsigned short *)cv.take((size_t)O * Ip * 2);
+    cv.take((size_t)B * Op * 2);
+    KMapW km{};
+    int rc = pad_rows(nullptr, km, 1, 0, B, nullptr, X, B, I, Ip, Xp, stream);
+    if (rc != WFS_OK) return rc;
+    rc = pad_f32(W, O, I, Ip, Wh, dtype, stream);
+    if (rc != WFS_OK) return rc;
     GemmArgs g{};
-    g.Ks = (int)R;
-    g.k_dev = r_dev;
-    g.nseg_total = K;
-    g.nseg = 1;
-    g.nz = K;
-    g.C = dW;
-    g.zC = (long long)Cs * Cg;
-    if (!swap) {
-        g.A = Sp, g.lda = Csp, g.sA = 0, g.M = Cs;
-        g.B = Gg, g.ldb = (long long)K * Cgp, g.sB = Cgp, g.N = Cg;
-        g.ldc = Cg;
-    } else {
-        g.A = Gg, g.lda = (long long)K * Cgp, g.sA = Cgp, g.M = Cg;
-        g.B = Sp, g.ldb = Csp, g.sB = 0, g.N = Cs;
-        g.ldc = Cs;
+    g.A = Xp, g.lda = Ip, g.M = (int)B;
+    g.B = Wh, g.ldb = Ip, g.N = O;
+    g.Ks = I;
+    g.nseg_total = 1, g.nseg = 1, g.nz = 1;
+    g.ksplit = lin_split(B, I, O, &g.kchunk);
+    float *part = (float *)cv.take((size_t)g.ksplit * B * Op * 4);
+    WFS_REQUIRE(part, WFS_EWORKSPACE, "workspace too small");
+    g.C = part, g.ldc = Op, g.pC = B * (long long)Op;
+    rc = gemm(g, 0, 0, dtype, stream);
+    if (rc != WFS_OK) return rc;
+    return launch_sum_rows<float>(nullptr, km, 1, -1, B, nullptr, part, B, Op, 0, g.ksplit, g.pC, bias, O, Y, stream);
+}
+
+// dX [B, I] (16-bit, may be NULL), dW [O, I] and db [O] (fp32, may be NULL) from fp32 dY [B, O]
+extern "C" int wfs_linear16_bwd(const void *X, const float *dY, int64_t B, int32_t I, const float *W, int32_t O,
+                                void *dX, float *dW, float *db, int32_t dtype, void *workspace, size_t workspace_bytes,
+                                void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(dtype == WFS_BF16 || dtype == WFS_F16, WFS_EINVAL, "16-bit rows only (dtype %d)", dtype);
+    WFS_REQUIRE(B >= 1 && B < (1ll << 31) && I >= 8 && O >= 1, WFS_EINVAL, "bad shape %lld x %d -> %d", (long long)B, I, O);
+    WFS_REQUIRE(X && dY && W && workspace, WFS_EINVAL, "NULL device pointer");
+    WFS_REQUIRE(workspace_bytes >= wfs_linear16_workspace_bytes(B, I, O), WFS_EWORKSPACE, "workspace %zu < %zu",
+                workspace_bytes, wfs_linear16_workspace_bytes(B, I, O));
+    WFS_REQUIRE(((uintptr_t)workspace & 15) == 0, WFS_EINVAL, "workspace must be 16-byte aligned");
+    const int Ip = pad8(I), Op = pad8(O);
+    Carver cv{(unsigned char *)workspace, workspace_bytes};
+    unsigned short *Xp = (unsigned short *)cv.take((size_t)B * Ip * 2);
+    unsigned short *Wh = (unsigned short *)cv.take((size_t)O * Ip * 2);
+    unsigned short *Gh = (unsigned short *)cv.take((size_t)B * Op * 2);
+    KMapW km{};
+    int rc = pad_f32(dY, B, O, Op, Gh, dtype, stream);                 // dY -> 16 bit [B][Op]
+    if (rc != WFS_OK) return rc;
+    if (dX) {
+        rc = pad_f32(W, O, I, Ip, Wh, dtype, stream);
+        if (rc != WFS_OK) return rc;
+        GemmArgs g{};                                                  // dX = dY . W: contraction over O
+        g.A = Gh, g.lda = Op, g.M = (int)B;
+        g.B = Wh, g.ldb = Ip, g.N = I;                                 // W as [k = O][n = I]: contraction-major
+        g.Ks = O;
+        g.nseg_total = 1, g.nseg = 1, g.nz = 1, g.ksplit = 1, g.kchunk = (int)(wfs_cdiv(O, GK) * GK);
+        g.C = dX, g.ldc = I, g.out_h = 1;
+        rc = gemm(g, 0, 1, dtype, stream);
+        if (rc != WFS_OK) return rc;
     }
-    return gemm(g, 1, 1, dtype, stream);
+    if (dW) {
+        rc = pad_rows(nullptr, km, 1, 0, B, nullptr, X, B, I, Ip, Xp, stream);
+        if (rc != WFS_OK) return rc;
+        int kc;
+        const int ks = plan_ksplit(wfs_cdiv(O, GT) * wfs_cdiv(I, GT), (int)B, &kc);
+        float *slabs = ks > 1 ? (float *)cv.take((size_t)ks * O * I * 4) : nullptr;
+        rc = rows_product(Gh, Op, 0, O, Xp, Ip, 0, I, B, nullptr, 1, dW, slabs, dtype, stream);   // dW = dY^T . X
+        if (rc != WFS_OK) return rc;
+    }
+    if (db) {
+        // column sums of dY in fp32, fixed order: one block per 256 columns walks the rows
+        return launch_sum_rows<float>(nullptr, km, 1, -1, 1, nullptr, dY, 1, 0, 0, (int)B, O, nullptr, O, db, stream);
+    }
+    return WFS_OK;
 }

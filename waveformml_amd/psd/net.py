@@ -106,9 +106,8 @@ class SPConvNet(nn.Module):
         fsp = getattr(self.spconv, "functional", None)
         out = self.sparseModel(st)
         out = out.view(-1, self.n_linear)
-        if (len(self.linear) == 1 and fsp is not None and hasattr(fsp, "can_use_skinny_linear")
-                and fsp.can_use_skinny_linear(self.linear[0], out)):
-            return fsp.skinny_linear(out, self.linear[0])       # few-output head: streaming HIP kernels
+        if fsp is not None and hasattr(fsp, "head_forward"):
+            return fsp.head_forward(out, self.linear)         # per layer: streaming / matrix-core HIP kernels or torch
         head_dtype = next(self.linear.parameters()).dtype
         if out.dtype != head_dtype:          # bf16 activations, fp32 master weights in the dense head
             out = out.to(head_dtype)

@@ -149,7 +149,22 @@ def _mm_f32(a, b):
     return torch.mm(a, b).float()
 
 
-def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev):
+def filters16(W, like):
+    """[K, Cin, Cout] fp32 filters in the row type of ``like``, padded as the wide products read them (one conversion
+    per layer and step: the forward pass keeps it for dX)."""
+    lib = _lib.load()
+    K, Cw_in, Cw_out = int(W.shape[0]), int(W.shape[1]), int(W.shape[2])
+    out = torch.empty((int(lib.wfs_wide_filters16_bytes(K, Cw_in, Cw_out)),), dtype=torch.uint8, device=W.device)
+    _lib.check(lib.wfs_wide_filters16(_lib.ptr(W), K, Cw_in, Cw_out, _lib.dtype_code(like), _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def takes_wide_path(K, R, X, Cy):
+    return bool(X.is_cuda and X.dtype in (torch.bfloat16, torch.float16)
+                and _lib.load().wfs_wide_conv_ok(K, R, X.shape[0], int(X.shape[1]), int(Cy), _lib.dtype_code(X)))
+
+
+def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev, w16=None):
     """16-bit rows, >= 256 channels on a side: one dense matrix-core product over the shorter side of the layer
     (csrc/wide.hip; include/wfsparse.h wfs_wide_gather_conv).  The BatchNorm statistics, when a BatchNorm1d follows,
     are taken by its own kernel (bn_request stays unanswered)."""
@@ -163,19 +178,19 @@ def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bia
     nbytes = lib.wfs_wide_conv_workspace_bytes(K, R, X.shape[0], Cx, Cy, 0 if table is None else 1)
     ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=X.device)
     _lib.check(lib.wfs_wide_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], Cx, _lib.ptr(W),
-                                        Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
+                                        _lib.ptr(w16), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
                                         _lib.dtype_code(X), _lib.ptr(r_dev), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
     _account("gather_conv", table, R, X.shape[0], Cx, R, Cy, K, Cw_in, Cw_out, X.element_size())
     return Y
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None):
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, w16=None):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
     With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
     if X.is_cuda and lib.wfs_wide_conv_ok(K, R, X.shape[0], int(X.shape[1]), Cw_in if transpose_w else Cw_out, _lib.dtype_code(X)):
-        return _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev)
+        return _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev, w16)
     if transpose_w and not _fast_shape(Cw_out, Cw_in):
         # the shape-generic MFMA kernel reads the filter with the OUTPUT channel on the lanes: for dX that is a strided
         # walk over W[k] (a new 128-B line per lane and step; 47 vs 26 us measured at 64 channels) -- hand it W[k]^T
@@ -405,17 +420,21 @@ class SparseConvFunction(Function):
         W = filters.detach().reshape(K, filters.shape[-2], filters.shape[-1]).float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
         ident = rb.centre_k if rb.subm else -1
+        w16 = None
         if mode == INVERSE:
             assert features.shape[0] == rb.M, "inverse conv input must be the coupled conv's output set"
-            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b, rb.n_dev, bn_request)
+            w16 = filters16(W, features) if takes_wide_path(K, rb.N, features, W.shape[2]) else None
+            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b, rb.n_dev, bn_request, w16)
         elif rb.has_dup:
             out = scatter_conv(rb.nbr_out, K, ident, rb.N, features, W, False, rb.M, b)
         else:
             assert features.shape[0] == rb.N
             table, kmap = rb.table_by_out()
-            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev, bn_request)
+            w16 = filters16(W, features) if takes_wide_path(K, rb.M, features, W.shape[2]) else None
+            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev, bn_request, w16)
         ctx.save_for_backward(features, filters, bias)
         ctx.rb, ctx.mode = rb, mode
+        ctx.w16 = w16 if ctx.needs_input_grad[0] else None       # the 16-bit filters of a wide layer: dX reads them again
         return out
 
     @staticmethod
@@ -436,7 +455,7 @@ class SparseConvFunction(Function):
                 if rb.has_dup:
                     dX = scatter_conv(rb.nbr_out, K, ident, rb.N, dY, W, True, rb.M, None)
                 else:
-                    dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev)
+                    dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev, None, ctx.w16)
             if ctx.needs_input_grad[1]:
                 dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev, ov, filters)
         else:
@@ -449,7 +468,7 @@ class SparseConvFunction(Function):
                 else:
                     dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov, filters)
             if ctx.needs_input_grad[0]:
-                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev)
+                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev, None, ctx.w16)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
@@ -469,9 +488,11 @@ class PointwiseConvFunction(Function):
         R = int(features.shape[0])
         W = filters.detach().reshape(1, filters.shape[-2], filters.shape[-1]).float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
-        out = gather_conv(None, None, 1, 0, R, features, W, False, b, n_dev)
+        w16 = filters16(W, features) if takes_wide_path(1, R, features, W.shape[2]) else None
+        out = gather_conv(None, None, 1, 0, R, features, W, False, b, n_dev, None, w16)
         ctx.save_for_backward(features, filters, bias)
         ctx.n_dev = n_dev
+        ctx.w16 = w16 if ctx.needs_input_grad[0] else None
         return out
 
     @staticmethod
@@ -488,7 +509,7 @@ class PointwiseConvFunction(Function):
             dW = gather_dw(None, 1, 0, R, features, dY, False, None, n_dev, False, filters)
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if ctx.needs_input_grad[0]:
-            dX = gather_conv(None, None, 1, 0, R, dY, W, True, None, n_dev)
+            dX = gather_conv(None, None, 1, 0, R, dY, W, True, None, n_dev, None, ctx.w16)
         if bias is not None and ctx.needs_input_grad[2]:
             db = _masked_column_sum(dY, n_dev).to(bias.dtype)
         return dX, dW, db, None
@@ -722,6 +743,70 @@ def can_use_skinny_linear(linear, x):
 
 def skinny_linear(x, linear):
     return SkinnyLinearFunction.apply(x, linear.weight, linear.bias)
+
+
+class WideLinearFunction(Function):
+    """nn.Linear with many outputs on 16-bit activations [B, I]: y = x W^T + b on the matrix cores (csrc/wide.hip;
+    include/wfsparse.h wfs_linear16_fwd), fp32 weights rounded to the row type as operands, fp32 accumulate, fp32
+    result -- the hybrid net's Linear(24150, 269) (reference src/models/SPConvNet.py:40-52)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x = _features_ok(x)
+        B, I = x.shape
+        O = weight.shape[0]
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        ws = torch.empty((int(lib.wfs_linear16_workspace_bytes(B, I, O)),), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.wfs_linear16_fwd(_lib.ptr(x), B, I, _lib.ptr(w), _lib.ptr(b), O, _lib.ptr(y), _lib.dtype_code(x),
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        x, weight, bias = ctx.saved_tensors
+        B, I = x.shape
+        O = weight.shape[0]
+        g = grad_output.float().contiguous()
+        w = weight.detach().float().contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = grad_like(weight, (O, I)) if ctx.needs_input_grad[1] else None
+        db = _masked_column_sum(g, None) if (bias is not None and ctx.needs_input_grad[2]) else None
+        ws = torch.empty((int(lib.wfs_linear16_workspace_bytes(B, I, O)),), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.wfs_linear16_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw),
+                                        None, _lib.dtype_code(x), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        return dx, (dw.to(weight.dtype) if dw is not None else None), (db.to(bias.dtype) if db is not None else None)
+
+
+def can_use_wide_linear(linear, x):
+    return bool(type(linear) is torch.nn.Linear and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
+                and x.dtype in (torch.bfloat16, torch.float16) and linear.weight.dtype == torch.float32
+                and _lib.load().wfs_linear16_ok(x.shape[0], x.shape[1], linear.out_features, _lib.dtype_code(x)))
+
+
+def wide_linear(x, linear):
+    return WideLinearFunction.apply(x, linear.weight, linear.bias)
+
+
+def head_forward(x, layers):
+    """The dense head (reference src/models/SPConvNet.py:40-52: a Sequential of nn.Linear built by LinearBlock) on
+    the flattened ToDense output: few-output layers on streamed 16-bit / fp32 rows (skinny_linear), wide layers of
+    16-bit rows on the matrix cores (wide_linear), anything else as the torch module in the head's own dtype."""
+    for layer in layers:
+        if can_use_skinny_linear(layer, x):
+            x = skinny_linear(x, layer)
+        elif can_use_wide_linear(layer, x):
+            x = wide_linear(x, layer)
+        else:
+            p = next(layer.parameters(), None)
+            if p is not None and x.dtype != p.dtype:          # 16-bit activations, fp32 master weights
+                x = x.to(p.dtype)
+            x = layer(x)
+    return x
 
 
 class CrossEntropyMeanFunction(Function):
