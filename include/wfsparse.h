@@ -172,7 +172,8 @@ int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, i
  * gathered rows and the per-offset products; 16-byte aligned. */
 int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy, int32_t dtype);
 /* A/B switch for benchmarks (tools/microbench_generic.py): 0 sends every layer back to the 32 x 32-tile kernels
- * (wfs_gather_conv / the narrow arm of wfs_gather_dw).  Returns the previous setting; default on. */
+ * (wfs_gather_conv / the narrow arm of wfs_gather_dw); a value >= 8 turns the path on for layers with at least that
+ * many channels on a side.  Returns the previous threshold (0 = was off). */
 int wfs_wide_enable(int32_t on);
 size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy,
                                      int32_t has_table);
@@ -385,7 +386,8 @@ int wfs_to_dense_bwd_mapped(const void *dY, const uint32_t *ticket, const int32_
  * The reference flattens ToDense's output and applies the LinearBlock (src/models/SPConvNet.py:67-68,
  * src/models/ConvBlocks.py:82-102); the final nn.Linear has n_type = 2..4 outputs over tens of
  * thousands of inputs, a streaming problem rather than a GEMM.  X [B, I] fp32 or bf16 (dtype),
- * W [O, I] fp32 (nn.Linear.weight), Y / G [B, O] fp32, 1 <= O <= 8, I % 8 == 0.
+ * W [O, I] fp32 (nn.Linear.weight), Y / G [B, O] fp32, 1 <= O <= 8.  Rows with I % 8 == 0 and I >= 1024 stream
+ * through vector kernels; any other row length (the short second layer of a two-layer head) takes scalar ones.
  *     Y = X W^T + bias;   dX = G W (X's dtype);   dW = G^T X (deterministic chunked reduction).
  * dX or dW may be NULL to skip that product; dB [O] (optional, computed with dW) = sum_b G[b][:].      */
 size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O);

@@ -496,10 +496,13 @@ def test_graph_captured_step_matches_eager_steps():
 @pytest.mark.parametrize("dtype,O", [(torch.float32, 3), (torch.bfloat16, 3), (torch.float32, 8), (torch.float32, 1),
                                      (torch.float16, 3)],
                          ids=["f32_o3", "bf16_o3", "f32_o8", "f32_o1", "f16_o3"])
-def test_skinny_linear_head_matches_torch(dtype, O):
+@pytest.mark.parametrize("I", [35840, 269], ids=["long_rows", "short_odd_rows"])
+def test_skinny_linear_head_matches_torch(dtype, O, I):
+    """I = 35840: the PSD head (streamed, vector loads).  I = 269: the second layer of the hybrid net's head
+    (Linear(269, 3), reference src/models/SPConvNet.py:40-52): rows of any length on the scalar kernels."""
     from waveformml_amd.spconv import functional as Fsp
     torch.manual_seed(4)
-    B, I = 37, 35840
+    B = 37
     lin = torch.nn.Linear(I, O)
     x = torch.randn(B, I).to(dtype)
     g = torch.randn(B, O)

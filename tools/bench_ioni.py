@@ -1,7 +1,7 @@
 """The reference's per-segment classifier (config/examples/IoniClassifierCNN.json: SPConvPreserveNet, six conv -> inverse
 conv layers 130 -> 138 -> 146 -> 154 -> 104 -> 54 -> 5 on the 14 x 11 grid, one logit row per active segment) as a
 training step on the GPU (eager and as a captured HIP graph; every layer in libwfsparse's shape-generic MFMA kernels) beside the CPU restatement on
-the host cores.  A parity case with a timing, not the headline bench.   usage: python tools/bench_ioni.py [events] [steps]"""
+the host cores.  A parity case with a timing, not the headline bench.   usage: python tools/bench_ioni.py [events] [steps] [f32|bf16|f16]"""
 import copy, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,7 @@ from waveformml_amd.psd.litseg import LitSegClassifier
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[sys.argv[3] if len(sys.argv) > 3 else "f32"]
 dev = torch.device("cuda:0")
 torch.cuda.set_stream(torch.cuda.Stream())
 
@@ -35,7 +36,7 @@ gpu = gpu.to(dev)
 c, f, _ = synthetic.generate(B, 65, 5, seed=11, layout="2d")          # [rows, 130] waveform rows on the 14 x 11 grid
 rng = np.random.default_rng(1)
 y = rng.integers(0, 5, len(c))
-cg, fg, yg = torch.from_numpy(c).to(dev), torch.from_numpy(f).to(dev), torch.from_numpy(y).to(dev)
+cg, fg, yg = torch.from_numpy(c).to(dev), torch.from_numpy(f).to(dev).to(dtype), torch.from_numpy(y).to(dev)
 cc, fc, yc = torch.from_numpy(c), torch.from_numpy(f), torch.from_numpy(y)
 og = torch.optim.SGD(gpu.model.parameters(), lr=0.02, momentum=0.98, nesterov=True)
 oc = torch.optim.SGD(cpu.model.parameters(), lr=0.02, momentum=0.98, nesterov=True)
@@ -86,7 +87,7 @@ t0 = time.perf_counter()
 for _ in range(n_cpu):
     step(cpu, oc, ([cc, fc], yc))
 cpu_ms = (time.perf_counter() - t0) / n_cpu * 1e3
-print(json.dumps({"config": "IoniClassifierCNN.json (SPConvPreserveNet, float32 rows)", "events": B, "rows": int(len(c)),
+print(json.dumps({"config": "IoniClassifierCNN.json (SPConvPreserveNet, %s rows)" % str(dtype).split(".")[-1], "events": B, "rows": int(len(c)),
                   "rel_loss_diff_first_step": abs(lg0 - lc0) / abs(lc0), "gpu_eager_ms_per_step": round(gpu_ms, 3),
                   "gpu_graph_ms_per_step": round(graph_ms, 3), "gpu_events_per_s": round(B / graph_ms * 1e3), "cpu_ms_per_step": round(cpu_ms, 2),
                   "cpu_events_per_s": round(B / cpu_ms * 1e3), "cpu_threads": host_cores()}))

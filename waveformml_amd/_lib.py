@@ -132,6 +132,10 @@ def load():
         if got != WFS_ABI_VERSION:
             raise ImportError("%s has ABI version %d, this binding was written for %d (struct layouts / signatures "
                               "differ): rebuild with `make -C waveformml_amd/csrc`" % (LIB_PATH, got, WFS_ABI_VERSION))
+        # WFS_WIDE_MIN_CHANNELS: A/B of the wide-layer path (csrc/wide.hip) -- 0 = off, >= 8 = its channel threshold
+        wide = os.environ.get("WFS_WIDE_MIN_CHANNELS")
+        if wide is not None:
+            lib.wfs_wide_enable(int(wide))
         _LIB = lib
     return _LIB
 

@@ -270,6 +270,79 @@ __global__ void __launch_bounds__(XE_TB) k_xent_mean(const float *__restrict__ Z
     }
 }
 
+// ---- rows of any length (scalar loads): the short second layer of a two-layer head (the hybrid net's Linear(269, 3),
+// reference src/models/SPConvNet.py:40-52) -- a few hundred inputs, nothing a library GEMM or a streaming kernel is for
+template <typename T, int O>
+__global__ void __launch_bounds__(64) k_head_fwd_any(const T *__restrict__ X, const float *__restrict__ W,
+                                                     const float *__restrict__ bias, float *__restrict__ Y, long long I) {
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    float acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) acc[o] = 0.f;
+    for (long long i = lane; i < I; i += 64) {
+        const float x = wfs_ld(X + b * I + i);
+#pragma unroll
+        for (int o = 0; o < O; ++o) acc[o] = fmaf(x, W[o * I + i], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        float v = acc[o];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);       // fixed tree
+        if (lane == 0) Y[b * O + o] = v + (bias ? bias[o] : 0.f);
+    }
+}
+
+// dX[b][i] = sum_o G[b][o] W[o][i]: one thread per element
+template <typename T, int O>
+__global__ void __launch_bounds__(TB) k_head_dx_any(const float *__restrict__ G, const float *__restrict__ W,
+                                                    T *__restrict__ dX, long long B, long long I) {
+    const long long e = (long long)blockIdx.x * TB + threadIdx.x;
+    if (e >= B * I) return;
+    const long long b = e / I, i = e % I;
+    float v = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) v = fmaf(G[b * O + o], W[o * I + i], v);
+    wfs_st(dX + e, v);
+}
+
+// dW[o][i] = sum_b G[b][o] X[b][i]; the column past the last input takes dB[o] = sum_b G[b][o].  Block = 16 columns x
+// 16 batch slots (slot s adds rows s, s + 16, ... in order; the slots are added in slot order: fixed, no atomics).
+template <typename T, int O>
+__global__ void __launch_bounds__(TB) k_head_dw_any(const float *__restrict__ G, const T *__restrict__ X,
+                                                    float *__restrict__ dW, float *__restrict__ dB, long long B,
+                                                    long long I) {
+    __shared__ float red[16][16][O];
+    const int col = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + col;
+    float acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) acc[o] = 0.f;
+    if (i <= I) {
+#pragma unroll 4
+        for (long long b = slot; b < B; b += 16) {
+            const float x = i < I ? wfs_ld(X + b * I + i) : 1.f;
+#pragma unroll
+            for (int o = 0; o < O; ++o) acc[o] = fmaf(G[b * O + o], x, acc[o]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) red[slot][col][o] = acc[o];
+    __syncthreads();
+    if (slot == 0 && i <= I) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float v = red[0][col][o];
+            for (int q = 1; q < 16; ++q) v += red[q][col][o];
+            if (i < I) dW[o * I + i] = v;
+            else if (dB) dB[o] = v;
+        }
+    }
+}
+
+// rows the vector kernels do not take (I % 8 != 0) or that are too short to be worth their chunked reduction
+inline bool head_any(long long I) { return I % 8 != 0 || I < 1024; }
+
 }  // namespace
 
 extern "C" size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O) {
@@ -291,11 +364,18 @@ extern "C" size_t wfs_head_workspace_bytes(int64_t B, int64_t I, int32_t O) {
 extern "C" int wfs_head_fwd(const void *X, int64_t B, int64_t I, const float *W, const float *bias, int32_t O,
                             float *Y, int32_t dtype, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
+    WFS_REQUIRE(O >= 1 && O <= MAXO && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8");
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (B == 0) return WFS_OK;
     WFS_REQUIRE(X && W && Y, WFS_EINVAL, "NULL device pointer");
     dim3 grid((unsigned)B);
+    if (head_any(I)) {
+#define WFS_HEAD_FWD_ANY(T) WFS_HEAD_DISPATCH(O, (k_head_fwd_any<T, OO><<<grid, dim3(64), 0, stream>>>((const T *)X, W, bias, Y, I)))
+        if (dtype == WFS_F32) { WFS_HEAD_FWD_ANY(float); } else if (dtype == WFS_BF16) { WFS_HEAD_FWD_ANY(wfs_bf16); } else { WFS_HEAD_FWD_ANY(wfs_f16); }
+#undef WFS_HEAD_FWD_ANY
+        WFS_LAUNCH_CHECK();
+        return WFS_OK;
+    }
 #define WFS_HEAD_FWD(T, NT)                                                                                          \
     WFS_HEAD_DISPATCH(O, (k_head_fwd<T, OO, NT><<<grid, dim3(NT), 0, stream>>>((const T *)X, W, bias, Y, I)))
     if (I >= 8192) {
@@ -312,13 +392,26 @@ extern "C" int wfs_head_bwd(const void *X, const float *G, int64_t B, int64_t I,
                             float *dW, float *dB, int32_t dtype, void *workspace, size_t workspace_bytes,
                             wfs_dw_job *defer, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    WFS_REQUIRE(O >= 1 && O <= MAXO && I % 8 == 0 && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8 and I %% 8 == 0");
+    WFS_REQUIRE(O >= 1 && O <= MAXO && I > 0, WFS_EINVAL, "head: need 1 <= O <= 8");
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     if (B == 0) {
         if (dW) WFS_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)O * I * sizeof(float), stream));
         return WFS_OK;
     }
     WFS_REQUIRE(X && G && W, WFS_EINVAL, "NULL device pointer");
+    if (head_any(I)) {
+        if (defer) *defer = wfs_dw_job{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
+        const dim3 gdx((unsigned)wfs_cdiv(B * I, TB)), gdw((unsigned)wfs_cdiv(I + 1, 16)), block(TB);
+#define WFS_HEAD_BWD_ANY(T)                                                                                          \
+    do {                                                                                                             \
+        if (dX) WFS_HEAD_DISPATCH(O, (k_head_dx_any<T, OO><<<gdx, block, 0, stream>>>(G, W, (T *)dX, B, I)));        \
+        if (dW) WFS_HEAD_DISPATCH(O, (k_head_dw_any<T, OO><<<gdw, block, 0, stream>>>(G, (const T *)X, dW, dB, B, I))); \
+    } while (0)
+        if (dtype == WFS_F32) { WFS_HEAD_BWD_ANY(float); } else if (dtype == WFS_BF16) { WFS_HEAD_BWD_ANY(wfs_bf16); } else { WFS_HEAD_BWD_ANY(wfs_f16); }
+#undef WFS_HEAD_BWD_ANY
+        WFS_LAUNCH_CHECK();
+        return WFS_OK;
+    }
     const unsigned gx = (unsigned)wfs_cdiv(I, TB * 8);
     if (defer) *defer = wfs_dw_job{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
     if (dX && dW && B + 16 <= 65535) {

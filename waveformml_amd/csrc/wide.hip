@@ -460,6 +460,7 @@ struct Carver {
 
 constexpr long long WIDE_MAX_WORKSPACE = 3ll << 30;
 bool g_wide_on = true;
+int g_wide_min_channels = 128;      // a side of the filter at least this wide (wfs_wide_enable)
 
 // A launch wants a block per CU: products with fewer output tiles than half the CUs cut the contraction into `ksplit`
 // parts of `kchunk` (each at least 128 deep), one fp32 slab per part, summed in part order afterwards (a split that
@@ -552,8 +553,9 @@ extern "C" size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_
 }
 
 extern "C" int wfs_wide_enable(int32_t on) {
-    const int was = g_wide_on ? 1 : 0;
+    const int was = g_wide_on ? g_wide_min_channels : 0;
     g_wide_on = on != 0;
+    if (on >= 8) g_wide_min_channels = on;            // benchmarks: the channel threshold itself
     return was;
 }
 
@@ -563,7 +565,7 @@ extern "C" int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx
     if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return 0;
     if (K < 1 || K > 128 || R < 1 || X_rows < 1 || Cx < 8 || Cy < 8) return 0;
     if (R >= (1ll << 31) || X_rows >= (1ll << 31)) return 0;
-    if ((Cx > Cy ? Cx : Cy) < 256) return 0;
+    if ((Cx > Cy ? Cx : Cy) < g_wide_min_channels) return 0;
     return (long long)wfs_wide_conv_workspace_bytes(K, R, X_rows, Cx, Cy, 1) <= WIDE_MAX_WORKSPACE;
 }
 
@@ -675,7 +677,7 @@ size_t wfs_wide_dw_workspace(int K, long long R, int Cs, int Cg) {
 
 bool wfs_wide_dw_ok(int K, long long R, int Cs, int Cg, int dtype) {
     if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return false;
-    if (K < 1 || K > 128 || R < 1 || R >= (1ll << 31) || Cs < 8 || Cg < 8 || (Cs > Cg ? Cs : Cg) < 256) return false;
+    if (K < 1 || K > 128 || R < 1 || R >= (1ll << 31) || Cs < 8 || Cg < 8 || (Cs > Cg ? Cs : Cg) < g_wide_min_channels) return false;
     return (long long)wfs_wide_dw_workspace(K, R, Cs, Cg) <= WIDE_MAX_WORKSPACE;
 }
 

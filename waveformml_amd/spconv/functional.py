@@ -736,9 +736,10 @@ class SkinnyLinearFunction(Function):
 
 
 def can_use_skinny_linear(linear, x):
+    # long rows (I % 8 == 0, >= 1024: streamed) or short ones of any length (<= 4096: scalar kernels)
     return (type(linear) is torch.nn.Linear and x.is_cuda and x.dim() == 2 and linear.out_features <= 8
-            and x.shape[1] % 8 == 0 and x.shape[1] >= 1024 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
-            and linear.weight.dtype == torch.float32)
+            and ((x.shape[1] % 8 == 0 and x.shape[1] >= 1024) or x.shape[1] <= 4096)
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and linear.weight.dtype == torch.float32)
 
 
 def skinny_linear(x, linear):
