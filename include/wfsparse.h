@@ -160,15 +160,16 @@ int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, i
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
                     int32_t dtype, const int64_t *r_dev, void *stream);
 
-/* Wide layers on the 16-bit matrix cores (round 3; csrc/wide.hip).
+/* Wide layers as dense matrix-core products (round 3; csrc/wide.hip).
  * Same contract as wfs_gather_conv -- replaces torch.ops.spconv.indice_conv / the dX half of
  * indice_conv_backward (spconv 1.2.1 ops.py; the reference reaches them from src/models/SPConvBlocks.py:450-516
  * with 1697 / 1021 / 345 channels, BASELINE configs[4]) and, with K == 1 && table == NULL, the torch.mm of a
- * 1 x 1 SparseConv2d (spconv conv.py: `features = torch.mm(input.features, weight.view(in, out))`) -- for
- * 16-bit rows (WFS_BF16 / WFS_F16) when a side of the filter has >= 256 channels: the layer runs as ONE dense
- * v_mfma_f32_32x32x16 product over whichever side (X_rows source rows, R destination rows) is shorter, fp32
- * accumulate, ordered fp32 sum over the kernel offsets, every output row written once (no atomics).
- * wfs_wide_conv_ok: does this path take the shape?  The workspace holds the 16-bit filters, the padded /
+ * 1 x 1 SparseConv2d (spconv conv.py: `features = torch.mm(input.features, weight.view(in, out))`) -- when a side
+ * of the filter has >= 128 channels: the layer runs as ONE dense product over whichever side (X_rows source rows,
+ * R destination rows) is shorter, on v_mfma_f32_32x32x16_{bf16,f16} for 16-bit rows (filters rounded to the row
+ * type) and on v_mfma_f32_32x32x2_f32 for fp32 rows (an exact fp32 fma chain: the 1e-5 path), fp32 accumulate,
+ * ordered fp32 sum over the kernel offsets, every output row written once (no atomics).
+ * wfs_wide_conv_ok: does this path take the shape?  The workspace holds the filters in the row type, the padded /
  * gathered rows and the per-offset products; 16-byte aligned. */
 int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy, int32_t dtype);
 /* A/B switch for benchmarks (tools/microbench_generic.py): 0 sends every layer back to the 32 x 32-tile kernels
@@ -176,33 +177,33 @@ int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t C
  * many channels on a side.  Returns the previous threshold (0 = was off). */
 int wfs_wide_enable(int32_t on);
 size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy,
-                                     int32_t has_table);
-/* The filters as the products read them: [K][Cw_in][Cw_out rounded up to 8] in the row type, zero padded.  A caller
- * that runs several products on the same filters (the forward pass and dX of one layer) converts them once
- * (wfs_wide_filters16) and hands the copy to wfs_wide_gather_conv as W16; with W16 == NULL every call converts W
- * into its workspace. */
-size_t wfs_wide_filters16_bytes(int32_t K, int32_t Cw_in, int32_t Cw_out);
-int wfs_wide_filters16(const float *W, int32_t K, int32_t Cw_in, int32_t Cw_out, int32_t dtype, void *W16,
-                       void *stream);
+                                     int32_t has_table, int32_t dtype);
+/* The filters as the products read them: [K][Cw_in][Cw_out rounded up to whole 16-byte pieces] in the row type,
+ * zero padded.  A caller that runs several products on the same filters (the forward pass and dX of one layer)
+ * converts them once (wfs_wide_filters) and hands the copy to wfs_wide_gather_conv as Wp; with Wp == NULL every
+ * call converts W into its workspace (fp32 filters whose rows are whole pieces are read in place). */
+size_t wfs_wide_filters_bytes(int32_t K, int32_t Cw_in, int32_t Cw_out, int32_t dtype);
+int wfs_wide_filters(const float *W, int32_t K, int32_t Cw_in, int32_t Cw_out, int32_t dtype, void *Wp,
+                     void *stream);
 int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
-                         int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, const void *W16,
+                         int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, const void *Wp,
                          int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
                          int32_t dtype, const int64_t *r_dev, void *workspace, size_t workspace_bytes,
                          void *stream);
 
-/* Dense head layer on the 16-bit matrix cores (round 3; csrc/wide.hip).
+/* Dense head layer on the matrix cores (round 3; csrc/wide.hip).
  * Replaces torch.nn.functional.linear for the reference's dense head when it is wide (the hybrid net's
- * Linear(24150, 269), src/models/SPConvNet.py:40-52 through LinearBlock): y = x W^T + b with 16-bit x [B, I],
- * fp32 W [O, I] (nn.Linear's layout, rounded to the row type for the product), fp32 accumulate, fp32 y.  The
- * backward takes fp32 dY (rounded to the row type as an operand) and returns dX in the row type, dW / db in fp32;
- * any of the three may be NULL.  Contractions with few output tiles are cut into parts and summed in a fixed order.
- * wfs_linear16_ok: I >= 256, O >= 9 (narrower heads: wfs_head_fwd), 16-bit rows. */
-int wfs_linear16_ok(int64_t B, int32_t I, int32_t O, int32_t dtype);
-size_t wfs_linear16_workspace_bytes(int64_t B, int32_t I, int32_t O);
-int wfs_linear16_fwd(const void *X, int64_t B, int32_t I, const float *W, const float *bias, int32_t O, float *Y,
-                     int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
-int wfs_linear16_bwd(const void *X, const float *dY, int64_t B, int32_t I, const float *W, int32_t O, void *dX,
-                     float *dW, float *db, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
+ * Linear(24150, 269), src/models/SPConvNet.py:40-52 through LinearBlock): y = x W^T + b with x [B, I] in the row
+ * type, fp32 W [O, I] (nn.Linear's layout; rounded to the row type for a 16-bit product), fp32 accumulate, fp32 y.
+ * The backward takes fp32 dY (rounded to the row type as an operand) and returns dX in the row type, dW / db in
+ * fp32; any of the three may be NULL.  Contractions with few output tiles are cut into parts and summed in a fixed
+ * order.  wfs_wide_linear_ok: I >= 256, O >= 9 (narrower heads: wfs_head_fwd). */
+int wfs_wide_linear_ok(int64_t B, int32_t I, int32_t O, int32_t dtype);
+size_t wfs_wide_linear_workspace_bytes(int64_t B, int32_t I, int32_t O, int32_t dtype);
+int wfs_wide_linear_fwd(const void *X, int64_t B, int32_t I, const float *W, const float *bias, int32_t O, float *Y,
+                        int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
+int wfs_wide_linear_bwd(const void *X, const float *dY, int64_t B, int32_t I, const float *W, int32_t O, void *dX,
+                        float *dW, float *db, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Event-local rulebook build (round 3; csrc/evrulebook.hip).
  * A sparse convolution never crosses events (the rulebook key includes the batch index) and the

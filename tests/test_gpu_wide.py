@@ -1,5 +1,7 @@
 """GPU checks of the wide-layer path (csrc/wide.hip; include/wfsparse.h wfs_wide_gather_conv and the wide arm of
-wfs_gather_dw): 16-bit rows with >= 256 channels on a side run as dense v_mfma_f32_32x32x16 products.
+wfs_gather_dw): layers with >= 128 channels on a side run as dense matrix-core products -- v_mfma_f32_32x32x16 for
+16-bit rows, the exact-fp32 v_mfma_f32_32x32x2_f32 for fp32 rows (the 1e-5 path: compared to 1e-5 of the tensor scale
+against fp64 on the unrounded operands).
 
 Primitive level: random gather tables, odd channel counts (rows only 2-byte aligned), both product orders (the dense
 product over the source rows + ordered sum, the gathered product over the destination rows, with and without the
@@ -20,7 +22,10 @@ from helpers import rand_coords
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-ULP = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+ULP = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 0.0}
+TOL = {torch.bfloat16: 1e-4, torch.float16: 1e-4, torch.float32: 1e-5}
+DTYPES = [torch.bfloat16, torch.float16, torch.float32]
+DTYPE_IDS = ["bf16", "f16", "f32"]
 
 
 def _round(a, dtype):
@@ -58,7 +63,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("case", CASES, ids=[str(c[:5]) for c in CASES])
 @pytest.mark.parametrize("transpose_w", [False, True], ids=["fwd", "dx"])
 def test_wide_gather_conv_against_fp64_on_rounded_operands(case, dtype, transpose_w):
@@ -87,7 +92,7 @@ def test_wide_gather_conv_against_fp64_on_rounded_operands(case, dtype, transpos
         want = want[:valid]
         scale = np.abs(want).max()
         err = np.abs(got - want) - ULP[dtype] * np.abs(want)
-        assert err.max() <= 1e-4 * scale, (err.max(), scale)
+        assert err.max() <= TOL[dtype] * scale, (err.max(), scale)
 
 
 DW_CASES = [
@@ -99,7 +104,7 @@ DW_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("case", DW_CASES, ids=[str(c[:5]) for c in DW_CASES])
 @pytest.mark.parametrize("swap", [False, True], ids=["dw", "dw_swapped"])
 def test_wide_gather_dw_against_fp64_on_rounded_operands(case, dtype, swap):
@@ -127,7 +132,7 @@ def test_wide_gather_dw_against_fp64_on_rounded_operands(case, dtype, swap):
             want = want.transpose(0, 2, 1)
         got = dW.cpu().numpy().astype(np.float64)
         assert got.shape == want.shape
-        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+        assert np.abs(got - want).max() <= TOL[dtype] * np.abs(want).max()
 
 
 def test_unaligned_views_are_read_correctly():
@@ -151,7 +156,8 @@ def test_unaligned_views_are_read_correctly():
         outs.append(got)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)], ids=["bf16", "f16"])
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3), (torch.float32, 1e-5)],
+                         ids=["bf16", "f16", "f32"])
 def test_wide_layers_forward_backward_against_the_cpu_oracle(dtype, tol):
     """1 x 1 conv 300 -> 264 (spconv's torch.mm), BatchNorm, ReLU, 3 x 3 conv 264 -> 130 with a bias, as the reference's
     block generator stacks them (src/models/SPConvBlocks.py:450-516), against the fp32 CPU restatement on the same
@@ -169,8 +175,8 @@ def test_wide_layers_forward_backward_against_the_cpu_oracle(dtype, tol):
     net = sp.SparseSequential(sp.SparseConv2d(300, 264, 1, 1, 0, 1, 1, True), torch.nn.BatchNorm1d(264), torch.nn.ReLU(),
                               sp.SparseConv2d(264, 130, 3, 1, 0, 1, 1, True)).to(DEV)
     net.load_state_dict(ref.state_dict())
-    fr = feat.float().requires_grad_(True)
     fg = feat.to(DEV).requires_grad_(True)
+    fr = feat.float().clone().requires_grad_(True)
     yr = ref(osp.SparseConvTensor(fr, torch.from_numpy(idx), list(shape), B))
     yg = net(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), list(shape), B))
     assert yg.features.dtype == dtype
@@ -192,7 +198,7 @@ def test_wide_layers_forward_backward_against_the_cpu_oracle(dtype, tol):
     # ReLU mask of the few elements that sit within a rounding step of zero, and each flip is a full-size error in one
     # element (measured, tools/exp/diag_wide2.py: the same net through the 32 x 32-tile kernels differs from this
     # path by 1e-2 in the L2 norm and 0.4 of the scale in single elements, with dX of the 3 x 3 layer equal to 3e-4).
-    l2 = {torch.bfloat16: 6e-2, torch.float16: 2.5e-2}[dtype]
+    l2 = {torch.bfloat16: 6e-2, torch.float16: 2.5e-2, torch.float32: 1e-4}[dtype]
     close_l2(fg.grad, fr.grad, "dX", l2)
     for (name, a), (_n, b) in zip(net.named_parameters(), ref.named_parameters()):
         if name == "0.bias":
@@ -240,8 +246,8 @@ def test_wide_batchnorm_with_a_device_side_row_count(C, dtype):
         assert np.abs(a - b).max() <= ulp * max(np.abs(a).max(), 1e-30)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("B,I,O", [(256, 24150, 269), (37, 1000, 33), (300, 515, 700)])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
+@pytest.mark.parametrize("B,I,O", [(256, 24150, 269), (37, 1000, 33), (300, 515, 700), (64, 512, 260)])
 def test_wide_linear_against_fp64_on_rounded_operands(B, I, O, dtype):
     """wfs_linear16_fwd / _bwd (the hybrid net's Linear(24150, 269)): y, dX, dW, db against numpy fp64 on the operands
     as the kernels see them (x, W and dY rounded to the row type): fp32 results within 1e-4 of scale, dX within one unit
@@ -263,9 +269,37 @@ def test_wide_linear_against_fp64_on_rounded_operands(B, I, O, dtype):
     def close(got, want, what, ulp=0.0):
         got = got.detach().float().cpu().numpy().astype(np.float64)
         err = np.abs(got - want) - ulp * np.abs(want)
-        assert err.max() <= 1e-4 * np.abs(want).max(), (what, err.max(), np.abs(want).max())
+        assert err.max() <= TOL[dtype] * np.abs(want).max(), (what, err.max(), np.abs(want).max())
 
     close(y, xr @ wr.T + b, "y")
     close(xg.grad, gr @ wr, "dX", ULP[dtype])
     close(lin.weight.grad, gr.T @ xr, "dW")
     close(lin.bias.grad, g.astype(np.float64).sum(0), "db")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)], ids=["f32", "bf16"])
+def test_narrow_pointwise_conv_runs_in_the_library(dtype, tol):
+    """A 1 x 1 SparseConv2d below the wide path's channel threshold (20 -> 12): spconv's torch.mm is replaced by the
+    gather kernels with the identity map (no table); forward and backward against the CPU oracle."""
+    import waveformml_amd.spconv as sp
+    from oracle import spconv as osp
+    rng = np.random.default_rng(5)
+    shape, B, n = (14, 11), 6, 150
+    idx = rand_coords(rng, B, shape, n)
+    idx = np.ascontiguousarray(idx[np.argsort(idx[:, 0], kind="stable")])
+    feat = torch.from_numpy(rng.standard_normal((n, 20)).astype(np.float32)).to(dtype)
+    torch.manual_seed(2)
+    ref = osp.SparseConv2d(20, 12, 1, 1, 0, 1, 1, True)
+    layer = sp.SparseConv2d(20, 12, 1, 1, 0, 1, 1, True).to(DEV)
+    layer.load_state_dict(ref.state_dict())
+    fg = feat.to(DEV).requires_grad_(True)
+    fr = feat.float().clone().requires_grad_(True)
+    yr = ref(osp.SparseConvTensor(fr, torch.from_numpy(idx), list(shape), B))
+    yg = layer(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), list(shape), B))
+    g = torch.from_numpy(rng.standard_normal(tuple(yr.features.shape)).astype(np.float32))
+    yr.features.backward(g)
+    yg.features.backward(g.to(DEV).to(dtype))
+    for what, a, b in (("y", yg.features, yr.features), ("dX", fg.grad, fr.grad), ("dW", layer.weight.grad, ref.weight.grad),
+                       ("db", layer.bias.grad, ref.bias.grad)):
+        a, b = a.detach().float().cpu().numpy(), b.detach().float().numpy()
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (what, np.abs(a - b).max(), np.abs(b).max())

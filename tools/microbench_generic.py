@@ -1,6 +1,6 @@
 """The shape-generic MFMA conv kernels (gather_conv.hip k_gconv_mfma / k_gdw_mfma) on the reference's 2-D layer shapes
-(GEP.json: 252 -> 158 and 158 -> 64 channels, 3 x 3, a few hundred rows) against the route they replace (rows gathered
-with torch index kernels into [R, K * C] + one library GEMM).  usage: python tools/microbench_generic.py [events] [dtype] [wide]      (wide: the hybrid net's 1697 -> 1021 -> 345 layers)"""
+(GEP.json: 252 -> 158 and 158 -> 64 channels, 3 x 3, a few hundred rows) against the dense 128 x 128-tile
+products of wide.hip (the round-2 library-GEMM route these replaced: profiles/r02_microbench_generic_mfma.txt).  usage: python tools/microbench_generic.py [events] [dtype] [wide]      (wide: the hybrid net's 1697 -> 1021 -> 345 layers)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -49,17 +49,14 @@ for (ci, co) in SHAPES:
     X = torch.randn(r.N, ci, device=dev).to(DT)
     dY = torch.randn(r.M, co, device=dev).to(DT)
     W = torch.randn(K, ci, co, device=dev) * 0.05
-    routes = [("libwfsparse wide (16-bit MFMA, 128 x 128 tiles)", 1, 1 << 30)] if DT != torch.float32 else []
-    routes += [("libwfsparse 32 x 32-tile MFMA", 0, 1 << 30), ("torch gather + library GEMM", 0, 8)]
+    routes = [("libwfsparse wide (128 x 128-tile MFMA)", 1, 0), ("libwfsparse 32 x 32-tile MFMA", 0, 0)]
     for route, wide, lim in routes:
         lib.wfs_wide_enable(wide)
-        Fsp.GEMM_ROUTE_MIN_CHANNELS = lim
-        Fsp.GEMM_ROUTE_ANY_DTYPE = True
         timeit("%d->%d fwd  %s" % (ci, co, route), lambda: Fsp.gather_conv(r.nbr_in, None, K, -1, r.M, X, W, False, None))
         timeit("%d->%d dX   %s" % (ci, co, route), lambda: Fsp.gather_conv(r.nbr_out, None, K, -1, r.N, dY, W, True, None))
         timeit("%d->%d dW   %s" % (ci, co, route), lambda: Fsp.gather_dw(r.nbr_out, K, -1, r.N, X, dY, False))
     lib.wfs_wide_enable(1)
-if WIDE and DT != torch.float32:
+if WIDE:
     # the hybrid net's 1 x 1 layer (2048 -> 1697): spconv's torch.mm against the wide path
     R = rb.N
     X = torch.randn(R, 2048, device=dev).to(DT)

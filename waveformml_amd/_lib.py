@@ -57,15 +57,15 @@ SIGNATURES = {
                                        _vp, _vp, _i32, _vp, _vp]),
     "wfs_wide_conv_ok": (ctypes.c_int, [_i32, _i64, _i64, _i32, _i32, _i32]),
     "wfs_wide_enable": (ctypes.c_int, [_i32]),
-    "wfs_wide_conv_workspace_bytes": (_sz, [_i32, _i64, _i64, _i32, _i32, _i32]),
-    "wfs_wide_filters16_bytes": (_sz, [_i32, _i32, _i32]),
-    "wfs_wide_filters16": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "wfs_wide_conv_workspace_bytes": (_sz, [_i32, _i64, _i64, _i32, _i32, _i32, _i32]),
+    "wfs_wide_filters_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "wfs_wide_filters": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "wfs_wide_gather_conv": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
-    "wfs_linear16_ok": (ctypes.c_int, [_i64, _i32, _i32, _i32]),
-    "wfs_linear16_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "wfs_linear16_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _sz, _vp]),
-    "wfs_linear16_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "wfs_wide_linear_ok": (ctypes.c_int, [_i64, _i32, _i32, _i32]),
+    "wfs_wide_linear_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "wfs_wide_linear_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "wfs_wide_linear_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "wfs_event_offsets_ints": (_sz, [_i32]),
     "wfs_event_offsets": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "wfs_event_rulebook_ok": (ctypes.c_int, [ctypes.POINTER(Geometry)]),

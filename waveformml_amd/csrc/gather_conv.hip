@@ -544,8 +544,8 @@ extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identit
 extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs, int32_t Cg) {
     size_t generic = (size_t)(gm_shape(Cs, Cg) ? dw_chunks_mfma(R, K, Cs, Cg) : dw_chunks(R)) * K * Cs * Cg * sizeof(float);
     size_t fast = wfs_dw_fast_workspace(K, R, Cs, Cg);
-    if (wfs_wide_dw_ok(K, R, Cs, Cg, WFS_BF16)) {
-        size_t wide = wfs_wide_dw_workspace(K, R, Cs, Cg);
+    if (wfs_wide_dw_ok(K, R, Cs, Cg, WFS_F32)) {                  // fp32 rows need the larger staging copies
+        size_t wide = wfs_wide_dw_workspace(K, R, Cs, Cg, WFS_F32);
         generic = generic > wide ? generic : wide;
     }
     return generic > fast ? generic : fast;

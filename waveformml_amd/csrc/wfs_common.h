@@ -118,9 +118,9 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
                            const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream);
 size_t wfs_conv_stats_fast_workspace(long long R);
-// wide layers (wide.hip): dW on the 16-bit matrix cores
+// wide layers (wide.hip): dW as dense matrix-core products
 bool wfs_wide_dw_ok(int K, long long R, int Cs, int Cg, int dtype);
-size_t wfs_wide_dw_workspace(int K, long long R, int Cs, int Cg);
+size_t wfs_wide_dw_workspace(int K, long long R, int Cs, int Cg, int dtype);
 int wfs_launch_wide_dw(const int *table, const int *kmap_host, int K, int identity_k, long long R, const long long *r_dev,
                        const void *S, int Cs, const void *G, long long G_rows, int Cg, int swap, float *dW, int dtype,
                        void *workspace, size_t workspace_bytes, hipStream_t stream);

@@ -1,13 +1,14 @@
-// wide.hip -- sparse convolutions with hundreds to thousands of channels on the 16-bit matrix cores.
+// wide.hip -- sparse convolutions with hundreds to thousands of channels as dense matrix-core products.
 //
 // The reference's hybrid net (BASELINE configs[4]: TemporalConvNet front end -> SparseConv2d 2048 -> 1697 (1 x 1)
 // -> 1021 -> 345 (3 x 3), src/models/SPConvBlocks.py:450-516 through spconv's indice_conv) spends its time in
 // products of tens of GFLOP per layer.  A 32-row x 32-column block (gather_conv.hip) re-reads 62 MB of filters per
 // row tile there; this file carries those layers instead:
 //
-//   k_gemm16      C[z] = A[z] . B[z]^T on v_mfma_f32_32x32x16_{bf16,f16}: 128 x 128 output tile, 64-deep steps, 4 waves
-//                 (64 x 64 each), double-buffered LDS filled from a register stage (next tile's global loads in flight
-//                 under the MFMAs of this one), fp32 accumulate.  Either operand may be stored contraction-contiguous
+//   k_gemm16      C[z] = A[z] . B[z]^T on v_mfma_f32_32x32x16_{bf16,f16} (16-bit rows) or v_mfma_f32_32x32x2_f32 (fp32
+//                 rows: bitwise an fp32 fma chain, the 1e-5 path): 128 x 128 output tile, 128-byte-deep steps (64 / 32
+//                 elements), 4 waves (64 x 64 each), double-buffered LDS filled from two register stages (the global
+//                 loads of tile t + 2 in flight under the MFMAs of tiles t and t + 1), fp32 accumulate.  Either operand may be stored contraction-contiguous
 //                 ([rows][k], read back with ds_read_b128 from an XOR-swizzled 128-B-row image) or contraction-major
 //                 ([k][rows], read back TRANSPOSED with ds_read_b64_tr_b16 from a 256-B-row image): forward, dX and dW
 //                 all take the filters and the rows in the layout they already have -- no transposed copies.
@@ -36,7 +37,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GT = 128;           // output tile edge
-constexpr int GK = 64;            // contraction depth of one step
+constexpr int GKB = 128;          // contraction depth of one step in BYTES: 64 16-bit or 32 fp32 elements
 constexpr int GTHREADS = 256;     // 4 waves: 2 (rows) x 2 (columns) of 64 x 64
 // Timing knock-outs (tools/exp/knock_gemm.sh): -DWFS_GEMM_KNOCK=bits builds a library whose k_gemm16 skips a phase --
 // 1 the global loads after the first two tiles, 2 the MFMAs, 4 the LDS stores after the first two tiles.  Results are
@@ -46,19 +47,19 @@ constexpr int GTHREADS = 256;     // 4 waves: 2 (rows) x 2 (columns) of 64 x 64
 #endif
 
 struct GemmArgs {
-    const unsigned short *A, *B;
+    const void *A, *B;            // elements of the row type (2 or 4 bytes)
     void *C;
     const float *bias;            // [N] or NULL (16-bit output only)
-    long long lda, ldb, ldc;      // row pitches in elements (lda, ldb: multiples of 8)
+    long long lda, ldb, ldc;      // row pitches in elements (lda, ldb: multiples of 16 bytes)
     long long sA, sB;             // element offset of segment s: A + s * sA, B + s * sB
     long long zC, pC;             // element offsets in C of segment batch zs and of contraction part `part`
     int M, N, Ks;                 // Ks: contraction length of ONE segment
     int nseg_total, nseg;         // segments in all / per batch: batch zs takes segments zs * nseg ...
     int nz;                       // segment batches
-    int ksplit, kchunk;           // every segment's contraction is cut into ksplit parts of kchunk (multiple of 64):
+    int ksplit, kchunk;           // every segment's contraction is cut into ksplit parts of kchunk (multiple of a step):
                                   // block z = zs * ksplit + part writes its own slab of C (summed by k_sum_rows)
     const long long *k_dev;       // optional device-side contraction length (<= Ks): rows of a dW product
-    int out_h;                    // 1: C holds 16-bit elements (bias added), 0: fp32
+    int out_h;                    // 1: C holds elements of the row type (bias added), 0: fp32 partial products
 };
 
 template <typename H>
@@ -79,64 +80,89 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
     return v;
 }
 
-// One operand tile (BO rows of the output dimension x 64 of the contraction) from global memory into BO / 32 x 16 bytes
-// per thread.  KM == false: stored [row][k]: a thread takes piece (t & 7) of rows (t >> 3) + 32 i -- 8 lanes read one
-// full 128-B line.  KM == true: stored [k][row]: chunk t % (BO / 8) of contraction rows t / (BO / 8) + (2048 / BO) i --
-// BO / 8 lanes read 2 BO contiguous bytes.  Rows / columns beyond the matrix edge are read from a clamped address (their
-// products are never stored); contraction indices beyond the segment give zeros.
-template <bool KM, int BO>
-__device__ __forceinline__ void g_load(uint4 (&r)[BO / 32], const unsigned short *__restrict__ base, long long ld, int o0,
-                                       int lim, int kk0, int Ks, int t) {
+// One operand tile (BO rows of the output dimension x 128 bytes of the contraction) from global memory into BO / 32 x 16
+// bytes per thread; ES = element size.  KM == false: stored [row][k]: a thread takes piece (t & 7) of rows (t >> 3) +
+// 32 i -- 8 lanes read one full 128-B line.  KM == true: stored [k][row]: 16-byte chunk t % CH of contraction rows
+// t / CH + RP i.  Rows / columns beyond the matrix edge are read from a clamped address (their products are never
+// stored); contraction indices beyond the segment are read from a clamped address too and zeroed when the tile is
+// written to LDS (s_store) -- a select right behind the load would make the wave wait for its prefetch before the MFMAs
+// it is meant to run under (measured: s_waitcnt vmcnt(0) ahead of the MFMA block, 41 % of the wave cycles waiting).
+template <bool KM, int BO, int ES>
+__device__ __forceinline__ void g_load(uint4 (&r)[BO / 32], const char *__restrict__ base, long long ld, int o0, int lim,
+                                       int kk0, int Ks, int t) {
+    constexpr int PE = 16 / ES;                      // elements per 16-byte piece
     if constexpr (!KM) {
         const int p = t & 7, rr = t >> 3;
-        const bool kok = kk0 + p * 8 < Ks;
-        const int kk = kok ? kk0 + p * 8 : 0;
+        const bool kok = kk0 + p * PE < Ks;
+        const int kk = kok ? kk0 + p * PE : 0;
 #pragma unroll
         for (int i = 0; i < BO / 32; ++i) {
             int row = o0 + rr + 32 * i;
             row = row < lim ? row : lim - 1;
-            r[i] = *reinterpret_cast<const uint4 *>(base + (long long)row * ld + kk);
+            r[i] = *reinterpret_cast<const uint4 *>(base + ((long long)row * ld + kk) * ES);
         }
     } else {
-        constexpr int CH = BO / 8, RP = GTHREADS / CH;      // chunks per contraction row, rows per pass
+        constexpr int CH = BO / PE, RP = GTHREADS / CH;      // chunks per contraction row, rows per pass
         const int ch = t % CH, rr = t / CH;
-        int col = o0 + ch * 8;
+        int col = o0 + ch * PE;
         col = col < lim ? col : o0;                  // whole chunks beyond the edge: any valid address
 #pragma unroll
         for (int i = 0; i < BO / 32; ++i) {
             const int kk = kk0 + rr + RP * i;
             const bool ok = kk < Ks;
-            r[i] = *reinterpret_cast<const uint4 *>(base + (long long)(ok ? kk : 0) * ld + col);
+            r[i] = *reinterpret_cast<const uint4 *>(base + ((long long)(ok ? kk : 0) * ld + col) * ES);
         }
     }
 }
 
-// LDS images (byte offsets inside one operand tile of BO x 64 elements):
-//   [row][k]: 128-B rows, 16-B piece p of row r at r * 128 + ((p ^ ((r >> 1) & 7)) << 4): the 16-lane groups of
-//             ds_read_b128 ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md "LDS") land on 16 distinct 16-B bank groups
-//   [k][row]: 2 BO-byte rows, 16-B chunk c of contraction row k at k * 2 BO + ((c ^ ((k & 3) << 2)) << 4): the 4 rows x
-//             32 columns one half-wave takes with ds_read_b64_tr_b16 cover all 64 banks once
-template <bool KM, int BO>
+// LDS images (byte offsets inside one operand tile of BO x 128 bytes), every read conflict-free (SQ_LDS_BANK_CONFLICT 0):
+//   16-bit [row][k]: 128-B rows, 16-B piece p of row r at r * 128 + ((p ^ ((r >> 1) & 7)) << 4): the 16-lane groups of
+//                    ds_read_b128 ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md "LDS") land on 16 distinct bank groups
+//   16-bit [k][row]: 2 BO-byte rows, chunk c of contraction row k at k * 2 BO + ((c ^ ((k & 3) << 2)) << 4): the 4 rows
+//                    x 32 columns one half-wave takes with ds_read_b64_tr_b16 cover all 64 banks once
+//   fp32 [row][k]:   128-B rows read one dword per lane (row = lane & 31): piece p at p ^ (r & 7), and the four words of
+//                    a piece rotated by (r >> 3) & 3 -- 32 rows, 32 banks
+//   fp32 [k][row]:   4 BO-byte rows, plain: a half-wave reads 32 consecutive dwords
+__device__ __forceinline__ uint4 rot_words(uint4 v, int rot) {       // word j of the result = word (j - rot) & 3 of v
+    const unsigned a = v.x, b = v.y, c = v.z, d = v.w;
+    uint4 o;
+    o.x = rot == 0 ? a : rot == 1 ? d : rot == 2 ? c : b;
+    o.y = rot == 0 ? b : rot == 1 ? a : rot == 2 ? d : c;
+    o.z = rot == 0 ? c : rot == 1 ? b : rot == 2 ? a : d;
+    o.w = rot == 0 ? d : rot == 1 ? c : rot == 2 ? b : a;
+    return o;
+}
+
+template <bool KM, int BO, int ES>
 __device__ __forceinline__ void s_store(unsigned char *tile, const uint4 (&r)[BO / 32], int kk0, int Ks, int t) {
+    constexpr int PE = 16 / ES;
     if constexpr (!KM) {
         const int p = t & 7, rr = t >> 3;
-        const bool kok = kk0 + p * 8 < Ks;
-        unsigned char *d = tile + rr * 128 + ((p ^ ((rr >> 1) & 7)) << 4);
+        const bool kok = kk0 + p * PE < Ks;
+        if constexpr (ES == 2) {
+            unsigned char *d = tile + rr * 128 + ((p ^ ((rr >> 1) & 7)) << 4);
 #pragma unroll
-        for (int i = 0; i < BO / 32; ++i) *reinterpret_cast<uint4 *>(d + i * 32 * 128) = keep_if(r[i], kok);
+            for (int i = 0; i < BO / 32; ++i) *reinterpret_cast<uint4 *>(d + i * 32 * 128) = keep_if(r[i], kok);
+        } else {
+            unsigned char *d = tile + rr * 128 + ((p ^ (rr & 7)) << 4);
+            const int rot = (rr >> 3) & 3;           // rows rr + 32 i share it
+#pragma unroll
+            for (int i = 0; i < BO / 32; ++i)
+                *reinterpret_cast<uint4 *>(d + i * 32 * 128) = rot_words(keep_if(r[i], kok), rot);
+        }
     } else {
-        constexpr int CH = BO / 8, RP = GTHREADS / CH;
+        constexpr int CH = BO / PE, RP = GTHREADS / CH, PITCH = BO * ES;
         static_assert(RP % 4 == 0, "the row swizzle must not change from pass to pass");
         const int ch = t % CH, rr = t / CH;
-        unsigned char *d = tile + rr * (2 * BO) + ((ch ^ ((rr & 3) << 2)) << 4);
+        unsigned char *d = tile + rr * PITCH + ((ES == 2 ? (ch ^ ((rr & 3) << 2)) : ch) << 4);
 #pragma unroll
         for (int i = 0; i < BO / 32; ++i)
-            *reinterpret_cast<uint4 *>(d + i * RP * (2 * BO)) = keep_if(r[i], kk0 + rr + RP * i < Ks);
+            *reinterpret_cast<uint4 *>(d + i * RP * PITCH) = keep_if(r[i], kk0 + rr + RP * i < Ks);
     }
 }
 
-// MFMA operand (32 rows of the output dimension starting at o, contraction sub-step s of 16) of lane (i = lane & 31,
-// h = lane >> 5): elements k = 16 s + 8 h .. + 7 of row o + i.
+// 16-bit MFMA operand (32 rows of the output dimension starting at o, contraction sub-step s of 16) of lane (i = lane &
+// 31, h = lane >> 5): elements k = 16 s + 8 h .. + 7 of row o + i.
 template <bool KM, int BO>
 __device__ __forceinline__ s16x8 frag(const unsigned char *tile, int o, int s, int lane) {
     if constexpr (!KM) {
@@ -156,15 +182,26 @@ __device__ __forceinline__ s16x8 frag(const unsigned char *tile, int o, int s, i
     }
 }
 
+// fp32 MFMA operand (v_mfma_f32_32x32x2_f32): element k = 2 s + h of row o + i
+template <bool KM, int BO>
+__device__ __forceinline__ float frag32(const unsigned char *tile, int o, int s, int lane) {
+    const int row = o + (lane & 31), kk = 2 * s + (lane >> 5);
+    if constexpr (!KM)
+        return *reinterpret_cast<const float *>(tile + row * 128 + ((((kk >> 2) ^ (row & 7))) << 4) +
+                                                (((kk & 3) + (row >> 3)) & 3) * 4);
+    else
+        return *reinterpret_cast<const float *>(tile + kk * (4 * BO) + row * 4);
+}
+
 // BM x BN output tile, 4 waves as 2 (rows) x 2 (columns), each BM / 2 x BN / 2.  Two LDS buffers; DEPTH register
 // stages: with DEPTH == 2 the global loads of tile t + 2 are issued before the MFMAs of tile t and written to LDS
-// after those of tile t + 1 -- two compute phases to arrive in (the 256 x 128 form: one block per CU, one wave per
-// SIMD, 1024 MFMA cycles per step against a load round trip of more than that under load).
+// after those of tile t + 1 -- two compute phases to arrive in.
 template <typename H, bool A_KM, bool B_KM, int BM, int BN, int DEPTH>
 __global__ void __launch_bounds__(GTHREADS) k_gemm16(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int ES = sizeof(H), GK = GKB / ES;
     constexpr int TM = BM / 64, TN = BN / 64;                   // 32 x 32 MFMA tiles of a wave
-    constexpr int A_BYTES = BM * GK * 2, STAGE = (BM + BN) * GK * 2;
+    constexpr int A_BYTES = BM * GKB, STAGE = (BM + BN) * GKB;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w & 1, wn = w >> 1;
     // consecutive block ids go round the 8 XCDs: give every XCD one contiguous range of tiles, rows fastest, so that
     // the blocks sharing a B panel (the large operand: filters / gathered rows) sit behind one L2
@@ -199,38 +236,55 @@ __global__ void __launch_bounds__(GTHREADS) k_gemm16(GemmArgs g) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     uint4 ra[DEPTH][BM / 32], rb[DEPTH][BN / 32];
+    const char *Ab = reinterpret_cast<const char *>(g.A), *Bb = reinterpret_cast<const char *>(g.B);
     auto fetch = [&](int st, uint4 (&xa)[BM / 32], uint4 (&xb)[BN / 32]) {
         if ((WFS_GEMM_KNOCK & 1) && st > 1) return;
         const int seg = seg0 + st / per_seg, kk0 = k_lo + (st % per_seg) * GK;
-        g_load<A_KM, BM>(xa, g.A + seg * g.sA, g.lda, m0, g.M, kk0, k_hi, t);
-        g_load<B_KM, BN>(xb, g.B + seg * g.sB, g.ldb, n0, g.N, kk0, k_hi, t);
+        g_load<A_KM, BM, ES>(xa, Ab + seg * g.sA * ES, g.lda, m0, g.M, kk0, k_hi, t);
+        g_load<B_KM, BN, ES>(xb, Bb + seg * g.sB * ES, g.ldb, n0, g.N, kk0, k_hi, t);
     };
     auto park = [&](int st, const uint4 (&xa)[BM / 32], const uint4 (&xb)[BN / 32]) {      // tile st -> buffer st & 1
         if ((WFS_GEMM_KNOCK & 4) && st > 1) return;
         const int kk0 = k_lo + (st % per_seg) * GK;
-        s_store<A_KM, BM>(lds + (st & 1) * STAGE, xa, kk0, k_hi, t);
-        s_store<B_KM, BN>(lds + (st & 1) * STAGE + A_BYTES, xb, kk0, k_hi, t);
+        s_store<A_KM, BM, ES>(lds + (st & 1) * STAGE, xa, kk0, k_hi, t);
+        s_store<B_KM, BN, ES>(lds + (st & 1) * STAGE + A_BYTES, xb, kk0, k_hi, t);
     };
     auto compute = [&](int buf) {
         const unsigned char *ta = lds + buf * STAGE, *tb = ta + A_BYTES;
+        if constexpr (ES == 2) {
 #pragma unroll
-        for (int s = 0; s < GK / 16; ++s) {
-            s16x8 af[TM], bf[TN];
+            for (int s = 0; s < GK / 16; ++s) {
+                s16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = frag<A_KM, BM>(ta, wm * (BM / 2) + a * 32, s, lane);
+                for (int a = 0; a < TM; ++a) af[a] = frag<A_KM, BM>(ta, wm * (BM / 2) + a * 32, s, lane);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = frag<B_KM, BN>(tb, wn * (BN / 2) + b * 32, s, lane);
-            if (WFS_GEMM_KNOCK & 2) {          // no MFMA: keep the fragment reads alive
+                for (int b = 0; b < TN; ++b) bf[b] = frag<B_KM, BN>(tb, wn * (BN / 2) + b * 32, s, lane);
+                if (WFS_GEMM_KNOCK & 2) {          // no MFMA: keep the fragment reads alive
 #pragma unroll
-                for (int a = 0; a < TM; ++a) asm volatile("" ::"v"(af[a]));
+                    for (int a = 0; a < TM; ++a) asm volatile("" ::"v"(af[a]));
 #pragma unroll
-                for (int b = 0; b < TN; ++b) asm volatile("" ::"v"(bf[b]));
-                continue;
+                    for (int b = 0; b < TN; ++b) asm volatile("" ::"v"(bf[b]));
+                    continue;
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<H>(af[a], bf[b], acc[a][b]);
             }
+        } else {
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+            for (int s = 0; s < GK / 2; ++s) {
+                float af[TM], bf[TN];
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<H>(af[a], bf[b], acc[a][b]);
+                for (int a = 0; a < TM; ++a) af[a] = frag32<A_KM, BM>(ta, wm * (BM / 2) + a * 32, s, lane);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[b] = frag32<B_KM, BN>(tb, wn * (BN / 2) + b * 32, s, lane);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
         }
     };
     if constexpr (DEPTH == 1) {
@@ -361,6 +415,35 @@ __global__ void __launch_bounds__(256) k_pad_f32(const float *__restrict__ src, 
     reinterpret_cast<unsigned *>(dst)[e] = wfs_pack2<H>(lo, hi);
 }
 
+// fp32 rows: dst[r, k * Cp + c] = src[row(k, r), c], Cp = C rounded up to 4 (16-byte aligned rows); row(k, r) as in
+// k_pad_rows.  One thread = one 16-byte piece of dst.  With no table and K == 1 this is the padded copy of a matrix
+// (filters whose output channel count is not a multiple of 4).
+__global__ void __launch_bounds__(256) k_pad_rows32(const int *__restrict__ table, KMapW kmap, int K, int identity_k,
+                                                    long long R, const long long *__restrict__ r_dev,
+                                                    const float *__restrict__ src, long long src_rows, int C, int Cp,
+                                                    float *__restrict__ dst) {
+    const int pieces = Cp >> 2;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * K * pieces) return;
+    const int pc = (int)(e % pieces);
+    const int k = (int)((e / pieces) % K);
+    const long long r = e / ((long long)pieces * K);
+    long long Rv = r_dev ? *r_dev : R;
+    Rv = Rv < R ? Rv : R;
+    long long s = -1;
+    if (r < Rv) s = (!table || k == identity_k) ? r : (long long)table[(long long)kmap.v[k] * R + r];
+    float4 out = {0.f, 0.f, 0.f, 0.f};
+    if (s >= 0 && s < src_rows) {
+        const float *q = src + s * C + pc * 4;
+        const int n = C - pc * 4;
+        out.x = q[0];
+        if (n > 1) out.y = q[1];
+        if (n > 2) out.z = q[2];
+        if (n > 3) out.w = q[3];
+    }
+    *reinterpret_cast<float4 *>(dst + (r * K + k) * (long long)Cp + pc * 4) = out;
+}
+
 // Y[r, c] = bias[c] + sum_k sum_p T[row(k, r) * row_pitch + k * k_pitch + p * p_pitch + c]  in the fixed order k = 0 ..
 // K - 1, p = 0 .. P - 1 (fp32), stored as H.  row(k, r) as in k_pad_rows (a missing neighbour contributes nothing).
 // One block per output row.  K <= 256.
@@ -403,11 +486,15 @@ __global__ void __launch_bounds__(256) k_sum_rows(const int *__restrict__ table,
     }
 }
 
-inline int pad8(int c) { return (c + 7) & ~7; }
+inline int esize(int dtype) { return dtype == WFS_F32 ? 4 : 2; }
+inline int padc(int c, int es) {                   // channel count rounded up to whole 16-byte pieces
+    const int q = 16 / es;
+    return (c + q - 1) / q * q;
+}
 
 template <typename H, int BM, int BN, int DEPTH>
 int launch_gemm_tile(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) {
-    constexpr int LDS = 2 * (BM + BN) * GK * 2;
+    constexpr int LDS = 2 * (BM + BN) * GKB;
     const long long nblk = (long long)wfs_cdiv(g.M, BM) * wfs_cdiv(g.N, BN) * g.nz * g.ksplit;
     if (nblk == 0) return WFS_OK;
     WFS_REQUIRE(nblk < (1ll << 30), WFS_EINVAL, "product of %d x %d x %d tiles is too large", g.M, g.N, g.nz);
@@ -435,12 +522,14 @@ int launch_gemm_tile(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) 
 // a single register stage were measured and lose: profiles/r03_gemm16_tile_and_pipeline_experiments.txt.
 template <typename H>
 int launch_gemm(const GemmArgs &g, int a_km, int b_km, hipStream_t stream) {
+    constexpr int GK = GKB / (int)sizeof(H);
     WFS_REQUIRE(g.ksplit >= 1 && g.kchunk % GK == 0 && (long long)g.ksplit * g.kchunk >= g.Ks, WFS_EINVAL,
                 "bad contraction split %d x %d for %d", g.ksplit, g.kchunk, g.Ks);
     return launch_gemm_tile<H, GT, GT, 2>(g, a_km, b_km, stream);
 }
 
 int gemm(const GemmArgs &g, int a_km, int b_km, int dtype, hipStream_t stream) {
+    if (dtype == WFS_F32) return launch_gemm<float>(g, a_km, b_km, stream);
     return dtype == WFS_F16 ? launch_gemm<wfs_f16>(g, a_km, b_km, stream) : launch_gemm<wfs_bf16>(g, a_km, b_km, stream);
 }
 
@@ -463,12 +552,13 @@ bool g_wide_on = true;
 int g_wide_min_channels = 128;      // a side of the filter at least this wide (wfs_wide_enable)
 
 // A launch wants a block per CU: products with fewer output tiles than half the CUs cut the contraction into `ksplit`
-// parts of `kchunk` (each at least 128 deep), one fp32 slab per part, summed in part order afterwards (a split that
+// parts of `kchunk` (each at least 2 steps deep), one fp32 slab per part, summed in part order afterwards (a split that
 // does not shorten the launch only adds the pass over the slabs: measured, 1.61 -> 1.80 ms per C5 step).
-int plan_ksplit(long long blocks, int Ks, int *kchunk) {
+int plan_ksplit(long long blocks, int Ks, int es, int *kchunk) {
+    const int GK = GKB / es;
     int ks = 1;
     if (blocks * 2 <= 256) {              // fewer 128 x 128 tiles than half the CUs: cut the contraction
-        const long long want = 256 / blocks, deep = wfs_cdiv(Ks, 128);
+        const long long want = 256 / blocks, deep = wfs_cdiv(Ks, 2 * GK);
         ks = (int)(want < deep ? want : deep);
         if (ks < 1) ks = 1;
     }
@@ -488,7 +578,30 @@ int launch_sum_rows(const int *table, const KMapW &km, int K, int identity_k, lo
     return WFS_OK;
 }
 
+int sum_rows(const int *table, const KMapW &km, int K, int identity_k, long long R, const long long *r_dev, const float *T,
+             long long t_rows, long long row_pitch, long long k_pitch, int P, long long p_pitch, const float *bias, int C,
+             void *Y, int dtype, hipStream_t stream) {
+    if (dtype == WFS_F32)
+        return launch_sum_rows<float>(table, km, K, identity_k, R, r_dev, T, t_rows, row_pitch, k_pitch, P, p_pitch, bias, C,
+                                      (float *)Y, stream);
+    if (dtype == WFS_F16)
+        return launch_sum_rows<wfs_f16>(table, km, K, identity_k, R, r_dev, T, t_rows, row_pitch, k_pitch, P, p_pitch, bias,
+                                        C, (wfs_f16 *)Y, stream);
+    return launch_sum_rows<wfs_bf16>(table, km, K, identity_k, R, r_dev, T, t_rows, row_pitch, k_pitch, P, p_pitch, bias, C,
+                                     (wfs_bf16 *)Y, stream);
+}
+
+// fp32 matrix [rows, C] -> the row type, rows padded to whole 16-byte pieces
 int pad_f32(const float *src, long long rows, int C, int Cp, void *dst, int dtype, hipStream_t stream) {
+    if (dtype == WFS_F32) {
+        const long long n = rows * (Cp >> 2);
+        if (n == 0) return WFS_OK;
+        KMapW km{};
+        k_pad_rows32<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(nullptr, km, 1, 0, rows, nullptr, src, rows, C, Cp,
+                                                                         (float *)dst);
+        WFS_LAUNCH_CHECK();
+        return WFS_OK;
+    }
     const long long n = rows * (Cp >> 1);
     if (n == 0) return WFS_OK;
     if (dtype == WFS_F16)
@@ -499,16 +612,24 @@ int pad_f32(const float *src, long long rows, int C, int Cp, void *dst, int dtyp
     return WFS_OK;
 }
 
+// rows of the row type -> 16-byte aligned, zero-padded rows, gathered through the table when given
 int pad_rows(const int *table, const KMapW &km, int K, int identity_k, long long R, const long long *r_dev,
-             const void *src, long long src_rows, int C, int Cp, void *dst, hipStream_t stream) {
-    const long long n = R * K * (Cp >> 3);
+             const void *src, long long src_rows, int C, int Cp, void *dst, int dtype, hipStream_t stream) {
+    const long long n = R * K * (Cp / (16 / esize(dtype)));
     if (n == 0) return WFS_OK;
-    k_pad_rows<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev,
-                                                                   (const unsigned short *)src, src_rows, C, Cp,
-                                                                   (unsigned short *)dst);
+    if (dtype == WFS_F32)
+        k_pad_rows32<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev,
+                                                                         (const float *)src, src_rows, C, Cp, (float *)dst);
+    else
+        k_pad_rows<<<dim3((unsigned)wfs_cdiv(n, 256)), 256, 0, stream>>>(table, km, K, identity_k, R, r_dev,
+                                                                       (const unsigned short *)src, src_rows, C, Cp,
+                                                                       (unsigned short *)dst);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
+
+// fp32 data whose rows are already whole 16-byte pieces at a 16-byte aligned address need no copy
+inline bool f32_in_place(const void *p, int C, int dtype) { return dtype == WFS_F32 && C % 4 == 0 && ((uintptr_t)p & 15) == 0; }
 
 // workspace of one wide product: padded filters + (gathered rows | padded rows + per-offset products) + split partials
 struct WidePlan {
@@ -518,16 +639,16 @@ struct WidePlan {
     size_t w_bytes, rows_bytes, t_bytes;
 };
 
-WidePlan conv_plan(int K, long long R, long long X_rows, int Cx, int Cy, int Cw_in, int Cw_out, bool has_table) {
+WidePlan conv_plan(int K, long long R, long long X_rows, int Cx, int Cy, int Cw_in, int Cw_out, bool has_table, int es) {
     WidePlan p;
     p.dense_first = has_table && X_rows < R;
-    p.w_bytes = wfs_align_up((size_t)K * Cw_in * pad8(Cw_out) * 2, 256);
+    p.w_bytes = wfs_align_up((size_t)K * Cw_in * padc(Cw_out, es) * es, 256);
     if (p.dense_first) {
         p.nz = K;
         p.nseg = 1;
-        p.ksplit = plan_ksplit(wfs_cdiv(X_rows, GT) * wfs_cdiv(Cy, GT) * K, Cx, &p.kchunk);
-        p.rows_bytes = wfs_align_up((size_t)X_rows * pad8(Cx) * 2, 256);
-        p.t_bytes = wfs_align_up((size_t)p.ksplit * X_rows * K * pad8(Cy) * 4, 256);
+        p.ksplit = plan_ksplit(wfs_cdiv(X_rows, GT) * wfs_cdiv(Cy, GT) * K, Cx, es, &p.kchunk);
+        p.rows_bytes = wfs_align_up((size_t)X_rows * padc(Cx, es) * es, 256);
+        p.t_bytes = wfs_align_up((size_t)p.ksplit * X_rows * K * padc(Cy, 4) * 4, 256);
     } else {
         // enough blocks for the chip: split the offsets over batches while the tiles alone leave CUs idle
         const long long tiles = wfs_cdiv(R, GT) * wfs_cdiv(Cy, GT);
@@ -535,9 +656,9 @@ WidePlan conv_plan(int K, long long R, long long X_rows, int Cx, int Cy, int Cw_
         while (nz < K && tiles * nz < 384) ++nz;
         p.nseg = (int)wfs_cdiv(K, nz);
         p.nz = (int)wfs_cdiv(K, p.nseg);
-        p.ksplit = plan_ksplit(tiles * p.nz, Cx, &p.kchunk);
-        p.rows_bytes = wfs_align_up((size_t)R * K * pad8(Cx) * 2, 256);
-        p.t_bytes = p.nz * p.ksplit > 1 ? wfs_align_up((size_t)p.nz * p.ksplit * R * pad8(Cy) * 4, 256) : 0;
+        p.ksplit = plan_ksplit(tiles * p.nz, Cx, es, &p.kchunk);
+        p.rows_bytes = wfs_align_up((size_t)R * K * padc(Cx, es) * es, 256);
+        p.t_bytes = p.nz * p.ksplit > 1 ? wfs_align_up((size_t)p.nz * p.ksplit * R * padc(Cy, 4) * 4, 256) : 0;
     }
     return p;
 }
@@ -545,10 +666,11 @@ WidePlan conv_plan(int K, long long R, long long X_rows, int Cx, int Cy, int Cw_
 }  // namespace
 
 extern "C" size_t wfs_wide_conv_workspace_bytes(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy,
-                                                int32_t has_table) {
+                                                int32_t has_table, int32_t dtype) {
     // the filter is [Cx][Cy] for the forward product and [Cy][Cx] for dX: padded differently, take the larger
-    const WidePlan p = conv_plan(K, R, X_rows, Cx, Cy, Cx, Cy, has_table != 0);
-    const WidePlan q = conv_plan(K, R, X_rows, Cx, Cy, Cy, Cx, has_table != 0);
+    const int es = esize(dtype);
+    const WidePlan p = conv_plan(K, R, X_rows, Cx, Cy, Cx, Cy, has_table != 0, es);
+    const WidePlan q = conv_plan(K, R, X_rows, Cx, Cy, Cy, Cx, has_table != 0, es);
     return (p.w_bytes > q.w_bytes ? p.w_bytes : q.w_bytes) + p.rows_bytes + p.t_bytes + 1024;
 }
 
@@ -559,44 +681,45 @@ extern "C" int wfs_wide_enable(int32_t on) {
     return was;
 }
 
-// which layers take this path: 16-bit rows, one side of the filter at least 256 channels wide (measured against the
-// 32 x 32-tile kernels of gather_conv.hip: profiles/r03_microbench_wide.txt), workspace within bounds
+// which layers take this path: one side of the filter at least 128 channels wide (measured against the 32 x 32-tile
+// kernels of gather_conv.hip: profiles/r03_wide_threshold_ab.txt), workspace within bounds
 extern "C" int wfs_wide_conv_ok(int32_t K, int64_t R, int64_t X_rows, int32_t Cx, int32_t Cy, int32_t dtype) {
-    if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return 0;
+    if (!g_wide_on || !wfs_dtype_ok(dtype)) return 0;
     if (K < 1 || K > 128 || R < 1 || X_rows < 1 || Cx < 8 || Cy < 8) return 0;
     if (R >= (1ll << 31) || X_rows >= (1ll << 31)) return 0;
     if ((Cx > Cy ? Cx : Cy) < g_wide_min_channels) return 0;
-    return (long long)wfs_wide_conv_workspace_bytes(K, R, X_rows, Cx, Cy, 1) <= WIDE_MAX_WORKSPACE;
+    return (long long)wfs_wide_conv_workspace_bytes(K, R, X_rows, Cx, Cy, 1, dtype) <= WIDE_MAX_WORKSPACE;
 }
 
-extern "C" size_t wfs_wide_filters16_bytes(int32_t K, int32_t Cw_in, int32_t Cw_out) {
-    return wfs_align_up((size_t)K * Cw_in * pad8(Cw_out) * 2, 256);
+extern "C" size_t wfs_wide_filters_bytes(int32_t K, int32_t Cw_in, int32_t Cw_out, int32_t dtype) {
+    const int es = esize(dtype);
+    return wfs_align_up((size_t)K * Cw_in * padc(Cw_out, es) * es, 256);
 }
 
-extern "C" int wfs_wide_filters16(const float *W, int32_t K, int32_t Cw_in, int32_t Cw_out, int32_t dtype, void *W16,
-                                  void *stream) {
-    WFS_REQUIRE(dtype == WFS_BF16 || dtype == WFS_F16, WFS_EINVAL, "16-bit filters only (dtype %d)", dtype);
-    WFS_REQUIRE(K >= 1 && Cw_in >= 1 && Cw_out >= 1 && W && W16, WFS_EINVAL, "bad filter block");
-    WFS_REQUIRE(((uintptr_t)W16 & 15) == 0, WFS_EINVAL, "W16 must be 16-byte aligned");
-    return pad_f32(W, (long long)K * Cw_in, Cw_out, pad8(Cw_out), W16, dtype, (hipStream_t)stream);
+extern "C" int wfs_wide_filters(const float *W, int32_t K, int32_t Cw_in, int32_t Cw_out, int32_t dtype, void *Wp,
+                                void *stream) {
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(K >= 1 && Cw_in >= 1 && Cw_out >= 1 && W && Wp, WFS_EINVAL, "bad filter block");
+    WFS_REQUIRE(((uintptr_t)Wp & 15) == 0, WFS_EINVAL, "the filter copy must be 16-byte aligned");
+    return pad_f32(W, (long long)K * Cw_in, Cw_out, padc(Cw_out, esize(dtype)), Wp, dtype, (hipStream_t)stream);
 }
 
 extern "C" int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                                     int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
-                                    const void *W16, int32_t Cw_in,
-                                    int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
-                                    const int64_t *r_dev_, void *workspace, size_t workspace_bytes, void *stream_) {
+                                    const void *Wp_, int32_t Cw_in, int32_t Cw_out, int32_t transpose_w,
+                                    const float *bias, void *Y, int32_t dtype, const int64_t *r_dev_, void *workspace,
+                                    size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long *r_dev = (const long long *)r_dev_;
-    WFS_REQUIRE(dtype == WFS_BF16 || dtype == WFS_F16, WFS_EINVAL, "the wide path takes 16-bit rows (dtype %d)", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(K >= 1 && K <= 128, WFS_EINVAL, "kernel volume %d not in [1,128]", K);
     const int Cy = transpose_w ? Cw_in : Cw_out;
     WFS_REQUIRE(Cx == (transpose_w ? Cw_out : Cw_in), WFS_EINVAL, "channel mismatch: X has %d, filter wants %d", Cx,
                 transpose_w ? Cw_out : Cw_in);
     if (R == 0) return WFS_OK;
-    WFS_REQUIRE((table || (K == 1 && identity_k == 0)) && X && (W || W16) && Y && workspace, WFS_EINVAL,
+    WFS_REQUIRE((table || (K == 1 && identity_k == 0)) && X && (W || Wp_) && Y && workspace, WFS_EINVAL,
                 "NULL device pointer");
-    WFS_REQUIRE(((uintptr_t)W16 & 15) == 0, WFS_EINVAL, "W16 must be 16-byte aligned");
+    WFS_REQUIRE(((uintptr_t)Wp_ & 15) == 0, WFS_EINVAL, "the filter copy must be 16-byte aligned");
     WFS_REQUIRE(X_rows >= 1, WFS_EINVAL, "no source rows");
     WFS_REQUIRE(table || X_rows == R, WFS_EINVAL, "a product without a table maps row r to row r (%lld vs %lld rows)",
                 (long long)X_rows, (long long)R);
@@ -606,21 +729,30 @@ extern "C" int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_ho
         km.v[k] = kmap_host ? kmap_host[k] : k;
         WFS_REQUIRE(km.v[k] >= 0 && km.v[k] < K, WFS_EINVAL, "kmap[%d] out of range", k);
     }
-    const WidePlan p = conv_plan(K, R, X_rows, Cx, Cy, Cw_in, Cw_out, table != nullptr);
+    const int es = esize(dtype);
+    const WidePlan p = conv_plan(K, R, X_rows, Cx, Cy, Cw_in, Cw_out, table != nullptr, es);
     WFS_REQUIRE(workspace_bytes >= p.w_bytes + p.rows_bytes + p.t_bytes, WFS_EWORKSPACE, "workspace %zu < %zu",
                 workspace_bytes, p.w_bytes + p.rows_bytes + p.t_bytes);
     WFS_REQUIRE(((uintptr_t)workspace & 15) == 0, WFS_EINVAL, "workspace must be 16-byte aligned");
     WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
     Carver cv{(unsigned char *)workspace, workspace_bytes};
-    unsigned short *Wh = (unsigned short *)cv.take(p.w_bytes);
-    unsigned short *rows = (unsigned short *)cv.take(p.rows_bytes);
+    void *Wh = cv.take(p.w_bytes);
+    void *rows = cv.take(p.rows_bytes);
     float *T = p.t_bytes ? (float *)cv.take(p.t_bytes) : nullptr;
-    const int Cxp = pad8(Cx), Cyp = pad8(Cy), Cwp = pad8(Cw_out);
+    const int Cxp = padc(Cx, es), Cyp = padc(Cy, 4), Cwp = padc(Cw_out, es);
     int rc = WFS_OK;
-    if (!W16) rc = pad_f32(W, (long long)K * Cw_in, Cw_out, Cwp, Wh, dtype, stream);   // filters -> 16 bit, [K][Cw_in][Cwp]
+    const void *Wp = Wp_;
+    if (!Wp) {      // filters in the row type, [K][Cw_in][Cwp]
+        if (f32_in_place(W, Cw_out, dtype)) {
+            Wp = W;
+        } else {
+            rc = pad_f32(W, (long long)K * Cw_in, Cw_out, Cwp, Wh, dtype, stream);
+            Wp = Wh;
+        }
+    }
     if (rc != WFS_OK) return rc;
     GemmArgs g{};
-    g.B = W16 ? (const unsigned short *)W16 : Wh;
+    g.B = Wp;
     g.ldb = Cwp;
     g.sB = (long long)Cw_in * Cwp;
     g.Ks = Cx;
@@ -630,23 +762,29 @@ extern "C" int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_ho
     // filter operand: forward W[k] is [contraction Cx][Cy] -> contraction-major; dX W[k] is [Cy][contraction Cx]
     const int b_km = transpose_w ? 0 : 1;
     if (p.dense_first) {
-        rc = pad_rows(nullptr, km, 1, 0, X_rows, nullptr, X, X_rows, Cx, Cxp, rows, stream);   // aligned, padded rows
-        if (rc != WFS_OK) return rc;
+        const void *Xa = X;                           // aligned, padded rows
+        if (!f32_in_place(X, Cx, dtype)) {
+            rc = pad_rows(nullptr, km, 1, 0, X_rows, nullptr, X, X_rows, Cx, Cxp, rows, dtype, stream);
+            if (rc != WFS_OK) return rc;
+            Xa = rows;
+        }
         const long long slab = X_rows * (long long)K * Cyp;
-        g.A = rows, g.lda = Cxp, g.sA = 0;
+        g.A = Xa, g.lda = Cxp, g.sA = 0;
         g.C = T, g.ldc = (long long)K * Cyp, g.zC = Cyp, g.pC = slab;
         g.M = (int)X_rows, g.N = Cy, g.nseg = 1, g.nz = K;
         rc = gemm(g, 0, b_km, dtype, stream);
         if (rc != WFS_OK) return rc;
-        if (dtype == WFS_F16)
-            return launch_sum_rows<wfs_f16>(table, km, K, identity_k, R, r_dev, T, X_rows, (long long)K * Cyp, Cyp,
-                                            p.ksplit, slab, bias, Cy, (wfs_f16 *)Y, stream);
-        return launch_sum_rows<wfs_bf16>(table, km, K, identity_k, R, r_dev, T, X_rows, (long long)K * Cyp, Cyp, p.ksplit,
-                                         slab, bias, Cy, (wfs_bf16 *)Y, stream);
+        return sum_rows(table, km, K, identity_k, R, r_dev, T, X_rows, (long long)K * Cyp, Cyp, p.ksplit, slab, bias, Cy, Y,
+                        dtype, stream);
     }
-    rc = pad_rows(table, km, K, identity_k, R, r_dev, X, X_rows, Cx, Cxp, rows, stream);      // gathered rows G[r, (k, c)]
-    if (rc != WFS_OK) return rc;
-    g.A = rows, g.lda = (long long)K * Cxp, g.sA = Cxp;
+    if (!table && f32_in_place(X, Cx, dtype) && !r_dev) {
+        g.A = X;                                      // a dense fp32 product on rows that need no copy
+    } else {
+        rc = pad_rows(table, km, K, identity_k, R, r_dev, X, X_rows, Cx, Cxp, rows, dtype, stream);   // G[r, (k, c)]
+        if (rc != WFS_OK) return rc;
+        g.A = rows;
+    }
+    g.lda = (long long)K * Cxp, g.sA = Cxp;
     g.M = (int)R, g.N = Cy, g.nseg = p.nseg, g.nz = p.nz;
     if (p.nz * p.ksplit == 1) {
         g.C = Y, g.ldc = Cy, g.out_h = 1, g.bias = bias;
@@ -656,42 +794,40 @@ extern "C" int wfs_wide_gather_conv(const int32_t *table, const int32_t *kmap_ho
     g.C = T, g.ldc = Cyp, g.zC = p.ksplit * slab, g.pC = slab;
     rc = gemm(g, 0, b_km, dtype, stream);
     if (rc != WFS_OK) return rc;
-    if (dtype == WFS_F16)
-        return launch_sum_rows<wfs_f16>(nullptr, km, p.nz * p.ksplit, -1, R, r_dev, T, R, Cyp, slab, 1, 0, bias, Cy,
-                                        (wfs_f16 *)Y, stream);
-    return launch_sum_rows<wfs_bf16>(nullptr, km, p.nz * p.ksplit, -1, R, r_dev, T, R, Cyp, slab, 1, 0, bias, Cy,
-                                     (wfs_bf16 *)Y, stream);
+    return sum_rows(nullptr, km, p.nz * p.ksplit, -1, R, r_dev, T, R, Cyp, slab, 1, 0, bias, Cy, Y, dtype, stream);
 }
 
 // dW of a wide layer (called from wfs_gather_dw): dW[k][a][b] (swap: dW[k][b][a]) = sum_r S[r][a] G[table[k][r]][b]
-static int dw_split(int K, long long R, int Cs, int Cg, int *kchunk) {
-    return plan_ksplit(wfs_cdiv(Cs, GT) * wfs_cdiv(Cg, GT) * K, (int)R, kchunk);
+static int dw_split(int K, long long R, int Cs, int Cg, int es, int *kchunk) {
+    return plan_ksplit(wfs_cdiv(Cs, GT) * wfs_cdiv(Cg, GT) * K, (int)R, es, kchunk);
 }
 
-size_t wfs_wide_dw_workspace(int K, long long R, int Cs, int Cg) {
+size_t wfs_wide_dw_workspace(int K, long long R, int Cs, int Cg, int dtype) {
+    const int es = esize(dtype);
     int kchunk;
-    const int ks = dw_split(K, R, Cs, Cg, &kchunk);
-    return wfs_align_up((size_t)R * pad8(Cs) * 2, 256) + wfs_align_up((size_t)R * K * pad8(Cg) * 2, 256) +
+    const int ks = dw_split(K, R, Cs, Cg, es, &kchunk);
+    return wfs_align_up((size_t)R * padc(Cs, es) * es, 256) + wfs_align_up((size_t)R * K * padc(Cg, es) * es, 256) +
            (ks > 1 ? wfs_align_up((size_t)ks * K * Cs * Cg * 4, 256) : 0) + 1024;
 }
 
 bool wfs_wide_dw_ok(int K, long long R, int Cs, int Cg, int dtype) {
-    if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return false;
-    if (K < 1 || K > 128 || R < 1 || R >= (1ll << 31) || Cs < 8 || Cg < 8 || (Cs > Cg ? Cs : Cg) < g_wide_min_channels) return false;
-    return (long long)wfs_wide_dw_workspace(K, R, Cs, Cg) <= WIDE_MAX_WORKSPACE;
+    if (!g_wide_on || !wfs_dtype_ok(dtype)) return false;
+    if (K < 1 || K > 128 || R < 1 || R >= (1ll << 31) || Cs < 8 || Cg < 8 || (Cs > Cg ? Cs : Cg) < g_wide_min_channels)
+        return false;
+    return (long long)wfs_wide_dw_workspace(K, R, Cs, Cg, dtype) <= WIDE_MAX_WORKSPACE;
 }
 
 // A^T . B over the rows of two contraction-major operands: C[z][m][n] = sum_r A[r][z sA + m] B[r][z sB + n]
-static int rows_product(const unsigned short *A, long long lda, long long sA, int M, const unsigned short *B, long long ldb,
-                        long long sB, int N, long long R, const long long *r_dev, int nz, float *C, float *slabs,
-                        int dtype, hipStream_t stream) {
+static int rows_product(const void *A, long long lda, long long sA, int M, const void *B, long long ldb, long long sB,
+                        int N, long long R, const long long *r_dev, int nz, float *C, float *slabs, int dtype,
+                        hipStream_t stream) {
     GemmArgs g{};
     g.A = A, g.lda = lda, g.sA = sA, g.M = M;
     g.B = B, g.ldb = ldb, g.sB = sB, g.N = N;
     g.Ks = (int)R;
     g.k_dev = r_dev;
     g.nseg_total = nz, g.nseg = 1, g.nz = nz;
-    g.ksplit = plan_ksplit(wfs_cdiv(M, GT) * wfs_cdiv(N, GT) * nz, (int)R, &g.kchunk);
+    g.ksplit = plan_ksplit(wfs_cdiv(M, GT) * wfs_cdiv(N, GT) * nz, (int)R, esize(dtype), &g.kchunk);
     g.ldc = N;
     g.zC = (long long)M * N;
     if (g.ksplit == 1) {
@@ -711,128 +847,160 @@ static int rows_product(const unsigned short *A, long long lda, long long sA, in
 int wfs_launch_wide_dw(const int *table, const int *kmap_host, int K, int identity_k, long long R, const long long *r_dev,
                        const void *S, int Cs, const void *G, long long G_rows, int Cg, int swap, float *dW, int dtype,
                        void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    WFS_REQUIRE(workspace_bytes >= wfs_wide_dw_workspace(K, R, Cs, Cg), WFS_EWORKSPACE, "workspace %zu < %zu",
-                workspace_bytes, wfs_wide_dw_workspace(K, R, Cs, Cg));
+    WFS_REQUIRE(workspace_bytes >= wfs_wide_dw_workspace(K, R, Cs, Cg, dtype), WFS_EWORKSPACE, "workspace %zu < %zu",
+                workspace_bytes, wfs_wide_dw_workspace(K, R, Cs, Cg, dtype));
     WFS_REQUIRE(((uintptr_t)workspace & 15) == 0, WFS_EINVAL, "workspace must be 16-byte aligned");
     KMapW km;
     for (int k = 0; k < K; ++k) km.v[k] = kmap_host ? kmap_host[k] : k;
     Carver cv{(unsigned char *)workspace, workspace_bytes};
-    const int Csp = pad8(Cs), Cgp = pad8(Cg);
+    const int es = esize(dtype);
+    const int Csp = padc(Cs, es), Cgp = padc(Cg, es);
     int kchunk;
-    const int ks = dw_split(K, R, Cs, Cg, &kchunk);
-    unsigned short *Sp = (unsigned short *)cv.take((size_t)R * Csp * 2);
-    unsigned short *Gg = (unsigned short *)cv.take((size_t)R * K * Cgp * 2);
+    const int ks = dw_split(K, R, Cs, Cg, es, &kchunk);
+    void *Sp = cv.take((size_t)R * Csp * es);
+    void *Gg = cv.take((size_t)R * K * Cgp * es);
     float *slabs = ks > 1 ? (float *)cv.take((size_t)ks * K * Cs * Cg * 4) : nullptr;
     WFS_REQUIRE(Sp && Gg && (ks == 1 || slabs), WFS_EWORKSPACE, "workspace too small");
-    int rc = pad_rows(nullptr, km, 1, 0, R, r_dev, S, R, Cs, Csp, Sp, stream);
-    if (rc != WFS_OK) return rc;
-    rc = pad_rows(table, km, K, identity_k, R, r_dev, G, G_rows, Cg, Cgp, Gg, stream);
+    const void *Sa = S;
+    int rc;
+    if (!f32_in_place(S, Cs, dtype)) {            // the contraction stops at the valid count: no need to zero rows
+        rc = pad_rows(nullptr, km, 1, 0, R, r_dev, S, R, Cs, Csp, Sp, dtype, stream);
+        if (rc != WFS_OK) return rc;
+        Sa = Sp;
+    }
+    rc = pad_rows(table, km, K, identity_k, R, r_dev, G, G_rows, Cg, Cgp, Gg, dtype, stream);
     if (rc != WFS_OK) return rc;
     if (!swap)
-        return rows_product(Sp, Csp, 0, Cs, Gg, (long long)K * Cgp, Cgp, Cg, R, r_dev, K, dW, slabs, dtype, stream);
-    return rows_product(Gg, (long long)K * Cgp, Cgp, Cg, Sp, Csp, 0, Cs, R, r_dev, K, dW, slabs, dtype, stream);
+        return rows_product(Sa, Csp, 0, Cs, Gg, (long long)K * Cgp, Cgp, Cg, R, r_dev, K, dW, slabs, dtype, stream);
+    return rows_product(Gg, (long long)K * Cgp, Cgp, Cg, Sa, Csp, 0, Cs, R, r_dev, K, dW, slabs, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------ dense linear layer
-// y = x W^T + b with 16-bit x [B, I], fp32 W [O, I] (torch.nn.Linear's layout), fp32 y: the hybrid net's head
+// y = x W^T + b with x [B, I] in the row type, fp32 W [O, I] (torch.nn.Linear's layout), fp32 y: the hybrid net's head
 // (Linear(24150, 269), reference src/models/SPConvNet.py:40-52 through LinearBlock) is a 3.3-GFLOP product that streams
 // 26 MB of weights: 2 x 3 output tiles, so the contraction is cut into parts (plan_ksplit) and summed in order.
-static int lin_split(long long B, int I, int O, int *kchunk) {
-    return plan_ksplit(wfs_cdiv(B, GT) * wfs_cdiv(O, GT), I, kchunk);
+static int lin_split(long long B, int I, int O, int es, int *kchunk) {
+    return plan_ksplit(wfs_cdiv(B, GT) * wfs_cdiv(O, GT), I, es, kchunk);
 }
 
-extern "C" size_t wfs_linear16_workspace_bytes(int64_t B, int32_t I, int32_t O) {
+extern "C" size_t wfs_wide_linear_workspace_bytes(int64_t B, int32_t I, int32_t O, int32_t dtype) {
+    const int es = esize(dtype);
     int kchunk;
-    const int ks = lin_split(B, I, O, &kchunk);
-    const size_t x = wfs_align_up((size_t)B * pad8(I) * 2, 256), w = wfs_align_up((size_t)O * pad8(I) * 2, 256);
-    const size_t g = wfs_align_up((size_t)B * pad8(O) * 2, 256), part = wfs_align_up((size_t)ks * B * pad8(O) * 4, 256);
+    const int ks = lin_split(B, I, O, es, &kchunk);
+    const size_t x = wfs_align_up((size_t)B * padc(I, es) * es, 256), w = wfs_align_up((size_t)O * padc(I, es) * es, 256);
+    const size_t g = wfs_align_up((size_t)B * padc(O, es) * es, 256);
+    const size_t part = wfs_align_up((size_t)ks * B * padc(O, 4) * 4, 256);
     int kc2;
-    const int ks2 = plan_ksplit(wfs_cdiv(O, GT) * wfs_cdiv(I, GT), (int)B, &kc2);
+    const int ks2 = plan_ksplit(wfs_cdiv(O, GT) * wfs_cdiv(I, GT), (int)B, es, &kc2);
     const size_t part2 = ks2 > 1 ? wfs_align_up((size_t)ks2 * O * I * 4, 256) : 0;
     return x + w + g + (part > part2 ? part : part2) + 1024;
 }
 
-extern "C" int wfs_linear16_ok(int64_t B, int32_t I, int32_t O, int32_t dtype) {
-    if (!g_wide_on || (dtype != WFS_BF16 && dtype != WFS_F16)) return 0;
+extern "C" int wfs_wide_linear_ok(int64_t B, int32_t I, int32_t O, int32_t dtype) {
+    if (!g_wide_on || !wfs_dtype_ok(dtype)) return 0;
     if (B < 1 || B >= (1ll << 31) || I < 256 || O < 9) return 0;
-    return (long long)wfs_linear16_workspace_bytes(B, I, O) <= WIDE_MAX_WORKSPACE;
+    return (long long)wfs_wide_linear_workspace_bytes(B, I, O, dtype) <= WIDE_MAX_WORKSPACE;
 }
 
-extern "C" int wfs_linear16_fwd(const void *X, int64_t B, int32_t I, const float *W, const float *bias, int32_t O,
-                                float *Y, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
+extern "C" int wfs_wide_linear_fwd(const void *X, int64_t B, int32_t I, const float *W, const float *bias, int32_t O,
+                                   float *Y, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    WFS_REQUIRE(dtype == WFS_BF16 || dtype == WFS_F16, WFS_EINVAL, "16-bit rows only (dtype %d)", dtype);
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(B >= 1 && B < (1ll << 31) && I >= 8 && O >= 1, WFS_EINVAL, "bad shape %lld x %d -> %d", (long long)B, I, O);
     WFS_REQUIRE(X && W && Y && workspace, WFS_EINVAL, "NULL device pointer");
-    WFS_REQUIRE(workspace_bytes >= wfs_linear16_workspace_bytes(B, I, O), WFS_EWORKSPACE, "workspace %zu < %zu",
-                workspace_bytes, wfs_linear16_workspace_bytes(B, I, O));
+    WFS_REQUIRE(workspace_bytes >= wfs_wide_linear_workspace_bytes(B, I, O, dtype), WFS_EWORKSPACE, "workspace %zu < %zu",
+                workspace_bytes, wfs_wide_linear_workspace_bytes(B, I, O, dtype));
     WFS_REQUIRE(((uintptr_t)workspace & 15) == 0, WFS_EINVAL, "workspace must be 16-byte aligned");
-    const int Ip = pad8(I), Op = pad8(O);
+    const int es = esize(dtype);
+    const int Ip = padc(I, es), Op = padc(O, es), Of = padc(O, 4);
     Carver cv{(unsigned char *)workspace, workspace_bytes};
-    unsigned short *Xp = (unsigned short *)cv.take((size_t)B * Ip * 2);
-    unsigned short *Wh = (unsigned short *)cv.take((size_t)O * Ip * 2);
-    cv.take((size_t)B * Op * 2);
+    void *Xp = cv.take((size_t)B * Ip * es);
+    void *Wh = cv.take((size_t)O * Ip * es);
+    cv.take((size_t)B * Op * es);
     KMapW km{};
-    int rc = pad_rows(nullptr, km, 1, 0, B, nullptr, X, B, I, Ip, Xp, stream);
-    if (rc != WFS_OK) return rc;
-    rc = pad_f32(W, O, I, Ip, Wh, dtype, stream);
-    if (rc != WFS_OK) return rc;
-    GemmArgs g{};
-    g.A = Xp, g.lda = Ip, g.M = (int)B;
-    g.B = Wh, g.ldb = Ip, g.N = O;
-    g.Ks = I;
-    g.nseg_total = 1, g.nseg = 1, g.nz = 1;
-    g.ksplit = lin_split(B, I, O, &g.kchunk);
-    float *part = (float *)cv.take((size_t)g.ksplit * B * Op * 4);
-    WFS_REQUIRE(part, WFS_EWORKSPACE, "workspace too small");
-    g.C = part, g.ldc = Op, g.pC = B * (long long)Op;
-    rc = gemm(g, 0, 0, dtype, stream);
-    if (rc != WFS_OK) return rc;
-    return launch_sum_rows<float>(nullptr, km, 1, -1, B, nullptr, part, B, Op, 0, g.ksplit, g.pC, bias, O, Y, stream);
-}
-
-// dX [B, I] (16-bit, may be NULL), dW [O, I] and db [O] (fp32, may be NULL) from fp32 dY [B, O]
-extern "C" int wfs_linear16_bwd(const void *X, const float *dY, int64_t B, int32_t I, const float *W, int32_t O,
-                                void *dX, float *dW, float *db, int32_t dtype, void *workspace, size_t workspace_bytes,
-                                void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    WFS_REQUIRE(dtype == WFS_BF16 || dtype == WFS_F16, WFS_EINVAL, "16-bit rows only (dtype %d)", dtype);
-    WFS_REQUIRE(B >= 1 && B < (1ll << 31) && I >= 8 && O >= 1, WFS_EINVAL, "bad shape %lld x %d -> %d", (long long)B, I, O);
-    WFS_REQUIRE(X && dY && W && workspace, WFS_EINVAL, "NULL device pointer");
-    WFS_REQUIRE(workspace_bytes >= wfs_linear16_workspace_bytes(B, I, O), WFS_EWORKSPACE, "workspace %zu < %zu",
-                workspace_bytes, wfs_linear16_workspace_bytes(B, I, O));
-    WFS_REQUIRE(((uintptr_t)workspace & 15) == 0, WFS_EINVAL, "workspace must be 16-byte aligned");
-    const int Ip = pad8(I), Op = pad8(O);
-    Carver cv{(unsigned char *)workspace, workspace_bytes};
-    unsigned short *Xp = (unsigned short *)cv.take((size_t)B * Ip * 2);
-    unsigned short *Wh = (unsigned short *)cv.take((size_t)O * Ip * 2);
-    unsigned short *Gh = (unsigned short *)cv.take((size_t)B * Op * 2);
-    KMapW km{};
-    int rc = pad_f32(dY, B, O, Op, Gh, dtype, stream);                 // dY -> 16 bit [B][Op]
-    if (rc != WFS_OK) return rc;
-    if (dX) {
+    int rc;
+    const void *Xa = X, *Wa = W;
+    if (!f32_in_place(X, I, dtype)) {
+        rc = pad_rows(nullptr, km, 1, 0, B, nullptr, X, B, I, Ip, Xp, dtype, stream);
+        if (rc != WFS_OK) return rc;
+        Xa = Xp;
+    }
+    if (!f32_in_place(W, I, dtype)) {
         rc = pad_f32(W, O, I, Ip, Wh, dtype, stream);
         if (rc != WFS_OK) return rc;
+        Wa = Wh;
+    }
+    GemmArgs g{};
+    g.A = Xa, g.lda = Ip, g.M = (int)B;
+    g.B = Wa, g.ldb = Ip, g.N = O;
+    g.Ks = I;
+    g.nseg_total = 1, g.nseg = 1, g.nz = 1;
+    g.ksplit = lin_split(B, I, O, es, &g.kchunk);
+    float *part = (float *)cv.take((size_t)g.ksplit * B * Of * 4);
+    WFS_REQUIRE(part, WFS_EWORKSPACE, "workspace too small");
+    g.C = part, g.ldc = Of, g.pC = B * (long long)Of;
+    rc = gemm(g, 0, 0, dtype, stream);
+    if (rc != WFS_OK) return rc;
+    return launch_sum_rows<float>(nullptr, km, 1, -1, B, nullptr, part, B, Of, 0, g.ksplit, g.pC, bias, O, Y, stream);
+}
+
+// dX [B, I] (row type, may be NULL), dW [O, I] and db [O] (fp32, may be NULL) from fp32 dY [B, O]
+extern "C" int wfs_wide_linear_bwd(const void *X, const float *dY, int64_t B, int32_t I, const float *W, int32_t O,
+                                   void *dX, float *dW, float *db, int32_t dtype, void *workspace,
+                                   size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
+    WFS_REQUIRE(B >= 1 && B < (1ll << 31) && I >= 8 && O >= 1, WFS_EINVAL, "bad shape %lld x %d -> %d", (long long)B, I, O);
+    WFS_REQUIRE(X && dY && W && workspace, WFS_EINVAL, "NULL device pointer");
+    WFS_REQUIRE(workspace_bytes >= wfs_wide_linear_workspace_bytes(B, I, O, dtype), WFS_EWORKSPACE, "workspace %zu < %zu",
+                workspace_bytes, wfs_wide_linear_workspace_bytes(B, I, O, dtype));
+    WFS_REQUIRE(((uintptr_t)workspace & 15) == 0, WFS_EINVAL, "workspace must be 16-byte aligned");
+    const int es = esize(dtype);
+    const int Ip = padc(I, es), Op = padc(O, es);
+    Carver cv{(unsigned char *)workspace, workspace_bytes};
+    void *Xp = cv.take((size_t)B * Ip * es);
+    void *Wh = cv.take((size_t)O * Ip * es);
+    void *Gh = cv.take((size_t)B * Op * es);
+    KMapW km{};
+    int rc;
+    const void *Ga = dY;                                               // dY in the row type, [B][Op]
+    if (!f32_in_place(dY, O, dtype)) {
+        rc = pad_f32(dY, B, O, Op, Gh, dtype, stream);
+        if (rc != WFS_OK) return rc;
+        Ga = Gh;
+    }
+    if (dX) {
+        const void *Wa = W;
+        if (!f32_in_place(W, I, dtype)) {
+            rc = pad_f32(W, O, I, Ip, Wh, dtype, stream);
+            if (rc != WFS_OK) return rc;
+            Wa = Wh;
+        }
         GemmArgs g{};                                                  // dX = dY . W: contraction over O
-        g.A = Gh, g.lda = Op, g.M = (int)B;
-        g.B = Wh, g.ldb = Ip, g.N = I;                                 // W as [k = O][n = I]: contraction-major
+        g.A = Ga, g.lda = Op, g.M = (int)B;
+        g.B = Wa, g.ldb = Ip, g.N = I;                                 // W as [k = O][n = I]: contraction-major
         g.Ks = O;
+        const int GK = GKB / es;
         g.nseg_total = 1, g.nseg = 1, g.nz = 1, g.ksplit = 1, g.kchunk = (int)(wfs_cdiv(O, GK) * GK);
         g.C = dX, g.ldc = I, g.out_h = 1;
         rc = gemm(g, 0, 1, dtype, stream);
         if (rc != WFS_OK) return rc;
     }
     if (dW) {
-        rc = pad_rows(nullptr, km, 1, 0, B, nullptr, X, B, I, Ip, Xp, stream);
-        if (rc != WFS_OK) return rc;
+        const void *Xa = X;
+        if (!f32_in_place(X, I, dtype)) {
+            rc = pad_rows(nullptr, km, 1, 0, B, nullptr, X, B, I, Ip, Xp, dtype, stream);
+            if (rc != WFS_OK) return rc;
+            Xa = Xp;
+        }
         int kc;
-        const int ks = plan_ksplit(wfs_cdiv(O, GT) * wfs_cdiv(I, GT), (int)B, &kc);
+        const int ks = plan_ksplit(wfs_cdiv(O, GT) * wfs_cdiv(I, GT), (int)B, es, &kc);
         float *slabs = ks > 1 ? (float *)cv.take((size_t)ks * O * I * 4) : nullptr;
-        rc = rows_product(Gh, Op, 0, O, Xp, Ip, 0, I, B, nullptr, 1, dW, slabs, dtype, stream);   // dW = dY^T . X
+        rc = rows_product(Ga, Op, 0, O, Xa, Ip, 0, I, B, nullptr, 1, dW, slabs, dtype, stream);   // dW = dY^T . X
         if (rc != WFS_OK) return rc;
     }
     if (db) {
-        // column sums of dY in fp32, fixed order: one block per 256 columns walks the rows
+        // column sums of dY in fp32, fixed order: one block walks the rows
         return launch_sum_rows<float>(nullptr, km, 1, -1, 1, nullptr, dY, 1, 0, 0, (int)B, O, nullptr, O, db, stream);
     }
     return WFS_OK;

@@ -68,13 +68,9 @@ class SparseConvolution(SparseModule):
         else:
             out_spatial_shape = spatial_shape
         if self.conv1x1:
-            if (features.dtype in (torch.bfloat16, torch.float16)
-                    and Fsp.can_use_pointwise_conv(features, self.in_channels, self.out_channels)):
-                features = Fsp.pointwise_conv(features, self.weight, self.bias, input.n_valid)
-            else:
-                features = torch.mm(features, self.weight.view(self.in_channels, self.out_channels).to(features.dtype))
-                if self.bias is not None:
-                    features = features + self.bias.to(features.dtype)
+            # spconv: torch.mm(features, weight.view(in, out)) (+ bias); here the same product in libwfsparse (the wide
+            # matrix-core path from 128 channels, the gather kernels with the identity map below that)
+            features = Fsp.pointwise_conv(features, self.weight, self.bias, input.n_valid)
             out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
             out_tensor.indice_dict = input.indice_dict
             out_tensor.grid = input.grid

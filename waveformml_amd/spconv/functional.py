@@ -81,16 +81,11 @@ def can_take_batch_norm_stats(bn, features):
             and (bn.training or bn.running_mean is None))
 
 
-# 16-bit rows: every layer runs in libwfsparse -- the 32- and 2-channel MFMA kernels of conv_mfma.hip, the shape-generic
-# MFMA kernels of gather_conv.hip (k_gconv_mfma / k_gdw_mfma: the reference's GEP.json 252 -> 158 -> 64 stack,
-# SparseConv2DPreserve's 130 ... 154 channels, 16 / 24 / 64-channel 3-D layers) and, from 256 channels on a side, the
-# dense 128 x 128-tile matrix-core products of wide.hip (the hybrid net's 2048 -> 1697 -> 1021 -> 345 stack, BASELINE
-# configs[4]).  fp32 rows wider than 512 channels still take the library's fp32 GEMM on rows gathered through the SAME
-# tables (output-stationary, no atomics, deterministic): the exact-fp32 matrix-core kernels tile 32 x 32 and re-read
-# the filters per row tile, which loses to the library there (profiles/r02_microbench_generic_mfma.txt).
-GEMM_ROUTE_MIN_CHANNELS = 513
-GEMM_ROUTE_MAX_ELEMENTS = 1 << 27
-GEMM_ROUTE_ANY_DTYPE = False        # benchmarks only (tools/microbench_generic.py): the library route for 16-bit rows too
+# Every layer runs in libwfsparse: the 32- and 2-channel MFMA kernels of conv_mfma.hip, the shape-generic 32 x 32-tile MFMA
+# kernels of gather_conv.hip (k_gconv_mfma / k_gdw_mfma: 16 / 24 / 64-channel layers) and, from 128 channels on a side,
+# the dense 128 x 128-tile matrix-core products of wide.hip (the reference's GEP.json 300 -> 252 -> 158 -> 64 stack,
+# SparseConv2DPreserve's 130 ... 154 channels, the hybrid net's 2048 -> 1697 -> 1021 -> 345 stack of BASELINE
+# configs[4]) -- 16-bit MFMA for 16-bit rows, exact-fp32 MFMA for fp32 rows.  No torch.mm / library GEMM on this path.
 
 
 def _fast_shape(Cx, Cy):
@@ -98,74 +93,26 @@ def _fast_shape(Cx, Cy):
     return (Cx == 32 and Cy == 32) or (Cx == 2 and Cy == 32) or (Cx == 32 and Cy == 2)
 
 
-def _gemm_route(Cx, Cy, K, R, r_dev, table, dtype=torch.float32):
-    fast = _fast_shape(Cx, Cy)
-    return (not fast and (dtype == torch.float32 or GEMM_ROUTE_ANY_DTYPE) and table is not None and R > 0 and max(Cx, Cy) >= GEMM_ROUTE_MIN_CHANNELS
-            and K * R * max(Cx, Cy) <= GEMM_ROUTE_MAX_ELEMENTS and ACCOUNT is None)
-
-
-def _row_ok(R, r_dev, device):
-    """[R] bool: rows below the device-side valid count (rows beyond it hold uninitialised table entries / features)."""
-    return None if r_dev is None else torch.arange(R, device=device) < r_dev
-
-
-def _gathered(table, kmap, K, identity_k, R, X, r_dev=None):
-    """[R, K * C]: for every output row the K gathered rows of X side by side (X[table[kmap[k], r]] at columns
-    k C .. (k+1) C; zeros where the entry is -1 or the row is beyond the valid count; the row itself at identity_k).
-    With the filters reshaped to [K * Cin, Cout] a whole layer is ONE library GEMM whose contraction runs over
-    (offset, channel) -- the sum over offsets happens inside the GEMM's fp32 accumulator."""
-    idx = table.long()
-    if kmap is not None:
-        idx = idx[torch.as_tensor(list(kmap), dtype=torch.long, device=table.device)]
-    if identity_k is not None and identity_k >= 0:
-        idx = idx.clone()
-        idx[identity_k] = torch.arange(R, device=table.device)
-    n = X.shape[0]
-    bad = idx < 0
-    ok = _row_ok(R, r_dev, table.device)
-    if ok is not None:
-        bad = bad | ~ok.unsqueeze(0) | (idx >= n)
-    idx = torch.where(bad, torch.full_like(idx, n), idx)
-    Xp = torch.cat([X, X.new_zeros((1, X.shape[1]))])
-    return Xp[idx.t().reshape(-1)].reshape(R, K * X.shape[1])
-
-
-_MM_OUT_DTYPE = [None]          # does torch.mm take out_dtype= (fp32 results from 16-bit operands)?  probed once
-
-
-def _mm_f32(a, b):
-    """a @ b with fp32 accumulation and an fp32 result.  16-bit operands (bf16 / fp16 rows) stay 16-bit -- the library
-    GEMM then runs on the 16-bit matrix cores -- and the result is taken in fp32 where torch.mm offers ``out_dtype``."""
-    if a.dtype == torch.float32:
-        return torch.mm(a, b)
-    if _MM_OUT_DTYPE[0] is None:
-        try:
-            torch.mm(a[:1], b, out_dtype=torch.float32)
-            _MM_OUT_DTYPE[0] = True
-        except (TypeError, RuntimeError):
-            _MM_OUT_DTYPE[0] = False
-    if _MM_OUT_DTYPE[0]:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    return torch.mm(a, b).float()
-
-
 def filters16(W, like):
     """[K, Cin, Cout] fp32 filters in the row type of ``like``, padded as the wide products read them (one conversion
-    per layer and step: the forward pass keeps it for dX)."""
+    per layer and step: the forward pass keeps it for dX).  None for fp32 rows whose filters are read in place."""
     lib = _lib.load()
     K, Cw_in, Cw_out = int(W.shape[0]), int(W.shape[1]), int(W.shape[2])
-    out = torch.empty((int(lib.wfs_wide_filters16_bytes(K, Cw_in, Cw_out)),), dtype=torch.uint8, device=W.device)
-    _lib.check(lib.wfs_wide_filters16(_lib.ptr(W), K, Cw_in, Cw_out, _lib.dtype_code(like), _lib.ptr(out), _lib.stream_ptr()))
+    if like.dtype == torch.float32 and Cw_out % 4 == 0:
+        return None
+    code = _lib.dtype_code(like)
+    out = torch.empty((int(lib.wfs_wide_filters_bytes(K, Cw_in, Cw_out, code)),), dtype=torch.uint8, device=W.device)
+    _lib.check(lib.wfs_wide_filters(_lib.ptr(W), K, Cw_in, Cw_out, code, _lib.ptr(out), _lib.stream_ptr()))
     return out
 
 
 def takes_wide_path(K, R, X, Cy):
-    return bool(X.is_cuda and X.dtype in (torch.bfloat16, torch.float16)
+    return bool(X.is_cuda and X.dtype in (torch.float32, torch.bfloat16, torch.float16)
                 and _lib.load().wfs_wide_conv_ok(K, R, X.shape[0], int(X.shape[1]), int(Cy), _lib.dtype_code(X)))
 
 
 def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev, w16=None):
-    """16-bit rows, >= 256 channels on a side: one dense matrix-core product over the shorter side of the layer
+    """>= 128 channels on a side: one dense matrix-core product over the shorter side of the layer
     (csrc/wide.hip; include/wfsparse.h wfs_wide_gather_conv).  The BatchNorm statistics, when a BatchNorm1d follows,
     are taken by its own kernel (bn_request stays unanswered)."""
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
@@ -175,7 +122,7 @@ def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bia
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
     Y = _rows((R, Cy), X, r_dev)
-    nbytes = lib.wfs_wide_conv_workspace_bytes(K, R, X.shape[0], Cx, Cy, 0 if table is None else 1)
+    nbytes = lib.wfs_wide_conv_workspace_bytes(K, R, X.shape[0], Cx, Cy, 0 if table is None else 1, _lib.dtype_code(X))
     ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=X.device)
     _lib.check(lib.wfs_wide_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], Cx, _lib.ptr(W),
                                         _lib.ptr(w16), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias), _lib.ptr(Y),
@@ -203,13 +150,6 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
-    if _gemm_route(X.shape[1], Cy, K, R, r_dev, table, X.dtype) and bn_request is None:
-        G = _gathered(table, kmap, K, identity_k, R, X, r_dev)                       # [R, K * Cx]
-        Wk = (W.transpose(1, 2) if transpose_w else W).reshape(K * X.shape[1], Cy)   # [K * Cx, Cy]
-        out = _mm_f32(G, Wk.to(X.dtype))
-        if bias is not None:
-            out = out + bias
-        return out.to(X.dtype)
     if bn_request is not None and not transpose_w and R > 0 and bn_request.bn.num_features == Cy:
         bn = bn_request.bn
         track = bn.track_running_stats and bn.running_mean is not None
@@ -372,12 +312,6 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
         dW = torch.empty(shape, dtype=torch.float32, device=S.device)
     assert S.dtype == G.dtype and S.shape[0] == R
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
-    if _gemm_route(Cs, Cg, K, R, r_dev, table, S.dtype) and not overlap:
-        Gk = _gathered(table, kmap, K, identity_k, R, G, r_dev)                      # [R, K * Cg]
-        ok = _row_ok(R, r_dev, S.device)
-        Sv = S if ok is None else torch.where(ok.unsqueeze(1), S, S.new_zeros(()))
-        dWk = _mm_f32(Sv.t(), Gk).reshape(Cs, K, Cg).permute(1, 0, 2)                 # [K, Cs, Cg]
-        return dW.copy_(dWk.transpose(1, 2) if swap else dWk)
     nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
 
@@ -478,7 +412,7 @@ class SparseConvFunction(Function):
 
 
 class PointwiseConvFunction(Function):
-    """1 x 1 convolution of 16-bit rows with >= 256 channels on a side: Y = X . W (+ bias) on the matrix cores of
+    """1 x 1 convolution with >= 128 channels on a side: Y = X . W (+ bias) on the matrix cores of
     csrc/wide.hip instead of spconv's ``torch.mm(features, weight.view(in, out))`` (spconv 1.2.1 conv.py; the hybrid
     net's 2048 -> 1697 layer, reference src/models/SPConvBlocks.py:498)."""
 
@@ -513,11 +447,6 @@ class PointwiseConvFunction(Function):
         if bias is not None and ctx.needs_input_grad[2]:
             db = _masked_column_sum(dY, n_dev).to(bias.dtype)
         return dX, dW, db, None
-
-
-def can_use_pointwise_conv(features, c_in, c_out):
-    return bool(features.is_cuda and features.dim() == 2 and features.shape[0] > 0 and _lib.load().wfs_wide_conv_ok(
-        1, features.shape[0], features.shape[0], int(c_in), int(c_out), _lib.dtype_code(features)))
 
 
 def pointwise_conv(features, filters, bias, n_dev=None):
@@ -747,9 +676,10 @@ def skinny_linear(x, linear):
 
 
 class WideLinearFunction(Function):
-    """nn.Linear with many outputs on 16-bit activations [B, I]: y = x W^T + b on the matrix cores (csrc/wide.hip;
-    include/wfsparse.h wfs_linear16_fwd), fp32 weights rounded to the row type as operands, fp32 accumulate, fp32
-    result -- the hybrid net's Linear(24150, 269) (reference src/models/SPConvNet.py:40-52)."""
+    """nn.Linear with many outputs on activations [B, I]: y = x W^T + b on the matrix cores (csrc/wide.hip;
+    include/wfsparse.h wfs_wide_linear_fwd): 16-bit activations with the fp32 weights rounded to their type as
+    operands, or fp32 activations on the exact-fp32 MFMA; fp32 accumulate, fp32 result -- the hybrid net's
+    Linear(24150, 269) (reference src/models/SPConvNet.py:40-52)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -760,8 +690,8 @@ class WideLinearFunction(Function):
         w = weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty((B, O), dtype=torch.float32, device=x.device)
-        ws = torch.empty((int(lib.wfs_linear16_workspace_bytes(B, I, O)),), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.wfs_linear16_fwd(_lib.ptr(x), B, I, _lib.ptr(w), _lib.ptr(b), O, _lib.ptr(y), _lib.dtype_code(x),
+        ws = torch.empty((int(lib.wfs_wide_linear_workspace_bytes(B, I, O, _lib.dtype_code(x))),), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.wfs_wide_linear_fwd(_lib.ptr(x), B, I, _lib.ptr(w), _lib.ptr(b), O, _lib.ptr(y), _lib.dtype_code(x),
                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
         ctx.save_for_backward(x, weight, bias)
         return y
@@ -777,16 +707,16 @@ class WideLinearFunction(Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = grad_like(weight, (O, I)) if ctx.needs_input_grad[1] else None
         db = _masked_column_sum(g, None) if (bias is not None and ctx.needs_input_grad[2]) else None
-        ws = torch.empty((int(lib.wfs_linear16_workspace_bytes(B, I, O)),), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.wfs_linear16_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw),
+        ws = torch.empty((int(lib.wfs_wide_linear_workspace_bytes(B, I, O, _lib.dtype_code(x))),), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.wfs_wide_linear_bwd(_lib.ptr(x), _lib.ptr(g), B, I, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw),
                                         None, _lib.dtype_code(x), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
         return dx, (dw.to(weight.dtype) if dw is not None else None), (db.to(bias.dtype) if db is not None else None)
 
 
 def can_use_wide_linear(linear, x):
     return bool(type(linear) is torch.nn.Linear and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
-                and x.dtype in (torch.bfloat16, torch.float16) and linear.weight.dtype == torch.float32
-                and _lib.load().wfs_linear16_ok(x.shape[0], x.shape[1], linear.out_features, _lib.dtype_code(x)))
+                and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and linear.weight.dtype == torch.float32
+                and _lib.load().wfs_wide_linear_ok(x.shape[0], x.shape[1], linear.out_features, _lib.dtype_code(x)))
 
 
 def wide_linear(x, linear):
