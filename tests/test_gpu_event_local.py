@@ -225,3 +225,39 @@ def test_resume_from_checkpoint_keeps_the_momentum_under_capture(tmp_path):
         res[capture] = torch.cat([p.detach().flatten().float().cpu() for p in m.model.parameters()])
     scale = float(res[False].abs().max())
     assert float((res[False] - res[True]).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("shape,ksize,stride,padding", [((14, 11, 64), (3, 3, 3), (1, 1, 4), (0, 0, 0)), ((14, 11), (3, 3), (1, 1), (0, 0)),
+                                                        ((12, 30), (3, 3), (2, 2), (1, 1)), ((9, 8, 20), (2, 2, 2), (2, 2, 2), (0, 0, 0))])
+def test_device_count_conv_build_equals_exact_build(shape, ksize, stride, padding):
+    """The regular / strided conv build with device-side counts (what a captured step runs: capacities for N and M, the
+    valid counts in device memory) against the exact-size build, which the oracle tests pin: same output coordinates in
+    spconv's first-seen order, same tables, bit for bit; rows beyond the device-side count never enter; a capacity that
+    is too small raises the overflow flag and keeps the first rows."""
+    from waveformml_amd.spconv import ops
+    rng = np.random.default_rng(17)
+    B = 7
+    ndim = len(shape)
+    idx = _sorted_by_event(rand_coords(rng, B, shape, min(1200, B * int(np.prod(shape)) // 3)))
+    t = torch.from_numpy(idx).to(DEV)
+    N = idx.shape[0]
+    exact = ops.build_rulebook(t, B, list(shape), list(ksize), list(stride), list(padding), [1] * ndim, False, known_unique=True)
+    cap_n = N + 313
+    pad = torch.cat([t, torch.full((cap_n - N, ndim + 1), 99999, dtype=torch.int32, device=DEV)])
+    nv = torch.tensor([N], dtype=torch.int64, device=DEV)
+    cap_m = exact.M + 77
+    rb = ops.build_rulebook(pad, B, list(shape), list(ksize), list(stride), list(padding), [1] * ndim, False, n_dev=nv,
+                            out_capacity=cap_m)
+    torch.cuda.synchronize()
+    M = int(rb.m_dev)
+    assert M == exact.M and int(rb.overflow) == 0
+    assert torch.equal(rb.out_indices[:M], exact.out_indices)
+    assert torch.equal(rb.nbr_out[:, :N], exact.nbr_out)
+    assert torch.equal(rb.nbr_in[:, :M], exact.nbr_in)
+    # a capacity that is too small: flagged, the tables hold what fits
+    small = ops.build_rulebook(pad, B, list(shape), list(ksize), list(stride), list(padding), [1] * ndim, False, n_dev=nv,
+                               out_capacity=max(exact.M // 2, 1))
+    torch.cuda.synchronize()
+    assert int(small.overflow) == 1 and int(small.m_dev) == max(exact.M // 2, 1)
+    keep = int(small.m_dev)
+    assert torch.equal(small.out_indices[:keep], exact.out_indices[:keep])
