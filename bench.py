@@ -230,6 +230,11 @@ def measure(env, args, dtype, steps, warmup, roofline):
                            "tflops": by["flops"] / max(by["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                            "timed_in": "eager pass after the timed region (HIP events on the launch stream)",
                            "per_step_ms": {k: timers[k][0] / nprof for k in timers}}
+        rp_us, rp_src = rocprof_launch_us(dom, dtype)
+        if rp_us:
+            out["roofline"]["rocprof"] = {"avg_launch_us": rp_us, "source": rp_src,
+                                          "achieved": bytes_per_launch / (rp_us * 1e-6) / 1e9,
+                                          "frac": bytes_per_launch / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if dtype == "f32":
             # the exact-fp32 path contracts on v_mfma_f32_32x32x2_f32, 1/16 of the bf16 matrix rate: next to the HBM
             # view, its launches priced against the fp32 MATRIX peak (MI355X_MICROARCH.md "Peak FP32 (matrix)")
@@ -237,6 +242,10 @@ def measure(env, args, dtype, steps, warmup, roofline):
             out["roofline"]["mfma"] = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": tf / F32_MFMA_PEAK_TFLOPS,
                                        "flops_per_launch": by["flops"] / max(by["launches"], 1)}
+            if rp_us:       # the same flops over the rocprof launch time of the graph replay
+                rtf = by["flops"] / max(by["launches"], 1) / (rp_us * 1e-6) / 1e12
+                out["roofline"]["mfma"]["rocprof"] = {"achieved": rtf, "frac": rtf / F32_MFMA_PEAK_TFLOPS,
+                                                      "avg_launch_us": rp_us}
     extras = {"init_state": init_state, "batch_np": (c, f, y), "logits0": logits0, "loss0": loss0}
     return out, extras
 
@@ -246,7 +255,7 @@ def pmc_traffic(kind, dtype):
     in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for 16-B-per-lane reads on gfx950),
     launch-weighted over the kernels of that class.  None when no PMC summary for this dtype is committed."""
     path = None
-    for rnd in ("r02", "r01"):                      # the newest committed summary
+    for rnd in ("r03", "r02", "r01"):               # the newest committed summary
         cand = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%s.json" % (rnd, dtype))
         if os.path.exists(cand):
             path = cand
@@ -268,6 +277,31 @@ def pmc_traffic(kind, dtype):
     if launches == 0:
         return None, None
     return tot / launches * 1024.0, "profiles/%s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, FETCH x2)" % os.path.basename(path)
+
+
+_KIND_PREFIXES = {"gather_conv": ("k_gconv", "k_gather_conv"), "gather_dw": ("k_gdw", "k_gather_dw")}
+
+
+def rocprof_launch_us(kind, dtype):
+    """Average launch duration of a kernel class in the committed rocprofv3 --kernel-trace --stats summary of this same
+    command's graph replay (profiles/rNN_hipgraph_<dtype>_kernel_stats.csv), launch-weighted: the cross-check of
+    ``avg_launch_us`` (HIP events, eager pass).  (None, None) when no summary for this dtype is committed."""
+    import csv
+    import re
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_hipgraph_%s_kernel_stats.csv" % (rnd, dtype))
+        if not os.path.exists(path):
+            continue
+        tot, calls = 0.0, 0
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = re.sub(r"\(anonymous namespace\)::|^void ", "", r["Name"])
+                if name.startswith(_KIND_PREFIXES[kind]):
+                    tot += float(r["TotalDurationNs"])
+                    calls += int(r["Calls"])
+        if calls:
+            return tot / calls / 1e3, "profiles/%s (rocprofv3 --kernel-trace --stats of the graph replay)" % os.path.basename(path)
+    return None, None
 
 
 def cpu_reference(env, extras, n_steps):
