@@ -255,3 +255,49 @@ def test_checkpoint_round_trip_in_lightning_layout(tmp_path):
     bare = str(tmp_path / "bare.ckpt")
     torch.save(mod.state_dict(), bare)
     assert set(read_checkpoint(bare)["state_dict"]) == set(mod.state_dict())
+
+
+def test_checkpoint_optimizer_state_is_per_parameter_both_ways(tmp_path):
+    """The trainer's optimizer owns ONE flat parameter; its checkpoints nevertheless carry the optimizer state the way a
+    torch optimizer over ``model.parameters()`` writes it (what Lightning stores for the reference), and a state written
+    in that layout -- by this trainer or by the reference -- is gathered back into the flat state on resume."""
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    from waveformml_amd.psd.trainer import load_optimizer_state, per_parameter_optimizer_state
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3))
+    twin = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3))
+    twin.load_state_dict(net.state_dict())
+    red = FlatGradAllReducer(net.parameters(), world_size=1)
+    flat_opt = torch.optim.SGD(red.optimizer_parameters(), lr=0.1, momentum=0.9, nesterov=True)
+    ref_opt = torch.optim.SGD(twin.parameters(), lr=0.1, momentum=0.9, nesterov=True)
+    x = torch.randn(7, 5)
+    for _ in range(2):
+        red.reset()                                   # the Trainer's sequence (psd/trainer.Trainer.training_step)
+        net(x).square().sum().backward()
+        red.finish()
+        flat_opt.step()
+        ref_opt.zero_grad()
+        twin(x).square().sum().backward()
+        ref_opt.step()
+    params = list(net.parameters())
+    sd = per_parameter_optimizer_state(flat_opt, params)
+    assert sorted(sd["state"]) == list(range(len(params))) and sd["param_groups"][0]["params"] == list(range(len(params)))
+    want = ref_opt.state_dict()
+    for i, p in enumerate(params):
+        assert tuple(sd["state"][i]["momentum_buffer"].shape) == tuple(p.shape)
+        assert torch.allclose(sd["state"][i]["momentum_buffer"], want["state"][i]["momentum_buffer"], atol=1e-7)
+    # the reference's optimizer takes it as it is
+    other = torch.optim.SGD(twin.parameters(), lr=0.1, momentum=0.9, nesterov=True)
+    other.load_state_dict(sd)
+    # and the flat optimizer takes the reference's layout
+    net2 = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3))
+    red2 = FlatGradAllReducer(net2.parameters(), world_size=1)
+    flat2 = torch.optim.SGD(red2.optimizer_parameters(), lr=0.1, momentum=0.9, nesterov=True)
+    load_optimizer_state(flat2, want, list(net2.parameters()))
+    back = per_parameter_optimizer_state(flat2, list(net2.parameters()))          # whatever order the flat layout has
+    for i in range(len(params)):
+        assert torch.equal(back["state"][i]["momentum_buffer"], want["state"][i]["momentum_buffer"])
+    # a state for another model: refused with both layouts named
+    with pytest.raises(RuntimeError, match="covers 2 parameters"):
+        bad = {"state": {}, "param_groups": [dict(want["param_groups"][0], params=[0, 1])]}
+        load_optimizer_state(flat2, bad, list(net2.parameters()))

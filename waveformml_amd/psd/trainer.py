@@ -55,6 +55,88 @@ def load_from_checkpoint(path, config, module_class=None, map_location="cpu", st
     return module
 
 
+def _offsets_in_flat(flat, params):
+    """Element offset of every model parameter inside the flat parameter it is a view of (the reducer lays buckets out
+    in reverse layer order, so this is NOT the running sum of the sizes); the running sum for parameters that are not
+    views of it."""
+    base, size, out, run = flat.data_ptr(), flat.element_size(), [], 0
+    for p in params:
+        off = (p.data_ptr() - base) // size if p.device == flat.device else -1
+        if not (0 <= off <= flat.numel() - p.numel() and (p.data_ptr() - base) % size == 0):
+            off = run
+        out.append(int(off))
+        run += p.numel()
+    return out
+
+
+def per_parameter_optimizer_state(optimizer, params):
+    """``optimizer.state_dict()`` in the layout a torch optimizer over ``model.parameters()`` writes -- what Lightning puts
+    into ``optimizer_states`` for the reference (src/engineering/LitPSD.py:60-76 builds the optimizer over
+    ``self.model.parameters()``): one state entry per parameter, indexed in parameter order.  This trainer's optimizer
+    holds ONE flat parameter (psd/ddp.FlatGradAllReducer); its per-element state tensors (``momentum_buffer``, Adam's
+    ``exp_avg`` ...) are cut at the parameters' offsets, scalar entries (``step``) are repeated."""
+    sd = optimizer.state_dict()
+    groups = sd["param_groups"]
+    total = sum(p.numel() for p in params)
+    flat = [p for g in optimizer.param_groups for p in g["params"]]
+    if len(flat) != 1 or flat[0].numel() != total or len(params) == 1:
+        return sd                                   # already one entry per parameter
+    state = {}
+    src = sd["state"].get(0, {})
+    offsets = _offsets_in_flat(flat[0], params)
+    for i, p in enumerate(params):
+        n, off = p.numel(), offsets[i]
+        entry = {}
+        for name, v in src.items():
+            if torch.is_tensor(v) and v.numel() == total:
+                entry[name] = v.reshape(-1)[off:off + n].reshape(p.shape).detach().cpu().clone()
+            else:
+                entry[name] = v.detach().cpu().clone() if torch.is_tensor(v) else v
+        if entry:
+            state[i] = entry
+    group = {k: v for k, v in groups[0].items() if k != "params"}
+    group["params"] = list(range(len(params)))
+    return {"state": state, "param_groups": [group]}
+
+
+def load_optimizer_state(optimizer, sd, params):
+    """Inverse of per_parameter_optimizer_state: accepts the optimizer's own layout or one entry per model parameter
+    (this trainer's checkpoints, or a checkpoint the reference's Lightning run wrote with the same optimizer class) and
+    gathers the per-parameter tensors into the flat parameter's state.  Anything else raises with both layouts named."""
+    flat = [p for g in optimizer.param_groups for p in g["params"]]
+    n_saved = sum(len(g["params"]) for g in sd["param_groups"])
+    if n_saved == len(flat):
+        optimizer.load_state_dict(sd)
+        return
+    if len(flat) != 1 or n_saved != len(params) or len(sd["param_groups"]) != 1:
+        raise RuntimeError("checkpoint optimizer state covers %d parameters in %d group(s); this run's optimizer has %d "
+                           "(the model has %d parameters): load the weights only (state_dict) or resume with the same "
+                           "optimizer configuration" % (n_saved, len(sd["param_groups"]), len(flat), len(params)))
+    names = set()
+    for st in sd["state"].values():
+        names.update(st.keys())
+    entry = {}
+    for name in names:
+        per_elem = any(torch.is_tensor(st.get(name)) and st[name].numel() > 1 for st in sd["state"].values())
+        if not per_elem:
+            entry[name] = next(st[name] for st in sd["state"].values() if name in st)
+            continue
+        buf = torch.zeros(flat[0].numel(), dtype=flat[0].dtype)
+        offsets = _offsets_in_flat(flat[0], params)
+        for i, p in enumerate(params):
+            v = sd["state"].get(i, {}).get(name)
+            if v is None:
+                continue
+            if tuple(v.shape) != tuple(p.shape):
+                raise RuntimeError("checkpoint optimizer state '%s' of parameter %d has shape %s, the parameter %s"
+                                   % (name, i, tuple(v.shape), tuple(p.shape)))
+            buf[offsets[i]:offsets[i] + p.numel()] = v.reshape(-1).to(flat[0].dtype).cpu()
+        entry[name] = buf.reshape(flat[0].shape)
+    group = {k: v for k, v in sd["param_groups"][0].items() if k != "params"}
+    group["params"] = [0]
+    optimizer.load_state_dict({"state": {0: entry} if entry else {}, "param_groups": [group]})
+
+
 class Trainer(object):
     def __init__(self, max_epochs=1, device="cuda:0", default_root_dir=None, feature_dtype=None, log_every=0,
                  capture=False, check_every=100, resume_from_checkpoint=None, recapture_after=4):
@@ -115,17 +197,18 @@ class Trainer(object):
         # more voxels than the capacity, or another number of events -> an ordinary step.  With several ranks the
         # decision is taken together: a rank replaying while another steps eagerly must never depend on the two paths
         # happening to issue the same collectives.
+        # Both inputs of the decision are host-side facts (tensor shapes, the optimizer's own bookkeeping), so the ranks
+        # agree over a gloo side group of host integers: no device collective, no stream synchronisation per step -- the
+        # host keeps queueing the next batch's copies and the next replay.  Bit 0: an ordinary step is
+        # needed; bit 1: because the batch has more rows than the captured capacity.
         misfit = not self._graph.fits(batch) or (hasattr(optimizer, "has_fresh") and optimizer.has_fresh())
+        too_big = batch[0][0].shape[0] > self._graph.n_cap
         if reducer.world > 1 and reducer.exchange:
-            flag = torch.tensor([1 if misfit else 0], dtype=torch.int32, device=self.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=reducer.group)
-            misfit = bool(flag.item())
+            from .graph import _agree_max
+            code = _agree_max((1 if misfit else 0) | (2 if (misfit and too_big) else 0), reducer.group)
+            # MAX of the codes: 1 < 2 < 3, and a rank reporting 2 cannot exist (too_big implies misfit)
+            misfit, too_big = code > 0, code >= 2
         if misfit:
-            too_big = batch[0][0].shape[0] > self._graph.n_cap
-            if reducer.world > 1 and reducer.exchange:
-                flag = torch.tensor([1 if too_big else 0], dtype=torch.int32, device=self.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=reducer.group)
-                too_big = bool(flag.item())
             self._size_misfits += 1 if too_big else 0
             if too_big and self.recapture_after > 0 and self._size_misfits >= self.recapture_after:
                 # the capacity is too small for this data: capture again, sized on this batch (never smaller than before)
@@ -200,20 +283,24 @@ class Trainer(object):
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         ck = {"epoch": int(epoch), "global_step": int(self.global_step),
               "state_dict": {k: v.detach().cpu().clone() for k, v in module.state_dict().items()},
-              "optimizer_states": [optimizer.state_dict()],
+              "optimizer_states": [per_parameter_optimizer_state(optimizer, list(module.model.parameters()))],
               "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else []}
         torch.save(ck, path)
         self.last_checkpoint = path
         return path
 
     def _resume(self, module, optimizer, scheduler, path):
-        """``resume_from_checkpoint`` (reference main.py ``--load_checkpoint``): weights, optimizer state (momentum),
-        scheduler state and the epoch / step counters; training continues with the NEXT epoch.  The parameters are
+        """``resume_from_checkpoint`` (reference main.py ``--load_checkpoint``): weights, optimizer state (momentum; one
+        entry per model parameter, as a Lightning run of the reference writes it, or this optimizer's own flat layout),
+        scheduler state and the epoch / step counters.  Epoch convention of THIS trainer's checkpoints: ``epoch`` = index of
+        the last finished epoch, training continues with ``epoch + 1``.  (pytorch_lightning is not installable here, so
+        which of its versions store ``current_epoch + 1`` instead could not be checked against a real file: a reference
+        checkpoint resumes at most one epoch late, never early.)  The parameters are
         views of the reducer's flat buffer at this point, so ``load_state_dict`` copies into it in place."""
         ck = read_checkpoint(path, map_location=self.device)
         module.load_state_dict(ck["state_dict"])
         if ck.get("optimizer_states"):
-            optimizer.load_state_dict(ck["optimizer_states"][0])
+            load_optimizer_state(optimizer, ck["optimizer_states"][0], list(module.model.parameters()))
         if scheduler is not None and ck.get("lr_schedulers"):
             scheduler.load_state_dict(ck["lr_schedulers"][0])
         self.global_step = int(ck.get("global_step", 0))
