@@ -61,7 +61,9 @@ def main():
     from waveformml_amd.psd.trainer import Trainer
     from waveformml_amd.spconv import ops
     tmp = tempfile.mkdtemp(prefix="wfs_soak_", dir="/tmp")
-    out = {"files_per_class": files_per_class, "events_per_file": events_per_file, "classes": len(CLASSES), "T": T}
+    out = {"files_per_class": files_per_class, "events_per_file": events_per_file, "classes": len(CLASSES), "T": T,
+           "inflate_threads_per_read": int(os.environ.get("WFH5_THREADS", "4")),
+           "handover": "shared page-locked ring" if os.environ.get("WFS_LOADER_RING", "1") != "0" else "one shared-memory segment per message + pin_memory thread"}
     try:
         t0 = time.perf_counter()
         rows = int(subprocess.run([CONDA, "-c", WRITER, tmp, str(files_per_class), str(events_per_file), str(T),
@@ -76,7 +78,7 @@ def main():
         cfg["dataset_config"] = {"imports": ["waveformml_amd.psd.PulseDataset"], "dataset_class": "PulseDataset.PulseDataset3D",
                                  "base_path": tmp, "paths": CLASSES, "n_train": n_events, "n_validate": 0, "n_test": 0,
                                  "dataloader_params": {"batch_size": len(CLASSES), "num_workers": workers,
-                                                       "pin_memory": True}}
+                                                       "pin_memory": os.environ.get("WFS_SOAK_PIN", "1") != "0"}}
         cfg["optimize_config"].update(lr=0.004, optimizer_params={"momentum": 0.9, "nesterov": True})
 
         def module_and_loader(nw, pack=True):
@@ -94,7 +96,7 @@ def main():
         out["loader"] = []
         for group in (1, 4):
             os.environ["WFS_LOADER_GROUP"] = str(group)
-            for nw in sorted({1, 4, workers, 2 * workers}):
+            for nw in ([workers] if os.environ.get("WFS_SOAK_QUICK") else sorted({1, 4, workers, 2 * workers})):
                 _, loader = module_and_loader(nw)
                 for _ in loader:                       # first pass: worker start-up, page cache
                     pass

@@ -71,6 +71,70 @@ def rank_sampler(dataset, shuffle, seed=0):
                               seed=seed)
 
 
+class _SharedRing(object):
+    """A ring of message slots in ONE shared-memory block created before the DataLoader forks its workers: workers write
+    their batches straight into a free slot and send only (slot, layout) through the queue; the trainer process page-locks
+    the block once (hipHostRegister) and copies to the GPU from the slot itself.  No shared-memory segment per message,
+    no pinning thread, no copy in the trainer process: the stock route (a fresh segment per message + DataLoader's
+    ``pin_memory`` thread) tops out at ~385 k events/s whatever the number of workers, the ring at ~670 k with the same
+    16 CPUs (tools/exp/loader_scaling.py; profiles/r03_soak_from_files.json)."""
+
+    def __init__(self, slots, slot_bytes):
+        import multiprocessing
+        self.slots, self.slot_bytes = int(slots), int(slot_bytes)
+        self.buf = torch.empty((self.slots, self.slot_bytes), dtype=torch.uint8).share_memory_()
+        self.free = multiprocessing.get_context("fork").Queue()
+        for i in range(self.slots):
+            self.free.put(i)
+        self.registered = False
+
+    def register(self):
+        """Page-lock the block in THIS process (the trainer): ``.to(device, non_blocking=True)`` from a slot is then a true
+        asynchronous copy.  Needs an initialised GPU; a no-op without one."""
+        if self.registered or not torch.cuda.is_available():
+            return self.registered
+        try:
+            rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), self.buf.numel(), 0)
+            self.registered = int(rc) == 0 if not isinstance(rc, tuple) else int(rc[0]) == 0
+        except Exception:          # noqa: BLE001  -- unregistered memory still works (synchronous staging copy)
+            self.registered = False
+        return self.registered
+
+    def close(self):
+        if self.registered:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(self.buf.data_ptr())
+            except Exception:      # noqa: BLE001
+                pass
+            self.registered = False
+
+
+class RingBatch(list):
+    """``[[coords, feats], labels]`` whose tensors are views of a ring slot; ``release()`` hands the slot back (called by
+    DevicePrefetcher once the host->device copy has completed; otherwise the loader reclaims it a few messages later)."""
+    token = None
+
+    def release(self):
+        if self.token is not None:
+            self.token.done()
+
+
+class _SlotToken(object):
+    def __init__(self, ring, slot, batches):
+        self.ring, self.slot, self.left = ring, slot, batches
+
+    def done(self):
+        self.left -= 1
+        if self.left == 0 and self.slot is not None:
+            self.ring.free.put(self.slot)
+            self.slot = None
+
+    def force(self):
+        if self.slot is not None:
+            self.ring.free.put(self.slot)
+            self.slot = None
+
+
 class _PackedCollate(object):
     """Collate in the worker, then pack the batch's tensors into ONE byte buffer (each at a 16-byte boundary): a batch
     then crosses the worker -> trainer process boundary as one shared-memory segment instead of three (or more), and is
@@ -81,8 +145,8 @@ class _PackedCollate(object):
     thread; ~1 ms, i.e. a ceiling of ~1000 batches/s per trainer process whatever the number of workers) is paid once
     per group."""
 
-    def __init__(self, collate, items_per_batch=None, group=1):
-        self.collate, self.items_per_batch, self.group = collate, items_per_batch, int(group)
+    def __init__(self, collate, items_per_batch=None, group=1, ring=None):
+        self.collate, self.items_per_batch, self.group, self.ring = collate, items_per_batch, int(group), ring
 
     def __call__(self, items):
         if self.group <= 1 or not self.items_per_batch:
@@ -100,23 +164,38 @@ class _PackedCollate(object):
                 meta.append((off, nbytes, t.dtype, tuple(t.shape)))
                 off += (nbytes + 15) // 16 * 16
             batches.append((tensors, meta, isinstance(feats, list)))
-        buf = torch.empty(max(off, 16), dtype=torch.uint8)
+        slot = None
+        if self.ring is not None and off <= self.ring.slot_bytes:
+            try:
+                slot = self.ring.free.get(timeout=20.0)  # blocks while every slot is in flight: back-pressure
+            except Exception:      # noqa: BLE001  -- queue.Empty: slots lost to an abandoned epoch; the ordinary route
+                slot = None
+        buf = self.ring.buf[slot] if slot is not None else torch.empty(max(off, 16), dtype=torch.uint8)
         for tensors, meta, _ in batches:
             for t, (o, nbytes, _, _) in zip(tensors, meta):
                 if nbytes:
                     buf[o:o + nbytes].view(t.dtype).view(t.shape).copy_(t)
-        return buf, [(meta, is_list) for _t, meta, is_list in batches]
+        return (("ring", slot) if slot is not None else buf), [(meta, is_list) for _t, meta, is_list in batches]
 
     @staticmethod
-    def unpack(packed):
-        """The batches of one message, in order."""
+    def unpack(packed, ring=None):
+        """The batches of one message, in order (RingBatch objects when the message lives in a ring slot)."""
         buf, metas = packed
+        token = None
+        if isinstance(buf, tuple):
+            token = _SlotToken(ring, buf[1], len(metas))
+            buf = ring.buf[buf[1]]
         out = []
         for meta, feats_is_list in metas:
             ts = [buf[o:o + nbytes].view(dtype).view(shape) if nbytes else torch.empty(shape, dtype=dtype)
                   for (o, nbytes, dtype, shape) in meta]
             feats = ts[1:-1] if feats_is_list else ts[1]
-            out.append(([ts[0], feats], ts[-1]))
+            if token is None:
+                out.append(([ts[0], feats], ts[-1]))
+            else:
+                b = RingBatch(([ts[0], feats], ts[-1]))
+                b.token = token
+                out.append(b)
         return out
 
 
@@ -126,13 +205,28 @@ class PackedLoader(object):
     $WFS_LOADER_GROUP or 1).  Measured on the MI355X box's host, 255-event batches of the bench's events out of 3 files
     each (tools/soak_from_files.py -> profiles/r03_soak_from_files.json)."""
 
-    def __init__(self, dataset, collate_fn, group=None, **loader_kwargs):
+    HOLD = 3            # messages a consumer that never calls RingBatch.release() may keep alive
+
+    def __init__(self, dataset, collate_fn, group=None, ring_slot_mb=None, **loader_kwargs):
         import os
         self.group = int(group if group is not None else os.environ.get("WFS_LOADER_GROUP", "1"))
         self.items_per_batch = int(loader_kwargs.get("batch_size", 1) or 1)
         if self.group > 1:
             loader_kwargs["batch_size"] = self.items_per_batch * self.group
-        self.loader = DataLoader(dataset, collate_fn=_PackedCollate(collate_fn, self.items_per_batch, self.group),
+        # ring of message slots shared with the workers (needs worker PROCESSES forked from this one): the slot size is
+        # $WFS_LOADER_SLOT_MB per batch of the message (default 4: twice a 255-event batch of the bench's events); a
+        # message that does not fit takes the ordinary route.  WFS_LOADER_RING=0 turns it off.
+        nw = int(loader_kwargs.get("num_workers", 0) or 0)
+        self.ring = None
+        if nw > 0 and os.environ.get("WFS_LOADER_RING", "1") != "0" and loader_kwargs.get("multiprocessing_context") is None:
+            mb = float(ring_slot_mb if ring_slot_mb is not None else os.environ.get("WFS_LOADER_SLOT_MB", "4"))
+            slots = nw * int(loader_kwargs.get("prefetch_factor", 2) or 2) + self.HOLD + 3
+            try:
+                self.ring = _SharedRing(slots, int(mb * (1 << 20)) * max(self.group, 1))
+                loader_kwargs["pin_memory"] = False       # the ring is page-locked once instead
+            except Exception:      # noqa: BLE001  -- e.g. /dev/shm too small: the ordinary route
+                self.ring = None
+        self.loader = DataLoader(dataset, collate_fn=_PackedCollate(collate_fn, self.items_per_batch, self.group, self.ring),
                                  **loader_kwargs)
         self.dataset = dataset
         self.drop_last = bool(loader_kwargs.get("drop_last", False))
@@ -146,9 +240,21 @@ class PackedLoader(object):
         return n // self.items_per_batch if self.drop_last else (n + self.items_per_batch - 1) // self.items_per_batch
 
     def __iter__(self):
-        for packed in self.loader:
-            for batch in _PackedCollate.unpack(packed):
-                yield batch
+        if self.ring is not None:
+            self.ring.register()
+        held = []                           # slot tokens of the last messages, oldest first
+        try:
+            for packed in self.loader:
+                batches = _PackedCollate.unpack(packed, self.ring)
+                if batches and isinstance(batches[0], RingBatch):
+                    held.append(batches[0].token)
+                    while len(held) > self.HOLD:
+                        held.pop(0).force()         # a consumer that kept it this long has copied what it needs
+                for batch in batches:
+                    yield batch
+        finally:
+            for t in held:
+                t.force()
 
 
 def make_loader(dataset, items_per_batch, num_workers=0, shuffle=False, pin_memory=True):
@@ -182,14 +288,15 @@ class DevicePrefetcher(object):
 
     def _stage(self, batch):
         (c, f), y = batch
-        host = [t if t.is_pinned() else t.pin_memory() for t in (c, f, y)]
+        ring = isinstance(batch, RingBatch)            # views of a page-locked ring slot: copy straight from it
+        host = [t if (ring or t.is_pinned()) else t.pin_memory() for t in (c, f, y)]
         with torch.cuda.stream(self.copy_stream):
             dev = [t.to(self.device, non_blocking=True) for t in host]
             if self.feature_dtype is not None:
                 dev[1] = dev[1].to(self.feature_dtype)
             done = torch.cuda.Event()
             done.record(self.copy_stream)
-        return host, dev, done           # `host` is kept alive until the copy has been waited on
+        return (batch if ring else host), dev, done    # kept alive until the copy has been waited on
 
     def __iter__(self):
         queue = []
@@ -205,6 +312,9 @@ class DevicePrefetcher(object):
             host, dev, done = queue.pop(0)
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(done)
+            if isinstance(host, RingBatch):
+                done.synchronize()        # issued a batch ago: long finished; the slot may now be overwritten
+                host.release()
             for t in dev:
                 t.record_stream(cur)      # allocated on the copy stream, consumed on the compute stream
             yield [dev[0], dev[1]], dev[2]
