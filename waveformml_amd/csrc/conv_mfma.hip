@@ -72,12 +72,18 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware tile map: blocks with equal blockIdx % 8 share an L2 -> give them one contiguous row range
+    // The ranges are cut from the VALID tiles, not from the capacity: with the capacity's ranges the padding tiles all
+    // fall to the last XCD's blocks, which idle while the others do capacity / valid times their share (a launch's time
+    // grew in proportion to the headroom: 87 -> 123 us per step for the four dX launches at 1.19 -> 1.60).
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const long long t_begin = (long long)xcd * tiles_per_xcd;
-    const long long t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
+    const long long Rv = valid_rows(R, r_dev);
+    const long long nt_v = (Rv + 31) >> 5, tpx_v = (nt_v + 7) >> 3;
+    (void)ntiles;
+    (void)tiles_per_xcd;
+    const long long t_begin = (long long)xcd * tpx_v;
+    const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
     const float bj = bias ? bias[r] : 0.f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const long long Rv = valid_rows(R, r_dev);
     for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
         if (tile * 32 >= Rv) break;
         const long long row = tile * 32 + r;
@@ -262,11 +268,15 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     int *myNb = sNb + (size_t)wid * K * 32;
+    // tile ranges per XCD cut from the VALID tiles (see k_gconv32_f32): the padding of a captured step costs nothing
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const long long t_begin = (long long)xcd * tiles_per_xcd;
-    const long long t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
-    const float bj = bias ? bias[r] : 0.f;
     const long long Rv = valid_rows(R, r_dev);
+    const long long nt_v = (Rv + 31) >> 5, tpx_v = (nt_v + 7) >> 3;
+    (void)ntiles;
+    (void)tiles_per_xcd;
+    const long long t_begin = (long long)xcd * tpx_v;
+    const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
+    const float bj = bias ? bias[r] : 0.f;
     for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
         if (tile * 32 >= Rv) break;
         const long long row = tile * 32 + r;
@@ -410,8 +420,10 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
     const int g = blockIdx.y;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
-    const long long t_begin = (long long)blockIdx.x * tiles_per_block;
-    const long long t_end = t_begin + tiles_per_block < ntiles ? t_begin + tiles_per_block : ntiles;
+    (void)tiles_per_block;                                   // cut from the capacity: the valid tiles are shared out instead
+    const long long tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long long t_begin = (long long)blockIdx.x * tpb;
+    const long long t_end = t_begin + tpb < ntiles ? t_begin + tpb : ntiles;
     f32x16 acc[DW_KG];
 #pragma unroll
     for (int q = 0; q < DW_KG; ++q)
@@ -683,8 +695,10 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
     const int g = blockIdx.y;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
-    const long long t_begin = (long long)blockIdx.x * tiles_per_block;
-    const long long t_end = t_begin + tiles_per_block < ntiles ? t_begin + tiles_per_block : ntiles;
+    (void)tiles_per_block;                                   // cut from the capacity: the valid tiles are shared out instead
+    const long long tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long long t_begin = (long long)blockIdx.x * tpb;
+    const long long t_end = t_begin + tpb < ntiles ? t_begin + tpb : ntiles;
     f32x16 acc[DWB_KG];
 #pragma unroll
     for (int q = 0; q < DWB_KG; ++q)

@@ -30,6 +30,8 @@ class GraphedTrainStep(object):
         # events: psd/synthetic, 40 batches), so the default is 6 sigma above the example batch: 1 + 3 / sqrt(E), i.e.
         # 1.19 at 256 events.  A batch beyond a capacity is detected (check()), never silently cut.
         (coords, feats), labels = example_batch
+        if headroom is None and os.environ.get("WFS_CAPTURE_HEADROOM"):
+            headroom = float(os.environ["WFS_CAPTURE_HEADROOM"])          # experiments: tools/exp (capacity is not free)
         if headroom is None:
             headroom = max(1.1, 1.0 + 3.0 / max(1.0, float(labels.shape[0])) ** 0.5)
         if granule is None:
