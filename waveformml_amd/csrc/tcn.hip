@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int TB = 256;
+constexpr int TBW = 1024;         // the backward kernel's block (one block per CU: make it wide)
 constexpr int MAXLV = 8, MAXK = 8;
 
 // the effective taps [levels][2][k] and biases [levels][2] are autograd tensors in device memory: every block
@@ -111,9 +112,10 @@ __global__ void __launch_bounds__(TB) k_tcn_fwd(const T *__restrict__ X, long lo
     for (int t = threadIdx.x; t < L; t += TB) wfs_st(y + t, A[t]);
 }
 
-// LDS: Xs[levels + 1][L], H1[levels][L], H2[levels][L], G[L], G2[L], G3[L]
+// LDS: Xs[levels + 1][L], H1[levels][L], H2[levels][L], G[L], G2[L], G3[L] -- 13 rows = 106 KB at L = 2048, 3 levels: one
+// block per CU, so the block is 16 waves (TBW): a row pass is 2 steps per thread instead of 8 (112 -> ? us at 776 rows)
 template <typename T, int K>
-__global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T *__restrict__ dY, long long N, int L,
+__global__ void __launch_bounds__(TBW) k_tcn_bwd(const T *__restrict__ X, const T *__restrict__ dY, long long N, int L,
                                                 const float *__restrict__ Wd, const float *__restrict__ Bd, int levels,
                                                 T *__restrict__ dX, float *__restrict__ partial, float drop_p,
                                                 const long long *__restrict__ seed_dev) {
@@ -126,12 +128,13 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
     float *G = H2 + (size_t)levels * L;
     float *G2 = G + L;
     float *G3 = G2 + L;
-    __shared__ float sred[TB];
+    __shared__ float sred[TBW];
     const long long row = blockIdx.x;
+    const int nthr = blockDim.x;                 // 256 or TBW (the host picks by the LDS a row needs)
     const T *x = X + row * L;
     const Drop dr = make_drop(drop_p, seed_dev);
     load_taps<K>(&tp, Wd, Bd, levels);
-    for (int t = threadIdx.x; t < L; t += TB) {
+    for (int t = threadIdx.x; t < L; t += nthr) {
         Xs[t] = ldv(x + t);
         G[t] = ldv(dY + row * L + t);
     }
@@ -141,12 +144,12 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
         const int d = 1 << lv;
         const float *A = Xs + (size_t)lv * L;
         float *h1 = H1 + (size_t)lv * L, *h2 = H2 + (size_t)lv * L, *An = Xs + (size_t)(lv + 1) * L;
-        for (int t = threadIdx.x; t < L; t += TB) {
+        for (int t = threadIdx.x; t < L; t += nthr) {
             float v = fir<K>(A, t, tp.w + (lv * 2 + 0) * K, tp.b[lv * 2 + 0], d);
             h1[t] = (v > 0.f ? v : 0.f) * drop_mult(dr, row, lv * 2 + 0, t);     // the value conv2 sees
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < L; t += TB) {
+        for (int t = threadIdx.x; t < L; t += nthr) {
             float v = fir<K>(h1, t, tp.w + (lv * 2 + 1) * K, tp.b[lv * 2 + 1], d);
             v = (v > 0.f ? v : 0.f) * drop_mult(dr, row, lv * 2 + 1, t);
             h2[t] = v;
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
 #pragma unroll
         for (int j = 0; j <= k; ++j) a2[j] = a1[j] = 0.f;
         // G  <- g_out = G * [x_{lv+1} > 0];   G2 <- g_h2 = g_out * [h2 > 0]
-        for (int t = threadIdx.x; t < L; t += TB) {
+        for (int t = threadIdx.x; t < L; t += nthr) {
             float go = An[t] > 0.f ? G[t] : 0.f;
             float gh = h2[t] > 0.f ? go * dr.scale : 0.f;     // h2 = relu(.) * mult > 0 <=> positive AND kept
             G[t] = go;
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
         }
         __syncthreads();
         // g_h1[s] = [h1 > 0] * sum_j w2[j] g_h2[s + (k-1-j) d]  -> G3;  its dW1 / dB1 sums in the same pass
-        for (int s = threadIdx.x; s < L; s += TB) {
+        for (int s = threadIdx.x; s < L; s += nthr) {
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < k; ++j) {
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
         }
         __syncthreads();
         // dX_lv[s] = g_out[s] (residual) + sum_j w1[j] g_h1[s + (k-1-j) d]   (G[s] is read only at index s)
-        for (int s = threadIdx.x; s < L; s += TB) {
+        for (int s = threadIdx.x; s < L; s += nthr) {
             float v = G[s];
 #pragma unroll
             for (int j = 0; j < k; ++j) {
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
             }
             G[s] = v;
         }
-        // block reduction of this level's 2 (k + 1) sums in a fixed order: butterfly inside each wave, then the four
+        // block reduction of this level's 2 (k + 1) sums in a fixed order: butterfly inside each wave, then the
         // waves' sums added in wave order -- one barrier per level
         {
             constexpr int P = 2 * (K + 1);
@@ -230,14 +233,14 @@ __global__ void __launch_bounds__(TB) k_tcn_bwd(const T *__restrict__ X, const T
             if (threadIdx.x < P) {
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < TB / 64; ++w) v += sred[w * P + threadIdx.x];
+                for (int w = 0; w < nthr / 64; ++w) v += sred[w * P + threadIdx.x];
                 partial[row * ((long long)levels * per) + lv * per + threadIdx.x] = v;
             }
         }
         __syncthreads();
     }
     T *dx = dX + row * L;
-    for (int t = threadIdx.x; t < L; t += TB) wfs_st(dx + t, G[t]);
+    for (int t = threadIdx.x; t < L; t += nthr) wfs_st(dx + t, G[t]);
 }
 
 }  // namespace
@@ -322,7 +325,8 @@ extern "C" int wfs_tcn_bwd(const void *X, const void *dY, int64_t N, int32_t L, 
     WFS_REQUIRE(lds <= 150 * 1024, WFS_EINVAL, "row of %d samples x %d levels needs %zu B of LDS", L, levels, lds);
     if (N == 0) return WFS_OK;
     WFS_REQUIRE(X && dY && dX && partial && taps && bias, WFS_EINVAL, "NULL device pointer");
-    const dim3 grid((unsigned)N), block(TB);
+    // rows that leave room for one or two blocks per CU get a 16-wave block, short rows keep 4 waves and more blocks
+    const dim3 grid((unsigned)N), block(lds > 48 * 1024 ? TBW : TB);
     if (dtype == WFS_F32) {
         int rc = tcn_bwd_attr_k<float>(k);
         if (rc != WFS_OK) return rc;
