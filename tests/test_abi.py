@@ -83,3 +83,13 @@ def test_surface_matches_what_the_reference_calls():
     assert x.batch_size == 1
     with pytest.raises(RuntimeError):
         seq(x)
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() (incremental make of both libraries and the oracle, import of
+    the package, ABI version of library and binding equal) must not raise."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
