@@ -77,6 +77,11 @@ class GraphedTrainStep(object):
         self.in_graph_exchange = (exchange and dist.is_available() and dist.is_initialized()
                                   and dist.get_backend(reducer.group) == "nccl"
                                   and os.environ.get("WFS_GRAPH_EXCHANGE", "1") != "0")
+        if self.in_graph_exchange:
+            # decided ONCE, on a scratch graph holding a single small all-reduce, before anything expensive is captured
+            # on this communicator -- and agreed between the ranks (no in-process retry of a failed capture
+            # that contained collectives)
+            self.in_graph_exchange = _collective_capture_works(reducer.group, dev)
         self.exchange_after = exchange and not self.in_graph_exchange
         self.in_graph_optimizer = not self.exchange_after
         self._convs = [m for m in module.modules()
@@ -261,6 +266,38 @@ class GraphedTrainStep(object):
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
         if bool(flag.item()):
             raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
+
+
+def _collective_capture_works(group, dev):
+    """Can this process group's all-reduce be captured into a HIP graph and replayed?  Probed with one 8-float
+    all-reduce on a scratch graph (after an eager one: a communicator must not be created inside a capture); every rank
+    gets the same answer (MAX of the failure flags over the gloo side group)."""
+    ok = True
+    try:
+        st = torch.cuda.current_stream(dev)
+        if st == torch.cuda.default_stream(dev):
+            st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            t = torch.ones((8,), dtype=torch.float32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(dev)
+            t.fill_(1.0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            g.replay()
+            torch.cuda.synchronize(dev)
+            ok = abs(float(t[0].item()) - float(dist.get_world_size(group))) < 1e-3
+            del g
+    except Exception as e:         # noqa: BLE001  -- whatever the library raises: the answer is "no"
+        print("[waveformml_amd] a captured all-reduce is not available here (%s: %s): gradients are exchanged after the "
+              "replay" % (type(e).__name__, e), file=sys.stderr, flush=True)
+        ok = False
+        try:
+            torch.cuda.synchronize(dev)
+        except Exception:          # noqa: BLE001
+            pass
+    return not _agree_max(0 if ok else 1, group)
 
 
 _GLOO_SIDE = {}
