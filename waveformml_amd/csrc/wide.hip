@@ -557,7 +557,10 @@ int g_wide_min_channels = 128;      // a side of the filter at least this wide (
 int plan_ksplit(long long blocks, int Ks, int es, int *kchunk) {
     const int GK = GKB / es;
     int ks = 1;
-    if (blocks * 2 <= 256) {              // fewer 128 x 128 tiles than half the CUs: cut the contraction
+    // fewer 128 x 128 tiles than half the CUs AND a contraction of at least 16 steps: cut it (a short contraction is a
+    // ~10-us launch either way, and the pass over the slabs is another launch: GEP's 763-row dW products lost 7 us each)
+    // (fp32 steps hold 64 MFMAs of 64 cycles instead of 16 of 32: there two steps already outweigh the extra launch)
+    if (blocks * 2 <= 256 && Ks >= (es == 4 ? 2 : 16) * GK) {
         const long long want = 256 / blocks, deep = wfs_cdiv(Ks, 2 * GK);
         ks = (int)(want < deep ? want : deep);
         if (ks < 1) ks = 1;
