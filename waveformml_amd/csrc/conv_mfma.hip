@@ -210,7 +210,8 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 }
 
 // Timing knock-outs (tools/exp/knock.sh, profiles/r01_gconv32_bf16_knockouts.txt): -DWFS_KNOCK=bits builds a library
-// whose k_gconv32_bf16 skips a phase -- 1 filter staging, 2 table reads, 4 gathers + MFMA, 8 stores -- to measure what
+// whose k_gconv32_bf16 skips a phase -- 1 filter staging, 2 table reads, 4 gathers + MFMA, 8 stores, 16 gathers read the
+// tile's own rows -- to measure what
 // each phase costs inside a replayed graph.  Results are wrong by construction; 0 (the default) compiles to nothing.
 #ifndef WFS_KNOCK
 #define WFS_KNOCK 0
@@ -316,7 +317,10 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
             for (int g = 0; g < BF_GROUP; ++g)
                 if (ks[g] >= 0) {
                     nbs[g] = myNb[ks[g] * 32 + r];
-                    const uint4 *xp = (const uint4 *)(X + (long long)(nbs[g] >= 0 ? nbs[g] : 0) * 32 + h * 16);
+                    // WFS_KNOCK & 16: every offset reads the tile's OWN rows (a coalesced window instead of a gather):
+                    // an upper bound on what run-structured window loads could save
+                    const long long src = (WFS_KNOCK & 16) ? rowc : (long long)(nbs[g] >= 0 ? nbs[g] : 0);
+                    const uint4 *xp = (const uint4 *)(X + src * 32 + h * 16);
                     a_lo[g] = xp[0];
                     a_hi[g] = xp[1];
                 }
