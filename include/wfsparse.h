@@ -457,10 +457,14 @@ int wfs_sgd_step(float *param, const float *grad, float *momentum_buf, int64_t n
  * One launch that places a device-resident batch into the fixed buffers a captured step reads: coords [n, cols]
  * int32 (copied as is to coords_dst and, columns permuted by perm_host, to indices_dst -- the batch-first order the
  * reference produces at src/models/SPConvNet.py:64 -- either destination may be NULL), feats (feat_bytes bytes),
- * labels int64 [B], and the row count n into *n_valid_dst (may be NULL). */
+ * labels int64 [B], and the row count n into *n_valid_dst (may be NULL).  event_offsets (may be NULL): the
+ * wfs_event_offsets table of the batch (`events` events, wfs_event_offsets_ints(events) ints; the batch index is the
+ * source column that perm_host moves to the front), written by the same launch -- the captured step then starts with
+ * the event-local rulebook build itself. */
 int wfs_load_batch(const int32_t *coords, int64_t n, int32_t cols, const int32_t *perm_host, int32_t *coords_dst,
                    int32_t *indices_dst, const void *feats, void *feats_dst, int64_t feat_bytes,
-                   const int64_t *labels, int64_t *labels_dst, int64_t B, int64_t *n_valid_dst, void *stream);
+                   const int64_t *labels, int64_t *labels_dst, int64_t B, int64_t *n_valid_dst,
+                   int32_t *event_offsets, int32_t events, void *stream);
 
 /* opt-in per-kernel timing (HIP events on the launch stream), used by bench.py's roofline ---- */
 #define WFS_TIMER_GATHER_CONV 0

@@ -1001,10 +1001,23 @@ def test_batch_hand_over_kernel_copies_and_permutes(cols, perm, C, dtype):
     fdst = torch.zeros((cap, C), dtype=dtype, device=DEV)
     ldst = torch.zeros_like(labels)
     nv = torch.zeros((1,), dtype=torch.int64, device=DEV)
+    # the batch index lives in the source column that the permutation moves to the front: make it a grouped event column
+    ev_col = perm[0]
+    evt = np.sort(rng.integers(0, B, n)).astype(np.int32)
+    evt = evt[evt != 5]                                    # an event without rows
+    n = len(evt)
+    coords, feats = coords[:n].clone(), feats[:n].clone()
+    coords[:, ev_col] = torch.from_numpy(evt).to(DEV)
+    from waveformml_amd.spconv import ops
+    events = torch.full((int(lib.wfs_event_offsets_ints(B)),), -3, dtype=torch.int32, device=DEV)
     _lib.check(lib.wfs_load_batch(_lib.ptr(coords), n, cols, _lib.i32_array(perm), _lib.ptr(cdst), _lib.ptr(idst),
                                   _lib.ptr(feats), _lib.ptr(fdst), feats.numel() * feats.element_size(), _lib.ptr(labels),
-                                  _lib.ptr(ldst), B, _lib.ptr(nv), _lib.stream_ptr()))
+                                  _lib.ptr(ldst), B, _lib.ptr(nv), _lib.ptr(events), B, _lib.stream_ptr()))
     torch.cuda.synchronize()
+    # the event offsets written by the same launch equal wfs_event_offsets on the batch-first copy, flag words included
+    want = ops.event_offsets(idst[:n].contiguous(), B)
+    assert torch.equal(events, want) and not bool(events[B + 1:].any())
+    assert np.array_equal(events[:B + 1].cpu().numpy(), np.searchsorted(evt, np.arange(B + 1)))
     assert torch.equal(cdst[:n], coords) and bool((cdst[n:] == -7).all())
     assert torch.equal(idst[:n], coords[:, perm]) and bool((idst[n:] == -7).all())
     assert torch.equal(fdst.reshape(-1)[:n * C], feats.reshape(-1)) and float(fdst.reshape(-1)[n * C:].abs().sum()) == 0.0

@@ -108,7 +108,8 @@ SIGNATURES = {
     "wfs_xent_mean_fwd_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "wfs_sgd_step": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _i32, _i32,
                                     _vp]),
-    "wfs_load_batch": (ctypes.c_int, [_vp, _i64, _i32, c_i32p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "wfs_load_batch": (ctypes.c_int, [_vp, _i64, _i32, c_i32p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32,
+                                      _vp]),
     "wfs_timing_enable": (ctypes.c_int, [_i32]),
     "wfs_timing_read": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_double), c_i64p]),
 }

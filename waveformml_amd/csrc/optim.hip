@@ -66,9 +66,30 @@ __global__ void __launch_bounds__(256) k_load_batch(const int *__restrict__ coor
                                                     long long feat_words, const unsigned char *__restrict__ feats_tail,
                                                     unsigned char *__restrict__ feats_tail_dst, int tail_bytes,
                                                     const long long *__restrict__ labels, long long *__restrict__ labels_dst,
-                                                    long long B, long long *__restrict__ n_valid_dst) {
+                                                    long long B, long long *__restrict__ n_valid_dst,
+                                                    int *__restrict__ ev_off, int ev_B, int ev_col) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
     if (tid == 0 && n_valid_dst) *n_valid_dst = n;
+    // event offsets of the batch (evrulebook.hip k_event_offsets, same words, same flags): the first WFS_EVENT_FLAG_WORDS
+    // blocks walk the batch column of the SOURCE rows -- the captured step then starts with the rulebook build itself
+    if (ev_off && blockIdx.x < WFS_EVENT_FLAG_WORDS) {
+        int bad = 0;
+        if (n == 0)
+            for (int e = blockIdx.x * 256 + threadIdx.x; e <= ev_B; e += WFS_EVENT_FLAG_WORDS * 256) ev_off[e] = 0;
+        for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)WFS_EVENT_FLAG_WORDS * 256) {
+            const int b = coords[j * cols + ev_col];
+            const int bp = j > 0 ? coords[(j - 1) * cols + ev_col] : -1;
+            const bool ok = b >= 0 && b < ev_B && b >= bp && bp >= -1 && bp < ev_B;
+            bad |= ok ? 0 : 1;
+            if (ok) {
+                for (int e = bp + 1; e <= b; ++e) ev_off[e] = (int)j;
+                if (j == n - 1)
+                    for (int e = b + 1; e <= ev_B; ++e) ev_off[e] = (int)n;
+            }
+        }
+        bad = __syncthreads_or(bad);
+        if (threadIdx.x == 0) ev_off[ev_B + 1 + blockIdx.x] = bad;
+    }
     for (long long i = tid; i < n * cols; i += nth) {
         const long long row = i / cols;
         const int col = (int)(i - row * cols);
@@ -85,7 +106,7 @@ __global__ void __launch_bounds__(256) k_load_batch(const int *__restrict__ coor
 extern "C" int wfs_load_batch(const int32_t *coords, int64_t n, int32_t cols, const int32_t *perm_host,
                               int32_t *coords_dst, int32_t *indices_dst, const void *feats, void *feats_dst,
                               int64_t feat_bytes, const int64_t *labels, int64_t *labels_dst, int64_t B,
-                              int64_t *n_valid_dst, void *stream_) {
+                              int64_t *n_valid_dst, int32_t *event_offsets, int32_t events, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(cols >= 1 && cols <= 8, WFS_EINVAL, "bad coordinate width %d", cols);
     WFS_REQUIRE(n >= 0 && B >= 0 && feat_bytes >= 0, WFS_EINVAL, "negative size");
@@ -103,10 +124,12 @@ extern "C" int wfs_load_batch(const int32_t *coords, int64_t n, int32_t cols, co
     long long work = n * cols > words ? n * cols : words;
     long long blocks = wfs_cdiv(work > 0 ? work : 1, 256);
     if (blocks > 1024) blocks = 1024;
+    WFS_REQUIRE(!event_offsets || events >= 1, WFS_EINVAL, "event offsets of %d events", events);
+    if (event_offsets && blocks < WFS_EVENT_FLAG_WORDS) blocks = WFS_EVENT_FLAG_WORDS;
     k_load_batch<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(
         coords, n, cols, pm, coords_dst, indices_dst, (const uint4 *)feats, (uint4 *)feats_dst, words,
         (const unsigned char *)feats + words * 16, (unsigned char *)feats_dst + words * 16, tail, (const long long *)labels,
-        (long long *)labels_dst, B, (long long *)n_valid_dst);
+        (long long *)labels_dst, B, (long long *)n_valid_dst, event_offsets, events, pm.v[0]);
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

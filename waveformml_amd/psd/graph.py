@@ -65,6 +65,17 @@ class GraphedTrainStep(object):
         perm = getattr(net, "permute_tensor", None)
         self._perm = [int(v) for v in perm.tolist()] if perm is not None else None
         self.indices = torch.zeros_like(self.coords) if self._perm is not None else None
+        # the event offsets the event-local rulebook build starts from (spconv.ops.EVENT_LOCAL) are written by the
+        # hand-over launch as well: one graph node fewer at the head of the step
+        from ..spconv import ops as _ops
+        self.n_events = int(self.n_cap if self.per_row else labels.shape[0])
+        self.events = None
+        if (_ops.EVENT_LOCAL and self.indices is not None and 1 <= self.n_events <= _ops.EVENT_LOCAL_MAX_BATCH
+                and hasattr(net, "batch_events")):
+            from .. import _lib as _l
+            self.events = torch.zeros((int(_l.load().wfs_event_offsets_ints(self.n_events)),), dtype=torch.int32,
+                                      device=dev)
+            net.batch_events = (self.coords, self.events)
         self.world = reducer.world
         # Gradient exchange of a captured step (world > 1).  With RCCL the collectives are captured INSIDE the graph:
         # the reducer's hooks stay armed, so during the captured backward each bucket (reverse layer order) is packed
@@ -216,6 +227,7 @@ class GraphedTrainStep(object):
             self.n_valid.fill_(n)
             if self.indices is not None:
                 self.indices[:n].copy_(coords[:, self._perm], non_blocking=True)
+            self._event_offsets()
             return
         if (coords.is_cuda and coords.dtype == torch.int32 and coords.is_contiguous() and feats.is_cuda
                 and feats.is_contiguous() and feats.dtype == self.feats.dtype and labels.is_cuda
@@ -224,10 +236,14 @@ class GraphedTrainStep(object):
             from .. import _lib
             lib = _lib.load()
             perm = _lib.i32_array(self._perm) if self._perm is not None else None
+            ev = self.events if (self.events is not None and perm is not None) else None
             _lib.check(lib.wfs_load_batch(_lib.ptr(coords), n, coords.shape[1], perm, _lib.ptr(self.coords),
                                           _lib.ptr(self.indices), _lib.ptr(feats), _lib.ptr(self.feats),
                                           feats.numel() * feats.element_size(), _lib.ptr(labels), _lib.ptr(self.labels),
-                                          labels.numel(), _lib.ptr(self.n_valid), _lib.stream_ptr()))
+                                          labels.numel(), _lib.ptr(self.n_valid), _lib.ptr(ev), self.n_events,
+                                          _lib.stream_ptr()))
+            if ev is None:
+                self._event_offsets()
             return
         self.coords[:n].copy_(coords, non_blocking=True)
         self.feats[:n].copy_(feats, non_blocking=True)
@@ -235,6 +251,16 @@ class GraphedTrainStep(object):
         self.n_valid.fill_(n)
         if self.indices is not None:
             self.indices[:n].copy_(coords[:, self._perm], non_blocking=True)
+        self._event_offsets()
+
+    def _event_offsets(self):
+        """The event offsets of the loaded batch when the hand-over launch did not write them (its own launch)."""
+        if self.events is None:
+            return
+        from .. import _lib
+        _lib.check(_lib.load().wfs_event_offsets(_lib.ptr(self.indices), self.indices.shape[0], self.indices.shape[1] - 1,
+                                                 self.n_events, _lib.ptr(self.n_valid), _lib.ptr(self.events),
+                                                 _lib.stream_ptr()))
 
     def __call__(self, batch):
         if torch.cuda.current_stream(self.coords.device) == torch.cuda.default_stream(self.coords.device):
@@ -417,6 +443,8 @@ class GraphedEvalStep(object):
         return net([self.coords, self.feats, self.n_valid]).float()
 
     _load = GraphedTrainStep._load
+    _event_offsets = GraphedTrainStep._event_offsets
+    events = None                 # the forward-only graphs compute their event offsets inside the graph
 
     def fits(self, batch):
         (coords, _f), labels = batch

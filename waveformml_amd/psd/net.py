@@ -70,6 +70,7 @@ class SPConvNet(nn.Module):
         self.spconv = self.modules_util.retrieve_module("spconv")
         self.sequence_class = self.modules_util.retrieve_class(self.net_config.sequence_class)
         self.batch_size_hint = None
+        self.batch_events = None              # (coords, event offsets) written by a captured step's hand-over launch
         self._build()
         net_type = getattr(self.net_config, "net_type", "2DConvolution")
         if net_type == "3DConvolution":
@@ -103,6 +104,9 @@ class SPConvNet(nn.Module):
                                           batch_size)
         if len(x) > 2 and x[2] is not None:       # [coords, feats, n_valid]: rows beyond n_valid[0] are padding
             st.n_valid = x[2]
+        ev = getattr(self, "batch_events", None)
+        if ev is not None and ev[0] is coords and handed is not None and handed[0] is coords:
+            st.events = ev[1]                     # first row of every event: what the event-local rulebook build starts from
         fsp = getattr(self.spconv, "functional", None)
         out = self.sparseModel(st)
         out = out.view(-1, self.n_linear)
