@@ -21,6 +21,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int F32_GROUP = 4;       // offsets whose row gathers a wave of k_gconv32_f32 has in flight together (64 VGPRs)
 
 struct KMap {
     int v[128];
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
     const float bj = bias ? bias[r] : 0.f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
+    for (long long tile = t_begin + (long long)wid * bpx + bi; tile < t_end; tile += (long long)bpx * nw) {
         if (tile * 32 >= Rv) break;
         const long long row = tile * 32 + r;
         const bool live = row < Rv;
@@ -109,49 +110,86 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = bj;
         if (mask != 0) {
-            // ---- phase 2: software-pipelined walk over the active offsets: while the 16 MFMAs of offset k
-            // run, the gathered rows of the next active offset and the table entry of the one after are in flight.
-            auto entry = [&](int k) -> int {
-                int t = table[(long long)(mirror ? K - 1 - k : k) * R + rowc];      // L1 hit: phase 1 touched the line
-                t = (k == identity_k) ? (int)rowc : t;
-                return live ? t : -1;
+            // ---- phase 2: the active offsets are taken F32_GROUP at a time, in ascending order (the fp32 sum of a
+            // row keeps the order of the oracle's loop): ALL the group's row gathers (4 x 16 B per lane and offset) are
+            // issued back to back, then the next group's table entries (L1 / L2 hits: phase 1 touched the lines), then
+            // the group's 16 MFMAs per offset run as their rows arrive.  One offset in flight at a time (round 2) left
+            // a wave waiting out a full gather round trip per offset: 9.7 dependent round trips per tile.
+            // the group's table entries: F32_GROUP loads on clamped addresses issued back to back, selects afterwards
+            // (a load per "slot in use?" branch made hipcc wait for each one -- and for the gathers in front of it)
+            auto entry_loads = [&](const int (&kk)[F32_GROUP], int (&t)[F32_GROUP]) {
+#pragma unroll
+                for (int g = 0; g < F32_GROUP; ++g) {
+                    const int k = kk[g] >= 0 ? kk[g] : 0;
+                    t[g] = table[(long long)(mirror ? K - 1 - k : k) * R + rowc];
+                }
             };
-            int k_cur = __builtin_ctz(mask);
-            mask &= mask - 1;
-            int nb_cur = entry(k_cur);
-            const f32x4 *xp = (const f32x4 *)(X + (long long)(nb_cur >= 0 ? nb_cur : 0) * 32 + h * 16);
-            f32x4 a0 = xp[0], a1 = xp[1], a2 = xp[2], a3 = xp[3];
-            int k_next = mask ? __builtin_ctz(mask) : k_cur;
-            int nb_next = entry(k_next);
+            auto entry_values = [&](const int (&kk)[F32_GROUP], const int (&t)[F32_GROUP], int (&nb)[F32_GROUP]) {
+#pragma unroll
+                for (int g = 0; g < F32_GROUP; ++g) {
+                    const int v1 = (kk[g] == identity_k) ? (int)rowc : t[g];
+                    nb[g] = (live && kk[g] >= 0) ? v1 : -1;
+                }
+            };
+            int kq[F32_GROUP], nbq[F32_GROUP];
+#pragma unroll
+            for (int g = 0; g < F32_GROUP; ++g) {
+                kq[g] = mask ? __builtin_ctz(mask) : -1;
+                mask = mask ? (mask & (mask - 1)) : 0u;
+            }
+            {
+                int t0[F32_GROUP];
+                entry_loads(kq, t0);
+                entry_values(kq, t0, nbq);
+            }
             while (true) {
-                const f32x4 *xn = (const f32x4 *)(X + (long long)(nb_next >= 0 ? nb_next : 0) * 32 + h * 16);
-                f32x4 n0 = xn[0], n1 = xn[1], n2 = xn[2], n3 = xn[3];
-                unsigned m2 = mask & (mask - 1);
-                int k_nn = m2 ? __builtin_ctz(m2) : k_next;
-                int nb_nn = entry(k_nn);
-                if (nb_cur < 0) a0 = a1 = a2 = a3 = zero4;
-                const f32x4 *bp = (const f32x4 *)(sW + (((k_cur * 2 + h) * 4) * 32 + r) * 4);
-                f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
+                f32x4 a[F32_GROUP][4];
+#pragma unroll
+                for (int g = 0; g < F32_GROUP; ++g) {
+                    // unconditional (an empty slot of the last group reads row 0): with the loads behind "slot in use?"
+                    // branches the first MFMA waited for the whole group's rows instead of its own
+                    const f32x4 *xp = (const f32x4 *)(X + (long long)(nbq[g] >= 0 ? nbq[g] : 0) * 32 + h * 16);
+                    a[g][0] = xp[0];
+                    a[g][1] = xp[1];
+                    a[g][2] = xp[2];
+                    a[g][3] = xp[3];
+                }
+                int kn[F32_GROUP], tn[F32_GROUP], nbn[F32_GROUP];
+#pragma unroll
+                for (int g = 0; g < F32_GROUP; ++g) {
+                    kn[g] = mask ? __builtin_ctz(mask) : -1;
+                    mask = mask ? (mask & (mask - 1)) : 0u;
+                }
+                entry_loads(kn, tn);
+                // keep hipcc from (a) issuing the first offset's rows last and (b) consuming the next group's entries --
+                // i.e. waiting for every load above -- in front of the MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < F32_GROUP; ++g)
+                    if (kq[g] >= 0) {
+                        f32x4 a0 = a[g][0], a1 = a[g][1], a2 = a[g][2], a3 = a[g][3];
+                        if (nbq[g] < 0) a0 = a1 = a2 = a3 = zero4;
+                        const f32x4 *bp = (const f32x4 *)(sW + (((kq[g] * 2 + h) * 4) * 32 + r) * 4);
+                        f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
 #define WFS_MFMA4(a, b)                                                          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-                WFS_MFMA4(a0, b0)
-                WFS_MFMA4(a1, b1)
-                WFS_MFMA4(a2, b2)
-                WFS_MFMA4(a3, b3)
+                        WFS_MFMA4(a0, b0)
+                        WFS_MFMA4(a1, b1)
+                        WFS_MFMA4(a2, b2)
+                        WFS_MFMA4(a3, b3)
 #undef WFS_MFMA4
-                if (mask == 0) break;
-                mask &= mask - 1;
-                a0 = n0;
-                a1 = n1;
-                a2 = n2;
-                a3 = n3;
-                k_cur = k_next;
-                nb_cur = nb_next;
-                k_next = k_nn;
-                nb_next = nb_nn;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kn[0] < 0) break;
+                entry_values(kn, tn, nbn);
+#pragma unroll
+                for (int g = 0; g < F32_GROUP; ++g) {
+                    kq[g] = kn[g];
+                    nbq[g] = nbn[g];
+                }
             }
         }
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -278,7 +316,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
     const long long t_begin = (long long)xcd * tpx_v;
     const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
     const float bj = bias ? bias[r] : 0.f;
-    for (long long tile = t_begin + (long long)bi * nw + wid; tile < t_end; tile += (long long)bpx * nw) {
+    for (long long tile = t_begin + (long long)wid * bpx + bi; tile < t_end; tile += (long long)bpx * nw) {
         if (tile * 32 >= Rv) break;
         const long long row = tile * 32 + r;
         const bool live = row < Rv;
