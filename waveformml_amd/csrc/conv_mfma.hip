@@ -463,15 +463,13 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
     (void)tiles_per_block;                                   // cut from the capacity: the valid tiles are shared out instead
-    const long long tpb = (ntiles + gridDim.x - 1) / gridDim.x;
-    const long long t_begin = (long long)blockIdx.x * tpb;
-    const long long t_end = t_begin + tpb < ntiles ? t_begin + tpb : ntiles;
+    // consecutive tiles go to different blocks: an event's tiles (similar numbers of active offsets) spread over the chip
     f32x16 acc[DW_KG];
 #pragma unroll
     for (int q = 0; q < DW_KG; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-    for (long long tile = t_begin + wid; tile < t_end; tile += DW_WAVES) {
+    for (long long tile = blockIdx.x + (long long)wid * gridDim.x; tile < ntiles; tile += (long long)DW_WAVES * gridDim.x) {
         const long long row0 = tile * 32;
         // lane j holds the table entries of row (row0 + j) for this wave's offsets.  Loads are unconditional
         // on clamped addresses (see k_gconv32_f32), validity is applied afterwards.
