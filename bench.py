@@ -104,7 +104,10 @@ def measure(env, args, dtype, steps, warmup, roofline):
     module.train()
     broadcast_parameters(module)
     init_state = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
-    reducer = FlatGradAllReducer(module.model.parameters())          # flat parameter + flat gradient buffers
+    # WFS_BENCH_ONE_RANK_RCCL=1 (a rehearsal, not a bench line): one rank with a real RCCL communicator and the whole
+    # bucket / hook / in-graph all-reduce machinery of an N-rank step -- what that structure costs before any link does
+    force = env.world == 1 and os.environ.get("WFS_BENCH_ONE_RANK_RCCL") == "1"
+    reducer = FlatGradAllReducer(module.model.parameters(), exchange=True if force else None)   # flat parameter + gradient buffers
     module.optimizer_parameters = reducer.optimizer_parameters()
     opt = module.configure_optimizers()
     optimizer = opt[0][0] if isinstance(opt, tuple) else opt
@@ -457,8 +460,9 @@ def main():
     # everything runs on an ordinary stream: on ROCm 7.2 eager work on the legacy default stream between two
     # HIP-graph replays hangs the next replay (psd/graph.py "Stream discipline")
     torch.cuda.set_stream(torch.cuda.Stream(env.dev))
-    if env.world > 1:
+    if env.world > 1 or os.environ.get("WFS_BENCH_ONE_RANK_RCCL") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if os.environ.get("WFS_REHEARSAL_ONE_GPU"):
             dist.init_process_group("gloo", rank=env.rank, world_size=env.world)
         else:
@@ -511,8 +515,9 @@ def main():
             else:
                 result["parity"] = parity(cpu_logits, cpu_loss, extras["logits0"], extras["loss0"])
         print(json.dumps(result), file=json_out, flush=True)
-    if env.world > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():
+        if env.world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -458,7 +458,7 @@ from waveformml_amd.psd.graph import GraphedTrainStep
 
 def run(exchange, graph):
     mod = _small_c2().to(dev); mod.train()
-    red = FlatGradAllReducer(mod.model.parameters(), exchange=exchange)
+    red = FlatGradAllReducer(mod.model.parameters(), exchange=exchange, n_buckets=2)
     mod.optimizer_parameters = red.optimizer_parameters()
     opt = mod.configure_optimizers(); opt = opt[0][0] if isinstance(opt, tuple) else opt
     batches = _rank_batches(0, dev)

@@ -8,19 +8,28 @@ exchange is latency-bound.  Layout:
 
   * all parameters live in ONE flat fp32 buffer (the module's parameters are views of it), so the
     optimizer updates a single tensor -- a handful of launches instead of one per parameter;
-  * all gradients land in ONE flat buffer cut into a few contiguous buckets in reverse layer order.
+  * all gradients land in ONE flat buffer cut into contiguous buckets in reverse layer order.
     A bucket is packed (one concatenation kernel) and its all-reduce launched asynchronously -- RCCL
-    runs it on its own stream -- the moment its last gradient has been produced, so the exchange
-    overlaps the rest of backward;
+    runs it on its own stream -- the moment its last gradient has been produced, so with several
+    buckets the exchange overlaps the rest of backward.  DEFAULT: ONE bucket (WFS_GRAD_BUCKETS or the
+    argument for more).  Inside a captured step every bucket is a fork / join pair between streams of
+    the HIP graph, and those cost more than overlapping a 0.5-MB all-reduce can return: the structure
+    alone (one rank, real RCCL communicator, `WFS_BENCH_ONE_RANK_RCCL=1 python bench.py`) costs
+    +3 us per step with 1 bucket, +26 us with 2, +107 us with 4 on a 0.515-ms step
+    (profiles/r03_one_rank_rccl_structure.txt); the last bucket's all-reduce is exposed either way;
   * BatchNorm statistics stay per rank, exactly as under the reference's DDP (no SyncBN).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class FlatGradAllReducer(object):
-    def __init__(self, parameters, n_buckets=2, process_group=None, world_size=None, flatten=True, exchange=None):
+    def __init__(self, parameters, n_buckets=None, process_group=None, world_size=None, flatten=True, exchange=None):
         self.params = [p for p in parameters if p.requires_grad]
+        if n_buckets is None:
+            n_buckets = int(os.environ.get("WFS_GRAD_BUCKETS", "1"))
         if not self.params:
             raise ValueError("no trainable parameters")
         self.group = process_group
