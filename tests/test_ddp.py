@@ -195,3 +195,39 @@ def test_bench_counts_gpus_from_sysfs_without_the_runtime(tmp_path, monkeypatch)
     assert bench.visible_gpus() == 2
     monkeypatch.setenv("WFS_KFD_TOPOLOGY", str(tmp_path / "nowhere"))
     assert bench.visible_gpus() is None
+
+
+def _agreement_worker(rank, world, port, block, out):
+    from waveformml_amd.psd.graph import ShapeAgreement
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # five batches; rank 1's third has more rows, rank 0's fifth one label fewer than rows
+        rows = [[100, 90, 110, 95, 80], [101, 88, 230, 95, 80]][rank]
+        labels = [[16, 16, 16, 16, 79], [16, 16, 16, 16, 80]][rank]
+        ag = ShapeAgreement(None, block)
+        got = []
+        # the prefetcher's pattern: `depth` batches staged ahead, flush when the loader is exhausted
+        depth, staged = block + 2, 0
+        for i in range(5):
+            while staged < 5 and staged < i + depth:
+                ag.stage(rows[staged], labels[staged])
+                staged += 1
+                if staged == 5:
+                    ag.flush()
+            got.append(ag.next())
+        assert not ag.local and not ag.ready
+        out[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("block", [1, 2, 4, 8])
+def test_shape_agreement_gives_every_rank_the_same_counts(block):
+    """psd/graph.ShapeAgreement (the multi-rank Trainer's replay-or-ordinary-step decision): rows MAX, labels MIN / MAX
+    and the rows != labels flag over the ranks, in staging order, whole and partial blocks."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_agreement_worker, args=(world, _free_port(), block, out), nprocs=world, join=True)
+    want = [(101, 16, 16, True), (90, 16, 16, True), (230, 16, 16, True), (95, 16, 16, True), (80, 79, 80, True)]
+    assert out[0] == out[1] == want

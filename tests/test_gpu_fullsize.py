@@ -271,7 +271,8 @@ def _trainer_run(rank, world, dev):
         n = 32 if (s == 2 and rank == 1) else 16
         c, f, y = synthetic.generate(n, 64, 3, seed=400 + s, rank=rank)
         batches.append(([torch.from_numpy(c), torch.from_numpy(f)], torch.from_numpy(y)))
-    tr = Trainer(max_epochs=1, device=str(dev), capture=True, check_every=2)
+    tr = Trainer(max_epochs=1, device=str(dev), capture=True, check_every=2,
+                 agree_block=int(os.environ.get("WFS_TEST_AGREE_BLOCK", "4")))
     hist = tr.fit(mod, batches)
     torch.cuda.synchronize()
     return {"params": torch.cat([p.detach().reshape(-1).cpu() for p in mod.model.parameters()]),
@@ -368,7 +369,7 @@ def test_two_ranks_step_the_hip_net_on_one_card(mode, tmp_path):
     _assert_close(r0["grads"][0].numpy(), want.numpy(), 1e-5 if mode == "eager" else 1e-4, "averaged gradient, step 1")
 
 
-def _launch_two_ranks(tmp_path, mode, backend="gloo"):
+def _launch_two_ranks(tmp_path, mode, backend="gloo", extra_env=None):
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT.format(root=ROOT))
     with socket.socket() as s:
@@ -382,6 +383,7 @@ def _launch_two_ranks(tmp_path, mode, backend="gloo"):
         if backend == "nccl":
             env.update(LOCAL_RANK=str(r), WFS_TEST_BACKEND="nccl")
             env.pop("WFS_REHEARSAL_ONE_GPU")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, cwd=ROOT))
     try:
         for p in procs:
@@ -425,14 +427,22 @@ def test_two_rank_trainer_misfit_over_rccl_on_two_devices(tmp_path):
     assert torch.equal(r0["params"], r1["params"])
 
 
-def test_two_rank_trainer_takes_the_eager_step_together_when_one_rank_misfits(tmp_path):
+@pytest.mark.parametrize("agree_block", [4, 2, 0], ids=["ahead_by_4", "ahead_by_2", "blocking_per_step"])
+def test_two_rank_trainer_takes_the_eager_step_together_when_one_rank_misfits(tmp_path, agree_block):
     """Trainer(capture=True) on two ranks (gloo, one card): the third batch is oversized on rank 1 ONLY.  The misfit is
-    agreed on collectively, so both ranks step eagerly for it (one fallback each, the same exchange), nobody hangs in a
-    mismatched collective, and the replicas end bit-identical."""
-    r0, r1 = _launch_two_ranks(tmp_path, "trainer_misfit")
+    agreed on collectively -- from batch shapes all-reduced asynchronously when the batches are staged, 4 or 2 per
+    all-reduce (five batches: the last block is a partial one), or by round 2's blocking all-reduce per step -- so both
+    ranks step eagerly for it (one fallback each, the same exchange), nobody hangs in a mismatched collective, and the
+    replicas end bit-identical; all three ways must train to the same parameters."""
+    r0, r1 = _launch_two_ranks(tmp_path, "trainer_misfit", extra_env={"WFS_TEST_AGREE_BLOCK": str(agree_block)})
     assert r0["eager_fallbacks"] == 1 and r1["eager_fallbacks"] == 1
     assert torch.equal(r0["params"], r1["params"])
     assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"])
+    ref = getattr(test_two_rank_trainer_takes_the_eager_step_together_when_one_rank_misfits, "_params", None)
+    if ref is None:
+        test_two_rank_trainer_takes_the_eager_step_together_when_one_rank_misfits._params = r0["params"]
+    else:
+        assert torch.equal(ref, r0["params"])
 
 
 def test_nccl_backend_world_one_exchange_and_in_graph_capture(tmp_path):

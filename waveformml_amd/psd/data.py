@@ -279,15 +279,20 @@ class DevicePrefetcher(object):
     host.  Replaces the reference's synchronous ``.to(self.device)`` inside ``_concat_range``
     (src/datasets/HDF5Dataset.py:250-300), which a forked DataLoader worker cannot do on a HIP device anyway."""
 
-    def __init__(self, loader, device, feature_dtype=None, depth=2):
+    def __init__(self, loader, device, feature_dtype=None, depth=2, on_stage=None, on_exhausted=None):
         self.loader, self.device, self.feature_dtype, self.depth = loader, torch.device(device), feature_dtype, depth
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        # on_stage(rows, labels) for every batch as it is staged (``depth`` batches before it is yielded), on_exhausted()
+        # when the loader has no more: the multi-rank Trainer agrees on batch shapes ahead of time through these
+        self.on_stage, self.on_exhausted = on_stage, on_exhausted
 
     def __len__(self):
         return len(self.loader)
 
     def _stage(self, batch):
         (c, f), y = batch
+        if self.on_stage is not None:
+            self.on_stage(int(c.shape[0]), int(y.shape[0]))
         ring = isinstance(batch, RingBatch)            # views of a page-locked ring slot: copy straight from it
         host = [t if (ring or t.is_pinned()) else t.pin_memory() for t in (c, f, y)]
         with torch.cuda.stream(self.copy_stream):
@@ -301,12 +306,15 @@ class DevicePrefetcher(object):
     def __iter__(self):
         queue = []
         it = iter(self.loader)
+        more = True
         while True:
-            while len(queue) < self.depth:
+            while more and len(queue) < self.depth:
                 try:
                     queue.append(self._stage(next(it)))
                 except StopIteration:
-                    break
+                    more = False
+                    if self.on_exhausted is not None:
+                        self.on_exhausted()
             if not queue:
                 return
             host, dev, done = queue.pop(0)

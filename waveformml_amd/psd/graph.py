@@ -214,6 +214,13 @@ class GraphedTrainStep(object):
             return coords.shape[0] <= self.n_cap and labels.shape[0] == coords.shape[0]
         return coords.shape[0] <= self.n_cap and tuple(labels.shape) == tuple(self.labels.shape)
 
+    def fits_counts(self, rows_max, labels_min, labels_max, rows_ne_labels):
+        """``fits`` from the counts the ranks agreed on (ShapeAgreement): the largest row count, the smallest / largest
+        label count and whether any rank's batch has a label count other than its row count."""
+        if self.per_row:
+            return rows_max <= self.n_cap and not rows_ne_labels
+        return rows_max <= self.n_cap and labels_min == labels_max == int(self.labels.shape[0])
+
     def _load(self, batch):
         (coords, feats), labels = batch
         n = coords.shape[0]
@@ -329,18 +336,60 @@ def _collective_capture_works(group, dev):
 _GLOO_SIDE = {}
 
 
+def _gloo_side(group):
+    """The gloo group over the ranks of ``group`` (created once, collectively, at first use)."""
+    key = id(group)
+    if key not in _GLOO_SIDE:
+        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+        _GLOO_SIDE[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _GLOO_SIDE[key]
+
+
 def _agree_max(flag, group):
     """MAX of a host-side integer over the ranks of ``group``, over a gloo group of the same ranks (created once): used
     to agree on things that must not depend on the device communicator being healthy."""
     if not (dist.is_available() and dist.is_initialized()):
         return flag
-    key = id(group)
-    if key not in _GLOO_SIDE:
-        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-        _GLOO_SIDE[key] = dist.new_group(ranks=ranks, backend="gloo")
     t = torch.tensor([int(flag)], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_GLOO_SIDE[key])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_gloo_side(group))
     return int(t.item())
+
+
+class ShapeAgreement(object):
+    """What every rank must know about a batch before it chooses between a replay and an ordinary step (ranks must
+    choose alike: the two issue their collectives differently): the largest row count over the ranks, the smallest and
+    largest label count, whether any rank's labels are not one per row.  Host integers, MAX-reduced over the gloo side
+    group, ``block`` batches per all-reduce, issued ASYNCHRONOUSLY when the prefetcher stages the batches -- several steps
+    before they are consumed -- so the host never waits for it.  It replaces one BLOCKING gloo all-reduce per step,
+    which costs 0.26 ms of host time with 2 ranks, 0.49 with 4, 0.85 with 8 (8 CPU cores) against a 0.6-ms step.
+    Every rank must stage the same number of batches per epoch (a DistributedSampler guarantees it)."""
+    FIELDS = 4
+
+    def __init__(self, group, block=4):
+        self.group, self.block = _gloo_side(group), max(1, int(block))
+        self.local, self.ready = [], []
+
+    def stage(self, rows, labels):
+        self.local.append((int(rows), int(labels), -int(labels), 1 if int(rows) != int(labels) else 0))
+        if len(self.local) >= self.block:
+            self.flush()
+
+    def flush(self):
+        if not self.local:
+            return
+        t = torch.tensor(self.local, dtype=torch.int64).reshape(-1)
+        n, self.local = len(self.local), []
+        work = dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        self.ready.extend((work, t, i) for i in range(n))
+
+    def next(self):
+        """(rows_max, labels_min, labels_max, rows_ne_labels) of the next staged batch, in staging order."""
+        if not self.ready:
+            self.flush()                    # fewer batches staged ahead than a block holds (the same on every rank)
+        work, t, i = self.ready.pop(0)
+        work.wait()
+        r = t[self.FIELDS * i: self.FIELDS * (i + 1)].tolist()
+        return int(r[0]), -int(r[2]), int(r[1]), bool(r[3])
 
 
 def _event_flags(module):

@@ -139,7 +139,7 @@ def load_optimizer_state(optimizer, sd, params):
 
 class Trainer(object):
     def __init__(self, max_epochs=1, device="cuda:0", default_root_dir=None, feature_dtype=None, log_every=0,
-                 capture=False, check_every=100, resume_from_checkpoint=None, recapture_after=4):
+                 capture=False, check_every=100, resume_from_checkpoint=None, recapture_after=4, agree_block=4):
         self.max_epochs, self.device = max_epochs, torch.device(device)
         self.root = default_root_dir
         self.feature_dtype = feature_dtype
@@ -152,6 +152,9 @@ class Trainer(object):
         # files differ systematically (one class per file, classes with different pulse lengths) can exceed them often:
         # after `recapture_after` misfits by SIZE the step is captured again on the batch that did not fit
         self.recapture_after = int(recapture_after)
+        # several ranks: batch shapes are agreed `agree_block` batches per (asynchronous, host-side) all-reduce, staged that
+        # many batches ahead (graph.ShapeAgreement); 0 = one blocking all-reduce per step, as in round 2
+        self.agree_block = int(agree_block)
         self.recaptures = 0
         self._size_misfits = 0
         self.eager_fallbacks = 0
@@ -191,7 +194,7 @@ class Trainer(object):
             optimizer.mark_fresh()             # dampening != 0: the first real step must be torch's "buf = g" (eager)
         return graph
 
-    def _captured_step(self, module, reducer, optimizer, batch, batch_idx):
+    def _captured_step(self, module, reducer, optimizer, batch, batch_idx, agreed=None):
         if self._graph is None:
             self._graph = self._capture(module, reducer, optimizer, batch)
         # more voxels than the capacity, or another number of events -> an ordinary step.  With several ranks the
@@ -203,7 +206,15 @@ class Trainer(object):
         # needed; bit 1: because the batch has more rows than the captured capacity.
         misfit = not self._graph.fits(batch) or (hasattr(optimizer, "has_fresh") and optimizer.has_fresh())
         too_big = batch[0][0].shape[0] > self._graph.n_cap
-        if reducer.world > 1 and reducer.exchange:
+        if reducer.world > 1 and reducer.exchange and agreed is not None:
+            # the counts were agreed when the batch was staged (graph.ShapeAgreement: asynchronous, batches ahead): every
+            # rank derives the same decision from them, whatever capacity the step has by now; the optimizer's
+            # bookkeeping (has_fresh) is the same on every rank by construction
+            rows_max, labels_min, labels_max, rows_ne_labels = agreed
+            fresh = hasattr(optimizer, "has_fresh") and optimizer.has_fresh()
+            misfit = fresh or not self._graph.fits_counts(rows_max, labels_min, labels_max, rows_ne_labels)
+            too_big = rows_max > self._graph.n_cap
+        elif reducer.world > 1 and reducer.exchange:
             from .graph import _agree_max
             code = _agree_max((1 if misfit else 0) | (2 if (misfit and too_big) else 0), reducer.group)
             # MAX of the codes: 1 < 2 < 3, and a rank reporting 2 cannot exist (too_big implies misfit)
@@ -252,9 +263,18 @@ class Trainer(object):
             sampler = getattr(train_loader, "sampler", None)
             if hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)        # DistributedSampler: another permutation per epoch, the same on all ranks
-            for i, batch in enumerate(DevicePrefetcher(train_loader, self.device, self.feature_dtype)):
+            agree = None
+            if self.capture and reducer.world > 1 and reducer.exchange and self.agree_block > 0:
+                from .graph import ShapeAgreement
+                agree = ShapeAgreement(reducer.group, self.agree_block)
+            prefetch = DevicePrefetcher(train_loader, self.device, self.feature_dtype,
+                                        depth=2 if agree is None else agree.block + 2,
+                                        on_stage=agree.stage if agree is not None else None,
+                                        on_exhausted=agree.flush if agree is not None else None)
+            for i, batch in enumerate(prefetch):
                 if self.capture:
-                    loss = self._captured_step(module, reducer, optimizer, batch, i)
+                    loss = self._captured_step(module, reducer, optimizer, batch, i,
+                                               agree.next() if agree is not None else None)
                 else:
                     loss = self.training_step(module, reducer, optimizer, batch, i)
                 self.global_step += 1
