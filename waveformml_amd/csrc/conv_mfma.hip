@@ -209,6 +209,190 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
     if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
 }
 
+// ------------------------------------------------------------------------------------------ 32 -> 32, fp32, 16-row tiles
+// k_gconv32_f32 gives every wave ONE 32-row tile, and a launch then lasts as long as its heaviest tile: 16 dependent
+// v_mfma_f32_32x32x2_f32 (1024 cycles) per active offset, up to K = 27 of them, on a SIMD shared with two other waves --
+// the matrix cores were busy for 24 % of a launch (profiles/r03_gconv32_f32_counters.txt).  Here a tile is 16 rows x 32
+// channels on v_mfma_f32_16x16x4_f32 (the same exact-fp32 fma chain at the same rate, 512 cycles per active offset), a
+// tile's offsets are fewer (the union is over 16 rows), and the waves of a block take the block's tiles off an LDS
+// counter as they finish, so the matrix pipes of a CU stay fed until its tiles run out.  Results are those of the
+// 32-row kernel up to the order of the 32 products inside one offset (channel order 8q + j instead of 16h + i); the
+// order over the offsets is unchanged.
+//   A: lane (r = lane & 15, q = lane >> 4) supplies row r, channels 8q .. 8q+7 (one contiguous 32-B read of its gathered row);
+//      MFMA step j contracts channels {8q + j : q = 0..3}.
+//   B: sW[k][cb][jq][q][n][e] = B[c = 8q + 4jq + e][col = 16cb + n]: one ds_read_b128 gives a lane four steps of a column block.
+//   D: lane holds rows 4q .. 4q+3 of column n (+ 16 per column block).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int F16_GROUP = 3;      // offsets whose gathers a wave has in flight together (2 x 16 B per lane each)
+
+template <bool TRANSPOSE_W>
+__global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                      long long R, const long long *__restrict__ r_dev,
+                                                      const float *__restrict__ X, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, float *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];
+    __shared__ int sNext;
+    const int nthreads = blockDim.x;
+    if (threadIdx.x == 0) sNext = 0;
+    if (!TRANSPOSE_W) {
+        for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
+            const int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;          // channels 4 c4 .., columns 4 j4 ..
+            const float *src = W + ((long long)k * 32 + c4 * 4) * 32 + j4 * 4;
+            const f32x4 r0 = *(const f32x4 *)(src), r1 = *(const f32x4 *)(src + 32);
+            const f32x4 r2 = *(const f32x4 *)(src + 64), r3 = *(const f32x4 *)(src + 96);
+            const int q = c4 >> 1, jq = c4 & 1, cb = j4 >> 2, n0 = (j4 & 3) * 4;
+            float *dst = sW + (((((k * 2 + cb) * 2 + jq) * 4 + q) * 16) + n0) * 4;
+            *(f32x4 *)(dst + 0) = f32x4{r0.x, r1.x, r2.x, r3.x};
+            *(f32x4 *)(dst + 4) = f32x4{r0.y, r1.y, r2.y, r3.y};
+            *(f32x4 *)(dst + 8) = f32x4{r0.z, r1.z, r2.z, r3.z};
+            *(f32x4 *)(dst + 12) = f32x4{r0.w, r1.w, r2.w, r3.w};
+        }
+    } else {
+        for (int e = threadIdx.x; e < K * 256; e += nthreads) {
+            const int k = e >> 8, col = (e >> 3) & 31, c4 = e & 7;
+            const f32x4 v = *(const f32x4 *)(W + ((long long)k * 32 + col) * 32 + c4 * 4);
+            const int q = c4 >> 1, jq = c4 & 1, cb = col >> 4, n = col & 15;
+            *(f32x4 *)(sW + (((((k * 2 + cb) * 2 + jq) * 4 + q) * 16) + n) * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    // XCD-aware: blocks with equal blockIdx % 8 share an L2 and take one contiguous range of the VALID tiles; inside it
+    // block bi owns tiles bi, bi + bpx, ... (consecutive tiles -- one event's, alike in cost -- go to different CUs)
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const long long Rv = valid_rows(R, r_dev);
+    const long long nt_v = (Rv + 15) >> 4, tpx_v = (nt_v + 7) >> 3;
+    const long long t_begin = (long long)xcd * tpx_v;
+    const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
+    const float bj0 = bias ? bias[r] : 0.f, bj1 = bias ? bias[16 + r] : 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    while (true) {
+        int mine = 0;
+        if (lane == 0) mine = atomicAdd(&sNext, 1);
+        mine = __builtin_amdgcn_readfirstlane(mine);
+        const long long tile = t_begin + bi + (long long)mine * bpx;
+        if (tile >= t_end || tile * 16 >= Rv) break;
+        const long long row = tile * 16 + r;
+        const bool live = row < Rv;
+        const long long rowc = live ? row : 0;
+        // ---- phase 1: which offsets does the tile use?  Quarter q of the wave reads the entries of offsets q, q + 4, ...
+        // (7 loads per lane instead of 27), all issued together; one ballot per offset over its quarter's lanes.
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 4 * i + q;
+            const int kk = k < K ? k : K - 1;
+            v[i] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+        }
+        unsigned mask = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 4 * i + q;
+            const bool ok = live && k < K && (k == identity_k || v[i] >= 0);
+            const unsigned long long bal = __ballot(ok);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                if (4 * i + qq < 32 && ((bal >> (16 * qq)) & 0xFFFFull) != 0ull) mask |= 1u << (4 * i + qq);
+        }
+        mask = __builtin_amdgcn_readfirstlane(mask);
+        f32x4v acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc0[i] = bj0;
+            acc1[i] = bj1;
+        }
+        if (mask != 0) {
+            // ---- phase 2: groups of F16_GROUP active offsets in ascending order: all the group's gathers are in flight
+            // before its MFMAs.  The table entry of (row r, offset k) sits in register k >> 2 of lane (r, k & 3) since
+            // phase 1: one select chain + one lane exchange per offset instead of a second read of the table.
+            auto entry_of = [&](int k) -> int {
+                const int i = k >> 2;
+                int val = v[0];
+#pragma unroll
+                for (int t = 1; t < 8; ++t) val = (i == t) ? v[t] : val;
+                int got = __shfl(val, r + 16 * (k & 3), 64);
+                got = (k == identity_k) ? (int)rowc : got;
+                return live ? got : -1;
+            };
+            // Software pipeline over the groups: while a group's MFMAs run, the NEXT group's gathers are in flight (two
+            // register sets, the loop body written out twice so that they swap without moves).
+            struct Group {
+                int k[F16_GROUP], nb[F16_GROUP];
+                f32x4 a[F16_GROUP][2];
+            };
+            auto fetch = [&](Group &gr) {                     // takes the next F16_GROUP offsets off the mask
+#pragma unroll
+                for (int g = 0; g < F16_GROUP; ++g) {
+                    gr.k[g] = mask ? __builtin_ctz(mask) : -1;
+                    mask = mask ? (mask & (mask - 1)) : 0u;
+                }
+#pragma unroll
+                for (int g = 0; g < F16_GROUP; ++g) {
+                    const int e = entry_of(gr.k[g] >= 0 ? gr.k[g] : 0);
+                    gr.nb[g] = gr.k[g] >= 0 ? e : -1;
+                }
+#pragma unroll
+                for (int g = 0; g < F16_GROUP; ++g) {
+                    // unconditional (an empty slot reads row 0): loads behind branches make hipcc wait for all of them
+                    const f32x4 *xp = (const f32x4 *)(X + (long long)(gr.nb[g] >= 0 ? gr.nb[g] : 0) * 32 + q * 8);
+                    gr.a[g][0] = xp[0];
+                    gr.a[g][1] = xp[1];
+                }
+            };
+            auto multiply = [&](const Group &gr) {
+#pragma unroll
+                for (int g = 0; g < F16_GROUP; ++g)
+                    if (gr.k[g] >= 0) {
+                        f32x4 a0 = gr.a[g][0], a1 = gr.a[g][1];
+                        if (gr.nb[g] < 0) a0 = a1 = zero4;
+                        const f32x4 *bp = (const f32x4 *)(sW + ((gr.k[g] * 16 + q) * 16 + r) * 4);   // (k, cb 0, jq 0, q, n)
+                        const f32x4 b00 = bp[0], b01 = bp[64], b10 = bp[128], b11 = bp[192];   // [cb][jq]: +64 f32x4 per jq, +128 per cb
+                        // the two column blocks' chains alternate: a dependent MFMA never follows its producer directly
+#define WFS_MFMA2(a, e, b0, b1)                                                       \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.e, b0.e, acc0, 0, 0, 0);            \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.e, b1.e, acc1, 0, 0, 0);
+                        WFS_MFMA2(a0, x, b00, b10)
+                        WFS_MFMA2(a0, y, b00, b10)
+                        WFS_MFMA2(a0, z, b00, b10)
+                        WFS_MFMA2(a0, w, b00, b10)
+                        WFS_MFMA2(a1, x, b01, b11)
+                        WFS_MFMA2(a1, y, b01, b11)
+                        WFS_MFMA2(a1, z, b01, b11)
+                        WFS_MFMA2(a1, w, b01, b11)
+#undef WFS_MFMA2
+                    }
+            };
+            Group ga, gb;
+            fetch(ga);
+            while (true) {
+                const bool more_b = mask != 0;
+                if (more_b) fetch(gb);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(ga);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!more_b) break;
+                const bool more_a = mask != 0;
+                if (more_a) fetch(ga);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(gb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!more_a) break;
+            }
+        }
+        // D map of the 16x16 MFMA: col = lane & 15 (+ 16 per column block), row = 4 (lane >> 4) + reg
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long orow = tile * 16 + 4 * q + i;
+            if (orow < Rv) {
+                Y[orow * 32 + r] = acc0[i];
+                Y[orow * 32 + 16 + r] = acc1[i];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 32 -> 32, bf16
 // bf16 rows in HBM (64 B per voxel), fp32 master filters converted to bf16 while they are staged into LDS,
 // fp32 accumulation: v_mfma_f32_32x32x16_bf16, 2 MFMAs per kernel offset and 32-row tile.  At 1/16 of the fp32
@@ -1185,6 +1369,26 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     gconv32_grid(R, r_dev != nullptr, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
     const size_t lds = (size_t)K * 4096;
     static bool attr[3] = {false, false, false};
+    static const bool tiles32 = getenv("WFS_F32_TILES32") != nullptr;        // the 32-row kernel for every launch (A/B)
+    if (!stats && !tiles32) {
+        // 16-row tiles taken off a per-block counter (k_gconv16_f32): up to 16 waves per block, <= 256 blocks
+        static bool attr16[2] = {false, false};
+        const long long nt16 = (R + 15) >> 4;
+        const long long expect = r_dev ? (nt16 * 7 + 7) / 8 : nt16;
+        int w = (int)((expect + 255) / 256);
+        w = w < 4 ? 4 : (w > 16 ? 16 : (w + 3) / 4 * 4);
+        static const int wcap = getenv("WFS_F16_WAVES") ? atoi(getenv("WFS_F16_WAVES")) : 16;
+        if (w > wcap) w = wcap;
+        long long nb = (expect + w - 1) / w;
+        nb = nb > 256 ? 256 : (nb + 7) / 8 * 8;
+        if (nb < 8) nb = 8;
+        const dim3 g16((unsigned)nb), b16(w * 64);
+        if (transpose_w)
+            return launch_big_lds(k_gconv16_f32<true>, &attr16[0], g16, b16, lds, stream, table, mirror, K, identity_k, R,
+                                  r_dev, X, W, bias, Y);
+        return launch_big_lds(k_gconv16_f32<false>, &attr16[1], g16, b16, lds, stream, table, mirror, K, identity_k, R,
+                              r_dev, X, W, bias, Y);
+    }
     const WfsStatsArgs sa = stats_args(stats, nblk);
     const dim3 grid((unsigned)nblk), block(wpb * 64);
     if (transpose_w)
