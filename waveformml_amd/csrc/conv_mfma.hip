@@ -647,6 +647,12 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
     (void)tiles_per_block;                                   // cut from the capacity: the valid tiles are shared out instead
+    static_assert(sizeof(T) == 4, "fp32 rows");
+    // raw buffers (stride 0, byte offsets): S holds R valid rows of 128 B; G is addressed below 2 GiB, anything at or
+    // above reads as 0 (the launcher checks both sizes)
+    const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc((void *)S, 0, (int)(R * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned j4 = (unsigned)j * 4u;
     // consecutive tiles go to different blocks: an event's tiles (similar numbers of active offsets) spread over the chip
     f32x16 acc[DW_KG];
 #pragma unroll
@@ -665,12 +671,17 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
             int kk = k < K ? k : K - 1;
             nbv[q] = table[(long long)kk * Rcap + trow];
         }
+        // S rows through a raw buffer whose size is the VALID rows: one lane offset per tile, the 16 rows of a lane by
+        // the instruction's immediate offset, rows past the end read as 0 -- no address arithmetic, no select per load
+        // (the pointer form spent ~11 VALU instructions on each of a tile's 16 + 16 x active offsets loads: 16 us of VALU
+        // per SIMD against 11 us of MFMA, profiles/r03_gdw32_f32_counters.txt)
         float a[16];
+        {
+            int voff = (int)((unsigned)(row0 + h) * 128u + (unsigned)j * 4u);
+            asm volatile("" : "+v"(voff));         // opaque: keeps "+ s * 256" a constant that folds into the immediate
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            long long row = row0 + 2 * s + h;
-            float t = wfs_ld(S + (row < R ? row : R - 1) * 32 + j);
-            a[s] = row < R ? t : 0.f;
+            for (int s = 0; s < 16; ++s)
+                a[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcS, voff + s * 256, 0, 0));
         }
         bool any = false;
 #pragma unroll
@@ -691,11 +702,13 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
             if (__ballot(nbv[q] >= 0) == 0ull) continue;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                int n0 = __builtin_amdgcn_readlane(nbv[q], 2 * s);
-                int n1 = __builtin_amdgcn_readlane(nbv[q], 2 * s + 1);
-                int nb = h ? n1 : n0;
-                float t = wfs_ld(G + (long long)(nb >= 0 ? nb : 0) * 32 + j);
-                b[q][s] = nb >= 0 ? t : 0.f;
+                // the two rows of an MFMA step are wave-uniform: their byte offsets are scalar work, a missing row gets an
+                // offset past the end of the buffer and reads as 0
+                const int n0 = __builtin_amdgcn_readlane(nbv[q], 2 * s);
+                const int n1 = __builtin_amdgcn_readlane(nbv[q], 2 * s + 1);
+                const unsigned o0 = n0 >= 0 ? (unsigned)n0 * 128u : 0x80000000u;
+                const unsigned o1 = n1 >= 0 ? (unsigned)n1 * 128u : 0x80000000u;
+                b[q][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcG, (h ? o1 : o0) + j4, 0, 0));
             }
         }
 #pragma unroll

@@ -557,7 +557,6 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
                           wfs_dw_job *defer, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const long long *r_dev = (const long long *)r_dev_;
-    (void)G_rows;
     WFS_REQUIRE(K >= 1 && K <= 65535, WFS_EINVAL, "bad K");
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
     WFS_REQUIRE(dW, WFS_EINVAL, "NULL dW");
@@ -576,7 +575,9 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
         return wfs_launch_wide_dw(table, kmap_host, K, identity_k, R, r_dev, S, Cs, G, G_rows, Cg, swap, dW, dtype, workspace,
                                   workspace_bytes, stream);
     }
-    if (Cs == 32 && Cg == 32 && table && !kmap_host)
+    // the fp32 kernel addresses S and G through 32-bit buffer offsets (128 B per row): fewer than 2^24 rows each
+    const bool rows_fit = dtype != WFS_F32 || (R < (1ll << 24) && G_rows < (1ll << 24));
+    if (Cs == 32 && Cg == 32 && table && !kmap_host && rows_fit)
         return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, defer, stream);
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K && kmap_host; ++k) {
