@@ -1377,21 +1377,14 @@ static WfsStatsArgs stats_args(const wfs_bn_stats *st, long long nblk) {
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
                            const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
-    long long ntiles, nblk, tiles_per_xcd;
-    int wpb;
-    gconv32_grid(R, r_dev != nullptr, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
     const size_t lds = (size_t)K * 4096;
-    static bool attr[3] = {false, false, false};
-    static const bool tiles32 = getenv("WFS_F32_TILES32") != nullptr;        // the 32-row kernel for every launch (A/B)
-    if (!stats && !tiles32) {
+    if (!stats) {
         // 16-row tiles taken off a per-block counter (k_gconv16_f32): up to 16 waves per block, <= 256 blocks
         static bool attr16[2] = {false, false};
         const long long nt16 = (R + 15) >> 4;
         const long long expect = r_dev ? (nt16 * 7 + 7) / 8 : nt16;
         int w = (int)((expect + 255) / 256);
         w = w < 4 ? 4 : (w > 16 ? 16 : (w + 3) / 4 * 4);
-        static const int wcap = getenv("WFS_F16_WAVES") ? atoi(getenv("WFS_F16_WAVES")) : 16;
-        if (w > wcap) w = wcap;
         long long nb = (expect + w - 1) / w;
         nb = nb > 256 ? 256 : (nb + 7) / 8 * 8;
         if (nb < 8) nb = 8;
@@ -1402,18 +1395,18 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
         return launch_big_lds(k_gconv16_f32<false>, &attr16[1], g16, b16, lds, stream, table, mirror, K, identity_k, R,
                               r_dev, X, W, bias, Y);
     }
+    // forward with the BatchNorm statistics in the epilogue (spconv.ops.FUSE_CONV_BN_STATS): the 32-row kernel, whose
+    // per-block statistics do not depend on which wave took which tile
+    WFS_REQUIRE(!transpose_w, WFS_EINVAL, "batch statistics are taken by forward products only");
+    long long ntiles, nblk, tiles_per_xcd;
+    int wpb;
+    gconv32_grid(R, r_dev != nullptr, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
+    static bool attr = false;
     const WfsStatsArgs sa = stats_args(stats, nblk);
     const dim3 grid((unsigned)nblk), block(wpb * 64);
-    if (transpose_w)
-        return launch_big_lds(k_gconv32_f32<true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
-    if (stats) {
-        const int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
-                                      identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
-        return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
-    }
-    return launch_big_lds(k_gconv32_f32<false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
-                          identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
+    const int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr, grid, block, lds, stream, table, mirror, K, identity_k, R,
+                                  r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
+    return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
 }
 
 template <typename H>
