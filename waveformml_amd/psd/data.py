@@ -317,6 +317,13 @@ class DevicePrefetcher(object):
                         self.on_exhausted()
             if not queue:
                 return
+            # ring slots go back as soon as their copy has completed (a query, no wait): a deep queue (the multi-rank
+            # Trainer stages several batches ahead) must not sit on slots the loader would otherwise reclaim by age
+            for j in range(1, len(queue)):
+                h, d, e = queue[j]
+                if isinstance(h, RingBatch) and e.query():
+                    h.release()
+                    queue[j] = (None, d, e)
             host, dev, done = queue.pop(0)
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(done)
