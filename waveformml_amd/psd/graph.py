@@ -30,15 +30,7 @@ class GraphedTrainStep(object):
         # events: psd/synthetic, 40 batches), so the default is 6 sigma above the example batch: 1 + 3 / sqrt(E), i.e.
         # 1.19 at 256 events.  A batch beyond a capacity is detected (check()), never silently cut.
         (coords, feats), labels = example_batch
-        if headroom is None and os.environ.get("WFS_CAPTURE_HEADROOM"):
-            headroom = float(os.environ["WFS_CAPTURE_HEADROOM"])          # experiments: tools/exp (capacity is not free)
-        if headroom is None:
-            headroom = max(1.1, 1.0 + 3.0 / max(1.0, float(labels.shape[0])) ** 0.5)
-        if granule is None:
-            # capacities are rounded up to a granule; padded rows cost real work in the wide-channel (GEMM route) layers
-            # of the 2-D nets, whose batches are a few hundred rows, so the granule follows the batch
-            n0 = int(coords.shape[0])
-            granule = 512 if n0 >= 32768 else (256 if n0 >= 2048 else 64)
+        headroom, granule = self._headroom_granule(int(coords.shape[0]), int(labels.shape[0]), headroom, granule)
         assert coords.is_cuda and feats.is_cuda and labels.is_cuda
         self.module, self.optimizer, self.reducer = module, optimizer, reducer
         dev = coords.device
@@ -115,7 +107,11 @@ class GraphedTrainStep(object):
         optimizer.step()
         del loss
         for m in self._convs:
-            m.out_capacity = _round_up(headroom * m.last_rulebook.M, granule)
+            # in proportion to the ROW capacity, which min_rows (a re-capture's floor, the largest batch among the ranks)
+            # may have raised above headroom x this batch: a batch that fits the rows must fit the strided layers too
+            own = _round_up(headroom * coords.shape[0], granule)
+            factor = headroom if self.n_cap <= own else self.n_cap / max(1.0, float(coords.shape[0]))
+            m.out_capacity = _round_up(factor * m.last_rulebook.M, granule)
         if self.exchange_after:
             reducer.remove()              # no collectives inside the graph: gradients are exchanged after the replay
         # ---- warm-up in device-count mode, then capture
@@ -143,6 +139,26 @@ class GraphedTrainStep(object):
             self._warm_and_capture(warmup)
         self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
         self._event_flags = _event_flags(module)
+
+    @staticmethod
+    def _headroom_granule(rows, labels, headroom=None, granule=None):
+        if headroom is None and os.environ.get("WFS_CAPTURE_HEADROOM"):
+            headroom = float(os.environ["WFS_CAPTURE_HEADROOM"])          # experiments: tools/exp (capacity is not free)
+        if headroom is None:
+            headroom = max(1.1, 1.0 + 3.0 / max(1.0, float(labels)) ** 0.5)
+        if granule is None:
+            # capacities are rounded up to a granule; padded rows cost real work in the wide-channel (GEMM route) layers
+            # of the 2-D nets, whose batches are a few hundred rows, so the granule follows the batch
+            granule = 512 if rows >= 32768 else (256 if rows >= 2048 else 64)
+        return headroom, granule
+
+    @classmethod
+    def capacity_for(cls, rows, labels):
+        """The row capacity a step captured on a batch of ``rows`` rows and ``labels`` labels gets: ranks that capture
+        together pass the LARGEST row count among them as ``min_rows`` so that they all hold the same capacity (their
+        replay-or-ordinary-step decisions are derived from agreed counts and must come out alike)."""
+        headroom, granule = cls._headroom_granule(int(rows), int(labels))
+        return _round_up(headroom * int(rows), granule)
 
     def _warm_and_capture(self, warmup):
         for _ in range(warmup):

@@ -195,8 +195,14 @@ class Trainer(object):
         return graph
 
     def _captured_step(self, module, reducer, optimizer, batch, batch_idx, agreed=None):
+        # several ranks deciding from agreed counts must hold the SAME capacity: a capture is sized on the largest batch
+        # any rank has at that step (each rank's own example batch would give each rank its own capacity)
+        floor = 0
+        if agreed is not None:
+            from .graph import GraphedTrainStep
+            floor = GraphedTrainStep.capacity_for(agreed[0], agreed[1])     # largest rows, smallest label count (= largest headroom)
         if self._graph is None:
-            self._graph = self._capture(module, reducer, optimizer, batch)
+            self._graph = self._capture(module, reducer, optimizer, batch, min_rows=floor)
         # more voxels than the capacity, or another number of events -> an ordinary step.  With several ranks the
         # decision is taken together: a rank replaying while another steps eagerly must never depend on the two paths
         # happening to issue the same collectives.
@@ -225,7 +231,7 @@ class Trainer(object):
                 # the capacity is too small for this data: capture again, sized on this batch (never smaller than before)
                 old = self._graph
                 self._graph = None
-                self._graph = self._capture(module, reducer, optimizer, batch, min_rows=old.n_cap)
+                self._graph = self._capture(module, reducer, optimizer, batch, min_rows=max(old.n_cap, floor))
                 del old
                 self._size_misfits = 0
                 self.recaptures += 1
