@@ -35,8 +35,11 @@ def child(tmp, files_per_class, events_per_file, epochs, workers, agree_block, o
     classes = ["Gamma", "Electron", "Positron"]
     cfg = json.load(open(os.path.join(ROOT, "config", "psd_c2_3d.json")))
     cfg["dataset_config"] = {"imports": ["waveformml_amd.psd.PulseDataset"], "dataset_class": "PulseDataset.PulseDataset3D",
-                             "base_path": tmp, "paths": classes, "n_train": files_per_class * events_per_file,
-                             "n_validate": 0, "n_test": 0, "pack_batches": True,
+                             "base_path": tmp, "paths": classes,
+                             "n_train": (files_per_class - 2 * int(os.environ.get("WFS_SOAK_VALIDATE", "0"))) * events_per_file,
+                             "n_validate": int(os.environ.get("WFS_SOAK_VALIDATE", "0")) * events_per_file,
+                             "n_test": int(os.environ.get("WFS_SOAK_VALIDATE", "0")) * events_per_file,
+                             "pack_batches": True,
                              "dataloader_params": {"batch_size": len(classes), "num_workers": workers, "pin_memory": True,
                                                    "persistent_workers": True, "prefetch_factor": 4}}
     cfg["optimize_config"].update(lr=0.004, optimizer_params={"momentum": 0.9, "nesterov": True})
@@ -51,11 +54,13 @@ def child(tmp, files_per_class, events_per_file, epochs, workers, agree_block, o
     mod = LitPSD(conf)
     tr = Trainer(max_epochs=epochs, device="cuda:0", feature_dtype=torch.bfloat16, capture=True, check_every=25,
                  agree_block=agree_block)
-    hist = tr.fit(mod, loader)
+    val = dm.val_dataloader() if os.environ.get("WFS_SOAK_VALIDATE", "0") != "0" else None
+    hist = tr.fit(mod, loader, val)
     torch.cuda.synchronize()
     params = torch.cat([p.detach().float().reshape(-1).cpu() for p in mod.model.parameters()])
     torch.save({"params": params, "steps": [h["steps"] for h in hist], "loss": [h["train_loss"] for h in hist],
                 "seconds": [h["train_seconds"] for h in hist], "eager_fallbacks": tr.eager_fallbacks,
+                "val_loss": [float(h.get("val_loss", float("nan"))) for h in hist],
                 "recaptures": tr.recaptures, "n_cap": tr._graph.n_cap}, out + ".rank%s" % os.environ["RANK"])
     dist.destroy_process_group()
 
@@ -95,7 +100,7 @@ def main():
         same = bool(torch.equal(r0["params"], r1["params"]))
         print(json.dumps({"files_per_class": fpc, "events_per_file": epf, "rows": rows, "epochs": epochs, "workers_per_rank": workers,
                           "agree_block": block, "replicas_bit_identical": same, "steps_per_epoch": r0["steps"],
-                          "loss_per_epoch": [r0["loss"], r1["loss"]], "seconds_per_epoch": [r0["seconds"], r1["seconds"]],
+                          "loss_per_epoch": [r0["loss"], r1["loss"]], "val_loss_per_epoch": [r0["val_loss"], r1["val_loss"]], "seconds_per_epoch": [r0["seconds"], r1["seconds"]],
                           "eager_fallbacks": [r0["eager_fallbacks"], r1["eager_fallbacks"]],
                           "recaptures": [r0["recaptures"], r1["recaptures"]], "n_cap": [r0["n_cap"], r1["n_cap"]]}))
         assert same and r0["steps"] == r1["steps"]
