@@ -121,8 +121,10 @@ int wfs_geometry_init(wfs_geometry *g);
  *
  * Device-count mode (no host synchronisation at all): host_info = NULL, n_dev = valid input rows,
  * m_dev = where the plan writes min(M, M_cap) for the consumers of the outputs, M_cap = the caller's
- * output capacity (rows of out_indices / nbr_in handed to emit as M); emit sets *overflow_dev != 0
- * if the true M exceeded it (the step's results are then invalid and must be redone with room). */
+ * output capacity (rows of out_indices / nbr_in handed to emit as M); emit sets *overflow_dev = 1
+ * if the true M exceeded it (the step's results are then invalid and must be redone with room) and
+ * leaves it alone otherwise: the flag is STICKY, the caller clears it before the first build and
+ * after reading it (a captured step replays many builds between two reads). */
 size_t wfs_rulebook_workspace_bytes(const wfs_geometry *g, int64_t N);
 
 int wfs_rulebook_plan(const wfs_geometry *g, const int32_t *indices, int64_t N,
@@ -217,8 +219,9 @@ int wfs_wide_linear_bwd(const void *X, const float *dY, int64_t B, int32_t I, co
  *   WORKGROUP PAIR PER EVENT with the event's site table in LDS (cell -> sample array, direct addressing) -- no site
  *   grid over the batch in HBM, no clearing launch, no global atomics: HBM traffic = the coordinates in, the table out.
  *   nbr_out is bit-identical to wfs_rulebook_plan's.  `events` = wfs_event_offsets of `indices`.
- *   flags: int32 [wfs_event_rulebook_flag_ints(batch)] = 3 x blocks words, every word written by every launch; any
- *   word != 0 in [0, blocks): the index set is not grouped by event or an event exceeds the LDS tables (64 KiB of
+ *   flags: int32 [wfs_event_rulebook_flag_ints(batch)] = 3 x blocks words, STICKY: a launch sets words and never
+ *   clears one -- the caller zeroes them before the first build and after reading them (a captured step replays many
+ *   builds between two reads).  Any word != 0 in [0, blocks): the index set is not grouped by event or an event exceeds the LDS tables (64 KiB of
  *   sample arrays: 128 active cells at 256 samples) -- nbr_out is then incomplete and the caller takes wfs_rulebook_plan instead;
  *   in [blocks, 2 blocks): duplicate coordinates (same remedy: "the last row wins" is resolved by the chip-wide build);
  *   in [2 blocks, 3 blocks): an index outside the spatial shape.

@@ -39,7 +39,7 @@ def _ev_subm(idx_t, B, shape, ksize, dilation=1, n_dev=None):
     N = idx_t.shape[0]
     ev = _offsets(idx_t, B, n_dev)
     nbr = torch.full((int(g.K), N), -7, dtype=torch.int32, device=DEV)
-    flags = torch.full((int(lib.wfs_event_rulebook_flag_ints(B)),), 7, dtype=torch.int32, device=DEV)
+    flags = torch.zeros((int(lib.wfs_event_rulebook_flag_ints(B)),), dtype=torch.int32, device=DEV)   # sticky: the caller clears
     L.check(lib.wfs_event_rulebook_subm(ctypes.byref(g), L.ptr(idx_t), N, L.ptr(n_dev), L.ptr(ev), L.ptr(nbr), None,
                                         L.ptr(flags), L.stream_ptr()))
     torch.cuda.synchronize()
@@ -261,3 +261,47 @@ def test_device_count_conv_build_equals_exact_build(shape, ksize, stride, paddin
     assert int(small.overflow) == 1 and int(small.m_dev) == max(exact.M // 2, 1)
     keep = int(small.m_dev)
     assert torch.equal(small.out_indices[:keep], exact.out_indices[:keep])
+
+
+def test_overflow_flag_of_a_captured_build_is_sticky():
+    """A captured step is checked every so many replays: the overflow flag of a strided build must survive the replays
+    that follow the one that overflowed (the build only ever SETS it; the reader clears it).  A build captured over a
+    capacity that fits index set A is replayed with A (flag clear), with B (more output sites: flag set) and with A
+    again: the flag is still set, and clearing it by hand brings it back to 0 for the next A."""
+    from waveformml_amd.spconv import ops
+    rng = np.random.default_rng(23)
+    B, shape, ksize, stride, padding = 6, (14, 11, 64), [3, 3, 3], [1, 1, 4], [0, 0, 0]
+    N = 900
+    a = _sorted_by_event(rand_coords(rng, B, (4, 3, 64), N))                       # one corner of the grid: few outputs
+    b = _sorted_by_event(rand_coords(rng, B, shape, N))                            # spread over the grid: many more
+    ta, tb = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)
+    ma = ops.build_rulebook(ta, B, list(shape), ksize, stride, padding, [1] * 3, False, known_unique=True).M
+    mb = ops.build_rulebook(tb, B, list(shape), ksize, stride, padding, [1] * 3, False, known_unique=True).M
+    assert mb > ma + 64
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        static = ta.clone()
+        nv = torch.tensor([N], dtype=torch.int64, device=DEV)
+        for _ in range(2):
+            ops.build_rulebook(static, B, list(shape), ksize, stride, padding, [1] * 3, False, n_dev=nv, out_capacity=ma + 8)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            rb = ops.build_rulebook(static, B, list(shape), ksize, stride, padding, [1] * 3, False, n_dev=nv,
+                                    out_capacity=ma + 8)
+        rb.overflow.zero_()                        # allocated inside the capture: the runner clears it once
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(rb.overflow) == 0 and int(rb.m_dev) == ma
+        static.copy_(tb)
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(rb.overflow) == 1
+        static.copy_(ta)
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(rb.overflow) == 1 and int(rb.m_dev) == ma          # a good replay does not clear it
+        rb.overflow.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(rb.overflow) == 0

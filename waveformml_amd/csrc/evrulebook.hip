@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(ER_THREADS) k_ev_subm(EGeo g, EQTab qt, int Q,
     __shared__ int2 sQt[32];
     __shared__ int sCount[ER_THREADS / 64 + 1];
     const int Nv = (int)valid_rows(N, n_dev);
-    // flags: one word per workgroup and kind, all written by every launch (nothing to clear): flags[kind * gridDim.x + block]
+    // flags: one word per workgroup and kind, flags[kind * gridDim.x + block]; set, never cleared, by a launch (see the end)
     int f_fail = 0, f_dup = 0, f_range = 0;
     const bool structured = ev_structured(ev, B);
     if (!structured) f_fail = 1;
@@ -257,9 +257,11 @@ __global__ void __launch_bounds__(ER_THREADS) k_ev_subm(EGeo g, EQTab qt, int Q,
     f_dup = __syncthreads_or(f_dup);
     f_range = __syncthreads_or(f_range);
     if (threadIdx.x == 0) {
-        flags[blockIdx.x] = f_fail;
-        flags[gridDim.x + blockIdx.x] = f_dup;
-        flags[2 * gridDim.x + blockIdx.x] = f_range;
+        // STICKY: a flag is only ever set here; whoever reads them clears them (a captured step is checked every so many
+        // replays: a failure of any replay in between must still be there)
+        if (f_fail) flags[blockIdx.x] = 1;
+        if (f_dup) flags[gridDim.x + blockIdx.x] = 1;
+        if (f_range) flags[2 * gridDim.x + blockIdx.x] = 1;
     }
 }
 

@@ -350,13 +350,18 @@ __global__ void __launch_bounds__(TB) k_conv_assign2(Geo g, long long N, const l
     o[0] = (int)key;
 }
 
+__global__ void k_set_if(const long long *__restrict__ cond, int *__restrict__ flag) {
+    if (*cond != 0) *flag = 1;
+}
+
 __global__ void __launch_bounds__(TB) k_conv_finalize2(int K, long long N, const long long *n_dev, long long M,
                                                        int *__restrict__ nbr_out, const int *__restrict__ slot_id,
                                                        int *__restrict__ nbr_in, const long long *__restrict__ info,
                                                        int *__restrict__ overflow) {
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    if (overflow && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *overflow = info[0] > M ? 1 : 0;
+    // STICKY: set when M exceeded the capacity, never cleared here (the reader clears it)
+    if (overflow && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && info[0] > M) *overflow = 1;
     if (k >= K || j >= valid_rows(N, n_dev)) return;
     int s = nbr_out[(long long)k * N + j];
     if (s < 0) return;
@@ -957,8 +962,10 @@ extern "C" int wfs_rulebook_emit(const wfs_geometry *g, const int32_t *indices, 
             WFS_LAUNCH_CHECK();
             k_conv_finalize<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, slot_id, nbr_in);
             WFS_LAUNCH_CHECK();
-            if (overflow_dev)   // info[3] (8 bytes) -> the caller's flag: non-zero = M exceeded the capacity
-                WFS_HIP_CHECK(hipMemcpyAsync(overflow_dev, info + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+            if (overflow_dev) {  // info[3] -> the caller's flag (sticky, as above): set if M exceeded the capacity
+                k_set_if<<<1, 1, 0, stream>>>(info + 3, overflow_dev);
+                WFS_LAUNCH_CHECK();
+            }
         }
     } else if (nbr_in) {
         k_invert_table<<<grid, block, 0, stream>>>(g->K, N, nd, M, nbr_out, nbr_in);

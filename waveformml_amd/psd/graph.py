@@ -139,6 +139,9 @@ class GraphedTrainStep(object):
             self._warm_and_capture(warmup)
         self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
         self._event_flags = _event_flags(module)
+        # the builds only ever SET these (sticky); allocated inside the capture they start undefined: cleared here and
+        # after every read, so that check() sees a failure of ANY replay since the last check()
+        _clear_flags(self._overflow, self._event_flags)
 
     @staticmethod
     def _headroom_granule(rows, labels, headroom=None, granule=None):
@@ -308,12 +311,14 @@ class GraphedTrainStep(object):
             evf = evf | f[: 2 * (f.numel() // 3)].any().to(torch.int32)
         if self.world > 1 and dist.is_available() and dist.is_initialized():
             dist.all_reduce(evf, op=dist.ReduceOp.MAX, group=self.reducer.group)
-        if bool(evf.item()):
-            raise RuntimeError("a batch was not grouped by event (or an event exceeded the LDS tables of the event-local "
-                               "rulebook build, or held duplicate coordinates); set WFS_EVENT_LOCAL=0 and re-capture")
         if self.world > 1 and dist.is_available() and dist.is_initialized():
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
-        if bool(flag.item()):
+        bad_events, overflow = bool(evf.item()), bool(flag.item())
+        _clear_flags(self._overflow, getattr(self, "_event_flags", ()))
+        if bad_events:
+            raise RuntimeError("a batch was not grouped by event (or an event exceeded the LDS tables of the event-local "
+                               "rulebook build, or held duplicate coordinates); set WFS_EVENT_LOCAL=0 and re-capture")
+        if overflow:
             raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
 
 
@@ -408,6 +413,12 @@ class ShapeAgreement(object):
         return int(r[0]), -int(r[2]), int(r[1]), bool(r[3])
 
 
+def _clear_flags(*groups):
+    for tensors in groups:
+        for t in tensors:
+            t.zero_()
+
+
 def _event_flags(module):
     """Failure flags of the event-local rulebook builds of the module's conv layers (spconv.ops.EVENT_LOCAL)."""
     out, seen = [], set()
@@ -489,6 +500,7 @@ class GraphedEvalStep(object):
                 with torch.cuda.graph(self.graph, stream=self.stream):
                     self.logits = self._forward()
                 self._overflow = [m.last_rulebook.overflow for m in self._convs if m.last_rulebook.overflow is not None]
+                _clear_flags(self._overflow)            # sticky flags allocated inside the capture (see GraphedTrainStep)
                 self.graph_fwd = None
                 if sweep:
                     # second capture inside the same reuse context: every rulebook build is a cache hit (same static
@@ -538,6 +550,7 @@ class GraphedEvalStep(object):
 
     def check(self):
         if self._overflow and bool(torch.stack([o.reshape(()) for o in self._overflow]).any().item()):
+            _clear_flags(self._overflow)
             raise RuntimeError("a sparse conv output exceeded its captured capacity; re-capture with more headroom")
 
     def close(self):

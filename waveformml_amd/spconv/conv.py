@@ -46,6 +46,14 @@ class SparseConvolution(SparseModule):
             self.register_parameter('bias', None)
         self.reset_parameters()
 
+    def _sticky_flags(self):
+        """This layer's store of failure flags that rulebook builds only ever set (ops._sticky_flags): plain tensors kept
+        across steps and graph replays, not parameters or buffers."""
+        store = self.__dict__.get("_flag_store")
+        if store is None:
+            store = self.__dict__["_flag_store"] = {}
+        return store
+
     def reset_parameters(self):
         init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
@@ -107,7 +115,7 @@ class SparseConvolution(SparseModule):
                                         self.padding, self.dilation, self.subm, known_unique=input.unique,
                                         n_dev=input.n_valid, out_capacity=getattr(self, "out_capacity", None),
                                         transposed=self.transposed, output_padding=self.output_padding,
-                                        events=getattr(input, "events", None))
+                                        events=getattr(input, "events", None), flags=self._sticky_flags())
                 if getattr(rb, "events_in", None) is not None:
                     input.events = rb.events_in          # the offsets of this row set, for the layers that follow
                 self.last_rulebook = rb          # capacity calibration / overflow checks of graph-captured steps

@@ -79,7 +79,7 @@ class SparseSequential(SparseModule):
                     else:
                         rb = ops.build_rulebook(indices, x.batch_size, spatial, m.kernel_size, m.stride, m.padding,
                                                 m.dilation, m.subm, known_unique=True, n_dev=n_dev,
-                                                out_capacity=getattr(m, "out_capacity", None))
+                                                out_capacity=getattr(m, "out_capacity", None), flags=m._sticky_flags())
                         rb.ready = torch.cuda.Event()
                         rb.ready.record(side)
                         if m.indice_key is not None:

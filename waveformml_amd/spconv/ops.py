@@ -226,19 +226,42 @@ def event_offsets(indices, batch_size, n_dev=None):
     return out
 
 
+def _sticky_flags(n, dev, store=None, name=None):
+    """Failure flags a build only ever SETS (overflow of an output capacity, event-local build failures); whoever reads
+    them clears them.  ``store`` (a dict owned by the calling layer): the tensor is created once, OUTSIDE any graph
+    capture, and handed to every later build of that layer -- memory allocated inside a capture can be the recycled block
+    of an earlier temporary of the same graph, which every replay then writes before the build runs: fine for a flag the
+    build rewrites, fatal for one it only sets.  Without a store: zeros (empty inside a capture: such a flag is only good
+    until the next replay)."""
+    capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if store is not None:
+        t = store.get(name)
+        if t is None or t.numel() != n or t.device != dev:
+            if capturing:
+                raise RuntimeError("waveformml_amd.spconv: the layer's failure flags must exist before a graph capture "
+                                   "(run the step once in device-count mode first, as psd/graph.py does)")
+            t = torch.zeros((n,), dtype=torch.int32, device=dev)
+            store[name] = t
+        return t
+    if capturing:
+        return torch.empty((n,), dtype=torch.int32, device=dev)
+    return torch.zeros((n,), dtype=torch.int32, device=dev)
+
+
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
                    known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None,
-                   events=None):
-    """Cached front of :func:`_build_rulebook` (see :class:`reuse_rulebooks`)."""
+                   events=None, flags=None):
+    """Cached front of :func:`_build_rulebook` (see :class:`reuse_rulebooks`).  ``flags``: the calling layer's store of
+    sticky failure flags (:func:`_sticky_flags`)."""
     global BUILD_COUNT
     if transposed:
         BUILD_COUNT += 1
         return _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, False,
-                               known_unique, n_dev, out_capacity, True, output_padding)
+                               known_unique, n_dev, out_capacity, True, output_padding, flags=flags)
     if _REUSE is None:
         BUILD_COUNT += 1
         return _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                               known_unique, n_dev, out_capacity, events=events)
+                               known_unique, n_dev, out_capacity, events=events, flags=flags)
     ndim = indices.shape[1] - 1
     key = (indices.data_ptr(), tuple(indices.shape), tuple(indices.stride()), int(batch_size),
            tuple(int(s) for s in spatial_shape), tuple(_listify(ksize, ndim)), tuple(_listify(stride, ndim)),
@@ -248,7 +271,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     if rb is None:
         BUILD_COUNT += 1
         rb = _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                             known_unique, n_dev, out_capacity)
+                             known_unique, n_dev, out_capacity, flags=flags)
         rb._keepalive = indices          # the key holds a data_ptr: keep the storage from being recycled
         _REUSE[key] = rb
     return rb
@@ -256,7 +279,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
 
 def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
                     known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None,
-                    events=None):
+                    events=None, flags=None):
     """Builds the device rulebook.  ``known_unique``: True if the caller knows the index rows are
     distinct sites (skips the duplicate check a regular conv would otherwise run once).
 
@@ -295,13 +318,12 @@ def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, 
             m_cap = int(out_capacity) if out_capacity else default_out_capacity(N, rb.K, cells)
             rb.M = m_cap
             rb.m_dev = torch.empty((1,), dtype=torch.int64, device=dev)        # written by the plan
-            rb.overflow = torch.empty((1,), dtype=torch.int32, device=dev)     # cleared, then set, by the emit
+            rb.overflow = _sticky_flags(1, dev, flags, "overflow")           # set (never cleared) by the emit
         if (subm and EVENT_LOCAL and N > 0 and 1 <= int(batch_size) <= EVENT_LOCAL_MAX_BATCH
                 and lib.wfs_event_rulebook_ok(ctypes.byref(g))):
             # a pair of workgroups per event, site table in LDS
             rb.events_in = events if events is not None else event_offsets(indices, batch_size, n_dev)
-            rb.event_flags = torch.empty((int(lib.wfs_event_rulebook_flag_ints(int(batch_size))),), dtype=torch.int32,
-                                         device=dev)
+            rb.event_flags = _sticky_flags(int(lib.wfs_event_rulebook_flag_ints(int(batch_size))), dev, flags, "events")
             _lib.check(lib.wfs_event_rulebook_subm(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(n_dev),
                                                    _lib.ptr(rb.events_in), _lib.ptr(rb.nbr_out), None,
                                                    _lib.ptr(rb.event_flags), stream))
