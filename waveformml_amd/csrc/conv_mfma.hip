@@ -636,7 +636,7 @@ constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator register
 constexpr int DW_WAVES = 8;
 
 template <typename T>
-__global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
+__global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
                                                   const long long *__restrict__ r_dev, const T *__restrict__ S,
                                                   const T *__restrict__ G,
                                                   float *__restrict__ part, int ngroups, long long tiles_per_block) {
@@ -693,13 +693,13 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
             any = any || (__ballot(nb >= 0) != 0ull);
         }
         if (!any) continue;
-        // the gathers of all the wave's ACTIVE offsets are issued together, ahead of the first MFMA: one memory round
-        // trip per tile (with load and MFMA under the same per-offset branch it was one per offset); inactive offsets
-        // (most of a SubM tile's) issue nothing
-        float b[DW_KG][16];
+        // one ACTIVE offset at a time (inactive ones -- most of a SubM tile's -- issue nothing): 16 registers of gathered
+        // rows instead of 64 leave room for two blocks = four waves per SIMD on a CU, whose MFMAs and address arithmetic
+        // run under this wave's gather round trip
 #pragma unroll
         for (int q = 0; q < DW_KG; ++q) {
             if (__ballot(nbv[q] >= 0) == 0ull) continue;
+            float b[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 // the two rows of an MFMA step are wave-uniform: their byte offsets are scalar work, a missing row gets an
@@ -708,14 +708,10 @@ __global__ void __launch_bounds__(512, 1) k_gdw32(const int *__restrict__ table,
                 const int n1 = __builtin_amdgcn_readlane(nbv[q], 2 * s + 1);
                 const unsigned o0 = n0 >= 0 ? (unsigned)n0 * 128u : 0x80000000u;
                 const unsigned o1 = n1 >= 0 ? (unsigned)n1 * 128u : 0x80000000u;
-                b[q][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcG, (h ? o1 : o0) + j4, 0, 0));
+                b[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcG, (h ? o1 : o0) + j4, 0, 0));
             }
-        }
 #pragma unroll
-        for (int q = 0; q < DW_KG; ++q) {
-            if (__ballot(nbv[q] >= 0) == 0ull) continue;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[q][s], acc[q], 0, 0, 0);
+            for (int s = 0; s < 16; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[q], 0, 0, 0);
         }
     }
     // deterministic block reduction, one offset at a time: the 8 waves park that offset's accumulator in LDS, then
@@ -1502,11 +1498,12 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
 }
 
 // slabs for the 32x32 dW: blocks over rows; returns the slab count through *nslabs
-static long long dw32_blocks(long long R) {
+static long long dw32_blocks(long long R, bool two_per_cu = false) {
     long long ntiles = (R + 31) >> 5;
-    long long nblk = (ntiles + 39) / 40;        // ~40 tiles (5 per wave) per block
+    long long nblk = (ntiles + (two_per_cu ? 19 : 39)) / (two_per_cu ? 20 : 40);        // ~40 (20) tiles per block
     if (nblk < 1) nblk = 1;
-    if (nblk > 36) nblk = 36;                   // x 7 offset sets = 252 blocks: one round on 256 CUs
+    const long long cap = two_per_cu ? 72 : 36; // x 7 offset sets = 252 (504) blocks: one round on 256 CUs, one (two) per CU
+    if (nblk > cap) nblk = cap;
     return nblk;
 }
 static long long dwc2_chunks(long long R) {
@@ -1517,14 +1514,14 @@ static long long dwc2_chunks(long long R) {
 }
 
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
-    if (Cs == 32 && Cg == 32) return (size_t)dw32_blocks(R) * K * 1024 * sizeof(float);
+    if (Cs == 32 && Cg == 32) return (size_t)dw32_blocks(R, true) * K * 1024 * sizeof(float);   // the larger (fp32) grid
     if (Cs == 32 && Cg == 2) return (size_t)dwc2_chunks(R) * K * 64 * sizeof(float);
     return 0;
 }
 
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
                      const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream) {
-    const long long nblk = dw32_blocks(R);
+    const long long nblk = dw32_blocks(R, dtype == WFS_F32);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
