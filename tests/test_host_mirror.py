@@ -301,3 +301,24 @@ def test_checkpoint_optimizer_state_is_per_parameter_both_ways(tmp_path):
     with pytest.raises(RuntimeError, match="covers 2 parameters"):
         bad = {"state": {}, "param_groups": [dict(want["param_groups"][0], params=[0, 1])]}
         load_optimizer_state(flat2, bad, list(net2.parameters()))
+
+
+def test_agreed_capacity_covers_every_ranks_own_capacity():
+    """psd/graph.GraphedTrainStep.capacity_for (the capacity ranks capture with when batch shapes are agreed ahead of
+    time): for any rank's own (rows, labels) below the agreed (largest rows, smallest label count) the rank's own
+    capacity never exceeds the agreed one -- across the granule steps (64 / 256 / 512) and the label-dependent headroom --
+    so max(own, agreed) is the same number on every rank; and fits_counts decides from the agreed counts alone."""
+    import types
+    from waveformml_amd.psd.graph import GraphedTrainStep as G
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        rows_max = int(rng.integers(1, 200000))
+        labels_min = int(rng.integers(1, 4096))
+        own_rows = int(rng.integers(1, rows_max + 1))
+        own_labels = int(rng.integers(labels_min, 2 * labels_min + 1))
+        assert G.capacity_for(own_rows, own_labels) <= G.capacity_for(rows_max, labels_min)
+    step = types.SimpleNamespace(per_row=False, n_cap=1000, labels=torch.zeros(16))
+    assert G.fits_counts(step, 1000, 16, 16, True) and not G.fits_counts(step, 1001, 16, 16, True)
+    assert not G.fits_counts(step, 900, 15, 16, True) and not G.fits_counts(step, 900, 16, 17, True)
+    seg = types.SimpleNamespace(per_row=True, n_cap=1000, labels=torch.zeros(1000))
+    assert G.fits_counts(seg, 1000, 1000, 1000, False) and not G.fits_counts(seg, 900, 900, 900, True)
