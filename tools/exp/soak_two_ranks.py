@@ -52,11 +52,24 @@ def child(tmp, files_per_class, events_per_file, epochs, workers, agree_block, o
     dm.setup("fit")
     loader = dm.train_dataloader()
     mod = LitPSD(conf)
+    root = os.path.join(tmp, "ckpt") if os.environ.get("WFS_SOAK_RESUME") == "1" else None
     tr = Trainer(max_epochs=epochs, device="cuda:0", feature_dtype=torch.bfloat16, capture=True, check_every=25,
-                 agree_block=agree_block)
+                 agree_block=agree_block, default_root_dir=root)
     val = dm.val_dataloader() if os.environ.get("WFS_SOAK_VALIDATE", "0") != "0" else None
     hist = tr.fit(mod, loader, val)
     torch.cuda.synchronize()
+    if root is not None:
+        # rank 0 wrote the checkpoints (best validation loss so far); BOTH ranks resume a fresh module from the last one
+        # and train one more epoch: the replicas must still be bit-identical afterwards
+        import glob
+        dist.barrier()
+        last = sorted(glob.glob(os.path.join(root, "*.ckpt")), key=os.path.getmtime)[-1]
+        torch.manual_seed(1)
+        mod = LitPSD(conf)
+        tr = Trainer(max_epochs=epochs + 1, device="cuda:0", feature_dtype=torch.bfloat16, capture=True, check_every=25,
+                     agree_block=agree_block, resume_from_checkpoint=last)
+        hist = hist + tr.fit(mod, loader, val)
+        torch.cuda.synchronize()
     params = torch.cat([p.detach().float().reshape(-1).cpu() for p in mod.model.parameters()])
     torch.save({"params": params, "steps": [h["steps"] for h in hist], "loss": [h["train_loss"] for h in hist],
                 "seconds": [h["train_seconds"] for h in hist], "eager_fallbacks": tr.eager_fallbacks,
