@@ -101,18 +101,20 @@ def main():
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         out = os.path.join(tmp, "res")
+        world = int(os.environ.get("WFS_SOAK_WORLD", "2"))          # at most 6 processes may use the card together
         procs = []
-        for r in range(2):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", tmp, str(fpc), str(epf),
                                            str(epochs), str(workers), str(block), out], env=env, cwd=ROOT))
         codes = [p.wait(timeout=int(os.environ.get("WFS_WATCHDOG", "880")) + 20) for p in procs]
-        assert codes == [0, 0], codes
-        r0, r1 = (torch.load(out + ".rank%d" % r, weights_only=True) for r in range(2))
-        same = bool(torch.equal(r0["params"], r1["params"]))
+        assert codes == [0] * world, codes
+        res = [torch.load(out + ".rank%d" % r, weights_only=True) for r in range(world)]
+        r0, r1 = res[0], res[-1]
+        same = all(bool(torch.equal(r0["params"], r["params"])) for r in res[1:])
         print(json.dumps({"files_per_class": fpc, "events_per_file": epf, "rows": rows, "epochs": epochs, "workers_per_rank": workers,
-                          "agree_block": block, "replicas_bit_identical": same, "steps_per_epoch": r0["steps"],
+                          "agree_block": block, "ranks": world, "replicas_bit_identical": same, "steps_per_epoch": r0["steps"],
                           "loss_per_epoch": [r0["loss"], r1["loss"]], "val_loss_per_epoch": [r0["val_loss"], r1["val_loss"]], "seconds_per_epoch": [r0["seconds"], r1["seconds"]],
                           "eager_fallbacks": [r0["eager_fallbacks"], r1["eager_fallbacks"]],
                           "recaptures": [r0["recaptures"], r1["recaptures"]], "n_cap": [r0["n_cap"], r1["n_cap"]]}))
