@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ ta
     const long long t_begin = (long long)xcd * tpx_v;
     const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
     const float bj0 = bias ? bias[r] : 0.f, bj1 = bias ? bias[16 + r] : 0.f;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the gathered rows through a raw buffer (byte offsets below 2 GiB: the dispatcher checks the row count)
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, 0x7FFFFFFF, 0x00020000);
     while (true) {
         int mine = 0;
         if (lane == 0) mine = atomicAdd(&sNext, 1);
@@ -335,18 +336,20 @@ __global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ ta
                 }
 #pragma unroll
                 for (int g = 0; g < F16_GROUP; ++g) {
-                    // unconditional (an empty slot reads row 0): loads behind branches make hipcc wait for all of them
-                    const f32x4 *xp = (const f32x4 *)(X + (long long)(gr.nb[g] >= 0 ? gr.nb[g] : 0) * 32 + q * 8);
-                    gr.a[g][0] = xp[0];
-                    gr.a[g][1] = xp[1];
+                    // unconditional (loads behind branches make hipcc wait for all of them), through a raw buffer: a
+                    // missing neighbour / empty slot points at or past the end of the buffer and reads as 0 -- no select
+                    // on the 8 registers afterwards, a 32-bit offset instead of a 64-bit address
+                    int voff = gr.nb[g] >= 0 ? (int)((unsigned)gr.nb[g] * 128u + (unsigned)q * 32u) : (int)0x80000000;
+                    asm volatile("" : "+v"(voff));         // opaque: "+ 16" folds into the instruction's immediate
+                    gr.a[g][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff, 0, 0));
+                    gr.a[g][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff + 16, 0, 0));
                 }
             };
             auto multiply = [&](const Group &gr) {
 #pragma unroll
                 for (int g = 0; g < F16_GROUP; ++g)
                     if (gr.k[g] >= 0) {
-                        f32x4 a0 = gr.a[g][0], a1 = gr.a[g][1];
-                        if (gr.nb[g] < 0) a0 = a1 = zero4;
+                        const f32x4 a0 = gr.a[g][0], a1 = gr.a[g][1];
                         const f32x4 *bp = (const f32x4 *)(sW + ((gr.k[g] * 16 + q) * 16 + r) * 4);   // (k, cb 0, jq 0, q, n)
                         const f32x4 b00 = bp[0], b01 = bp[64], b10 = bp[128], b11 = bp[192];   // [cb][jq]: +64 f32x4 per jq, +128 per cb
                         // the two column blocks' chains alternate: a dependent MFMA never follows its producer directly

@@ -431,7 +431,9 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
         is_ident = is_ident && km.v[k] == k;
         is_mirror = is_mirror && km.v[k] == K - 1 - k;
     }
-    if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror)) {
+    // (the fp32 kernel addresses the gathered rows through 32-bit byte offsets: fewer than 2^24 rows of 128 B)
+    if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror) &&
+        X_rows < (1ll << 24)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
                                       bias, (float *)Y, stats, pending, stream);
