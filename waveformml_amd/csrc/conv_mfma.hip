@@ -503,6 +503,8 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
     const long long t_begin = (long long)xcd * tpx_v;
     const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
     const float bj = bias ? bias[r] : 0.f;
+    // the gathered rows through a raw buffer (byte offsets below 2 GiB: the dispatcher checks the row count)
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, 0x7FFFFFFF, 0x00020000);
     for (long long tile = t_begin + (long long)wid * bpx + bi; tile < t_end; tile += (long long)bpx * nw) {
         if (tile * 32 >= Rv) break;
         const long long row = tile * 32 + r;
@@ -544,17 +546,18 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
                     nbs[g] = myNb[ks[g] * 32 + r];
                     // WFS_KNOCK & 16: every offset reads the tile's OWN rows (a coalesced window instead of a gather):
                     // an upper bound on what run-structured window loads could save
-                    const long long src = (WFS_KNOCK & 16) ? rowc : (long long)(nbs[g] >= 0 ? nbs[g] : 0);
-                    const uint4 *xp = (const uint4 *)(X + src * 32 + h * 16);
-                    a_lo[g] = xp[0];
-                    a_hi[g] = xp[1];
+                    // through a raw buffer: a missing neighbour points past the end of the buffer and reads as 0 (no select
+                    // on the 8 registers afterwards), a 32-bit byte offset instead of a 64-bit address
+                    const int src = (WFS_KNOCK & 16) ? (int)rowc : nbs[g];
+                    int voff = src >= 0 ? (int)((unsigned)src * 64u + (unsigned)h * 32u) : (int)0x80000000;
+                    asm volatile("" : "+v"(voff));
+                    a_lo[g] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff, 0, 0));
+                    a_hi[g] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff + 16, 0, 0));
                 }
 #pragma unroll
             for (int g = 0; g < BF_GROUP; ++g)
                 if (ks[g] >= 0) {
-                    uint4 lo = a_lo[g], hi = a_hi[g];
-                    lo = keep_if(lo, nbs[g] >= 0);
-                    hi = keep_if(hi, nbs[g] >= 0);
+                    const uint4 lo = a_lo[g], hi = a_hi[g];
                     const uint4 *bp = sWb + (size_t)ks[g] * 128 + h * 32 + r;
                     uint4 b0 = bp[0], b1 = bp[64];
                     acc = mfma16<H>(lo, b0, acc);

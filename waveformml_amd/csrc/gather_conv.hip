@@ -438,7 +438,7 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
                                       bias, (float *)Y, stats, pending, stream);
     }
-    if (dtype != WFS_F32 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror)) {
+    if (dtype != WFS_F32 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror) && X_rows < (1ll << 25)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_h16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
                                       dtype, stats, pending, stream);
