@@ -60,10 +60,11 @@ extern "C" {
 #define WFS_MAX_DIM 4
 
 /* library / device ------------------------------------------------------------------------
- * WFS_ABI_VERSION changes whenever a struct layout or an exported signature does (3: wfs_geometry grew
- * `transposed` / `output_padding` in round 2, the event-local build joined in round 3; 4: the wide-layer entry points).  A binding compiled against
+ * WFS_ABI_VERSION changes whenever a struct layout, an exported signature or the meaning of an argument does (3: wfs_geometry grew
+ * `transposed` / `output_padding` in round 2, the event-local build joined in round 3; 4: the wide-layer entry points; 5: the failure flags of wfs_rulebook_emit and
+ * wfs_event_rulebook_subm are sticky -- set, never cleared, by the library).  A binding compiled against
  * another version must refuse the library: waveformml_amd/_lib.py does. */
-#define WFS_ABI_VERSION 4
+#define WFS_ABI_VERSION 5
 int wfs_abi_version(void);
 const char *wfs_last_error(void);
 
