@@ -62,9 +62,10 @@ extern "C" {
 /* library / device ------------------------------------------------------------------------
  * WFS_ABI_VERSION changes whenever a struct layout, an exported signature or the meaning of an argument does (3: wfs_geometry grew
  * `transposed` / `output_padding` in round 2, the event-local build joined in round 3; 4: the wide-layer entry points; 5: the failure flags of wfs_rulebook_emit and
- * wfs_event_rulebook_subm are sticky -- set, never cleared, by the library).  A binding compiled against
- * another version must refuse the library: waveformml_amd/_lib.py does. */
-#define WFS_ABI_VERSION 5
+ * wfs_event_rulebook_subm are sticky -- set, never cleared, by the library; 6: round 4 -- wfs_gather_conv / wfs_gather_dw take
+ * `packed_kl`, the event-local build of regular convolutions and the packed by-input table joined).  A binding
+ * compiled against another version must refuse the library: waveformml_amd/_lib.py does. */
+#define WFS_ABI_VERSION 6
 int wfs_abi_version(void);
 const char *wfs_last_error(void);
 
@@ -157,11 +158,22 @@ int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indices, int64_
  * identity_k >= 0 names the offset whose source row is r itself (SubM centre: spconv computes
  * it as a plain X.W[k*] with k* = argmax indice_pair_num, A.4); -1 = none.  table may be NULL
  * only for K == 1 && identity_k == 0.
- * No atomics: each output row is written exactly once, results are run-to-run reproducible. */
+ * No atomics: each output row is written exactly once, results are run-to-run reproducible.
+ * Packed tables (round 4).  Where a regular conv's kernel is no longer than its stride along the LAST dimension
+ * (the PSD nets' SparseConv3d k 3, stride (1,1,4): reference src/models/SPConvBlocks.py:498 through config strings) an
+ * input row reaches at most ONE output cell per leading kernel offset q, so the by-input table of
+ * wfs_event_rulebook_conv is [K / kl, R] instead of [K, R]: entry e >= 0 means "row e >> 3, at kernel offset
+ * k = q * kl + (e & 7)", -1 = none (9 instead of 27 table rows at that geometry, 54 % instead of 18 % of them used).
+ * packed_kl = kl hands such a table to wfs_gather_conv (transpose_w products, i.e. dX) and wfs_gather_dw; 0 = the
+ * dense form.  wfs_gather_packed_ok(kl, K, Ca, Cb, dtype, which) tells whether a product takes it (which = 1: dX,
+ * 2: forward, 3: dW); wfs_unpack_table expands a packed table to the dense one for every other consumer. */
 int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                     int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,
-                    int32_t dtype, const int64_t *r_dev, void *stream);
+                    int32_t dtype, const int64_t *r_dev, int32_t packed_kl, void *stream);
+int wfs_gather_packed_ok(int32_t packed_kl, int32_t K, int32_t Ca, int32_t Cb, int32_t dtype, int32_t which);
+int wfs_unpack_table(const int32_t *packed, int32_t K, int32_t packed_kl, int64_t R, const int64_t *r_dev,
+                     int32_t *dense, void *stream);
 
 /* Wide layers as dense matrix-core products (round 3; csrc/wide.hip).
  * Same contract as wfs_gather_conv -- replaces torch.ops.spconv.indice_conv / the dX half of
@@ -237,6 +249,37 @@ size_t wfs_event_rulebook_flag_ints(int32_t batch_size);
 int wfs_event_rulebook_subm(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
                             const int32_t *events, int32_t *nbr_out, void *slots, int32_t *flags, void *stream);
 
+/* Event-local build of REGULAR (strided) convolutions, ONE launch (round 4; csrc/evconv.hip).
+ * torch.ops.spconv.get_indice_pairs(subm=False) -- the reference's SparseConv3d / SparseConv2d layers,
+ * src/models/SPConvBlocks.py:75,498 -- for an index set grouped by event, in device-count mode: one workgroup per event
+ * keeps the event's OUTPUT grid in LDS (wfs_event_rulebook_conv_ok: <= 16384 cells per event, K <= 32, leading kernel
+ * dims <= 4, not transposed), takes first-seen tickets with LDS atomics, numbers the event's sites by a block scan over
+ * its rows and learns the ids of the events in front from per-event counts published in `state` (a single pass: no
+ * site grid in HBM, no clearing launch, no global read-modify-write, every table written once).  Results are
+ * bit-identical to wfs_rulebook_plan + wfs_rulebook_emit (oracle/spconv_ref.c:208-276).
+ *   events_in   wfs_event_offsets table of `indices` (or the events_out of the conv that produced them)
+ *   M_cap       rows of out_indices / stride of nbr_in; *m_dev = min(M, M_cap); *overflow_dev = 1 (sticky) if M > M_cap
+ *   events_out  int32 [wfs_event_offsets_ints(batch)]: the same table for the OUTPUT rows (first-seen numbering of an
+ *               event-grouped input is event-grouped)
+ *   nbr_out     by-input table: packed_kl == 0: [K, N]; packed_kl == wfs_event_rulebook_conv_packed_kl(g) > 0:
+ *               [K / kl, N] packed (see wfs_gather_conv)
+ *   nbr_in      by-output table [K, M_cap] (may be NULL)
+ *   cell_row    (may be NULL) int32 [batch * out_volume]: output row of every cell or -1 -- what wfs_to_dense_mapped
+ *               takes as both `ticket` and `slot_id`
+ *   flags       int32 [3], STICKY (set, never cleared): [0] the index set is not grouped by event, or a workgroup
+ *               gave up waiting for a count (then *m_dev = 0 / tables invalid: take wfs_rulebook_plan), [2] an index
+ *               outside the spatial shape (that row has no outputs)
+ *   state       wfs_event_rulebook_conv_state_bytes(batch) bytes, 8-byte aligned, ZEROED once by the caller and then
+ *               owned by this layer's builds (launch epoch + per-event counts); two builds must not run concurrently
+ *               on one state. */
+int wfs_event_rulebook_conv_ok(const wfs_geometry *g);
+int wfs_event_rulebook_conv_packed_kl(const wfs_geometry *g);
+size_t wfs_event_rulebook_conv_state_bytes(int32_t batch_size);
+int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
+                            const int32_t *events_in, int64_t M_cap, int32_t *out_indices, int64_t *m_dev,
+                            int32_t *events_out, int32_t *nbr_out, int32_t packed_kl, int32_t *nbr_in,
+                            int32_t *cell_row, int32_t *overflow_dev, int32_t *flags, void *state, void *stream);
+
 /* The same product when an nn.BatchNorm1d in TRAINING mode directly follows the convolution inside
  * spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508, SURVEY.md 8a rows a9 + a12): the conv
  * kernel's epilogue also takes the per-channel batch statistics of the rows it stores, so BatchNorm needs no
@@ -296,7 +339,7 @@ typedef struct wfs_dw_job {
 int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                   int64_t R, const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg,
                   int32_t swap, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
-                  const int64_t *r_dev, wfs_dw_job *defer, void *stream);
+                  const int64_t *r_dev, wfs_dw_job *defer, int32_t packed_kl, void *stream);
 
 /* Second stage of up to 16 deferred wfs_gather_dw calls in one launch (deterministic: fixed summation order). */
 int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream);

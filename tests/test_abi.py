@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_mirrors_header():
     from waveformml_amd import _lib
     assert sorted(_lib.SIGNATURES) == _header_functions()
-    assert _lib.load().wfs_abi_version() == _lib.WFS_ABI_VERSION == 5
+    assert _lib.load().wfs_abi_version() == _lib.WFS_ABI_VERSION == 6
 
 
 def test_h5_reader_library_exports_and_ctypes_table_mirror_its_header():

@@ -122,8 +122,9 @@ def test_event_local_subm_flags():
     # batch column not sorted
     bad = idx.copy()
     bad[[10, 700]] = bad[[700, 10]]
-    _, flags, _ = _ev_subm(torch.from_numpy(bad).to(DEV), B, shape, 3)
+    nbr, flags, _ = _ev_subm(torch.from_numpy(bad).to(DEV), B, shape, 3)
     assert flags[0] == 1
+    assert bool((nbr == -1).all())          # a failed build leaves "no neighbour" everywhere, never unwritten entries
     # duplicate coordinates: detected (the caller then takes the chip-wide build, which resolves "the last row wins")
     dup = np.concatenate([idx[:50], idx[:1], idx[50:]])
     dup = _sorted_by_event(dup)
@@ -136,8 +137,56 @@ def test_event_local_subm_flags():
     assert flags[2] == 1
     # more active cells in one event than the LDS sample arrays hold (64 KiB = 32 cells of 1024 samples): flagged, not wrong
     many = np.array([(0, x, y, 0) for x in range(14) for y in range(11)], np.int32)
-    _, flags, _ = _ev_subm(torch.from_numpy(many).to(DEV), 1, (14, 11, 1024), 3)
-    assert flags[0] == 1
+    nbr, flags, _ = _ev_subm(torch.from_numpy(many).to(DEV), 1, (14, 11, 1024), 3)
+    assert flags[0] == 1 and bool((nbr == -1).all())
+    # ... and the other events of such a batch are built as usual
+    rest = idx.copy()
+    rest[:, 0] += 1
+    both = np.concatenate([np.concatenate([many[:, :3], np.zeros((len(many), 1), np.int32)], 1), rest])
+    want = _oracle_nbr_out(rest, B + 1, (14, 11, 32), 3)
+    big = both.copy()
+    nbr, flags, _ = _ev_subm(torch.from_numpy(np.ascontiguousarray(big)).to(DEV), B + 1, (14, 11, 32), 3)
+    assert flags == (0, 0, 0)               # 154 cells of 32 samples fit the pool: nothing to flag at this length
+    assert np.array_equal(nbr.cpu().numpy()[:, len(many):], np.where(want >= 0, want + len(many), -1))
+
+
+def test_captured_step_survives_an_ungrouped_batch_until_check_raises():
+    """a batch that is not grouped by event, fed to a captured step: the event-local builds flag it and leave
+    benign tables (no stale indices are gathered through), the step's loss is finite, and check() raises."""
+    import copy
+    import json
+    import os
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.psd.config import DictionaryUtility
+    from waveformml_amd.psd.ddp import FlatGradAllReducer
+    from waveformml_amd.psd.graph import GraphedTrainStep
+    from waveformml_amd.psd.lit import LitPSD
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "config", "psd_c2_3d.json")) as f:
+        cfg = json.load(f)
+    T, B = 64, 32
+    cfg["system_config"]["n_samples"] = T
+    cfg["net_config"]["algorithm"][-1] = [32 * 10 * 7 * 4, 3]
+    c, f, y = synthetic.generate(B, T, 3, seed=5)
+    good = ([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV))
+    c2, f2 = c.copy(), f.copy()
+    i, j = 3, len(c) - 5                      # rows of the first and the last event change places
+    c2[[i, j]], f2[[i, j]] = c2[[j, i]], f2[[j, i]]
+    bad = ([torch.from_numpy(c2).to(DEV), torch.from_numpy(f2).to(DEV)], torch.from_numpy(y).to(DEV))
+    torch.manual_seed(0)
+    mod = LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg))).to(DEV)
+    red = FlatGradAllReducer(mod.model.parameters(), world_size=1)
+    mod.optimizer_parameters = red.optimizer_parameters()
+    opt = mod.configure_optimizers()[0][0]
+    step = GraphedTrainStep(mod, opt, red, good)
+    assert np.isfinite(float(step(good)))
+    step.check()
+    assert np.isfinite(float(step(bad)))
+    assert np.isfinite(float(step(good)))       # sticky: the good replay in between does not hide the failure
+    with pytest.raises(RuntimeError, match="grouped by event"):
+        step.check()
+    assert np.isfinite(float(step(good)))
+    step.check()
 
 
 def test_captured_step_identical_with_and_without_event_local_build():
@@ -162,10 +211,10 @@ def test_captured_step_identical_with_and_without_event_local_build():
         c, f, y = synthetic.generate(B, T, 3, seed=seed)
         batches.append(([torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV)], torch.from_numpy(y).to(DEV)))
     losses, params = [], []
-    old = ops.EVENT_LOCAL
+    old = ops.EVENT_LOCAL, ops.EVENT_LOCAL_CONV
     try:
         for on in (False, True):
-            ops.EVENT_LOCAL = on
+            ops.EVENT_LOCAL = ops.EVENT_LOCAL_CONV = on          # SubM (evrulebook.hip) and strided (evconv.hip) builds
             torch.manual_seed(0)
             mod = LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg))).to(DEV)
             red = FlatGradAllReducer(mod.model.parameters(), world_size=1)
@@ -178,7 +227,7 @@ def test_captured_step_identical_with_and_without_event_local_build():
             losses.append(ls)
             params.append(red.flat_param.detach().clone())
     finally:
-        ops.EVENT_LOCAL = old
+        ops.EVENT_LOCAL, ops.EVENT_LOCAL_CONV = old
     assert losses[0] == losses[1], losses
     assert torch.equal(params[0], params[1])
 
@@ -227,9 +276,22 @@ def test_resume_from_checkpoint_keeps_the_momentum_under_capture(tmp_path):
     assert float((res[False] - res[True]).abs().max()) <= 2e-5 * scale
 
 
+@pytest.fixture(params=[True, False], ids=["event_local_conv", "chip_wide_conv"])
+def conv_build(request):
+    """Both device-count builds of a regular conv: csrc/evconv.hip (one launch, one workgroup per event; the default)
+    and rulebook.hip's chip-wide build."""
+    from waveformml_amd.spconv import ops
+    old = ops.EVENT_LOCAL_CONV
+    ops.EVENT_LOCAL_CONV = request.param
+    yield request.param
+    ops.EVENT_LOCAL_CONV = old
+
+
 @pytest.mark.parametrize("shape,ksize,stride,padding", [((14, 11, 64), (3, 3, 3), (1, 1, 4), (0, 0, 0)), ((14, 11), (3, 3), (1, 1), (0, 0)),
-                                                        ((12, 30), (3, 3), (2, 2), (1, 1)), ((9, 8, 20), (2, 2, 2), (2, 2, 2), (0, 0, 0))])
-def test_device_count_conv_build_equals_exact_build(shape, ksize, stride, padding):
+                                                        ((12, 30), (3, 3), (2, 2), (1, 1)), ((9, 8, 20), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
+                                                        ((14, 11, 64), (3, 3, 3), (1, 1, 4), (0, 0, 1)), ((10, 7, 33), (3, 2, 3), (2, 1, 3), (1, 0, 2)),
+                                                        ((40,), (3,), (2,), (1,)), ((6, 5, 4, 12), (1, 2, 2, 3), (1, 1, 2, 2), (0, 0, 1, 1))])
+def test_device_count_conv_build_equals_exact_build(shape, ksize, stride, padding, conv_build):
     """The regular / strided conv build with device-side counts (what a captured step runs: capacities for N and M, the
     valid counts in device memory) against the exact-size build, which the oracle tests pin: same output coordinates in
     spconv's first-seen order, same tables, bit for bit; rows beyond the device-side count never enter; a capacity that
@@ -250,10 +312,26 @@ def test_device_count_conv_build_equals_exact_build(shape, ksize, stride, paddin
                             out_capacity=cap_m)
     torch.cuda.synchronize()
     M = int(rb.m_dev)
+    assert (rb.events_out is not None) == conv_build
     assert M == exact.M and int(rb.overflow) == 0
     assert torch.equal(rb.out_indices[:M], exact.out_indices)
     assert torch.equal(rb.nbr_out[:, :N], exact.nbr_out)
     assert torch.equal(rb.nbr_in[:, :M], exact.nbr_in)
+    if conv_build:
+        assert not rb.event_flags.any()
+        # the event offsets of the OUTPUT rows, and the cell -> row map dense() takes
+        out_b = exact.out_indices[:, 0].cpu().numpy()
+        assert np.array_equal(rb.events_out[:B + 1].cpu().numpy(), np.searchsorted(out_b, np.arange(B + 1)))
+        assert not rb.events_out[B + 1:].any()
+        V = int(np.prod(rb.out_spatial_shape))
+        cells = rb.cell_map[2].cpu().numpy()
+        oi = exact.out_indices.cpu().numpy().astype(np.int64)
+        lin = oi[:, 0]
+        for d in range(ndim):
+            lin = lin * rb.out_spatial_shape[d] + oi[:, 1 + d]
+        want = np.full(B * V, -1, np.int32)
+        want[lin] = np.arange(M, dtype=np.int32)
+        assert np.array_equal(cells, want)
     # a capacity that is too small: flagged, the tables hold what fits
     small = ops.build_rulebook(pad, B, list(shape), list(ksize), list(stride), list(padding), [1] * ndim, False, n_dev=nv,
                                out_capacity=max(exact.M // 2, 1))
@@ -263,7 +341,97 @@ def test_device_count_conv_build_equals_exact_build(shape, ksize, stride, paddin
     assert torch.equal(small.out_indices[:keep], exact.out_indices[:keep])
 
 
-def test_overflow_flag_of_a_captured_build_is_sticky():
+def test_event_local_conv_chain_at_psd_scale_and_packed_tables():
+    """The bench's two strided layers (14 x 11 x 256 -> 12 x 9 x 64 -> 10 x 7 x 16, 256 events) built event-locally, the
+    second from the first one's output rows and event offsets, against the exact builds; the packed by-input table
+    [9, N] expands to the dense [27, N] bit for bit."""
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.spconv import ops
+    B, T = 256, 256
+    c, _f, _y = synthetic.generate(B, T, 3, seed=1234)
+    idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(DEV)
+    N = idx.shape[0]
+    geo = ([3] * 3, [1, 1, 4], [0] * 3, [1] * 3)
+    e1 = ops.build_rulebook(idx, B, [14, 11, T], *geo, False, known_unique=True)
+    e2 = ops.build_rulebook(e1.out_indices, B, e1.out_spatial_shape, *geo, False, known_unique=True)
+    cap = N + 2048
+    pad = torch.cat([idx, torch.full((cap - N, 4), 7, dtype=torch.int32, device=DEV)])
+    nv = torch.tensor([N], dtype=torch.int64, device=DEV)
+    store1, store2 = {}, {}
+    for _rep in range(3):                     # the same state three times: epochs 1, 2, 3
+        r1 = ops.build_rulebook(pad, B, [14, 11, T], *geo, False, n_dev=nv, out_capacity=e1.M + 1000, flags=store1,
+                                want_cell_map=False)
+        r2 = ops.build_rulebook(r1.out_indices, B, r1.out_spatial_shape, *geo, False, n_dev=r1.m_dev,
+                                out_capacity=e2.M + 500, events=r1.events_out, flags=store2)
+        torch.cuda.synchronize()
+        assert r1.packed_kl == 3 and r1.nbr_out_packed.shape == (9, cap) and r1.cell_map is None
+        assert int(r1.m_dev) == e1.M and int(r2.m_dev) == e2.M
+        assert torch.equal(r1.out_indices[:e1.M], e1.out_indices) and torch.equal(r2.out_indices[:e2.M], e2.out_indices)
+        assert torch.equal(r1.nbr_out[:, :N], e1.nbr_out) and torch.equal(r1.nbr_in[:, :e1.M], e1.nbr_in)
+        assert torch.equal(r2.nbr_out[:, :e1.M], e2.nbr_out) and torch.equal(r2.nbr_in[:, :e2.M], e2.nbr_in)
+        assert not r1.event_flags.any() and not r2.event_flags.any() and int(r1.overflow) == 0 and int(r2.overflow) == 0
+    assert int(store1["conv_state"][0]) == 3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_packed_table_products_equal_the_dense_table_products(dtype):
+    """dX and dW of a 32 -> 32 strided layer through the packed [9, N] table against the same kernels on the dense
+    [27, N] table: the same gathers, the same order -> bit-identical."""
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.spconv import functional as Fsp
+    from waveformml_amd.spconv import ops
+    B, T = 64, 128
+    c, _f, _y = synthetic.generate(B, T, 3, seed=5)
+    idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(DEV)
+    N = idx.shape[0]
+    nv = torch.tensor([N - 17], dtype=torch.int64, device=DEV)
+    rb = ops.build_rulebook(idx, B, [14, 11, T], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, n_dev=nv, out_capacity=2 * N)
+    assert rb.packed_kl == 3
+    M = rb.M
+    g = torch.Generator(device=DEV).manual_seed(1)
+    X = torch.randn((N, 32), device=DEV, generator=g).to(dtype)
+    dY = torch.randn((M, 32), device=DEV, generator=g).to(dtype)
+    W = torch.randn((27, 32, 32), device=DEV, generator=g)
+    t_p, pk = rb.table_by_in(32, 32, X, 1)
+    assert pk == 3 and t_p is rb.nbr_out_packed
+    dx_p = Fsp.gather_conv(t_p, None, 27, -1, N, dY, W, True, None, nv, None, None, pk)
+    dx_d = Fsp.gather_conv(rb.nbr_out, None, 27, -1, N, dY, W, True, None, nv)
+    t_p, pk = rb.table_by_in(32, 32, X, 3)
+    assert pk == 3
+    dw_p = Fsp.gather_dw(t_p, 27, -1, N, X, dY, False, None, nv, False, None, pk)
+    dw_d = Fsp.gather_dw(rb.nbr_out, 27, -1, N, X, dY, False, None, nv)
+    torch.cuda.synchronize()
+    nvv = int(nv)
+    assert torch.equal(dx_p[:nvv], dx_d[:nvv]) and torch.equal(dw_p, dw_d)
+    assert float(dx_d[:nvv].float().abs().max()) > 0 and float(dw_d.abs().max()) > 0
+
+
+def test_event_local_conv_build_flags_an_ungrouped_batch_and_leaves_benign_tables():
+    """A batch that is not grouped by event: flag [0] is set, the outputs are empty (m_dev = 0) and every by-input table
+    entry the consumers can reach says "none" -- a captured step then computes garbage-free zeros until check() raises."""
+    from waveformml_amd.spconv import ops
+    rng = np.random.default_rng(3)
+    B, shape = 6, (14, 11, 64)
+    idx = _sorted_by_event(rand_coords(rng, B, shape, 900))
+    bad = idx.copy()
+    bad[[10, 700]] = bad[[700, 10]]
+    t = torch.from_numpy(bad).to(DEV)
+    nv = torch.tensor([900], dtype=torch.int64, device=DEV)
+    rb = ops.build_rulebook(t, B, list(shape), [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, n_dev=nv, out_capacity=4000)
+    torch.cuda.synchronize()
+    assert int(rb.event_flags[0]) == 1 and int(rb.m_dev) == 0
+    assert bool((rb.nbr_out_packed == -1).all()) and bool((rb.cell_map[2] == -1).all())
+    # an index outside the spatial shape: flag [2], the row has no outputs, everything else is built
+    out = idx.copy()
+    out[5, 3] = 64
+    rb = ops.build_rulebook(torch.from_numpy(out).to(DEV), B, list(shape), [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False,
+                            n_dev=nv, out_capacity=4000)
+    torch.cuda.synchronize()
+    assert int(rb.event_flags[2]) == 1 and int(rb.event_flags[0]) == 0 and bool((rb.nbr_out[:, 5] == -1).all())
+    assert int(rb.m_dev) > 0
+
+
+def test_overflow_flag_of_a_captured_build_is_sticky(conv_build):
     """A captured step is checked every so many replays: the overflow flag of a strided build must survive the replays
     that follow the one that overflowed (the build only ever SETS it; the reader clears it).  A build captured over a
     capacity that fits index set A is replayed with A (flag clear), with B (more output sites: flag set) and with A

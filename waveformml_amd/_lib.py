@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("WFS_LIB") or os.path.join(_HERE, "lib", "libwfsparse.
 WFS_OK, WFS_EINVAL, WFS_EOVERFLOW, WFS_EHIP, WFS_EWORKSPACE = 0, 1, 2, 3, 4
 WFS_F32, WFS_BF16, WFS_F16 = 0, 1, 2
 WFS_MAX_DIM = 4
-WFS_ABI_VERSION = 5         # include/wfsparse.h: this binding's struct layouts and signatures
+WFS_ABI_VERSION = 6         # include/wfsparse.h: this binding's struct layouts and signatures
 TIMER_GATHER_CONV, TIMER_GATHER_DW, TIMER_RULEBOOK = 0, 1, 2
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -54,7 +54,14 @@ SIGNATURES = {
                                          _vp, _sz, _vp, _vp, _vp]),
     "wfs_indices_check": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _sz, c_i64p, _vp]),
     "wfs_gather_conv": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _i32,
-                                       _vp, _vp, _i32, _vp, _vp]),
+                                       _vp, _vp, _i32, _vp, _i32, _vp]),
+    "wfs_gather_packed_ok": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "wfs_unpack_table": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp]),
+    "wfs_event_rulebook_conv_ok": (ctypes.c_int, [ctypes.POINTER(Geometry)]),
+    "wfs_event_rulebook_conv_packed_kl": (ctypes.c_int, [ctypes.POINTER(Geometry)]),
+    "wfs_event_rulebook_conv_state_bytes": (_sz, [_i32]),
+    "wfs_event_rulebook_conv": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                               _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wfs_wide_conv_ok": (ctypes.c_int, [_i32, _i64, _i64, _i32, _i32, _i32]),
     "wfs_wide_enable": (ctypes.c_int, [_i32]),
     "wfs_wide_conv_workspace_bytes": (_sz, [_i32, _i64, _i64, _i32, _i32, _i32, _i32]),
@@ -79,7 +86,7 @@ SIGNATURES = {
                                              _vp, _vp]),
     "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "wfs_gather_dw": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
-                                     _sz, _vp, ctypes.POINTER(DwJob), _vp]),
+                                     _sz, _vp, ctypes.POINTER(DwJob), _i32, _vp]),
     "wfs_dw_reduce_jobs": (ctypes.c_int, [ctypes.POINTER(DwJob), _i32, _vp]),
     "wfs_scatter_conv": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "wfs_bn_workspace_bytes": (_sz, [_i64, _i32]),

@@ -33,6 +33,19 @@ __device__ __forceinline__ long long valid_rows(long long R, const long long *r_
     return v < R ? v : R;
 }
 
+// Packed by-input tables (evconv.hip; include/wfsparse.h "packed tables"): where the kernel is no longer than the
+// stride along the last dimension an input row reaches at most ONE output cell per leading offset q, so the table is
+// [K / pk, R] and an entry e >= 0 means "row e >> 3, at offset k = q * pk + (e & 7)".  pk == 0: the dense [K, R] form.
+__device__ __forceinline__ int packed_entry(int e, int o) { return (e >= 0 && (e & 7) == o) ? (e >> 3) : -1; }
+// which table row serves offset k, and which packed offset it must carry (-1: dense table, the entry is the row);
+// wave-uniform, computed once per kernel -- the loads themselves stay unconditional
+__device__ __forceinline__ void table_row_of(int pk, int k, int *trow, int *osel) {
+    const int kq = pk ? k / pk : k;
+    *trow = kq;
+    *osel = pk ? k - kq * pk : -1;
+}
+__device__ __forceinline__ int table_value(int e, int osel) { return osel < 0 ? e : packed_entry(e, osel); }
+
 // ------------------------------------------------------------------------------------------ 32 -> 32
 // LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
 // (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
@@ -225,7 +238,7 @@ __global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ ta
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int F16_GROUP = 3;      // offsets whose gathers a wave has in flight together (2 x 16 B per lane each)
 
-template <bool TRANSPOSE_W>
+template <bool TRANSPOSE_W, int PK = 0>
 __global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
                                                       long long R, const long long *__restrict__ r_dev,
                                                       const float *__restrict__ X, const float *__restrict__ W,
@@ -285,7 +298,10 @@ __global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ ta
         for (int i = 0; i < 8; ++i) {
             const int k = 4 * i + q;
             const int kk = k < K ? k : K - 1;
-            v[i] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+            if constexpr (PK == 0)
+                v[i] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+            else
+                v[i] = packed_entry(table[(long long)(kk / PK) * R + rowc], kk % PK);       // packed table: K / PK rows
         }
         unsigned mask = 0;
 #pragma unroll
@@ -441,7 +457,7 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 #ifndef WFS_KNOCK
 #define WFS_KNOCK 0
 #endif
-template <typename H, bool TRANSPOSE_W, bool STATS>
+template <typename H, bool TRANSPOSE_W, bool STATS, int PK = 0>
 __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
                                                        int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
@@ -512,10 +528,23 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
         const long long rowc = live ? row : 0;
         // ---- phase 1
         int v[32];
+        if constexpr (PK == 0) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            int kk = k < K ? k : K - 1;
-            v[k] = (WFS_KNOCK & 2) ? -1 : table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+            for (int k = 0; k < 32; ++k) {
+                int kk = k < K ? k : K - 1;
+                v[k] = (WFS_KNOCK & 2) ? -1 : table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
+            }
+        } else {
+            // packed table: K / PK loads instead of K (9 instead of 27 at the PSD geometry)
+            constexpr int NQ = 32 / PK;
+            int ev[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int qq = q * PK < K ? q : (K - 1) / PK;
+                ev[q] = (WFS_KNOCK & 2) ? -1 : table[(long long)qq * R + rowc];
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = packed_entry(ev[k / PK < NQ ? k / PK : NQ - 1], k % PK);
         }
         unsigned mask = 0;
 #pragma unroll
@@ -642,7 +671,7 @@ constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator register
 constexpr int DW_WAVES = 8;
 
 template <typename T>
-__global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table, int K, int identity_k, long long Rcap,
+__global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table, int pk, int K, int identity_k, long long Rcap,
                                                   const long long *__restrict__ r_dev, const T *__restrict__ S,
                                                   const T *__restrict__ G,
                                                   float *__restrict__ part, int ngroups, long long tiles_per_block) {
@@ -665,6 +694,12 @@ __global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table,
     for (int q = 0; q < DW_KG; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    int trw[DW_KG], osel[DW_KG];
+#pragma unroll
+    for (int q = 0; q < DW_KG; ++q) {
+        const int k = g + q * ngroups;
+        table_row_of(pk, k < K ? k : K - 1, &trw[q], &osel[q]);
+    }
     for (long long tile = blockIdx.x + (long long)wid * gridDim.x; tile < ntiles; tile += (long long)DW_WAVES * gridDim.x) {
         const long long row0 = tile * 32;
         // lane j holds the table entries of row (row0 + j) for this wave's offsets.  Loads are unconditional
@@ -672,11 +707,7 @@ __global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table,
         const long long trow = row0 + j < R ? row0 + j : R - 1;
         int nbv[DW_KG];
 #pragma unroll
-        for (int q = 0; q < DW_KG; ++q) {
-            int k = g + q * ngroups;
-            int kk = k < K ? k : K - 1;
-            nbv[q] = table[(long long)kk * Rcap + trow];
-        }
+        for (int q = 0; q < DW_KG; ++q) nbv[q] = table_value(table[(long long)trw[q] * Rcap + trow], osel[q]);
         // S rows through a raw buffer whose size is the VALID rows: one lane offset per tile, the 16 rows of a lane by
         // the instruction's immediate offset, rows past the end read as 0 -- no address arithmetic, no select per load
         // (the pointer form spent ~11 VALU instructions on each of a tile's 16 + 16 x active offsets loads: 16 us of VALU
@@ -922,7 +953,7 @@ __device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, in
 }
 
 template <typename H>
-__global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int K, int identity_k,
+__global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int pk, int K, int identity_k,
                                                      long long Rcap, const long long *__restrict__ r_dev,
                                                      const H *__restrict__ S, const H *__restrict__ G,
                                                      float *__restrict__ part, int ngroups, long long tiles_per_block) {
@@ -943,6 +974,12 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
     for (int q = 0; q < DWB_KG; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    int trw[DWB_KG], osel[DWB_KG];
+#pragma unroll
+    for (int q = 0; q < DWB_KG; ++q) {
+        const int k = g + q * ngroups;
+        table_row_of(pk, k < K ? k : K - 1, &trw[q], &osel[q]);
+    }
     for (long long tile = t_begin + wid; tile < t_end; tile += DWB_WAVES) {
         const long long row0 = tile * 32;
         const long long ra = row0 + grow, rb = row0 + grow + 16;
@@ -952,10 +989,8 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
         int ta[DWB_KG], tb[DWB_KG];
 #pragma unroll
         for (int q = 0; q < DWB_KG; ++q) {
-            int k = g + q * ngroups;
-            int kk = k < K ? k : K - 1;
-            ta[q] = table[(long long)kk * Rcap + rac];
-            tb[q] = table[(long long)kk * Rcap + rbc];
+            ta[q] = table_value(table[(long long)trw[q] * Rcap + rac], osel[q]);
+            tb[q] = table_value(table[(long long)trw[q] * Rcap + rbc], osel[q]);
         }
         // the S tile is needed whenever any offset is active; issue its loads together with the table reads
         uint4 s0 = *(const uint4 *)(S + rac * 32 + gchunk * 8);
@@ -1378,8 +1413,10 @@ static WfsStatsArgs stats_args(const wfs_bn_stats *st, long long nblk) {
 
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl) {
     const size_t lds = (size_t)K * 4096;
+    WFS_REQUIRE(packed_kl == 0 || (packed_kl == 3 && transpose_w && !stats && !mirror && identity_k < 0), WFS_EINVAL,
+                "packed tables: kl = 3, dX products only");
     if (!stats) {
         // 16-row tiles taken off a per-block counter (k_gconv16_f32): up to 16 waves per block, <= 256 blocks
         static bool attr16[2] = {false, false};
@@ -1391,6 +1428,11 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
         nb = nb > 256 ? 256 : (nb + 7) / 8 * 8;
         if (nb < 8) nb = 8;
         const dim3 g16((unsigned)nb), b16(w * 64);
+        if (packed_kl) {
+            static bool attr16p = false;
+            return launch_big_lds(k_gconv16_f32<true, 3>, &attr16p, g16, b16, lds, stream, table, mirror, K, identity_k, R,
+                                  r_dev, X, W, bias, Y);
+        }
         if (transpose_w)
             return launch_big_lds(k_gconv16_f32<true>, &attr16[0], g16, b16, lds, stream, table, mirror, K, identity_k, R,
                                   r_dev, X, W, bias, Y);
@@ -1414,7 +1456,7 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
 template <typename H>
 static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                               const H *Xb, const float *W, int transpose_w, const float *bias, H *Yb,
-                              const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
+                              const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
     gconv32_grid(R, r_dev != nullptr, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
@@ -1422,6 +1464,13 @@ static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_
     static bool attr[3] = {false, false, false};          // per instantiation of this template, i.e. per H
     const WfsStatsArgs sa = stats_args(stats, nblk);
     const dim3 grid((unsigned)nblk), block(wpb * 64);
+    WFS_REQUIRE(packed_kl == 0 || (packed_kl == 3 && transpose_w && !stats && !mirror && identity_k < 0), WFS_EINVAL,
+                "packed tables: kl = 3, dX products only");
+    if (packed_kl) {
+        static bool attr_p = false;
+        return launch_big_lds(k_gconv32_bf16<H, true, false, 3>, &attr_p, grid, block, lds, stream, table, mirror, K,
+                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+    }
     if (transpose_w)
         return launch_big_lds(k_gconv32_bf16<H, true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
                               identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
@@ -1436,12 +1485,12 @@ static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_
 
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream) {
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl) {
     if (dtype == WFS_F16)
         return launch_gconv32_h16<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, transpose_w,
-                                           bias, (wfs_f16 *)Y, stats, pending, stream);
+                                           bias, (wfs_f16 *)Y, stats, pending, stream, packed_kl);
     return launch_gconv32_h16<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, transpose_w, bias,
-                                        (wfs_bf16 *)Y, stats, pending, stream);
+                                        (wfs_bf16 *)Y, stats, pending, stream, packed_kl);
 }
 
 // 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.
@@ -1526,14 +1575,17 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg) {
 }
 
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
-                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream) {
+                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream,
+                     int packed_kl) {
+    WFS_REQUIRE(packed_kl == 0 || (packed_kl >= 1 && packed_kl <= 8 && K % packed_kl == 0 && identity_k < 0), WFS_EINVAL,
+                "packed tables: K must be a multiple of kl <= 8, no identity offset");
     const long long nblk = dw32_blocks(R, dtype == WFS_F32);
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
     const dim3 grid((unsigned)nblk, (unsigned)ngroups);
 #define WFS_DW32(KERNEL, T, THREADS)                                                                                  \
-    KERNEL<T><<<grid, dim3(THREADS), 0, stream>>>(table, K, identity_k, R, r_dev, (const T *)S, (const T *)G, part,    \
+    KERNEL<T><<<grid, dim3(THREADS), 0, stream>>>(table, packed_kl, K, identity_k, R, r_dev, (const T *)S, (const T *)G, part, \
                                                   ngroups, tiles_per_block);
     if (dtype == WFS_F32) WFS_DW32(k_gdw32, float, 512)
     else if (dtype == WFS_BF16) WFS_DW32(k_gdw32_bf16, wfs_bf16, 1024)

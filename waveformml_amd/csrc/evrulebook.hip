@@ -30,10 +30,6 @@ struct EGeo {
 #endif
 constexpr int EV_FLAG_BLOCKS = WFS_EVENT_FLAG_WORDS;      // k_event_offsets runs this many blocks, one flag word each
 constexpr int ER_THREADS = 512;
-constexpr int ER_MAXROWS = 2048;          // rows of one event the LDS tables cover (4 per thread)
-constexpr int ER_RPT = ER_MAXROWS / ER_THREADS;
-   // hash slots: load factor <= 1/4 (a miss ends at the first empty slot: the longest probe
-                                          // sequence among a wave's lanes sets the pace, and it grows fast with the load)
 
 __device__ __forceinline__ long long valid_rows(long long R, const long long *r_dev) {
     long long v = r_dev ? *r_dev : R;
@@ -91,7 +87,8 @@ __global__ void __launch_bounds__(256) k_event_offsets(const int *__restrict__ i
 // last dim's offset share the first.  (An open-addressing hash was measured first: at ~110 instructions per candidate --
 // probe loops under divergence -- the largest event kept one CU busy for 30 us.)
 // Capacity: L <= ER_MAXCELLS, active cells * T * 2 bytes <= ER_POOL bytes, rows <= 65534 per event; beyond that
-// flags[0] is set and the caller takes rulebook.hip's build.  Duplicate coordinates are DETECTED (flags[1]; a row that
+// flags[0] is set, the affected rows' table entries all say "no neighbour" (never left unwritten) and the caller takes
+// rulebook.hip's build.  Duplicate coordinates are DETECTED (flags[1]; a row that
 // does not read its own index back), not resolved: "the last row wins" (A.3) is then the caller's, i.e. rulebook.hip's.
 // flags: int32 [3 * blocks] (wfs_event_rulebook_flag_ints), every word written by every launch: [0 .. blocks) not grouped
 // by event / capacity, [blocks .. 2 blocks) duplicates, [2 blocks .. 3 blocks) an index outside the spatial shape.
@@ -123,6 +120,19 @@ __global__ void __launch_bounds__(ER_THREADS) k_ev_subm(EGeo g, EQTab qt, int Q,
     const int cols = g.ndim + 1, last = g.ndim - 1;
     const int T = g.spatial[last];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // A build that fails (flags below) must not leave table entries unwritten: the table lives in recycled memory and the
+    // consumers gather through it until the runner reads the flags.  "No neighbour" everywhere is benign (the products
+    // add the centre offset themselves).
+    auto fill_none = [&](long long j_lo, long long j_hi) {
+        for (int k = 0; k < g.K; ++k)
+            for (long long j = j_lo + threadIdx.x; j < j_hi; j += ER_THREADS) nbr_out[(long long)k * N + j] = -1;
+    };
+    if (!structured) {
+        // the event table is meaningless: the workgroups share ALL the valid rows out evenly
+        const long long per = (Nv + gridDim.x - 1) / gridDim.x;
+        const long long lo = (long long)blockIdx.x * per;
+        fill_none(lo, lo + per < Nv ? lo + per : Nv);
+    }
     // `split` workgroups per event: each builds the event's table and serves its share of the rows
     for (int item = blockIdx.x; structured && item < B * split; item += gridDim.x) {
         const int e = item / split, part = item % split;
@@ -134,6 +144,7 @@ __global__ void __launch_bounds__(ER_THREADS) k_ev_subm(EGeo g, EQTab qt, int Q,
         const int j_lo = (int)((long long)n * part / split), j_hi = (int)((long long)n * (part + 1) / split);
         if (n > 65534) {
             f_fail = 1;
+            fill_none(o0 + j_lo, o0 + j_hi);
             continue;
         }
         // a row's leading coordinates -> cell (-1: outside the shape), last coordinate -> t
@@ -189,6 +200,7 @@ __global__ void __launch_bounds__(ER_THREADS) k_ev_subm(EGeo g, EQTab qt, int Q,
         const int nslot = carry;
         if ((long long)nslot * T * 2 > pool_bytes) {
             f_fail = 1;
+            fill_none(o0 + j_lo, o0 + j_hi);
             continue;
         }
         // pass C: clear the active cells' sample arrays (dwords)

@@ -407,9 +407,12 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
                             int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
                             int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
                             const int64_t *r_dev_, const wfs_bn_stats *stats, bool *stats_done, int *pending,
-                            void *stream_) {
+                            void *stream_, int packed_kl = 0) {
     hipStream_t stream = (hipStream_t)stream_;
     *stats_done = false;
+    WFS_REQUIRE(packed_kl == 0 || wfs_gather_packed_ok(packed_kl, K, Cx, transpose_w ? Cw_in : Cw_out, dtype, transpose_w ? 1 : 2),
+                WFS_EINVAL, "a packed table (kl %d) is not taken by this product (wfs_gather_packed_ok): expand it with "
+                "wfs_unpack_table", packed_kl);
     const long long *r_dev = (const long long *)r_dev_;
     (void)X_rows;
     WFS_REQUIRE(K >= 1 && K <= 128, WFS_EINVAL, "kernel volume %d not in [1,128]", K);
@@ -436,13 +439,14 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
         X_rows < (1ll << 24)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
-                                      bias, (float *)Y, stats, pending, stream);
+                                      bias, (float *)Y, stats, pending, stream, packed_kl);
     }
     if (dtype != WFS_F32 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror) && X_rows < (1ll << 25)) {
         *stats_done = stats != nullptr;
         return wfs_launch_gconv32_h16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
-                                      dtype, stats, pending, stream);
+                                      dtype, stats, pending, stream, packed_kl);
     }
+    WFS_REQUIRE(packed_kl == 0, WFS_EINVAL, "a packed table reached a kernel that reads dense ones");
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
         return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stats, stats_done,
                                       pending, stream);
@@ -481,10 +485,19 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
 extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                                int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
                                int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
-                               const int64_t *r_dev, void *stream) {
+                               const int64_t *r_dev, int32_t packed_kl, void *stream) {
     bool unused;
+    WFS_REQUIRE(packed_kl == 0 || !kmap_host, WFS_EINVAL, "a packed table takes no column map");
     return gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, transpose_w, bias, Y,
-                            dtype, r_dev, nullptr, &unused, nullptr, stream);
+                            dtype, r_dev, nullptr, &unused, nullptr, stream, packed_kl);
+}
+
+// which = 1: wfs_gather_conv with transpose_w (dX), 2: wfs_gather_conv forward, 3: wfs_gather_dw
+extern "C" int wfs_gather_packed_ok(int32_t packed_kl, int32_t K, int32_t Ca, int32_t Cb, int32_t dtype, int32_t which) {
+    if (packed_kl < 1 || packed_kl > 8 || K < 1 || K > 32 || K % packed_kl != 0 || Ca != 32 || Cb != 32 || !wfs_dtype_ok(dtype))
+        return 0;
+    if (which == 3) return 1;
+    return which == 1 && packed_kl == 3 && K <= 27;
 }
 
 extern "C" size_t wfs_conv_stats_workspace_bytes(int64_t R, int32_t C) {
@@ -556,8 +569,11 @@ extern "C" size_t wfs_gather_dw_workspace_bytes(int32_t K, int64_t R, int32_t Cs
 static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
                           const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
                           int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev_,
-                          wfs_dw_job *defer, void *stream_) {
+                          wfs_dw_job *defer, void *stream_, int packed_kl = 0) {
     hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(packed_kl == 0 || (wfs_gather_packed_ok(packed_kl, K, Cs, Cg, dtype, 3) && !kmap_host), WFS_EINVAL,
+                "a packed table (kl %d) is not taken by this product (wfs_gather_packed_ok): expand it with wfs_unpack_table",
+                packed_kl);
     const long long *r_dev = (const long long *)r_dev_;
     WFS_REQUIRE(K >= 1 && K <= 65535, WFS_EINVAL, "bad K");
     WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
@@ -571,7 +587,7 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
     size_t need = wfs_gather_dw_workspace_bytes(K, R, Cs, Cg);
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     WfsTimerScope timer(WFS_TIMER_GATHER_DW, stream);
-    if (wfs_wide_dw_ok(K, R, Cs, Cg, dtype) && K <= 128 && ((uintptr_t)workspace & 15) == 0) {
+    if (!packed_kl && wfs_wide_dw_ok(K, R, Cs, Cg, dtype) && K <= 128 && ((uintptr_t)workspace & 15) == 0) {
         for (int k = 0; k < K && kmap_host; ++k)
             WFS_REQUIRE(kmap_host[k] >= 0 && kmap_host[k] < K, WFS_EINVAL, "kmap[%d] out of range", k);
         return wfs_launch_wide_dw(table, kmap_host, K, identity_k, R, r_dev, S, Cs, G, G_rows, Cg, swap, dW, dtype, workspace,
@@ -580,7 +596,9 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
     // the fp32 kernel addresses S and G through 32-bit buffer offsets (128 B per row): fewer than 2^24 rows each
     const bool rows_fit = dtype != WFS_F32 || (R < (1ll << 24) && G_rows < (1ll << 24));
     if (Cs == 32 && Cg == 32 && table && !kmap_host && rows_fit)
-        return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, defer, stream);
+        return wfs_launch_gdw32(table, K, identity_k, R, r_dev, S, G, swap, dW, (float *)workspace, dtype, defer, stream,
+                                packed_kl);
+    WFS_REQUIRE(packed_kl == 0, WFS_EINVAL, "a packed table reached a kernel that reads dense ones");
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K && kmap_host; ++k) {
         is_ident = is_ident && kmap_host[k] == k;
@@ -629,9 +647,9 @@ static int gather_dw_impl(const int32_t *table, const int32_t *kmap_host, int32_
 extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k, int64_t R,
                              const void *S, int32_t Cs, const void *G, int64_t G_rows, int32_t Cg, int32_t swap, float *dW,
                              int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev,
-                             wfs_dw_job *defer, void *stream) {
+                             wfs_dw_job *defer, int32_t packed_kl, void *stream) {
     return gather_dw_impl(table, kmap_host, K, identity_k, R, S, Cs, G, G_rows, Cg, swap, dW, dtype, workspace,
-                          workspace_bytes, r_dev, defer, stream);
+                          workspace_bytes, r_dev, defer, stream, packed_kl);
 }
 
 extern "C" int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream) {

@@ -109,11 +109,11 @@ bool wfs_mfma_gconv32_ok(int K);
 bool wfs_bn_fold_ok(long long N, int C);          // bn.hip: can the apply kernel fold conv partials for this batch?
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream);
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl = 0);
 // 16-bit rows (dtype WFS_BF16 or WFS_F16)
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream);
+                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl = 0);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
                            const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream);
@@ -129,7 +129,8 @@ int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long
                         hipStream_t stream);
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg);
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
-                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream);
+                     const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream,
+                     int packed_kl = 0);
 int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                          const void *S, const void *G, int swap, float *dW, float *part, int dtype,
                          wfs_dw_job *defer, hipStream_t stream);

@@ -115,7 +115,8 @@ class SparseConvolution(SparseModule):
                                         self.padding, self.dilation, self.subm, known_unique=input.unique,
                                         n_dev=input.n_valid, out_capacity=getattr(self, "out_capacity", None),
                                         transposed=self.transposed, output_padding=self.output_padding,
-                                        events=getattr(input, "events", None), flags=self._sticky_flags())
+                                        events=getattr(input, "events", None), flags=self._sticky_flags(),
+                                        want_cell_map=getattr(input, "dense_follows", True))
                 if getattr(rb, "events_in", None) is not None:
                     input.events = rb.events_in          # the offsets of this row set, for the layers that follow
                 self.last_rulebook = rb          # capacity calibration / overflow checks of graph-captured steps
@@ -137,6 +138,8 @@ class SparseConvolution(SparseModule):
         out_tensor.prefetched = getattr(input, "prefetched", None)
         if self.subm:
             out_tensor.events = getattr(input, "events", None)          # same row set, same event offsets
+        elif not self.inverse and getattr(rb, "events_out", None) is not None:
+            out_tensor.events = rb.events_out                           # the event-local build numbered them by event
         out_tensor.bn_stats = bn_request if (bn_request is not None and bn_request.stats is not None) else None
         if not self.subm and not self.inverse:
             out_tensor.cell_map = getattr(rb, "cell_map", None)      # dense() of THIS row set can use the build's map

@@ -131,11 +131,23 @@ def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bia
     return Y
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, w16=None):
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, w16=None,
+                packed_kl=0):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
-    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only)."""
+    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only).
+    ``packed_kl`` > 0: ``table`` is the packed by-input table [K / packed_kl, R] (Rulebook.table_by_in)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
+    if packed_kl:
+        assert transpose_w and kmap is None and table.shape == (K // packed_kl, R), (table.shape, K, packed_kl, R)
+        Y = _rows((R, Cw_in), X, r_dev)
+        _lib.check(lib.wfs_gather_conv(_lib.ptr(table), None, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
+                                       _lib.ptr(W), Cw_in, Cw_out, 1, None, _lib.ptr(Y), _lib.dtype_code(X),
+                                       _lib.ptr(r_dev), packed_kl, _lib.stream_ptr()))
+        if ACCOUNT is not None:
+            _account("gather_conv", (table >> 3).clamp_(min=-1), R, X.shape[0], X.shape[1], R, Cw_in, K, Cw_in, Cw_out,
+                     X.element_size())
+        return Y
     if X.is_cuda and lib.wfs_wide_conv_ok(K, R, X.shape[0], int(X.shape[1]), Cw_in if transpose_w else Cw_out, _lib.dtype_code(X)):
         return _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev, w16)
     if transpose_w and not _fast_shape(Cw_out, Cw_in):
@@ -172,7 +184,7 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     else:
         _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
                                        _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias),
-                                       _lib.ptr(Y), _lib.dtype_code(X), _lib.ptr(r_dev), _lib.stream_ptr()))
+                                       _lib.ptr(Y), _lib.dtype_code(X), _lib.ptr(r_dev), 0, _lib.stream_ptr()))
     _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
     return Y
 
@@ -296,7 +308,7 @@ def join_side_streams():
         del _PENDING_SIDE[:]
 
 
-def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False, like=None):
+def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overlap=False, like=None, packed_kl=0):
     """dW[k,a,b] = sum_r S[r,a] G[table[kmap[k],r], b]  (swap: dW[k,b,a]).
     overlap=True launches on the side stream (see ops.OVERLAP_DW): memory is allocated on the calling stream
     and every operand is kept alive until join_side_streams().  ``like``: the parameter this is the gradient of
@@ -311,7 +323,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
     else:
         dW = torch.empty(shape, dtype=torch.float32, device=S.device)
     assert S.dtype == G.dtype and S.shape[0] == R
-    assert table is None or (table.dtype == torch.int32 and table.shape == (K, R))
+    assert table is None or (table.dtype == torch.int32 and table.shape == ((K // packed_kl if packed_kl else K), R))
     nbytes = lib.wfs_gather_dw_workspace_bytes(K, R, Cs, Cg)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=S.device)
 
@@ -320,7 +332,7 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
         job = _lib.DwJob() if defer else None
         _lib.check(lib.wfs_gather_dw(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(S), Cs, _lib.ptr(G), G.shape[0],
                                      Cg, 1 if swap else 0, _lib.ptr(dW), _lib.dtype_code(S), _lib.ptr(ws), ws.numel(),
-                                     _lib.ptr(r_dev), ctypes.byref(job) if defer else None, _lib.stream_ptr()))
+                                     _lib.ptr(r_dev), ctypes.byref(job) if defer else None, packed_kl, _lib.stream_ptr()))
         if defer and job.nslabs > 0:
             _DEFERRED_DW.append((job, ws))          # second stage pending: flush_deferred_dw()
 
@@ -339,7 +351,9 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
         _PENDING_SIDE.append((ev, (table, S, G, dW, ws, r_dev)))
     else:
         launch()
-    _account("gather_dw", table, R, R, Cs, G.shape[0], Cg, K, Cs, Cg, S.element_size())
+    if ACCOUNT is not None:
+        _account("gather_dw", (table >> 3).clamp_(min=-1) if packed_kl else table, R, R, Cs, G.shape[0], Cg, K, Cs, Cg,
+                 S.element_size())
     return dW
 
 
@@ -400,9 +414,11 @@ class SparseConvFunction(Function):
                     table, kmap = rb.table_by_out()
                     dW = gather_dw(table, K, ident, rb.M, dY, features, True, kmap, rb.m_dev, ov, filters)
                 else:
-                    dW = gather_dw(rb.nbr_out, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov, filters)
+                    table, pk = rb.table_by_in(features.shape[1], dY.shape[1], features, 3)
+                    dW = gather_dw(table, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov, filters, pk)
             if ctx.needs_input_grad[0]:
-                dX = gather_conv(rb.nbr_out, None, K, ident, rb.N, dY, W, True, None, rb.n_dev, None, ctx.w16)
+                table, pk = rb.table_by_in(dY.shape[1], W.shape[1], dY, 1)
+                dX = gather_conv(table, None, K, ident, rb.N, dY, W, True, None, rb.n_dev, None, ctx.w16, pk)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:

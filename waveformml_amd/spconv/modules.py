@@ -55,6 +55,15 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     @staticmethod
+    def _dense_follows(mods, i):
+        """Is the next sparse module after mods[i] a ToDense?  (The conv at i then asks its rulebook build for the
+        cell -> row map that dense() of its output uses; csrc/evconv.hip writes it only on request.)"""
+        for m in mods[i + 1:]:
+            if isinstance(m, SparseModule):
+                return isinstance(m, ToDense)
+        return False
+
+    @staticmethod
     def _prefetch_rulebooks(mods, x):
         """Build every layer's rulebook on a side stream now (device-count mode: nothing synchronises with the
         host).  Rulebooks depend on indices only, so the strided layers' builds run while the first layers
@@ -67,8 +76,9 @@ class SparseSequential(SparseModule):
         plan = {}
         keyed = {k: v.rulebook for k, v in x.indice_dict.items() if hasattr(v, "rulebook")}      # already built
         indices, spatial, n_dev = x.indices, x.spatial_shape, x.n_valid
+        events = getattr(x, "events", None)
         with torch.cuda.stream(side):
-            for m in mods:
+            for at, m in enumerate(mods):
                 if isinstance(m, SparseConvolution):
                     if m.conv1x1:
                         continue
@@ -79,7 +89,9 @@ class SparseSequential(SparseModule):
                     else:
                         rb = ops.build_rulebook(indices, x.batch_size, spatial, m.kernel_size, m.stride, m.padding,
                                                 m.dilation, m.subm, known_unique=True, n_dev=n_dev,
-                                                out_capacity=getattr(m, "out_capacity", None), flags=m._sticky_flags())
+                                                out_capacity=getattr(m, "out_capacity", None), events=events,
+                                                flags=m._sticky_flags(),
+                                                want_cell_map=SparseSequential._dense_follows(mods, at))
                         rb.ready = torch.cuda.Event()
                         rb.ready.record(side)
                         if m.indice_key is not None:
@@ -87,6 +99,7 @@ class SparseSequential(SparseModule):
                     plan[id(m)] = rb
                     if not m.subm:
                         indices, spatial, n_dev = rb.out_indices, rb.out_spatial_shape, rb.m_dev
+                        events = getattr(rb, "events_out", None)
                 elif isinstance(m, SparseModule):
                     break                           # ToDense or an unknown sparse module ends the sparse stack
         x.prefetched = plan
@@ -111,6 +124,8 @@ class SparseSequential(SparseModule):
                         and Fsp.can_take_batch_norm_stats(mods[i + 1], input.features)):
                     # conv -> BatchNorm1d (training): the conv's epilogue takes the batch statistics
                     input.bn_request = Fsp.BatchNormRequest(mods[i + 1])
+                if _is_sparse_tensor(input):
+                    input.dense_follows = self._dense_follows(mods, i)
                 input = module(input)
                 if want_prefetch and _is_sparse_tensor(input):
                     # the first layer has built its own rulebook and launched its conv on this stream; the

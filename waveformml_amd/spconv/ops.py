@@ -50,6 +50,14 @@ FUSE_CONV_BN_STATS = os.environ.get("WFS_FUSE_CONV_BN_STATS", "0") != "0"
 EVENT_LOCAL = os.environ.get("WFS_EVENT_LOCAL", "1") != "0"
 EVENT_LOCAL_MAX_BATCH = 16384
 
+# Event-local build of REGULAR (strided) convolutions (round 4; csrc/evconv.hip): in device-count mode one launch, one
+# workgroup per event with the event's output grid in LDS, instead of the chip-wide build's six launches over dense
+# -1-padded tables.  WFS_EVENT_LOCAL_CONV=0: the chip-wide build.  PACKED_TABLES: where the kernel is no longer than the
+# stride along the last dimension the by-input table is [K / kl, N] (include/wfsparse.h "packed tables"), consumed as it
+# is by the 32 -> 32 dX / dW kernels and expanded on demand for everybody else (Rulebook.nbr_out).
+EVENT_LOCAL_CONV = os.environ.get("WFS_EVENT_LOCAL_CONV", "1") != "0"
+PACKED_TABLES = os.environ.get("WFS_PACKED_TABLES", "1") != "0"
+
 _SIDE_STREAMS = {}
 
 
@@ -104,7 +112,11 @@ class Rulebook(object):
         self.has_dup = False
         self.indices = None          # input indices [N, D+1]
         self.out_indices = None      # [M, D+1] (SubM: the input indices)
-        self.nbr_out = None
+        self._nbr_out = None
+        # packed by-input table [K / packed_kl, N] of the event-local conv build (include/wfsparse.h "packed tables");
+        # .nbr_out then expands it on first use
+        self.nbr_out_packed = None
+        self.packed_kl = 0
         self.nbr_in = None
         self.kmap_in = None          # ctypes int32[K] or None
         self.centre_k = -1           # SubM: offset computed as a plain X.W[k] (spconv's k*), else -1
@@ -121,9 +133,32 @@ class Rulebook(object):
         # (wfs_event_offsets) and the build's failure flags (any word != 0 in the first two thirds: the table is
         # incomplete -- reported by the captured step's check())
         self.events_in = None
+        self.events_out = None       # event-local conv build: the event offsets of the OUTPUT rows
         self.event_flags = None
         self._pairs = None
         self._pair_num = None
+
+    @property
+    def nbr_out(self):
+        if self._nbr_out is None and self.nbr_out_packed is not None:
+            dense = torch.empty((self.K, self.N), dtype=torch.int32, device=self.nbr_out_packed.device)
+            _lib.check(_lib.load().wfs_unpack_table(_lib.ptr(self.nbr_out_packed), self.K, self.packed_kl, self.N,
+                                                    _lib.ptr(self.n_dev), _lib.ptr(dense), _lib.stream_ptr()))
+            self._nbr_out = dense
+        return self._nbr_out
+
+    @nbr_out.setter
+    def nbr_out(self, t):
+        self._nbr_out = t
+
+    def table_by_in(self, Ca, Cb, like, which):
+        """(table, packed_kl) for a product gathering through the by-input table: the packed form when the kernels of
+        that product take it (which = 1: dX, 3: dW), else the dense one."""
+        if (self.nbr_out_packed is not None and like.is_cuda
+                and like.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                and _lib.load().wfs_gather_packed_ok(self.packed_kl, self.K, int(Ca), int(Cb), _lib.dtype_code(like), which)):
+            return self.nbr_out_packed, self.packed_kl
+        return self.nbr_out, 0
 
     # gather table addressed by OUTPUT rows, for the forward of conv / SubM
     def table_by_out(self):
@@ -250,7 +285,7 @@ def _sticky_flags(n, dev, store=None, name=None):
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
                    known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None,
-                   events=None, flags=None):
+                   events=None, flags=None, want_cell_map=True):
     """Cached front of :func:`_build_rulebook` (see :class:`reuse_rulebooks`).  ``flags``: the calling layer's store of
     sticky failure flags (:func:`_sticky_flags`)."""
     global BUILD_COUNT
@@ -261,7 +296,8 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     if _REUSE is None:
         BUILD_COUNT += 1
         return _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                               known_unique, n_dev, out_capacity, events=events, flags=flags)
+                               known_unique, n_dev, out_capacity, events=events, flags=flags,
+                               want_cell_map=want_cell_map)
     ndim = indices.shape[1] - 1
     key = (indices.data_ptr(), tuple(indices.shape), tuple(indices.stride()), int(batch_size),
            tuple(int(s) for s in spatial_shape), tuple(_listify(ksize, ndim)), tuple(_listify(stride, ndim)),
@@ -271,15 +307,54 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     if rb is None:
         BUILD_COUNT += 1
         rb = _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
-                             known_unique, n_dev, out_capacity, flags=flags)
+                             known_unique, n_dev, out_capacity, events=events, flags=flags)
         rb._keepalive = indices          # the key holds a data_ptr: keep the storage from being recycled
         _REUSE[key] = rb
     return rb
 
 
+def _event_local_conv(rb, g, lib, indices, batch_size, n_dev, m_cap, events, flags, want_cell_map, stream):
+    """Device-count build of a regular conv by wfs_event_rulebook_conv (csrc/evconv.hip): one launch."""
+    dev = indices.device
+    N, ndim, K = rb.N, indices.shape[1] - 1, rb.K
+    B = int(batch_size)
+    kl = int(lib.wfs_event_rulebook_conv_packed_kl(ctypes.byref(g))) if PACKED_TABLES else 0
+    rb.M = m_cap
+    rb.m_dev = torch.empty((1,), dtype=torch.int64, device=dev)
+    rb.overflow = _sticky_flags(1, dev, flags, "overflow")
+    rb.event_flags = _sticky_flags(3, dev, flags, "conv_events")
+    # the launch epoch and the per-event counts the workgroups exchange: zeroed ONCE, then owned by this layer's builds
+    n_state = int(lib.wfs_event_rulebook_conv_state_bytes(B)) // 4
+    if flags is not None:
+        state = _sticky_flags(n_state, dev, flags, "conv_state")
+    else:
+        state = torch.zeros((n_state,), dtype=torch.int32, device=dev)      # inside a capture: re-zeroed by every replay
+    rb.events_in = events if events is not None else event_offsets(indices, B, n_dev)
+    rb.events_out = torch.empty((int(lib.wfs_event_offsets_ints(B)),), dtype=torch.int32, device=dev)
+    rb.out_indices = torch.empty((m_cap, ndim + 1), dtype=torch.int32, device=dev)
+    rb.nbr_in = torch.empty((K, m_cap), dtype=torch.int32, device=dev)
+    if kl:
+        rb.nbr_out_packed, rb.packed_kl = torch.empty((K // kl, N), dtype=torch.int32, device=dev), kl
+        table = rb.nbr_out_packed
+    else:
+        rb._nbr_out = torch.empty((K, N), dtype=torch.int32, device=dev)
+        table = rb._nbr_out
+    V = int(np.prod(rb.out_spatial_shape))
+    cell_row = torch.empty((B * V,), dtype=torch.int32, device=dev) if want_cell_map else None
+    _lib.check(lib.wfs_event_rulebook_conv(ctypes.byref(g), _lib.ptr(indices), N, _lib.ptr(n_dev), _lib.ptr(rb.events_in),
+                                           m_cap, _lib.ptr(rb.out_indices), _lib.ptr(rb.m_dev), _lib.ptr(rb.events_out),
+                                           _lib.ptr(table), kl, _lib.ptr(rb.nbr_in), _lib.ptr(cell_row),
+                                           _lib.ptr(rb.overflow), _lib.ptr(rb.event_flags), _lib.ptr(state), stream))
+    if cell_row is not None:
+        # wfs_to_dense_mapped's (ticket, slot_id) pair: "-1 = no row" reads as an unset ticket
+        rb.cell_map = (cell_row.data_ptr(), cell_row.data_ptr(), cell_row, V)
+    rb.has_dup = False
+    return rb
+
+
 def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
                     known_unique=None, n_dev=None, out_capacity=None, transposed=False, output_padding=None,
-                    events=None, flags=None):
+                    events=None, flags=None, want_cell_map=True):
     """Builds the device rulebook.  ``known_unique``: True if the caller knows the index rows are
     distinct sites (skips the duplicate check a regular conv would otherwise run once).
 
@@ -302,11 +377,19 @@ def _build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, 
     rb.out_spatial_shape = [int(g.out_shape[i]) for i in range(ndim)]
     dev = indices.device
     stream = _lib.stream_ptr()
+    if known_unique is None and (ASSUME_VALID_UNIQUE_INDICES or n_dev is not None):
+        known_unique = True
+    if (n_dev is not None and not subm and not transposed and EVENT_LOCAL_CONV and known_unique and N > 0
+            and 1 <= int(batch_size) <= EVENT_LOCAL_MAX_BATCH and lib.wfs_event_rulebook_conv_ok(ctypes.byref(g))):
+        assert n_dev.dtype == torch.int64 and n_dev.is_cuda and n_dev.numel() == 1
+        rb.n_dev = n_dev
+        cells = int(batch_size) * int(np.prod(rb.out_spatial_shape))
+        m_cap = int(out_capacity) if out_capacity else default_out_capacity(N, rb.K, cells)
+        if rb.K * m_cap < 2 ** 31 and m_cap < 2 ** 28:
+            return _event_local_conv(rb, g, lib, indices, batch_size, n_dev, m_cap, events, flags, want_cell_map, stream)
     nbytes = lib.wfs_rulebook_workspace_bytes(ctypes.byref(g), N)
     ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
     rb.nbr_out = torch.empty((rb.K, N), dtype=torch.int32, device=dev)
-    if known_unique is None and (ASSUME_VALID_UNIQUE_INDICES or n_dev is not None):
-        known_unique = True
     if n_dev is not None:
         assert n_dev.dtype == torch.int64 and n_dev.is_cuda and n_dev.numel() == 1
         rb.n_dev = n_dev
