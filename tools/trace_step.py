@@ -6,7 +6,9 @@ f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # steps are delimited by the optimizer's kernel (last kernel of a step): use the k_site_insert / subm plan as the start marker
-starts = [i for i, r in enumerate(rows) if "k_site_insert" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "k_load_batch" in r["Kernel_Name"]]
+if len(starts) < 4:
+    starts = [i for i, r in enumerate(rows) if "k_site_insert" in r["Kernel_Name"]]
 if len(starts) < 4:
     print("not enough steps"); sys.exit()
 a, b = starts[-3], starts[-2]            # one full steady-state step
@@ -21,7 +23,8 @@ for r in step:
     name = re.sub(r"\(anonymous namespace\)::|void |at::native::", "", r["Kernel_Name"])[:58]
     gap = (s - prev_end) / 1e3
     if "-v" in sys.argv:
-        print("%8.1f  +gap %6.1f  dur %6.1f  %s" % ((s - t0) / 1e3, gap, (e - s) / 1e3, name))
+        print("%8.1f  +gap %6.1f  dur %6.1f  end %7.1f  q%s  %s" % ((s - t0) / 1e3, gap, (e - s) / 1e3, (e - t0) / 1e3,
+                                                                  r.get("Queue_Id", "?"), name))
     k = agg.setdefault(name, [0, 0.0]); k[0] += 1; k[1] += (e - s) / 1e3
     prev_end = max(prev_end, e)
 for name, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:

@@ -16,7 +16,8 @@
 //   3  the event's site count is published (one 64-bit word, tagged with the launch's epoch) and the counts of all
 //      events in front are read back: ids of event e start at the sum of the counts of events < e (events are
 //      numbered in row order, so this IS first-seen order)            [one global store + one round of loads]
-//   4  every candidate reads its site's id from LDS and the tables are written ONCE: out_indices, the by-input
+//   4  every candidate reads its site's id from LDS and the tables are written ONCE, coalesced (the by-output table
+//      through an LDS image, the coordinates one thread per site): out_indices, the by-input
 //      table (packed [K / kl, N] when at most one offset along the last dimension can reach an output cell, i.e.
 //      kernel <= stride there: 9 instead of 27 rows at the PSD geometry), the by-output table [K, M], the event
 //      offsets of the OUTPUT set (the next strided layer starts from them) and, on request, the cell -> row map
@@ -33,11 +34,14 @@ namespace {
 #ifndef EC_KNOCK
 #define EC_KNOCK 0
 #endif
-constexpr int EC_THREADS = 1024;
-constexpr int EC_WAVES = EC_THREADS / 64;
-constexpr int EC_MAXCELLS = 16384;            // output cells of one event: 4 B ticket + 2 B id each in LDS
+// threads per workgroup: 1024 (one row per thread for all but the largest events)
+constexpr int EC_MAXCELLS = 16384;            // output cells of one event: 4 B ticket / image + 2 B id in LDS
 constexpr int EC_FLAG_WORDS = WFS_EVENT_FLAG_WORDS;
 constexpr unsigned EC_SPIN_LIMIT = 1u << 22;  // polls of a predecessor's count before the launch gives up (flagged)
+// every count is published EC_REPLICAS times, EC_REPLICA_STRIDE(B) bytes apart, and event e reads replica e % EC_REPLICAS:
+// all events behind a slow one poll ITS word, and polls of one word queue at one memory channel
+constexpr int EC_REPLICAS = 8;
+inline __host__ __device__ size_t ec_replica_stride(int B) { return ((size_t)B * 8 + 4095) / 4096 * 4096 + 256; }
 
 struct ECGeo {
     int ndim, K, Kq, kl, sl, pl, dl, out_last, cells_e;
@@ -45,7 +49,11 @@ struct ECGeo {
     // leading dims (all but the last; unused ones: ksize 1, out 1, mult 0)
     int lks[3], ls[3], lp[3], ld[3], lout[3], lmult[3];
     unsigned lmagic[3], last_magic;          // floor(t / s) == (t * magic) >> 16 for the t that occur (host-verified)
-    unsigned qdig[32];                       // leading-offset digits of q, 8 bits per dim
+    unsigned dmagic[4];                      // floor(c / out_shape[d]) == umulhi(c, dmagic[d]) for c < 2^16 (cell decoding)
+    int oshape[4];
+    // candidate slots: packed form: slot = leading-offset index q (the last dim's offset follows from the row);
+    // dense form: slot = kernel offset k.  Digits of the offsets, 8 bits per dim (leading dims 0..2, last dim in 24..31)
+    unsigned dig[32];
 };
 
 __device__ __forceinline__ long long valid_rows(long long R, const long long *r_dev) {
@@ -53,76 +61,139 @@ __device__ __forceinline__ long long valid_rows(long long R, const long long *r_
     return v < R ? v : R;
 }
 
-// a row's coordinates, digested: per leading dim the offsets that reach an output cell (bit mask) and that cell's
-// coordinate (8 bits per offset); for the last dim the coordinate itself
-struct RowC {
-    bool ok;
-    unsigned vm[3], pk[3];
-    int tl;                 // x_last + padding_last
+// The candidates of one input row, in registers: slot t (compile-time index) holds the event-local output cell the
+// row reaches through that slot's kernel offset, or -1.  PACKED: o_star = the one offset along the last dim that can
+// divide (kernel <= stride there), so the kernel offset of slot q is q * kl + o_star.
+template <int NQ>
+struct Cand {
+    int cell[NQ];
+    int o_star;
+    bool ok;                 // coordinates inside the spatial shape
 };
 
-__device__ __forceinline__ RowC digest_row(const ECGeo &g, const int *__restrict__ row) {
-    RowC r;
-    r.ok = true;
+template <bool PACKED, int NQ>
+__device__ __forceinline__ Cand<NQ> digest_row(const ECGeo &g, const int *__restrict__ row) {
+    Cand<NQ> c;
+    bool ok = true;
     const int last = g.ndim - 1;
+    unsigned vm[3], pk[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        r.vm[d] = 1u;
-        r.pk[d] = 0u;
+        vm[d] = 1u;
+        pk[d] = 0u;
         if (d < last) {
             const int x = row[1 + d];
-            r.ok = r.ok && x >= 0 && x < g.spatial[d];
-            unsigned vm = 0u, pk = 0u;
+            ok = ok && x >= 0 && x < g.spatial[d];
+            unsigned m = 0u, p = 0u;
             for (int o = 0; o < g.lks[d]; ++o) {
                 const int t = x + g.lp[d] - o * g.ld[d];
                 const int oc = (int)(((unsigned)(t < 0 ? 0 : t) * g.lmagic[d]) >> 16);
                 const bool v = t >= 0 && oc * g.ls[d] == t && oc < g.lout[d];
-                vm |= v ? (1u << o) : 0u;
-                pk |= (unsigned)(v ? oc : 0) << (8 * o);
+                m |= v ? (1u << o) : 0u;
+                p |= (unsigned)(v ? oc : 0) << (8 * o);
             }
-            r.vm[d] = vm;
-            r.pk[d] = pk;
+            vm[d] = m;
+            pk[d] = p;
         }
     }
     const int xl = row[1 + last];
-    r.ok = r.ok && xl >= 0 && xl < g.spatial[last];
-    r.tl = xl + g.pl;
-    return r;
-}
-
-// calls f(q, o, cell) for every candidate of the row that reaches an output cell, in increasing k = q * kl + o
-template <bool PACKED, typename F>
-__device__ __forceinline__ void each_candidate(const ECGeo &g, const RowC &r, F f) {
-    if (!r.ok) return;
-    int o_star = 0, oc_star = 0;
+    ok = ok && xl >= 0 && xl < g.spatial[last];
+    const int tl = xl + g.pl;
+    c.ok = ok;
+    c.o_star = 0;
+    int oc_star = 0;
     bool l_ok = true;
     if (PACKED) {
         // kernel <= stride along the last dim (dilation 1): only offset (x + p) mod s can divide
-        oc_star = (int)(((unsigned)r.tl * g.last_magic) >> 16);
-        o_star = r.tl - oc_star * g.sl;
-        l_ok = o_star < g.kl && oc_star < g.out_last;
+        oc_star = (int)(((unsigned)(tl < 0 ? 0 : tl) * g.last_magic) >> 16);
+        c.o_star = tl - oc_star * g.sl;
+        l_ok = c.o_star < g.kl && oc_star < g.out_last;
     }
-#pragma unroll 1
-    for (int q = 0; q < g.Kq; ++q) {
-        const unsigned dg = g.qdig[q];
+    const int nslots = PACKED ? g.Kq : g.K;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const unsigned dg = g.dig[t];
         const unsigned o0 = dg & 255u, o1 = (dg >> 8) & 255u, o2 = (dg >> 16) & 255u;
-        if (!((r.vm[0] >> o0) & (r.vm[1] >> o1) & (r.vm[2] >> o2) & 1u)) continue;
-        const int lead = (int)((r.pk[0] >> (8 * o0)) & 255u) * g.lmult[0] + (int)((r.pk[1] >> (8 * o1)) & 255u) * g.lmult[1] +
-                         (int)((r.pk[2] >> (8 * o2)) & 255u) * g.lmult[2];
+        bool v = ok && t < nslots && (((vm[0] >> o0) & (vm[1] >> o1) & (vm[2] >> o2) & 1u) != 0u);
+        const int lead = (int)((pk[0] >> (8 * o0)) & 255u) * g.lmult[0] + (int)((pk[1] >> (8 * o1)) & 255u) * g.lmult[1] +
+                         (int)((pk[2] >> (8 * o2)) & 255u) * g.lmult[2];
+        int oc = oc_star;
         if (PACKED) {
-            if (l_ok) f(q, o_star, lead * g.out_last + oc_star);
+            v = v && l_ok;
         } else {
-            for (int o = 0; o < g.kl; ++o) {
-                const int t = r.tl - o * g.dl;
-                if (t < 0) continue;
-                const int oc = (int)(((unsigned)t * g.last_magic) >> 16);
-                if (oc * g.sl == t && oc < g.out_last) f(q, o, lead * g.out_last + oc);
+            const int tt = tl - (int)(dg >> 24) * g.dl;
+            oc = (int)(((unsigned)(tt < 0 ? 0 : tt) * g.last_magic) >> 16);
+            v = v && tt >= 0 && oc * g.sl == tt && oc < g.out_last;
+        }
+        c.cell[t] = v ? lead * g.out_last + oc : -1;
+    }
+    return c;
+}
+
+// The same enumeration without the register cache, for geometries with more slots than fit one (NQ > 16): calls
+// f(t, cell, k) for every slot of the row that reaches an output cell, in increasing t
+template <bool PACKED, typename F>
+__device__ __forceinline__ void stream_row(const ECGeo &g, const int *__restrict__ row, bool *ok_out, F f) {
+    bool ok = true;
+    const int last = g.ndim - 1;
+    unsigned vm[3], pk[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        vm[d] = 1u;
+        pk[d] = 0u;
+        if (d < last) {
+            const int x = row[1 + d];
+            ok = ok && x >= 0 && x < g.spatial[d];
+            unsigned m = 0u, p = 0u;
+            for (int o = 0; o < g.lks[d]; ++o) {
+                const int t = x + g.lp[d] - o * g.ld[d];
+                const int oc = (int)(((unsigned)(t < 0 ? 0 : t) * g.lmagic[d]) >> 16);
+                const bool v = t >= 0 && oc * g.ls[d] == t && oc < g.lout[d];
+                m |= v ? (1u << o) : 0u;
+                p |= (unsigned)(v ? oc : 0) << (8 * o);
             }
+            vm[d] = m;
+            pk[d] = p;
+        }
+    }
+    const int xl = row[1 + last];
+    ok = ok && xl >= 0 && xl < g.spatial[last];
+    *ok_out = ok;
+    if (!ok) return;
+    const int tl = xl + g.pl;
+    int o_star = 0, oc_star = 0;
+    bool l_ok = true;
+    if (PACKED) {
+        oc_star = (int)(((unsigned)tl * g.last_magic) >> 16);
+        o_star = tl - oc_star * g.sl;
+        l_ok = o_star < g.kl && oc_star < g.out_last;
+        if (!l_ok) return;
+    }
+    const int nslots = PACKED ? g.Kq : g.K;
+#pragma unroll 1
+    for (int t = 0; t < nslots; ++t) {
+        const unsigned dg = g.dig[t];
+        const unsigned o0 = dg & 255u, o1 = (dg >> 8) & 255u, o2 = (dg >> 16) & 255u;
+        if (!((vm[0] >> o0) & (vm[1] >> o1) & (vm[2] >> o2) & 1u)) continue;
+        const int lead = (int)((pk[0] >> (8 * o0)) & 255u) * g.lmult[0] + (int)((pk[1] >> (8 * o1)) & 255u) * g.lmult[1] +
+                         (int)((pk[2] >> (8 * o2)) & 255u) * g.lmult[2];
+        if (PACKED) {
+            f(t, lead * g.out_last + oc_star, t * g.kl + o_star);
+        } else {
+            const int tt = tl - (int)(dg >> 24) * g.dl;
+            if (tt < 0) continue;
+            const int oc = (int)(((unsigned)tt * g.last_magic) >> 16);
+            if (oc * g.sl == tt && oc < g.out_last) f(t, lead * g.out_last + oc, t);
         }
     }
 }
 
 // block-wide exclusive scan of one int per thread (threads in order); *total = the block's sum
+// Barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for its outstanding global loads
+// / stores (__syncthreads() would: the look-back's loads and the table stores are meant to stay in flight across it)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int EC_WAVES>
 __device__ __forceinline__ int ec_block_scan(int v, int *sWave, int *total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int inc = v;
@@ -131,9 +202,9 @@ __device__ __forceinline__ int ec_block_scan(int v, int *sWave, int *total) {
         const int n = __shfl_up(inc, d, 64);
         if (lane >= d) inc += n;
     }
-    __syncthreads();                        // the previous use of sWave is over
+    lds_barrier();                        // the previous use of sWave is over
     if (lane == 63) sWave[wid] = inc;
-    __syncthreads();
+    lds_barrier();
     int base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < EC_WAVES; ++w) {
@@ -145,8 +216,8 @@ __device__ __forceinline__ int ec_block_scan(int v, int *sWave, int *total) {
     return base + inc - v;
 }
 
-template <bool PACKED>
-__global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, const int *__restrict__ idx, long long N,
+template <bool PACKED, int NQ, int EC_THREADS>
+__global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, int img_bytes, const int *__restrict__ idx, long long N,
                                                         const long long *__restrict__ n_dev,
                                                         const int *__restrict__ ev_in, int B, long long M_cap,
                                                         int *__restrict__ out_idx, long long *__restrict__ m_dev,
@@ -156,8 +227,14 @@ __global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, const int *__re
                                                         unsigned long long *__restrict__ pub,
                                                         unsigned *__restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ec_lds[];
-    unsigned *ticket = reinterpret_cast<unsigned *>(ec_lds);                                  // [cells_e]
-    unsigned short *cellid = reinterpret_cast<unsigned short *>(ec_lds + (size_t)g.cells_e * 4);   // [cells_e]
+    // LDS: [ tickets (4 B per cell), later the by-output image | cell -> id (2 B) ].  The image takes the tickets' place
+    // once the ids exist (img_bytes >= 4 * cells_e): a workgroup of the PSD geometry holds 41 KB -- three to a CU when a
+    // batch has more events than the chip has CUs, and the 96-KB blocks of the layers' conv kernels, which run beside the
+    // builds in a training step, still find room on the same CU
+    unsigned *ticket = reinterpret_cast<unsigned *>(ec_lds);                                        // [cells_e]
+    unsigned short *img = reinterpret_cast<unsigned short *>(ec_lds);                               // [group][M_e (even)]
+    unsigned short *cellid = reinterpret_cast<unsigned short *>(ec_lds + (size_t)img_bytes);       // [cells_e] cell -> id in the event (0xFFFF: not an output site)
+    constexpr int EC_WAVES = EC_THREADS / 64;
     __shared__ int sWave[EC_WAVES];
     __shared__ long long sSum[EC_WAVES];
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -168,60 +245,110 @@ __global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, const int *__re
     const bool structured = __ballot(ev_in[B + 1 + lane] != 0) == 0ull;
     int r0 = ev_in[e], r1 = ev_in[e + 1];
     r1 = r1 < (int)Nv ? r1 : (int)Nv;
-    const int n = structured && r1 > r0 ? r1 - r0 : 0;
+    int n = structured && r1 > r0 ? r1 - r0 : 0;
+    int f_fail = 0;
+    if (n > 65534) {                                    // local rows travel as uint16 through the image
+        n = 0;
+        f_fail = 1;
+    }
     int f_range = 0;
+    const int nslots = PACKED ? g.Kq : g.K;
 
-    for (int c = tid; c < g.cells_e; c += EC_THREADS) ticket[c] = 0xFFFFFFFFu;
-    // this thread's first row stays in registers through all phases; events beyond EC_THREADS rows reload
-    RowC mine;
-    mine.ok = false;
-    if (tid < n) {
-        mine = digest_row(g, idx + (long long)(r0 + tid) * cols);
-        if (!mine.ok) f_range = 1;
+    for (int c = tid; c < g.cells_e; c += EC_THREADS) {
+        ticket[c] = 0xFFFFFFFFu;
+        cellid[c] = 0xFFFFu;
     }
-    __syncthreads();
+    // CACHE (<= 16 candidate slots): this thread's first row stays digested in registers through all phases (events
+    // beyond EC_THREADS rows re-digest the further ones); wider geometries stream their candidates in every phase
+    constexpr bool CACHE = NQ <= 16;
+    constexpr int NC = CACHE ? NQ : 1;
+    Cand<NC> mine;
+#pragma unroll
+    for (int t = 0; t < NC; ++t) mine.cell[t] = -1;
+    mine.o_star = 0;
+    mine.ok = true;
+    if (CACHE && tid < n) mine = digest_row<PACKED, NC>(g, idx + (long long)(r0 + tid) * cols);
+    // visit(jl, f): f(t, cell, k) for every candidate of local row jl that reaches an output cell, in increasing t
+    auto visit = [&](int jl, auto f) {
+        if constexpr (CACHE) {
+            Cand<NC> c = mine;
+            if (jl != tid) c = digest_row<PACKED, NC>(g, idx + (long long)(r0 + jl) * cols);
+            if (!c.ok) f_range = 1;
+#pragma unroll
+            for (int t = 0; t < NC; ++t)
+                if (c.cell[t] >= 0) f(t, c.cell[t], PACKED ? t * g.kl + c.o_star : t);
+        } else {
+            bool ok;
+            stream_row<PACKED>(g, idx + (long long)(r0 + jl) * cols, &ok, f);
+            if (!ok) f_range = 1;
+        }
+    };
+    lds_barrier();
     // ---- 1: tickets
-    for (int jl = tid; jl < n && !(EC_KNOCK & 8); jl += EC_THREADS) {
-        const RowC r = jl == tid ? mine : digest_row(g, idx + (long long)(r0 + jl) * cols);
-        if (jl != tid && !r.ok) f_range = 1;
-        each_candidate<PACKED>(g, r, [&](int q, int o, int cell) {
-            atomicMin(&ticket[cell], (unsigned)jl * 32u + (unsigned)(q * g.kl + o));
-        });
-    }
-    __syncthreads();
-    // ---- 2: first flags -> ids within the event
+    for (int jl = tid; jl < n && !(EC_KNOCK & 8); jl += EC_THREADS)
+        visit(jl, [&](int, int cell, int k) { atomicMin(&ticket[cell], (unsigned)jl * 32u + (unsigned)k); });
+    lds_barrier();
+    // ---- 2: first flags -> ids within the event (cellid)
     int carry = 0;
     for (int j0 = 0; j0 < n && !(EC_KNOCK & 8); j0 += EC_THREADS) {
         const int jl = j0 + tid;
-        RowC r;
-        r.ok = false;
-        if (jl < n) r = jl == tid ? mine : digest_row(g, idx + (long long)(r0 + jl) * cols);
         unsigned mask = 0u;
-        each_candidate<PACKED>(g, r, [&](int q, int o, int cell) {
-            const int k = q * g.kl + o;
-            mask |= ticket[cell] == (unsigned)jl * 32u + (unsigned)k ? (1u << k) : 0u;
-        });
+        if (jl < n)
+            visit(jl, [&](int t, int cell, int k) {
+                mask |= ticket[cell] == (unsigned)jl * 32u + (unsigned)k ? (1u << t) : 0u;
+            });
         int tot;
-        const int rowbase = carry + ec_block_scan(__popc(mask), sWave, &tot);
-        each_candidate<PACKED>(g, r, [&](int q, int o, int cell) {
-            const int k = q * g.kl + o;
-            if ((mask >> k) & 1u) cellid[cell] = (unsigned short)(rowbase + __popc(mask & ((1u << k) - 1u)));
-        });
+        const int rowbase = carry + ec_block_scan<EC_WAVES>(__popc(mask), sWave, &tot);
+        if (mask != 0u)
+            visit(jl, [&](int t, int cell, int) {
+                if ((mask >> t) & 1u) {
+                    const int il = rowbase + __popc(mask & ((1u << t) - 1u));
+                    cellid[cell] = (unsigned short)il;
+                }
+            });
         carry += tot;
     }
     const int M_e = carry;
-    // ---- 3: publish the count, read the counts in front
-    if (tid == 0)
-        __hip_atomic_store(&pub[e], ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)M_e, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    // ---- 3: publish the count; the counts in front are asked for now and looked at after the work that does not need
+    // them (the first pass of the by-output image, the ids of this thread's candidates)
+    const size_t rstride = ec_replica_stride(B) / 8;
+    if (tid < EC_REPLICAS)
+        __hip_atomic_store(&pub[tid * rstride + e], ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)M_e,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long *mypub = pub + (size_t)(e % EC_REPLICAS) * rstride;
+    unsigned long long w_first = 0ull;
+    if (tid < e && !(EC_KNOCK & 1)) w_first = __hip_atomic_load(&mypub[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds_barrier();                                    // cellid is complete
+    // by-output table through an LDS image [offsets of the pass][M_e]: every row of nbr_in is written once, coalesced,
+    // values and "none" alike (no -1 fill behind it, no scattered 4-byte stores)
+    if (EC_KNOCK & (2 | 4)) nbr_in = nullptr;
+    const int mstride = (M_e + 1) & ~1;
+    int gs = M_e > 0 ? img_bytes / (2 * mstride) : g.K;  // offsets per pass (>= 1: the image holds 2 * cells_e bytes at least)
+    gs = gs < 1 ? 1 : (gs > g.K ? g.K : gs);
+    auto image_pass = [&](int k0, int k1) {             // fills the image of offsets [k0, k1); ends with a barrier
+        unsigned *img32 = reinterpret_cast<unsigned *>(img);
+        const int nd = ((k1 - k0) * mstride) >> 1;
+        for (int i = tid; i < nd; i += EC_THREADS) img32[i] = 0xFFFFFFFFu;
+        lds_barrier();
+        for (int jl = tid; jl < n; jl += EC_THREADS)
+            visit(jl, [&](int, int cell, int k) {
+                if (k >= k0 && k < k1) img[(k - k0) * mstride + (int)cellid[cell]] = (unsigned short)jl;
+            });
+        lds_barrier();
+    };
+    if (nbr_in && M_e > 0) image_pass(0, gs < g.K ? gs : g.K);
+    // ids (within the event) of this thread's cached row
+    int il_mine[NC];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) il_mine[t] = (CACHE && tid < n && mine.cell[t] >= 0) ? (int)cellid[mine.cell[t]] : -1;
     long long part = 0;
     int timed_out = 0;
     for (int p = tid; p < e && !(EC_KNOCK & 1); p += EC_THREADS) {
-        unsigned long long w = __hip_atomic_load(&pub[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long w = p == tid ? w_first : __hip_atomic_load(&mypub[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while ((unsigned)(w >> 32) != tag && spins < EC_SPIN_LIMIT) {
-            __builtin_amdgcn_s_sleep(2);
-            w = __hip_atomic_load(&pub[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_sleep(1);
+            w = __hip_atomic_load(&mypub[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ++spins;
         }
         if ((unsigned)(w >> 32) != tag) timed_out = 1;
@@ -230,73 +357,97 @@ __global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, const int *__re
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if (lane == 0) sSum[wid] = part;
-    __syncthreads();                                    // also: cellid is complete
+    lds_barrier();
     long long base = 0;
 #pragma unroll
     for (int w = 0; w < EC_WAVES; ++w) base += sSum[w];
     const long long m_total = base + M_e;               // meaningful in the last event's workgroup
     const long long m_room = base < M_cap ? M_cap - base : 0;        // ids of this event below m_room exist
-    // ---- 4: the by-output table's rows of this event start as "no input" ...
-    if (EC_KNOCK & 2) nbr_in = nullptr;
-    if (nbr_in && !(EC_KNOCK & 4)) {
-        const int mw = (long long)M_e < m_room ? M_e : (int)m_room;
-        for (int k = wid; k < g.K; k += EC_WAVES) {
-            int *dst = nbr_in + (long long)k * M_cap + base;
-            for (int i = lane; i < mw; i += 64) dst[i] = -1;
-        }
-        __syncthreads();                                // ... before the candidates below fill theirs in
-    }
-    for (int jl = tid; jl < n && !(EC_KNOCK & 4); jl += EC_THREADS) {
-        const RowC r = jl == tid ? mine : digest_row(g, idx + (long long)(r0 + jl) * cols);
-        const long long j = (long long)r0 + jl;
-        unsigned done = 0u;                             // offsets (PACKED: leading-offset rows) already written
-        each_candidate<PACKED>(g, r, [&](int q, int o, int cell) {
-            const int k = q * g.kl + o;
-            const int il = (int)cellid[cell];
-            const bool exists = il < m_room;
-            const int id = exists ? (int)(base + il) : -1;
-            if (PACKED) {
-                nbr_out[(long long)q * N + j] = exists ? ((id << 3) | o) : -1;
-                done |= 1u << q;
-            } else {
-                nbr_out[(long long)k * N + j] = id;
-                done |= 1u << k;
-            }
-            if (!exists) return;
-            if (nbr_in) nbr_in[(long long)k * M_cap + id] = (int)j;
-            if (ticket[cell] == (unsigned)jl * 32u + (unsigned)k) {
-                // first to reach the site: its coordinates
-                int *o = out_idx + (long long)id * cols;
-                int rem = cell;
-                o[cols - 1] = rem % g.out_last;
-                rem /= g.out_last;
+    const int mw = (long long)M_e < m_room ? M_e : (int)m_room;     // rows of this event that exist
+    // ---- 4a: the by-input table (coalesced over the rows)
+    if (!(EC_KNOCK & 4)) {
+        for (int jl = tid; jl < n; jl += EC_THREADS) {
+            const long long j = (long long)r0 + jl;
+            if (CACHE && jl == tid) {
 #pragma unroll
-                for (int d = 2; d >= 0; --d)
-                    if (d < last) {
-                        o[1 + d] = rem % g.lout[d];
-                        rem /= g.lout[d];
+                for (int t = 0; t < NC; ++t)
+                    if (t < nslots) {
+                        const int il = il_mine[t];
+                        int v = -1;
+                        if (il >= 0 && il < mw) v = PACKED ? ((((int)base + il) << 3) | mine.o_star) : (int)base + il;
+                        nbr_out[(long long)t * N + j] = v;
                     }
-                o[0] = e;
+            } else {
+                unsigned done = 0u;
+                visit(jl, [&](int t, int cell, int k) {
+                    const int il = (int)cellid[cell];
+                    int v = -1;
+                    if (il < mw) v = PACKED ? ((((int)base + il) << 3) | (k - t * g.kl)) : (int)base + il;
+                    nbr_out[(long long)t * N + j] = v;
+                    done |= 1u << t;
+                });
+                for (int t = 0; t < nslots; ++t)
+                    if (!((done >> t) & 1u)) nbr_out[(long long)t * N + j] = -1;
             }
-        });
-        const int nrows = PACKED ? g.Kq : g.K;
-        for (int t = 0; t < nrows; ++t)
-            if (!((done >> t) & 1u)) nbr_out[(long long)t * N + j] = -1;
+        }
+        // ---- 4b: coordinates of the event's sites, one thread per CELL of the event's grid (the cell is the coordinate)
+        for (int c = tid; c < g.cells_e; c += EC_THREADS) {
+            const int il = (int)cellid[c];
+            if (il >= mw) continue;                     // 0xFFFF: not a site; beyond the capacity: dropped
+            unsigned rem = (unsigned)c;
+            int *o = out_idx + (base + il) * cols;
+            o[0] = e;
+#pragma unroll
+            for (int d = 3; d >= 0; --d)
+                if (d <= last) {
+                    if (g.oshape[d] > 1) {
+                        const unsigned qd = __umulhi(rem, g.dmagic[d]);
+                        o[1 + d] = (int)(rem - qd * (unsigned)g.oshape[d]);
+                        rem = qd;
+                    } else {
+                        o[1 + d] = 0;
+                    }
+                }
+        }
     }
-    if (!structured) {
-        // the event table is meaningless: no row has an output (the consumers of the by-input table are bounded by the
-        // INPUT row count, so every row they can reach must hold "none"); the workgroups share the rows out evenly
-        const long long per = (Nv + B - 1) / B;
-        const long long j_lo = (long long)e * per, j_hi = j_lo + per < Nv ? j_lo + per : Nv;
-        const int nrows = PACKED ? g.Kq : g.K;
-        for (int t = 0; t < nrows; ++t)
+    // ---- 4c: the image passes written out (the first one was built above, beside the look-back)
+    if (nbr_in && M_e > 0) {
+        for (int k0 = 0; k0 < g.K; k0 += gs) {
+            const int k1 = k0 + gs < g.K ? k0 + gs : g.K;
+            if (k0 > 0) {
+                lds_barrier();                        // the previous pass has been written out
+                image_pass(k0, k1);
+            }
+            for (int k = k0 + wid; k < k1; k += EC_WAVES) {
+                const unsigned short *src = img + (k - k0) * mstride;
+                int *dst = nbr_in + (long long)k * M_cap + base;
+                for (int i = lane; i < mw; i += 64) {
+                    const unsigned v = src[i];
+                    dst[i] = v == 0xFFFFu ? -1 : r0 + (int)v;
+                }
+            }
+        }
+    }
+    if (!structured || f_fail) {
+        // the event table is meaningless (or this event is beyond the tables): no row has an output -- the consumers of
+        // the by-input table are bounded by the INPUT row count, so every row they can reach must say "none"
+        long long j_lo, j_hi;
+        if (!structured) {                              // the workgroups share ALL the rows out evenly
+            const long long per = (Nv + B - 1) / B;
+            j_lo = (long long)e * per;
+            j_hi = j_lo + per < Nv ? j_lo + per : Nv;
+        } else {
+            j_lo = r0;
+            j_hi = r1;
+        }
+        for (int t = 0; t < nslots; ++t)
             for (long long j = j_lo + tid; j < j_hi; j += EC_THREADS) nbr_out[(long long)t * N + j] = -1;
     }
     if (cell_row) {
         int *dst = cell_row + (long long)e * g.cells_e;
         for (int c = tid; c < g.cells_e; c += EC_THREADS) {
             const int il = (int)cellid[c];
-            dst[c] = (n > 0 && ticket[c] != 0xFFFFFFFFu && il < m_room) ? (int)(base + il) : -1;
+            dst[c] = (n > 0 && il < mw) ? (int)(base + il) : -1;          // il = 0xFFFF: no site
         }
     }
     f_range = __syncthreads_or(f_range);
@@ -304,7 +455,7 @@ __global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, const int *__re
     if (tid == 0) {
         ev_out[e] = (int)(base < M_cap ? base : M_cap);
         // STICKY: only ever set here (a captured step is checked every so many replays)
-        if (!structured || timed_out) flags[0] = 1;
+        if (!structured || timed_out || f_fail) flags[0] = 1;
         if (f_range) flags[2] = 1;
         if (e == B - 1) {
             const long long m = !structured ? 0 : (m_total < M_cap ? m_total : M_cap);
@@ -381,18 +532,29 @@ bool make_ecgeo(const wfs_geometry *g, ECGeo *G) {
         G->lmult[d] = mult;
         mult *= g->out_shape[d];
     }
-    for (int q = 0; q < 32; ++q) {
-        G->qdig[q] = 0;
-        if (q >= kq) continue;
-        int rem = q;
-        unsigned dg = 0;
+    for (int d = 0; d < 4; ++d) {
+        G->oshape[d] = d < g->ndim ? g->out_shape[d] : 1;
+        // floor(c / s) == umulhi(c, floor(2^32 / s) + 1) for c < 2^16, s < 2^16
+        G->dmagic[d] = G->oshape[d] > 1 ? (unsigned)((1ull << 32) / (unsigned long long)G->oshape[d]) + 1u : 0u;
+    }
+    return true;
+}
+
+// candidate slots of the kernel's register cache (see Cand): packed form one per leading offset, dense form one per offset
+void fill_digits(const wfs_geometry *g, ECGeo *G, bool packed) {
+    const int last = g->ndim - 1;
+    const int nslots = packed ? G->Kq : g->K;
+    for (int t = 0; t < 32; ++t) {
+        G->dig[t] = 0;
+        if (t >= nslots) continue;
+        int rem = packed ? t : t / G->kl;
+        unsigned dg = packed ? 0u : (unsigned)(t % G->kl) << 24;
         for (int d = last - 1; d >= 0; --d) {
             dg |= (unsigned)(rem % g->ksize[d]) << (8 * d);
             rem /= g->ksize[d];
         }
-        G->qdig[q] = dg;
+        G->dig[t] = dg;
     }
-    return true;
 }
 
 }  // namespace
@@ -410,7 +572,7 @@ extern "C" int wfs_event_rulebook_conv_packed_kl(const wfs_geometry *g) {
 }
 
 extern "C" size_t wfs_event_rulebook_conv_state_bytes(int32_t batch_size) {
-    return 64 + (size_t)(batch_size > 0 ? batch_size : 1) * sizeof(unsigned long long);
+    return 64 + (size_t)EC_REPLICAS * ec_replica_stride(batch_size > 0 ? batch_size : 1);
 }
 
 extern "C" int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *indices, int64_t N, const int64_t *n_dev,
@@ -433,30 +595,53 @@ extern "C" int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *ind
     WFS_REQUIRE(((uintptr_t)state & 7) == 0, WFS_EINVAL, "state must be 8-byte aligned");
     WfsTimerScope timer(WFS_TIMER_RULEBOOK, stream);
     const int B = g->batch_size;
-    const size_t lds = (size_t)G.cells_e * 6;
+    // LDS: the tickets (4 B per cell) and, in their place once the ids exist, the image of the by-output table's rows of
+    // one event ([offsets of a pass][M_e] uint16); two uint16 maps per cell behind them.  Small grids get a larger image
+    // (up to 24 KB) so that a pass covers most offsets
+    long long img = (long long)G.cells_e * 4;
+    long long want = (long long)g->K * (((long long)G.cells_e + 1) & ~1ll) * 2;
+    if (want > 24 * 1024) want = 24 * 1024;
+    if (img < want) img = want;
+    img = (img + 15) / 16 * 16;
+    const size_t lds = (size_t)img + (size_t)G.cells_e * 2;
     unsigned *st = (unsigned *)state;
     unsigned long long *pub = (unsigned long long *)((char *)state + 64);
-    const dim3 grid((unsigned)B), block(EC_THREADS);
-    static bool attr_p = false, attr_d = false;
-    if (packed_kl) {
-        if (!attr_p && lds > 48 * 1024) {
-            WFS_HIP_CHECK(hipFuncSetAttribute((const void *)k_ev_conv<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              EC_MAXCELLS * 6));
-            attr_p = true;
-        }
-        k_ev_conv<true><<<grid, block, lds, stream>>>(G, indices, N, (const long long *)n_dev, events_in, B, M_cap,
-                                                      out_indices, (long long *)m_dev, events_out, nbr_out, nbr_in, cell_row,
-                                                      overflow_dev, flags, pub, st);
-    } else {
-        if (!attr_d && lds > 48 * 1024) {
-            WFS_HIP_CHECK(hipFuncSetAttribute((const void *)k_ev_conv<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              EC_MAXCELLS * 6));
-            attr_d = true;
-        }
-        k_ev_conv<false><<<grid, block, lds, stream>>>(G, indices, N, (const long long *)n_dev, events_in, B, M_cap,
-                                                       out_indices, (long long *)m_dev, events_out, nbr_out, nbr_in,
-                                                       cell_row, overflow_dev, flags, pub, st);
-    }
+    const dim3 grid((unsigned)B);
+    const bool packed = packed_kl != 0;
+    fill_digits(g, &G, packed);
+    const int nslots = packed ? G.Kq : g->K;
+#define WFS_EC(P, NQ, TH)                                                                                                \
+    do {                                                                                                                 \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            WFS_HIP_CHECK(hipFuncSetAttribute((const void *)k_ev_conv<P, NQ, TH>,                                        \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,                                \
+                                              158 * 1024));                                                              \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        k_ev_conv<P, NQ, TH><<<grid, dim3(TH), lds, stream>>>(G, (int)img, indices, N, (const long long *)n_dev, events_in, B, \
+                                                       M_cap, out_indices, (long long *)m_dev, events_out, nbr_out,      \
+                                                       nbr_in, cell_row, overflow_dev, flags, pub, st);                   \
+    } while (0)
+    // threads per workgroup: while the events fit the chip in one round (B <= 256) the launch lasts as long as its largest
+    // event: 1024 threads = one row per thread and phase (31 vs 45 us alone at the PSD batch, 0.509 vs 0.514 ms per captured
+    // step); beyond that throughput counts: 512 threads, three workgroups to a CU (128 vs 174 us at 2048 events).
+    // WFS_EC_THREADS = 256 / 512 / 1024 overrides (experiments)
+    static const int ec_forced = [] {
+        const char *e = getenv("WFS_EC_THREADS");
+        const int v = e ? atoi(e) : 0;
+        return v == 256 || v == 512 || v == 1024 ? v : 0;
+    }();
+    const int ec_threads = ec_forced ? ec_forced : (B <= 256 ? 1024 : 512);
+    if (packed && nslots <= 9 && ec_threads == 512) WFS_EC(true, 9, 512);
+    else if (packed && nslots <= 9 && ec_threads == 256) WFS_EC(true, 9, 256);
+    else if (packed && nslots <= 9) WFS_EC(true, 9, 1024);
+    else if (packed && nslots <= 16) WFS_EC(true, 16, 1024);
+    else if (packed) WFS_EC(true, 32, 1024);
+    else if (nslots <= 9) WFS_EC(false, 9, 1024);
+    else if (nslots <= 16) WFS_EC(false, 16, 1024);
+    else WFS_EC(false, 32, 1024);
+#undef WFS_EC
     WFS_LAUNCH_CHECK();
     return WFS_OK;
 }

@@ -103,7 +103,7 @@ class SparseConvolution(SparseModule):
             if pre is not None and id(self) in pre:
                 rb = pre[id(self)]                  # built on the side stream by SparseSequential's prefetch
                 if rb.ready is not None:
-                    torch.cuda.current_stream().wait_event(rb.ready)
+                    rb.ready.wait()                 # modules._SideJoin: the branch's end, waited for once
                 self.last_rulebook = rb
                 input.unique = not rb.has_dup
                 if datas is None:
