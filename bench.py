@@ -250,6 +250,12 @@ def measure(env, args, dtype, steps, warmup, roofline):
                 out["roofline"]["mfma"]["rocprof"] = {"achieved": rtf, "frac": rtf / F32_MFMA_PEAK_TFLOPS,
                                                       "avg_launch_us": rp_us}
     extras = {"init_state": init_state, "batch_np": (c, f, y), "logits0": logits0, "loss0": loss0}
+    # orderly end of this measurement: hooks off, device idle, the captured graph -- RCCL nodes included --
+    # destroyed NOW, not by the garbage collector inside the next capture or after the process group is gone
+    if gstep is not None:
+        gstep.close()
+    reducer.remove()
+    torch.cuda.synchronize()
     return out, extras
 
 
@@ -351,7 +357,10 @@ def cpu_reference(env, extras, n_steps):
         log("cpu_baseline: %d steps, median %.3f s" % (len(times), med))
         base = {"value": len(y) / med, "unit": "events/s", "cores": cores, "kind": "port",
                 "sample": "%d timed training steps (after 1 warm-up) on the same %d-event batch, median; restatement "
-                          "of spconv 1.2.1's Native CPU algorithm, fp32, torch threads = %d" % (len(times), len(y), cores),
+                          "of spconv 1.2.1's Native CPU algorithm, fp32, torch threads = %d = min(CPU affinity mask, "
+                          "cgroup cpu.max quota, 32) -- this process's share of the host (os.cpu_count() = %d counts the "
+                          "whole node; per-offset [n_k x 32] x [32 x 32] products do not scale past 32 threads)"
+                          % (len(times), len(y), cores, os.cpu_count() or 0),
                 "ms_per_step": med * 1e3}
     return logits, loss, base
 
@@ -516,8 +525,12 @@ def main():
                 result["parity"] = parity(cpu_logits, cpu_loss, extras["logits0"], extras["loss0"])
         print(json.dumps(result), file=json_out, flush=True)
     if dist.is_available() and dist.is_initialized():
+        # every captured step was closed in measure(); drain the device, meet the other ranks, only then take the
+        # communicator down
+        torch.cuda.synchronize()
         if env.world > 1:
             dist.barrier()
+            torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -233,7 +233,9 @@ else:
 from test_gpu_fullsize import _rank_run
 res = _rank_run(rank, world, mode, dev)
 torch.save(res, out + ".rank%d" % rank)
+torch.cuda.synchronize()
 dist.barrier()
+torch.cuda.synchronize()
 dist.destroy_process_group()
 """
 
@@ -285,7 +287,7 @@ def _trainer_run(rank, world, dev):
     hist = tr.fit(mod, batches)
     torch.cuda.synchronize()
     return {"params": torch.cat([p.detach().reshape(-1).cpu() for p in mod.model.parameters()]),
-            "eager_fallbacks": tr.eager_fallbacks, "loss": hist[-1]["train_loss"], "n_cap": int(tr._graph.n_cap),
+            "eager_fallbacks": tr.eager_fallbacks, "loss": hist[-1]["train_loss"], "n_cap": int(tr.last_capacity),
             "recaptures": tr.recaptures}
 
 
@@ -334,6 +336,9 @@ def _rank_run(rank, world, mode, dev):
             grads.append(red.flat_grad.detach().cpu().clone())
         step.check()
         in_graph = bool(step.in_graph_exchange)
+        step.close()                             # hooks off, device idle, the captured graph destroyed: before the
+        del step                                 # caller destroys the process group
+    red.remove()
     torch.cuda.synchronize()
     return {"grads": grads, "params": red.flat_param.detach().cpu().clone(),
             "bn": [t.detach().float().cpu().clone() for t in mod.buffers()],
@@ -465,14 +470,21 @@ def test_nccl_backend_world_one_exchange_and_in_graph_capture(tmp_path):
     must reproduce the plain single-process step."""
     script = tmp_path / "nccl1.py"
     script.write_text(r"""
-import os, sys
+import faulthandler, gc, os, sys
+faulthandler.enable(all_threads=True)                 # a fatal signal dumps every thread's Python stack to stderr
 sys.path.insert(0, %r)
 sys.path.insert(0, os.path.join(sys.path[0], "tests"))
 import torch
 import torch.distributed as dist
+
+def phase(msg):
+    print("[phase] " + msg, flush=True)
+    print("[phase] " + msg, file=sys.stderr, flush=True)
+
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(dev))
+phase("init_process_group")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 from test_gpu_fullsize import _small_c2, _rank_batches
 from waveformml_amd.psd.ddp import FlatGradAllReducer
@@ -484,11 +496,11 @@ def run(exchange, graph):
     mod.optimizer_parameters = red.optimizer_parameters()
     opt = mod.configure_optimizers(); opt = opt[0][0] if isinstance(opt, tuple) else opt
     batches = _rank_batches(0, dev)
-    info = {}
+    info = {"exchange": red.exchange, "buckets": len(red.buckets), "hooks": len(red._hooks), "avg": red._avg}
     if graph:
         start = red.flat_param.detach().clone(); bufs = [t.detach().clone() for t in mod.buffers()]
         step = GraphedTrainStep(mod, opt, red, max(batches, key=lambda b: b[0][0].shape[0]))
-        info = {"in_graph_exchange": step.in_graph_exchange, "in_graph_optimizer": step.in_graph_optimizer}
+        info.update({"in_graph_exchange": step.in_graph_exchange, "in_graph_optimizer": step.in_graph_optimizer})
         with torch.no_grad():
             red.flat_param.copy_(start)
             for t, q in zip(mod.buffers(), bufs): t.copy_(q)
@@ -497,41 +509,57 @@ def run(exchange, graph):
                     if torch.is_tensor(v): v.zero_()
         for b in batches: step(b)
         step.check()
+        out = red.flat_param.detach().cpu().clone()
+        step.close()                                   # hooks off, device idle, graph (RCCL nodes) destroyed -- now
+        del step
     else:
         for b in batches:
             red.reset(); mod.training_step(b, 0).backward(); red.finish(); opt.step()
+        torch.cuda.synchronize()
+        out = red.flat_param.detach().cpu().clone()
+    red.remove()
     torch.cuda.synchronize()
-    return red.flat_param.detach().cpu().clone(), red, info
+    del red, mod, opt, batches
+    gc.collect()                                       # this run's cycles go here, with the device idle -- not inside the next capture
+    torch.cuda.synchronize()
+    return out, info
 
-plain, _, _ = run(False, False)
-eager, red, _ = run(True, False)
-assert red.exchange and len(red.buckets) == 2 and len(red._hooks) > 0
-print("ncclAvg available:", red._avg)
+phase("run plain eager")
+plain, _ = run(False, False)
+phase("run exchange eager")
+eager, info_e = run(True, False)
+assert info_e["exchange"] and info_e["buckets"] == 2 and info_e["hooks"] > 0, info_e
+print("ncclAvg available:", info_e["avg"])
 assert torch.equal(plain, eager), float((plain - eager).abs().max())
-gplain, _, _ = run(False, True)
-graphed, red_g, info = run(True, True)
+phase("run plain graph")
+gplain, _ = run(False, True)
+phase("run exchange graph")
+graphed, info = run(True, True)
 print("graph:", info)
 assert info["in_graph_exchange"] and info["in_graph_optimizer"], info
 assert torch.equal(gplain, graphed), float((gplain - graphed).abs().max())
+phase("destroy_process_group")
+torch.cuda.synchronize()
 dist.destroy_process_group()
-print("OK")
+phase("destroyed")
+print("OK", flush=True)
 """ % ROOT)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
-    if p.returncode < 0:
-        # killed by a signal (seen once in ~20 runs: SIGABRT out of a library thread, message lost): show everything the
-        # child wrote, then run it ONE more time so that a one-off does not take the whole tier down unexplained
-        print("first attempt died with signal %d" % -p.returncode)
-        print(p.stdout[-3000:])
-        print(p.stderr[-8000:])
-        p = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
-    if p.returncode != 0 or "OK" not in p.stdout:
-        print(p.stdout[-3000:])                  # in full (an assertion message is abbreviated)
-        print(p.stderr[-8000:])
-    assert p.returncode == 0 and "OK" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TORCH_SHOW_CPP_STACKTRACES="1", TORCH_CPP_LOG_LEVEL="WARNING")
+    # everything the child writes is KEPT (gpurun_out/ travels back from the GPU box): a death by signal is a failure,
+    # and whatever killed it must be readable afterwards -- no second attempt (ADVICE r3 / VERDICT r3 item 2)
+    keep_dir = os.path.join(ROOT, "gpurun_out")
+    log_path = os.path.join(keep_dir if os.path.isdir(keep_dir) else str(tmp_path), "nccl_world_one_child.log")
+    with open(log_path, "w") as logf:
+        p = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, timeout=300, stdout=logf, stderr=subprocess.STDOUT,
+                           text=True)
+    text = open(log_path).read()
+    if p.returncode != 0 or "\nOK" not in text:
+        print(text[-12000:])                     # in full (an assertion message is abbreviated)
+    assert p.returncode == 0 and "\nOK" in text, (p.returncode, log_path, text[-1500:])
 
 
 @pytest.mark.parametrize("agree_block", [4, 0], ids=["ahead_by_4", "blocking_per_step"])

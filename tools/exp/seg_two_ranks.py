@@ -32,7 +32,7 @@ def child(out):
     torch.cuda.synchronize()
     torch.save({"params": torch.cat([p.detach().reshape(-1).cpu() for p in mod.model.parameters()]),
                 "rows": [int(b[0][0].shape[0]) for b in batches], "fallbacks": tr.eager_fallbacks,
-                "recaptures": tr.recaptures, "n_cap": int(tr._graph.n_cap), "loss": [h["train_loss"] for h in hist]},
+                "recaptures": tr.recaptures, "n_cap": int(tr.last_capacity), "loss": [h["train_loss"] for h in hist]},
                out + ".rank%d" % rank)
     dist.destroy_process_group()
 

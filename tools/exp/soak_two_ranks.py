@@ -74,7 +74,7 @@ def child(tmp, files_per_class, events_per_file, epochs, workers, agree_block, o
     torch.save({"params": params, "steps": [h["steps"] for h in hist], "loss": [h["train_loss"] for h in hist],
                 "seconds": [h["train_seconds"] for h in hist], "eager_fallbacks": tr.eager_fallbacks,
                 "val_loss": [float(h.get("val_loss", float("nan"))) for h in hist],
-                "recaptures": tr.recaptures, "n_cap": tr._graph.n_cap}, out + ".rank%s" % os.environ["RANK"])
+                "recaptures": tr.recaptures, "n_cap": tr.last_capacity}, out + ".rank%s" % os.environ["RANK"])
     dist.destroy_process_group()
 
 

@@ -143,7 +143,7 @@ def main():
                         "events_per_s_per_epoch": [round(h["steps"] * len(CLASSES) * events_per_file / h["train_seconds"])
                                                    for h in hist],
                         "voxels_per_s_per_epoch": [round(rows / h["train_seconds"]) for h in hist],
-                        "n_cap": tr._graph.n_cap if tr._graph is not None else None, "eager_fallbacks": tr.eager_fallbacks,
+                        "n_cap": tr.last_capacity or None, "eager_fallbacks": tr.eager_fallbacks,
                         "recaptures": tr.recaptures, "loader_group": int(os.environ.get("WFS_LOADER_GROUP", "1")),
                         "history": hist}
     finally:

@@ -29,4 +29,4 @@ hist = tr.fit(mod, batches)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"steps": epochs * n_batches, "seconds": round(dt, 2), "steps_per_s_incl_capture_and_h2d": round(epochs * n_batches / dt, 1),
-                  "n_cap": tr._graph.n_cap, "eager_fallbacks": tr.eager_fallbacks, "history": hist}))
+                  "n_cap": tr.last_capacity, "eager_fallbacks": tr.eager_fallbacks, "history": hist}))

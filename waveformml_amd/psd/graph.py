@@ -11,11 +11,30 @@ shapes and is captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed
     loss = step(batch)            # copies the batch into the static buffers, replays the graph
     step.check()                  # occasionally: raises if a capacity was exceeded (results invalid)
 """
+import contextlib
+import gc
 import os
 import sys
 
 import torch
 import torch.distributed as dist
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """The cyclic garbage collector off for the length of a capture.  Objects of an EARLIER captured step (its CUDAGraph
+    with RCCL nodes, collective work objects, tensors of its private pool) sit in reference cycles -- hook closures <->
+    reducer <-> parameters -- so only the cyclic collector frees them, at whatever allocation it happens to run on; run
+    inside a later capture, their destructors free device memory and graph resources on a capturing thread (the abort
+    seen once in the one-rank RCCL test).  torch.cuda.graph() collects once BEFORE the capture starts; this
+    keeps the collector from running again until the capture has ended."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _round_up(v, m):
@@ -172,8 +191,30 @@ class GraphedTrainStep(object):
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: the process group's watchdog thread queries events while this thread captures
         mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
-        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
+        with _no_gc(), torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=mode):
             self.loss = self._body()
+
+    def close(self, remove_hooks=True):
+        """Orderly end of a captured step, BEFORE its process group is destroyed or another step is captured on the same
+        reducer: the reducer's hooks come off (``remove_hooks=False``: the reducer goes on to serve the next capture), the
+        device drains, the graph (whose nodes include the RCCL kernels and the communicator's stream when the exchange
+        was captured) is destroyed and its memory pool released, the references the net holds to the static buffers are
+        dropped.  Idempotent; the step cannot be called afterwards."""
+        if getattr(self, "graph", None) is None:
+            return
+        if remove_hooks:
+            self.reducer.remove()
+        torch.cuda.synchronize(self.coords.device)
+        self.graph.reset()
+        self.graph = None
+        self.loss = None
+        net = getattr(self.module, "model", None)
+        if net is not None:
+            if getattr(net, "batch_events", None) is not None and net.batch_events[0] is self.coords:
+                net.batch_events = None
+            if getattr(net, "batch_first_indices", None) is not None and net.batch_first_indices[0] is self.coords:
+                net.batch_first_indices = None
+        torch.cuda.synchronize(self.coords.device)
 
     def _static_batch(self):
         return ([self.coords, self.feats, self.n_valid], self.labels)
@@ -337,11 +378,13 @@ def _collective_capture_works(group, dev):
             torch.cuda.synchronize(dev)
             t.fill_(1.0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+            with _no_gc(), torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             g.replay()
             torch.cuda.synchronize(dev)
             ok = abs(float(t[0].item()) - float(dist.get_world_size(group))) < 1e-3
+            g.reset()                       # destroyed here, with the device idle -- not whenever the collector gets to it
+            torch.cuda.synchronize(dev)
             del g
     except Exception as e:         # noqa: BLE001  -- whatever the library raises: the answer is "no"
         print("[waveformml_amd] a captured all-reduce is not available here (%s: %s): gradients are exchanged after the "

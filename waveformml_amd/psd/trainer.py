@@ -156,6 +156,7 @@ class Trainer(object):
         # many batches ahead (graph.ShapeAgreement); 0 = one blocking all-reduce per step, as in round 2
         self.agree_block = int(agree_block)
         self.recaptures = 0
+        self.last_capacity = 0
         self._size_misfits = 0
         self.eager_fallbacks = 0
         self.global_step = 0
@@ -231,8 +232,10 @@ class Trainer(object):
                 # the capacity is too small for this data: capture again, sized on this batch (never smaller than before)
                 old = self._graph
                 self._graph = None
-                self._graph = self._capture(module, reducer, optimizer, batch, min_rows=max(old.n_cap, floor))
+                n_old = old.n_cap
+                old.close(remove_hooks=False)          # the old graph goes (device idle) before the new one is captured
                 del old
+                self._graph = self._capture(module, reducer, optimizer, batch, min_rows=max(n_old, floor))
                 self._size_misfits = 0
                 self.recaptures += 1
                 return self._graph(batch)
@@ -300,6 +303,12 @@ class Trainer(object):
                         self.save_checkpoint(module, optimizer, scheduler, epoch,
                                              os.path.join(self.root, "epoch=%d-val_loss=%.2f.ckpt" % (epoch, best)))
             self.history.append(rec)
+        # orderly end: hooks off, device idle, the captured graph destroyed -- before anybody destroys the process group
+        # (the reference relies on Lightning's DDP teardown, src/utils/util.py:236)
+        if self._graph is not None:
+            self.last_capacity = int(self._graph.n_cap)      # row capacity of the last captured step (diagnostics, tests)
+            self._graph.close()
+            self._graph = None
         reducer.remove()
         return self.history
 
