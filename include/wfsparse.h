@@ -430,6 +430,29 @@ int wfs_to_dense_bwd_mapped(const void *dY, const uint32_t *ticket, const int32_
                             const int64_t *m_dev, int32_t batch_size, int64_t V, int32_t C, void *dX, int32_t dtype,
                             void *stream);
 
+/* The head straight off the sparse rows (round 4; csrc/shead.hip).
+ * Replaces the whole tail spconv.ToDense -> view(-1, n_linear) -> nn.Linear(n_linear, n_type) of the reference's
+ * SPConvNet (src/models/SPConvNet.py:65-68; one-layer LinearBlock, src/models/ConvBlocks.py:82-102) AND its backward,
+ * without materialising the dense tensor:
+ *     Y[b][o]  = bias[o] + sum over rows i of event b, channels c:  X[i][c] * W[o][c * V + cell(i)]
+ *     dX[i][c] = sum_o G[b(i)][o] * W[o][c * V + cell(i)];   dW[o][c * V + cell] = sum_b G[b][o] * X[row(b, cell)][c]
+ * X [M, C] rows of the last conv's output (dtype), (ticket, slot_id) = that conv's cell -> row map (wfs_rulebook_cell_map,
+ * or wfs_event_rulebook_conv's cell_row passed as both), V = its out volume, W fp32 [O, C * V] = nn.Linear.weight as it
+ * is (channels first over the grid), Y / G fp32 [batch, O].  Cell-major kernels: a lane owns a cell, reads its weights
+ * coalesced in the parameter's own layout and walks the events through the map.  O <= 4, C % 8 == 0, C <= 64
+ * (wfs_sparse_head_ok).  dX / dW may be NULL; dB comes with dW.  defer as in wfs_gather_dw (the per-slice dW partials
+ * then join the step's deferred slab reduction).  Deterministic (no atomics, fixed orders). */
+int wfs_sparse_head_ok(int32_t batch, int64_t V, int32_t C, int32_t O, int32_t dtype);
+size_t wfs_sparse_head_workspace_bytes(int32_t batch, int64_t V, int32_t C, int32_t O);
+int wfs_sparse_head_fwd(const void *X, const uint32_t *ticket, const int32_t *slot_id, int64_t M,
+                        const int64_t *m_dev, int32_t batch, int64_t V, int32_t C, const float *W,
+                        const float *bias, int32_t O, float *Y, int32_t dtype, void *workspace,
+                        size_t workspace_bytes, void *stream);
+int wfs_sparse_head_bwd(const void *X, const float *G, const uint32_t *ticket, const int32_t *slot_id,
+                        int64_t M, const int64_t *m_dev, int32_t batch, int64_t V, int32_t C, const float *W,
+                        int32_t O, void *dX, float *dW, float *dB, int32_t dtype, void *workspace,
+                        size_t workspace_bytes, wfs_dw_job *defer, void *stream);
+
 /* classification head -----------------------------------------------------------------------
  * The reference flattens ToDense's output and applies the LinearBlock (src/models/SPConvNet.py:67-68,
  * src/models/ConvBlocks.py:82-102); the final nn.Linear has n_type = 2..4 outputs over tens of

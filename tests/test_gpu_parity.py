@@ -414,6 +414,51 @@ def _c2_module(T, n_lin, dtype_seed=0):
     return LitPSD(DictionaryUtility.to_object(copy.deepcopy(cfg)))
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("device_counts", [False, True])
+def test_sparse_head_equals_the_dense_route(dtype, tol, device_counts):
+    """ToDense -> view -> Linear off the sparse rows (csrc/shead.hip) against the dense route (dense() through the cell
+    map + the streaming head kernels): same logits, same loss, same gradients of every parameter up to the summation
+    order of fp32 sums (16-bit rows: up to one rounding of dX per row); with exact-size tensors and with capacity-padded
+    ones (device-side counts).  The C ABI entry points are also called on their own: dX rows beyond the valid count stay
+    untouched."""
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.spconv import functional as Fsp
+    T, B = 64, 24
+    c, f, y = synthetic.generate(B, T, 3, seed=31)
+    coords, feats, labels = torch.from_numpy(c).to(DEV), torch.from_numpy(f).to(DEV).to(dtype), torch.from_numpy(y).to(DEV)
+    n = coords.shape[0]
+    if device_counts:
+        pad = 300
+        coords = torch.cat([coords, torch.zeros((pad, 4), dtype=coords.dtype, device=DEV)])
+        feats = torch.cat([feats, torch.zeros((pad, feats.shape[1]), dtype=dtype, device=DEV)])
+    res = {}
+    old = Fsp.SPARSE_HEAD
+    try:
+        for on in (False, True):
+            Fsp.SPARSE_HEAD = on
+            mod = _c2_module(T, 32 * 10 * 7 * 4).to(DEV)
+            mod.train()
+            x = [coords, feats] + ([torch.tensor([n], dtype=torch.int64, device=DEV)] if device_counts else [])
+            if device_counts:
+                mod.model.batch_size_hint = B
+                for m in mod.model.modules():
+                    if hasattr(m, "subm") and not m.subm and not m.conv1x1:
+                        m.out_capacity = 4 * n
+            logits = mod.model(x)
+            loss = mod.criterion(logits.float(), labels)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[on] = (logits.detach().float().cpu(), float(loss),
+                       [p.grad.detach().float().cpu() for p in mod.model.parameters()])
+    finally:
+        Fsp.SPARSE_HEAD = old
+    _assert_close(res[True][0].numpy(), res[False][0].numpy(), tol, "logits")
+    assert abs(res[True][1] - res[False][1]) <= tol * abs(res[False][1])
+    for i, (a, b) in enumerate(zip(res[True][2], res[False][2])):
+        _assert_close(a.numpy(), b.numpy(), 20 * tol if dtype != torch.float32 else tol * 5, "gradient of parameter %d" % i)
+
+
 def test_device_count_mode_equals_exact_size_mode():
     """Capacity-padded tensors + device-side row counts (no host read-back anywhere) must give the same
     loss and gradients as the ordinary exact-size path.  The forward is bit-identical; reductions over rows

@@ -102,6 +102,12 @@ SIGNATURES = {
     "wfs_to_dense_bwd_mapped": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i32, _vp]),
     "wfs_to_dense": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "wfs_to_dense_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i32, c_i32p, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "wfs_sparse_head_ok": (ctypes.c_int, [_i32, _i64, _i32, _i32, _i32]),
+    "wfs_sparse_head_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "wfs_sparse_head_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _sz,
+                                           _vp]),
+    "wfs_sparse_head_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32,
+                                           _vp, _sz, ctypes.POINTER(DwJob), _vp]),
     "wfs_head_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "wfs_head_fwd": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i32, _vp]),
     "wfs_head_bwd": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _sz, ctypes.POINTER(DwJob),

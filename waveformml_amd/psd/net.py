@@ -108,7 +108,16 @@ class SPConvNet(nn.Module):
         if ev is not None and ev[0] is coords and handed is not None and handed[0] is coords:
             st.events = ev[1]                     # first row of every event: what the event-local rulebook build starts from
         fsp = getattr(self.spconv, "functional", None)
-        out = self.sparseModel(st)
+        if fsp is not None and hasattr(fsp, "sparse_head") and hasattr(self.sparseModel, "run"):
+            # ToDense -> view -> Linear off the sparse rows (csrc/shead.hip) when the tail has that shape
+            layers = list(self.linear)
+            out = self.sparseModel.run(st, list(self.sparseModel._modules.values()), stop_before_dense=True)
+            if hasattr(out, "features") and hasattr(out, "dense"):
+                if fsp.can_use_sparse_head(out, layers):
+                    return fsp.sparse_head(out, layers[0])
+                out = out.dense()
+        else:
+            out = self.sparseModel(st)
         out = out.view(-1, self.n_linear)
         if fsp is not None and hasattr(fsp, "head_forward"):
             return fsp.head_forward(out, self.linear)         # per layer: streaming / matrix-core HIP kernels or torch

@@ -680,6 +680,86 @@ class SkinnyLinearFunction(Function):
         return dx, (dw.to(weight.dtype) if dw is not None else None), (db.to(bias.dtype) if db is not None else None)
 
 
+class SparseHeadFunction(Function):
+    """ToDense -> view(-1, n_linear) -> nn.Linear(n_linear, n_type) straight off the sparse rows (csrc/shead.hip;
+    include/wfsparse.h wfs_sparse_head_fwd): features [M, C] of the last conv, its cell -> row map, fp32 weight
+    [O, C * V] / bias [O] of the Linear -> logits [batch, O] fp32.  The dense [batch, C, *spatial] tensor never exists
+    (reference src/models/SPConvNet.py:65-68)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, cell_map, batch_size, m_dev):
+        lib = _lib.load()
+        features = _features_ok(features)
+        M, C = features.shape
+        ticket, slot, _keep, V = cell_map
+        O = int(weight.shape[0])
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty((int(batch_size), O), dtype=torch.float32, device=features.device)
+        ws = torch.empty((int(lib.wfs_sparse_head_workspace_bytes(int(batch_size), V, C, O)),), dtype=torch.uint8,
+                         device=features.device)
+        _lib.check(lib.wfs_sparse_head_fwd(_lib.ptr(features), ticket, slot, M, _lib.ptr(m_dev), int(batch_size), V, C,
+                                           _lib.ptr(w), _lib.ptr(b), O, _lib.ptr(y), _lib.dtype_code(features),
+                                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        ctx.save_for_backward(features, weight, bias)
+        ctx.cell_map, ctx.batch_size, ctx.m_dev = cell_map, int(batch_size), m_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lib = _lib.load()
+        features, weight, bias = ctx.saved_tensors
+        M, C = features.shape
+        ticket, slot, _keep, V = ctx.cell_map
+        O = int(weight.shape[0])
+        g = grad_output.float().contiguous()
+        w = weight.detach().float().contiguous()
+        dx = _rows((M, C), features, ctx.m_dev) if ctx.needs_input_grad[0] else None
+        dw = grad_like(weight, (O, C * V)) if ctx.needs_input_grad[1] else None
+        want_db = bias is not None and ctx.needs_input_grad[2]
+        db = grad_like(bias, (O,)) if (want_db and dw is not None) else None
+        ws = torch.empty((int(lib.wfs_sparse_head_workspace_bytes(ctx.batch_size, V, C, O)),), dtype=torch.uint8,
+                         device=features.device)
+        defer = _DEFERRED_DW is not None and dw is not None and dw._base is not None
+        job = _lib.DwJob() if defer else None
+        _lib.check(lib.wfs_sparse_head_bwd(_lib.ptr(features), _lib.ptr(g), ticket, slot, M, _lib.ptr(ctx.m_dev),
+                                           ctx.batch_size, V, C, _lib.ptr(w), O, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                           _lib.dtype_code(features), _lib.ptr(ws), ws.numel(),
+                                           ctypes.byref(job) if defer else None, _lib.stream_ptr()))
+        if defer and job.nslabs > 0:
+            _DEFERRED_DW.append((job, ws))          # the sum over the per-slice dW partials joins the deferred reductions
+        if want_db and db is None:
+            db = g.sum(0)
+        return (dx, (dw.to(weight.dtype) if dw is not None else None), (db.to(bias.dtype) if db is not None else None),
+                None, None, None)
+
+
+# WFS_SPARSE_HEAD=0: the dense route (dense() + the streaming head kernels)
+SPARSE_HEAD = __import__("os").environ.get("WFS_SPARSE_HEAD", "1") != "0"
+
+
+def can_use_sparse_head(x, layers):
+    """x: the SparseConvTensor in front of a trailing ToDense; layers: the Linear stack behind the flatten."""
+    if not SPARSE_HEAD or len(layers) != 1 or type(layers[0]) is not torch.nn.Linear:
+        return False
+    lin, f = layers[0], x.features
+    cm = getattr(x, "cell_map", None)
+    if cm is None or not f.is_cuda or f.dim() != 2 or f.shape[0] == 0 or lin.weight.dtype != torch.float32:
+        return False
+    if not (x.unique is True or x.n_valid is not None):
+        return False
+    V = 1
+    for s_ in x.spatial_shape:
+        V *= int(s_)
+    C = int(f.shape[1])
+    return bool(cm[3] == V and lin.in_features == C * V and f.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                and _lib.load().wfs_sparse_head_ok(int(x.batch_size), V, C, int(lin.out_features), _lib.dtype_code(f)))
+
+
+def sparse_head(x, linear):
+    return SparseHeadFunction.apply(x.features, linear.weight, linear.bias, x.cell_map, x.batch_size, x.n_valid)
+
+
 def can_use_skinny_linear(linear, x):
     # long rows (I % 8 == 0, >= 1024: streamed) or short ones of any length (<= 4096: scalar kernels)
     return (type(linear) is torch.nn.Linear and x.is_cuda and x.dim() == 2 and linear.out_features <= 8

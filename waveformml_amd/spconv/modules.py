@@ -129,9 +129,10 @@ class SparseSequential(SparseModule):
     def forward(self, input):
         return self.run(input, list(self._modules.values()))
 
-    def run(self, input, mods):
-        """``forward`` over an explicit module list (a prefix of this container's modules: psd/net.py stops before a
-        trailing ToDense when the head can consume the sparse rows directly)."""
+    def run(self, input, mods, stop_before_dense=False):
+        """``forward`` over an explicit module list.  ``stop_before_dense``: a TRAILING ToDense is not applied -- the
+        SparseConvTensor in front of it is returned (psd/net.py hands it to the sparse head, functional.sparse_head),
+        while the layers still see that a ToDense follows (the last conv's build leaves its cell -> row map)."""
         from . import functional as Fsp
         from . import ops
         want_prefetch = (ops.PREFETCH_RULEBOOKS and _is_sparse_tensor(input) and input.n_valid is not None
@@ -139,6 +140,8 @@ class SparseSequential(SparseModule):
         i = 0
         while i < len(mods):
             module = mods[i]
+            if stop_before_dense and i == len(mods) - 1 and isinstance(module, ToDense) and _is_sparse_tensor(input):
+                break
             if isinstance(module, SparseModule):
                 if (ops.FUSE_CONV_BN_STATS and _is_sparse_tensor(input) and i + 1 < len(mods)
                         and isinstance(mods[i + 1], nn.BatchNorm1d)
