@@ -341,6 +341,18 @@ int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int32_t K, int
                   int32_t swap, float *dW, int32_t dtype, void *workspace, size_t workspace_bytes,
                   const int64_t *r_dev, wfs_dw_job *defer, int32_t packed_kl, void *stream);
 
+/* torch.ops.spconv.indice_conv_backward as ONE call (round 4): dW[k] = X^T . dY[table[k]] (as wfs_gather_dw with
+ * swap == 0) and dX = sum_k dY[table[k]] . W[k]^T (as wfs_gather_conv with transpose_w), both through the by-input
+ * table of a conv / SubM layer (dense [K, R] or packed, packed_kl as above).  X [R, Cin] = the layer's input rows, dY
+ * [dY_rows, Cout], W fp32 [K, Cin, Cout], dX [R, Cin], dW fp32 [K, Cin, Cout].  For 32 -> 32 layers with 16-bit rows
+ * both products run in ONE launch (independent blocks of one grid: the second product no longer waits for the first
+ * one's last block, and a kernel boundary of ~4.6 us inside a captured step goes); other shapes run the two entry
+ * points one after the other.  Results are bit-identical to the separate calls.  workspace / defer as wfs_gather_dw. */
+int wfs_conv_backward(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X, const void *dY,
+                      int64_t dY_rows, int32_t Cin, int32_t Cout, const float *W, void *dX, float *dW, int32_t dtype,
+                      void *workspace, size_t workspace_bytes, const int64_t *r_dev, wfs_dw_job *defer,
+                      int32_t packed_kl, void *stream);
+
 /* Second stage of up to 16 deferred wfs_gather_dw calls in one launch (deterministic: fixed summation order). */
 int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream);
 

@@ -406,6 +406,42 @@ def test_packed_table_products_equal_the_dense_table_products(dtype):
     assert float(dx_d[:nvv].float().abs().max()) > 0 and float(dw_d.abs().max()) > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("device_counts", [False, True])
+def test_one_launch_conv_backward_equals_the_two_products(dtype, device_counts):
+    """wfs_conv_backward (dW and dX of a 32 -> 32 layer in ONE launch, conv_mfma.hip k_bwd32_bf16) against wfs_gather_dw +
+    wfs_gather_conv: the same bodies on the same tables -> bit-identical, for a SubM table (centre offset = the row
+    itself), a strided layer's dense table and its packed [9, N] table."""
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.spconv import functional as Fsp
+    from waveformml_amd.spconv import ops
+    B, T = 64, 128
+    c, _f, _y = synthetic.generate(B, T, 3, seed=9)
+    idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(DEV)
+    N = idx.shape[0]
+    nv = torch.tensor([N - 33], dtype=torch.int64, device=DEV) if device_counts else None
+    g = torch.Generator(device=DEV).manual_seed(2)
+    W = torch.randn((27, 32, 32), device=DEV, generator=g)
+    X = torch.randn((N, 32), device=DEV, generator=g).to(dtype)
+    sub = ops.build_rulebook(idx, B, [14, 11, T], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True, n_dev=nv)
+    con = ops.build_rulebook(idx, B, [14, 11, T], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, known_unique=True,
+                             n_dev=nv, out_capacity=2 * N if device_counts else None)
+    cases = [("subm", sub.nbr_out, 0, sub.centre_k, N)]
+    cases.append(("conv dense", con.nbr_out, 0, -1, con.M))
+    if con.nbr_out_packed is not None:
+        cases.append(("conv packed", con.nbr_out_packed, con.packed_kl, -1, con.M))
+    for name, table, pk, ident, rows_out in cases:
+        dY = torch.randn((rows_out, 32), device=DEV, generator=g).to(dtype)
+        dx1 = Fsp.gather_conv(table, None, 27, ident, N, dY, W, True, None, nv, None, None, pk)
+        dw1 = Fsp.gather_dw(table, 27, ident, N, X, dY, False, None, nv, False, None, pk)
+        dx2, dw2 = Fsp.conv_backward(table, 27, ident, N, X, dY, W, nv, None, pk)
+        torch.cuda.synchronize()
+        nvv = int(nv) if nv is not None else N
+        assert torch.equal(dx1[:nvv], dx2[:nvv]), name
+        assert torch.equal(dw1, dw2), name
+        assert float(dw1.abs().max()) > 0 and float(dx1[:nvv].float().abs().max()) > 0
+
+
 def test_event_local_conv_build_flags_an_ungrouped_batch_and_leaves_benign_tables():
     """A batch that is not grouped by event: flag [0] is set, the outputs are empty (m_dev = 0) and every by-input table
     entry the consumers can reach says "none" -- a captured step then computes garbage-free zeros until check() raises."""

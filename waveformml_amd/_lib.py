@@ -87,6 +87,8 @@ SIGNATURES = {
     "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "wfs_gather_dw": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
                                      _sz, _vp, ctypes.POINTER(DwJob), _i32, _vp]),
+    "wfs_conv_backward": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _sz,
+                                         _vp, ctypes.POINTER(DwJob), _i32, _vp]),
     "wfs_dw_reduce_jobs": (ctypes.c_int, [ctypes.POINTER(DwJob), _i32, _vp]),
     "wfs_scatter_conv": (ctypes.c_int, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "wfs_bn_workspace_bytes": (_sz, [_i64, _i32]),

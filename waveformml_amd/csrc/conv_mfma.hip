@@ -457,20 +457,19 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 #ifndef WFS_KNOCK
 #define WFS_KNOCK 0
 #endif
+// (the body is a device function so that the backward pass can run it beside the dW kernel's body in ONE launch:
+// k_bwd32_bf16 below; vbid / vgrid = this product's block index and block count, nthreads = its threads)
 template <typename H, bool TRANSPOSE_W, bool STATS, int PK = 0>
-__global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
-                                                       int identity_k,
-                                                       long long R, const long long *__restrict__ r_dev,
-                                                       const H *__restrict__ X,
-                                                       const float *__restrict__ W, const float *__restrict__ bias,
-                                                       H *__restrict__ Y, long long ntiles,
-                                                       long long tiles_per_xcd, WfsStatsArgs sa) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void gconv32_bf16_body(unsigned char *smem, int vbid, int vgrid, int nthreads,
+                                                  const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                  long long R, const long long *__restrict__ r_dev,
+                                                  const H *__restrict__ X, const float *__restrict__ W,
+                                                  const float *__restrict__ bias, H *__restrict__ Y, long long ntiles,
+                                                  long long tiles_per_xcd, WfsStatsArgs sa) {
     __shared__ float sStat[STATS ? 16 * 65 : 1];
     WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     uint4 *sWb = reinterpret_cast<uint4 *>(smem);                           // K * 128 fragments of 16 B
     int *sNb = reinterpret_cast<int *>(smem + (size_t)K * 2048);            // [waves][K][32]
-    const int nthreads = blockDim.x;
     // filter staging, WSB fragments per thread at a time: all their loads are issued (unconditionally, clamped)
     // before the first conversion, so a block pays one memory round trip per batch instead of one per fragment
     constexpr int WSB = 5;
@@ -507,11 +506,11 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = nthreads >> 6;
     const int r = lane & 31, h = lane >> 5;
     int *myNb = sNb + (size_t)wid * K * 32;
     // tile ranges per XCD cut from the VALID tiles (see k_gconv32_f32): the padding of a captured step costs nothing
-    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int xcd = vbid & 7, bi = vbid >> 3, bpx = vgrid >> 3;
     const long long Rv = valid_rows(R, r_dev);
     const long long nt_v = (Rv + 31) >> 5, tpx_v = (nt_v + 7) >> 3;
     (void)ntiles;
@@ -616,6 +615,19 @@ __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ t
         }
     }
     if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
+}
+
+template <typename H, bool TRANSPOSE_W, bool STATS, int PK = 0>
+__global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
+                                                       int identity_k,
+                                                       long long R, const long long *__restrict__ r_dev,
+                                                       const H *__restrict__ X,
+                                                       const float *__restrict__ W, const float *__restrict__ bias,
+                                                       H *__restrict__ Y, long long ntiles,
+                                                       long long tiles_per_xcd, WfsStatsArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gconv32_bf16_body<H, TRANSPOSE_W, STATS, PK>(smem, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, table, mirror, K,
+                                                 identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
 }
 
 // ------------------------------------------------------------------------------------------ 2 -> 32
@@ -952,22 +964,25 @@ __device__ __forceinline__ bf16x8 lds_column_frag(const unsigned short *tile, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
+constexpr int DWB_LDS = DWB_WAVES * 2 * 32 * 32 * 2;          // per wave: S tile, G tile (64 KiB)
+// (body as a device function: see gconv32_bf16_body; bx / by / nbx = the block's coordinates in this product's grid)
 template <typename H>
-__global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int pk, int K, int identity_k,
-                                                     long long Rcap, const long long *__restrict__ r_dev,
-                                                     const H *__restrict__ S, const H *__restrict__ G,
-                                                     float *__restrict__ part, int ngroups, long long tiles_per_block) {
-    __shared__ __attribute__((aligned(16))) unsigned short sTiles[DWB_WAVES][2][32 * 32];   // per wave: S tile, G tile
+__device__ __forceinline__ void gdw32_bf16_body(unsigned char *smem, int bx, int by, int nbx,
+                                                const int *__restrict__ table, int pk, int K, int identity_k,
+                                                long long Rcap, const long long *__restrict__ r_dev,
+                                                const H *__restrict__ S, const H *__restrict__ G,
+                                                float *__restrict__ part, int ngroups) {
+    unsigned short(*sTiles)[2][32 * 32] = reinterpret_cast<unsigned short(*)[2][32 * 32]>(smem);   // [DWB_WAVES][2][1024]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;          // fragment coordinates
     const int grow = lane >> 2, gchunk = lane & 3;   // staging coordinates: rows grow and grow+16, 16-B chunk gchunk
     unsigned short *sS = sTiles[wid][0], *sG = sTiles[wid][1];
-    const int g = blockIdx.y;
+    const int g = by;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
-    (void)tiles_per_block;                                   // cut from the capacity: the valid tiles are shared out instead
-    const long long tpb = (ntiles + gridDim.x - 1) / gridDim.x;
-    const long long t_begin = (long long)blockIdx.x * tpb;
+    // cut from the VALID tiles (not the capacity): the padding of a captured step costs nothing
+    const long long tpb = (ntiles + nbx - 1) / nbx;
+    const long long t_begin = (long long)bx * tpb;
     const long long t_end = t_begin + tpb < ntiles ? t_begin + tpb : ntiles;
     f32x16 acc[DWB_KG];
 #pragma unroll
@@ -1049,8 +1064,44 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
 #pragma unroll
         for (int w = 0; w < DWB_WAVES; ++w) v += sRed[w * 1024 + threadIdx.x];
         const int k = g + q * ngroups;
-        if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + threadIdx.x] = v;
+        if (k < K) part[((long long)bx * K + k) * 1024 + threadIdx.x] = v;
         __syncthreads();
+    }
+}
+
+template <typename H>
+__global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ table, int pk, int K, int identity_k,
+                                                     long long Rcap, const long long *__restrict__ r_dev,
+                                                     const H *__restrict__ S, const H *__restrict__ G,
+                                                     float *__restrict__ part, int ngroups, long long tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    (void)tiles_per_block;
+    gdw32_bf16_body<H>(smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, table, pk, K, identity_k, Rcap, r_dev, S, G,
+                       part, ngroups);
+}
+
+// dW and dX of a 32 -> 32 layer in ONE launch (round 4): both gather dY through the same by-input table and neither
+// reads what the other writes, but as two launches the second waits for the first one's last block and pays a kernel
+// boundary of its own (~4.6 us inside a captured step, as much as its bytes).  Blocks [0, n_dw) run the dW body --
+// grid (nbx_dw, ngroups), rounded up to a multiple of 8 blocks so that the dX blocks keep their XCD (block % 8) -- the
+// rest the dX body: same arithmetic, same summation orders, bit-identical results.
+template <typename H, int PK>
+__global__ void __launch_bounds__(1024) k_bwd32_bf16(const int *__restrict__ table, int K, int identity_k, long long Rcap,
+                                                     const long long *__restrict__ r_dev, const H *__restrict__ S,
+                                                     const H *__restrict__ G, const float *__restrict__ W,
+                                                     H *__restrict__ dX, float *__restrict__ part, int ngroups,
+                                                     int nbx_dw, int n_dw_pad, int n_dx, int dx_threads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = (int)blockIdx.x;
+    if (bid < n_dw_pad) {
+        if (bid >= nbx_dw * ngroups) return;
+        gdw32_bf16_body<H>(smem, bid % nbx_dw, bid / nbx_dw, nbx_dw, table, PK, K, identity_k, Rcap, r_dev, S, G, part,
+                           ngroups);
+    } else {
+        if ((int)threadIdx.x >= dx_threads) return;          // the dX body was tuned for fewer waves per block
+        const WfsStatsArgs none = {};
+        gconv32_bf16_body<H, true, false, PK>(smem, bid - n_dw_pad, n_dx, dx_threads, table, 0, K, identity_k, Rcap, r_dev, G,
+                                              W, nullptr, dX, 0, 0, none);
     }
 }
 
@@ -1584,14 +1635,72 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
     const dim3 grid((unsigned)nblk, (unsigned)ngroups);
-#define WFS_DW32(KERNEL, T, THREADS)                                                                                  \
-    KERNEL<T><<<grid, dim3(THREADS), 0, stream>>>(table, packed_kl, K, identity_k, R, r_dev, (const T *)S, (const T *)G, part, \
-                                                  ngroups, tiles_per_block);
-    if (dtype == WFS_F32) WFS_DW32(k_gdw32, float, 512)
-    else if (dtype == WFS_BF16) WFS_DW32(k_gdw32_bf16, wfs_bf16, 1024)
-    else WFS_DW32(k_gdw32_bf16, wfs_f16, 1024)
-#undef WFS_DW32
+    if (dtype == WFS_F32) {
+        k_gdw32<float><<<grid, dim3(512), 0, stream>>>(table, packed_kl, K, identity_k, R, r_dev, (const float *)S,
+                                                       (const float *)G, part, ngroups, tiles_per_block);
+        WFS_LAUNCH_CHECK();
+    } else if (dtype == WFS_BF16) {
+        static bool attr = false;
+        const int rc = launch_big_lds(k_gdw32_bf16<wfs_bf16>, &attr, grid, dim3(1024), DWB_LDS, stream, table, packed_kl, K,
+                                      identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G, part, ngroups,
+                                      tiles_per_block);
+        if (rc != WFS_OK) return rc;
+    } else {
+        static bool attr = false;
+        const int rc = launch_big_lds(k_gdw32_bf16<wfs_f16>, &attr, grid, dim3(1024), DWB_LDS, stream, table, packed_kl, K,
+                                      identity_k, R, r_dev, (const wfs_f16 *)S, (const wfs_f16 *)G, part, ngroups,
+                                      tiles_per_block);
+        if (rc != WFS_OK) return rc;
+    }
+    const long long per = (long long)K * 1024;
+    if (defer) {
+        *defer = wfs_dw_job{part, nblk, per, K, 32, 32, swap, dW};
+        return WFS_OK;
+    }
+    k_slab_reduce<<<dim3((unsigned)((per + 31) / 32)), dim3(nblk > 64 ? 1024 : 256), 0, stream>>>(part, nblk, per, K, 32, 32, swap, dW);
     WFS_LAUNCH_CHECK();
+    return WFS_OK;
+}
+
+// dW and dX of a 32 -> 32 layer with 16-bit rows in one launch (k_bwd32_bf16)
+template <typename H>
+static int launch_bwd32_h16(const int *table, int packed_kl, int K, int identity_k, long long R, const long long *r_dev,
+                            const H *S, const H *G, const float *W, H *dX, float *part, hipStream_t stream) {
+    const long long nbx_dw = dw32_blocks(R, false);
+    const int ngroups = (K + DWB_KG - 1) / DWB_KG;
+    const long long n_dw = nbx_dw * ngroups, n_dw_pad = (n_dw + 7) / 8 * 8;
+    long long ntiles, n_dx, tiles_per_xcd;
+    int wpb;
+    gconv32_grid(R, r_dev != nullptr, &ntiles, &wpb, &n_dx, &tiles_per_xcd, 16);
+    size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
+    if (lds < (size_t)DWB_LDS) lds = DWB_LDS;
+    const dim3 grid((unsigned)(n_dw_pad + n_dx)), block(1024);
+    if (packed_kl) {
+        static bool attr = false;
+        return launch_big_lds(k_bwd32_bf16<H, 3>, &attr, grid, block, lds, stream, table, K, identity_k, R, r_dev, S, G, W, dX,
+                              part, ngroups, (int)nbx_dw, (int)n_dw_pad, (int)n_dx, wpb * 64);
+    }
+    static bool attr0 = false;
+    return launch_big_lds(k_bwd32_bf16<H, 0>, &attr0, grid, block, lds, stream, table, K, identity_k, R, r_dev, S, G, W, dX,
+                          part, ngroups, (int)nbx_dw, (int)n_dw_pad, (int)n_dx, wpb * 64);
+}
+
+bool wfs_bwd32_fused_ok(int K, int packed_kl, int dtype) {
+    return (dtype == WFS_BF16 || dtype == WFS_F16) && K >= 1 && K <= 27 && (packed_kl == 0 || (packed_kl == 3 && K % 3 == 0));
+}
+
+int wfs_launch_bwd32_h16(const int *table, int packed_kl, int K, int identity_k, long long R, const long long *r_dev,
+                         const void *S, const void *G, const float *W, void *dX, int swap, float *dW, float *part, int dtype,
+                         wfs_dw_job *defer, hipStream_t stream) {
+    int rc;
+    if (dtype == WFS_F16)
+        rc = launch_bwd32_h16<wfs_f16>(table, packed_kl, K, identity_k, R, r_dev, (const wfs_f16 *)S, (const wfs_f16 *)G, W,
+                                       (wfs_f16 *)dX, part, stream);
+    else
+        rc = launch_bwd32_h16<wfs_bf16>(table, packed_kl, K, identity_k, R, r_dev, (const wfs_bf16 *)S, (const wfs_bf16 *)G,
+                                        W, (wfs_bf16 *)dX, part, stream);
+    if (rc != WFS_OK) return rc;
+    const long long nblk = dw32_blocks(R, false);
     const long long per = (long long)K * 1024;
     if (defer) {
         *defer = wfs_dw_job{part, nblk, per, K, 32, 32, swap, dW};

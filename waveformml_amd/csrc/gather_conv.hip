@@ -652,6 +652,34 @@ extern "C" int wfs_gather_dw(const int32_t *table, const int32_t *kmap_host, int
                           workspace_bytes, r_dev, defer, stream, packed_kl);
 }
 
+// torch.ops.spconv.indice_conv_backward as ONE call: dW (as wfs_gather_dw, swap == 0) and dX (as wfs_gather_conv with
+// transpose_w) of a conv / SubM layer, both through the by-input table.  32 -> 32 layers with 16-bit rows run both
+// products in one launch (conv_mfma.hip k_bwd32_bf16); every other shape runs the two entry points one after the other.
+extern "C" int wfs_conv_backward(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X,
+                                 const void *dY, int64_t dY_rows, int32_t Cin, int32_t Cout, const float *W, void *dX,
+                                 float *dW, int32_t dtype, void *workspace, size_t workspace_bytes, const int64_t *r_dev,
+                                 wfs_dw_job *defer, int32_t packed_kl, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    WFS_REQUIRE(dX && dW, WFS_EINVAL, "wfs_conv_backward computes both gradients (use wfs_gather_conv / wfs_gather_dw for one)");
+    const bool fused = Cin == 32 && Cout == 32 && table && wfs_bwd32_fused_ok(K, packed_kl, dtype) && R > 0 &&
+                       R < (1ll << 25) && dY_rows < (1ll << 25) && (packed_kl == 0 || identity_k < 0);
+    if (!fused) {
+        int rc = gather_dw_impl(table, nullptr, K, identity_k, R, X, Cin, dY, dY_rows, Cout, 0, dW, dtype, workspace,
+                                workspace_bytes, r_dev, defer, stream_, packed_kl);
+        if (rc != WFS_OK) return rc;
+        bool unused;
+        return gather_conv_impl(table, nullptr, K, identity_k, R, dY, dY_rows, Cout, W, Cin, Cout, 1, nullptr, dX, dtype, r_dev,
+                                nullptr, &unused, nullptr, stream_, packed_kl);
+    }
+    WFS_REQUIRE(X && dY && W && workspace, WFS_EINVAL, "NULL device pointer");
+    const size_t need = wfs_gather_dw_workspace_bytes(K, R, Cin, Cout);
+    WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
+    if (defer) *defer = wfs_dw_job{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
+    WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
+    return wfs_launch_bwd32_h16(table, packed_kl, K, identity_k, R, (const long long *)r_dev, X, dY, W, dX, 0, dW,
+                                (float *)workspace, dtype, defer, stream);
+}
+
 extern "C" int wfs_dw_reduce_jobs(const wfs_dw_job *jobs, int32_t n, void *stream) {
     WFS_REQUIRE(n >= 0 && n <= 16 && (n == 0 || jobs), WFS_EINVAL, "%d jobs (0 .. 16)", n);
     wfs_dw_job live[16];

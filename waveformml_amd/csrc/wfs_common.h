@@ -131,6 +131,11 @@ size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg);
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
                      const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream,
                      int packed_kl = 0);
+// dW and dX of a 32 -> 32 layer with 16-bit rows in ONE launch (conv_mfma.hip k_bwd32_bf16)
+bool wfs_bwd32_fused_ok(int K, int packed_kl, int dtype);
+int wfs_launch_bwd32_h16(const int *table, int packed_kl, int K, int identity_k, long long R, const long long *r_dev,
+                         const void *S, const void *G, const float *W, void *dX, int swap, float *dW, float *part, int dtype,
+                         wfs_dw_job *defer, hipStream_t stream);
 int wfs_launch_gdw_c32c2(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                          const void *S, const void *G, int swap, float *dW, float *part, int dtype,
                          wfs_dw_job *defer, hipStream_t stream);

@@ -357,6 +357,37 @@ def gather_dw(table, K, identity_k, R, S, G, swap, kmap=None, r_dev=None, overla
     return dW
 
 
+def conv_backward(table, K, identity_k, R, X, dY, W, r_dev=None, like=None, packed_kl=0):
+    """(dX, dW) of a conv / SubM layer in one call (include/wfsparse.h wfs_conv_backward): 32 -> 32 layers with 16-bit
+    rows run both products in ONE launch.  ``like``: the filter parameter (its gradient goes straight into its slot of a
+    registered flat gradient buffer, the slab reduction joins the step's deferred ones)."""
+    lib = _lib.load()
+    Cin, Cout = int(X.shape[1]), int(dY.shape[1])
+    if like is not None and like.numel() == K * Cin * Cout:
+        dW = grad_like(like, (K, Cin, Cout))
+        in_slot = dW._base is not None
+    else:
+        dW, in_slot = torch.empty((K, Cin, Cout), dtype=torch.float32, device=X.device), False
+    dX = _rows((R, Cin), dY, r_dev)
+    ws = torch.empty((max(int(lib.wfs_gather_dw_workspace_bytes(K, R, Cin, Cout)), 1),), dtype=torch.uint8, device=X.device)
+    defer = _DEFERRED_DW is not None and in_slot
+    job = _lib.DwJob() if defer else None
+    _lib.check(lib.wfs_conv_backward(_lib.ptr(table), K, identity_k, R, _lib.ptr(X), _lib.ptr(dY), dY.shape[0], Cin, Cout,
+                                     _lib.ptr(W), _lib.ptr(dX), _lib.ptr(dW), _lib.dtype_code(X), _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(r_dev), ctypes.byref(job) if defer else None, packed_kl, _lib.stream_ptr()))
+    if defer and job.nslabs > 0:
+        _DEFERRED_DW.append((job, ws))
+    if ACCOUNT is not None:
+        dense = (table >> 3).clamp_(min=-1) if packed_kl else table
+        _account("gather_dw", dense, R, R, Cin, dY.shape[0], Cout, K, Cin, Cout, X.element_size())
+        _account("gather_conv", dense, R, dY.shape[0], Cout, R, Cin, K, Cin, Cout, X.element_size())
+    return dX, dW
+
+
+# dW and dX of a 32 -> 32 layer with 16-bit rows in one launch (WFS_FUSED_CONV_BACKWARD=0: two launches)
+FUSED_CONV_BACKWARD = __import__("os").environ.get("WFS_FUSED_CONV_BACKWARD", "1") != "0"
+
+
 class SparseConvFunction(Function):
     """features [n_in, Cin], filters [*k, Cin, Cout] fp32, bias [Cout] or None -> [n_out, Cout]."""
 
@@ -406,6 +437,13 @@ class SparseConvFunction(Function):
                     dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev, None, ctx.w16)
             if ctx.needs_input_grad[1]:
                 dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev, ov, filters)
+        elif (FUSED_CONV_BACKWARD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ov and not rb.has_dup
+              and features.shape[1] == 32 and dY.shape[1] == 32 and features.dtype in (torch.bfloat16, torch.float16)
+              and features.is_cuda):
+            table, pk = rb.table_by_in(32, 32, features, 3)
+            if pk and rb.table_by_in(32, 32, dY, 1)[1] != pk:
+                table, pk = rb.nbr_out, 0
+            dX, dW = conv_backward(table, K, ident, rb.N, features, dY, W, rb.n_dev, filters, pk)
         else:
             # dW first: with OVERLAP_DW it goes to the side stream and runs beside the dX launched next
             if ctx.needs_input_grad[1]:
