@@ -34,6 +34,14 @@ namespace {
 #ifndef EC_KNOCK
 #define EC_KNOCK 0
 #endif
+// minimum waves per SIMD the build is compiled for = its register cap.  7 -> 72 registers: a 512-thread workgroup then
+// holds 2 x 72 of a SIMD's 512 registers, and what runs BESIDE the builds in a training step still fits the same SIMD --
+// the register-resident BatchNorm kernels (200 registers) and the 12-wave conv blocks (3 x 120).  Same-box A/B of the
+// captured step (tools/exp/ab_multi.sh): 1024 threads uncapped 0.4825 / 0.4884 / 0.4983 ms, 512 threads capped at 72
+// registers 0.4727 / 0.4810, at 64 registers (36 B of scratch) 0.4766 / 0.4774
+#ifndef EC_MIN_WAVES
+#define EC_MIN_WAVES 7
+#endif
 // threads per workgroup: 1024 (one row per thread for all but the largest events)
 constexpr int EC_MAXCELLS = 16384;            // output cells of one event: 4 B ticket / image + 2 B id in LDS
 constexpr int EC_FLAG_WORDS = WFS_EVENT_FLAG_WORDS;
@@ -130,7 +138,7 @@ __device__ __forceinline__ Cand<NQ> digest_row(const ECGeo &g, const int *__rest
     return c;
 }
 
-// The same enumeration without the register cache, for geometries with more slots than fit one (NQ > 16): calls
+// The same enumeration without the register cache, for geometries with more slots than fit one (NQ > 9): calls
 // f(t, cell, k) for every slot of the row that reaches an output cell, in increasing t
 template <bool PACKED, typename F>
 __device__ __forceinline__ void stream_row(const ECGeo &g, const int *__restrict__ row, bool *ok_out, F f) {
@@ -217,7 +225,7 @@ __device__ __forceinline__ int ec_block_scan(int v, int *sWave, int *total) {
 }
 
 template <bool PACKED, int NQ, int EC_THREADS>
-__global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, int img_bytes, const int *__restrict__ idx, long long N,
+__global__ void __launch_bounds__(EC_THREADS) __attribute__((amdgpu_waves_per_eu(EC_THREADS <= 512 ? EC_MIN_WAVES : 4))) k_ev_conv(ECGeo g, int img_bytes, const int *__restrict__ idx, long long N,
                                                         const long long *__restrict__ n_dev,
                                                         const int *__restrict__ ev_in, int B, long long M_cap,
                                                         int *__restrict__ out_idx, long long *__restrict__ m_dev,
@@ -258,9 +266,9 @@ __global__ void __launch_bounds__(EC_THREADS) k_ev_conv(ECGeo g, int img_bytes, 
         ticket[c] = 0xFFFFFFFFu;
         cellid[c] = 0xFFFFu;
     }
-    // CACHE (<= 16 candidate slots): this thread's first row stays digested in registers through all phases (events
+    // CACHE (<= 9 candidate slots): this thread's first row stays digested in registers through all phases (events
     // beyond EC_THREADS rows re-digest the further ones); wider geometries stream their candidates in every phase
-    constexpr bool CACHE = NQ <= 16;
+    constexpr bool CACHE = NQ <= 9;
     constexpr int NC = CACHE ? NQ : 1;
     Cand<NC> mine;
 #pragma unroll
@@ -623,24 +631,23 @@ extern "C" int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *ind
                                                        M_cap, out_indices, (long long *)m_dev, events_out, nbr_out,      \
                                                        nbr_in, cell_row, overflow_dev, flags, pub, st);                   \
     } while (0)
-    // threads per workgroup: while the events fit the chip in one round (B <= 256) the launch lasts as long as its largest
-    // event: 1024 threads = one row per thread and phase (31 vs 45 us alone at the PSD batch, 0.509 vs 0.514 ms per captured
-    // step); beyond that throughput counts: 512 threads, three workgroups to a CU (128 vs 174 us at 2048 events).
-    // WFS_EC_THREADS = 256 / 512 / 1024 overrides (experiments)
+    // threads per workgroup: 512.  Alone, at the PSD batch (one event per CU), 1024 threads are faster (31 vs 45 us: the
+    // launch lasts as long as its largest event, one row per thread and phase) -- but inside a training step the builds
+    // run on a side branch beside the first layers with time to spare, and what counts is the room they leave those
+    // layers' kernels on every CU (EC_MIN_WAVES above); beyond 256 events throughput counts: three 512-thread workgroups
+    // to a CU (128 vs 174 us at 2048 events).  WFS_EC_THREADS = 256 / 512 / 1024 overrides (experiments)
     static const int ec_forced = [] {
         const char *e = getenv("WFS_EC_THREADS");
         const int v = e ? atoi(e) : 0;
         return v == 256 || v == 512 || v == 1024 ? v : 0;
     }();
-    const int ec_threads = ec_forced ? ec_forced : (B <= 256 ? 1024 : 512);
-    if (packed && nslots <= 9 && ec_threads == 512) WFS_EC(true, 9, 512);
+    const int ec_threads = ec_forced ? ec_forced : 512;
+    if (packed && nslots <= 9 && ec_threads == 1024) WFS_EC(true, 9, 1024);
     else if (packed && nslots <= 9 && ec_threads == 256) WFS_EC(true, 9, 256);
-    else if (packed && nslots <= 9) WFS_EC(true, 9, 1024);
-    else if (packed && nslots <= 16) WFS_EC(true, 16, 1024);
-    else if (packed) WFS_EC(true, 32, 1024);
-    else if (nslots <= 9) WFS_EC(false, 9, 1024);
-    else if (nslots <= 16) WFS_EC(false, 16, 1024);
-    else WFS_EC(false, 32, 1024);
+    else if (packed && nslots <= 9) WFS_EC(true, 9, 512);
+    else if (packed) WFS_EC(true, 32, 512);
+    else if (nslots <= 9) WFS_EC(false, 9, 512);
+    else WFS_EC(false, 32, 512);
 #undef WFS_EC
     WFS_LAUNCH_CHECK();
     return WFS_OK;
