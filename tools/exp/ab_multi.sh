@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 for round in 1 2; do
   for setting in "$@"; do
-    env $setting python bench.py --cpu-steps 0 --no-roofline --steps 200 --warmup 10 2>/dev/null | python -c "
+    env $setting python bench.py --cpu-steps 0 --no-roofline --steps 200 --warmup 10 $BENCH_ARGS 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

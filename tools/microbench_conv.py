@@ -1,5 +1,5 @@
 """Micro-benchmark of the conv kernels on the bench workload's layers (run on the GPU box).
-usage: python tools/microbench_conv.py [iters]"""
+usage: python tools/microbench_conv.py [iters] [f32|bf16] [events] [samples]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,12 +9,13 @@ from waveformml_amd.spconv import ops, functional as Fsp
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 DT = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 NB = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+TS = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 dev = torch.device("cuda:0")
-c, f, y = synthetic.generate(NB, 256, 3, seed=1234)
+c, f, y = synthetic.generate(NB, TS, 3, seed=1234)
 torch.cuda.set_stream(torch.cuda.Stream())
 idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(dev)
-rb = ops.build_rulebook(idx, NB, [14, 11, 256], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True)
-rb1 = ops.build_rulebook(idx, NB, [14, 11, 256], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, known_unique=True)
+rb = ops.build_rulebook(idx, NB, [14, 11, TS], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True)
+rb1 = ops.build_rulebook(idx, NB, [14, 11, TS], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, known_unique=True)
 N, M1 = rb.N, rb1.M
 X = torch.randn(N, 32, device=dev).to(DT)
 dY = torch.randn(N, 32, device=dev).to(DT)
@@ -66,8 +67,8 @@ timeit("conv s4 dW", lambda: Fsp.gather_dw(rb1.nbr_out, 27, -1, N, X, dY1, False
 timeit("subm fwd 2->32", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X2, W2, False, None), N * 136 + P * 8)
 timeit("subm dW 32x2 (dY stationary)", lambda: Fsp.gather_dw(t, 27, rb.centre_k, N, dY, X2, True, km), N * 34 * ES + P * 8)
 nv = torch.tensor([N], dtype=torch.int64, device=dev)
-timeit("rulebook subm (device counts)", lambda: ops.build_rulebook(idx, NB, [14, 11, 256], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True, n_dev=nv))
-timeit("rulebook conv s4 (device counts)", lambda: ops.build_rulebook(idx, NB, [14, 11, 256], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, n_dev=nv, out_capacity=int(M1 * 1.25)))
+timeit("rulebook subm (device counts)", lambda: ops.build_rulebook(idx, NB, [14, 11, TS], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True, n_dev=nv))
+timeit("rulebook conv s4 (device counts)", lambda: ops.build_rulebook(idx, NB, [14, 11, TS], [3] * 3, [1, 1, 4], [0] * 3, [1] * 3, False, n_dev=nv, out_capacity=int(M1 * 1.25)))
 bn = torch.nn.BatchNorm1d(32).to(dev)
 Xg = X.clone().requires_grad_(True)
 timeit("bn+relu fwd", lambda: Fsp.batch_norm_relu(X, bn, True), N * 32 * ES * 3)

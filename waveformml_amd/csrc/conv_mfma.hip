@@ -452,7 +452,7 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 
 // Timing knock-outs (tools/exp/knock.sh, profiles/r01_gconv32_bf16_knockouts.txt): -DWFS_KNOCK=bits builds a library
 // whose k_gconv32_bf16 skips a phase -- 1 filter staging, 2 table reads, 4 gathers + MFMA, 8 stores, 16 gathers read the
-// tile's own rows -- to measure what
+// tile's own rows, 32 only one of a plane's three time offsets is gathered -- to measure what
 // each phase costs inside a replayed graph.  Results are wrong by construction; 0 (the default) compiles to nothing.
 #ifndef WFS_KNOCK
 #define WFS_KNOCK 0
@@ -579,8 +579,16 @@ __device__ __forceinline__ void gconv32_bf16_body(unsigned char *smem, int vbid,
                     const int src = (WFS_KNOCK & 16) ? (int)rowc : nbs[g];
                     int voff = src >= 0 ? (int)((unsigned)src * 64u + (unsigned)h * 32u) : (int)0x80000000;
                     asm volatile("" : "+v"(voff));
-                    a_lo[g] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff, 0, 0));
-                    a_hi[g] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff + 16, 0, 0));
+                    // WFS_KNOCK & 32: only the MIDDLE time offset of every (kx, ky) plane is gathered, its neighbours reuse
+                    // a constant: the gather VOLUME of a kernel that stages one row window per plane in LDS (~34 rows
+                    // instead of 3 x 32), without charging it anything for the staging -- an upper bound on that design
+                    if ((WFS_KNOCK & 32) && (ks[g] % 3) != 1) {
+                        a_lo[g] = uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                        a_hi[g] = a_lo[g];
+                    } else {
+                        a_lo[g] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff, 0, 0));
+                        a_hi[g] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff + 16, 0, 0));
+                    }
                 }
 #pragma unroll
             for (int g = 0; g < BF_GROUP; ++g)
