@@ -207,7 +207,8 @@ def measure(env, args, dtype, steps, warmup, roofline):
         torch.cuda.synchronize()
         timers = {name: _lib.timing_read(tid) for name, tid in (("gather_conv", _lib.TIMER_GATHER_CONV),
                                                                 ("gather_dw", _lib.TIMER_GATHER_DW),
-                                                                ("rulebook", _lib.TIMER_RULEBOOK))}
+                                                                ("rulebook", _lib.TIMER_RULEBOOK),
+                                                                ("conv_backward", _lib.TIMER_CONV_BACKWARD))}
         _lib.timing_enable(False)
         Fsp.ACCOUNT = []
         eager_step()
@@ -219,7 +220,9 @@ def measure(env, args, dtype, steps, warmup, roofline):
             d["bytes"] += a["bytes"]
             d["flops"] += a["flops"]
             d["launches"] += 1
-        dom = max(("gather_conv", "gather_dw"), key=lambda k: timers[k][0])
+        # the dominant conv kernel class by time: forward / dX launches, dW launches, or -- 32 -> 32 layers with 16-bit
+        # rows, round 4 -- the one-launch backward (dW + dX, priced with SURVEY 8d's backward bytes)
+        dom = max(("gather_conv", "gather_dw", "conv_backward"), key=lambda k: timers[k][0])
         ms, n = timers[dom]
         by = per_kind.get(dom, {"bytes": 0, "flops": 0, "launches": 1})
         avg_ms = ms / max(n, 1)
@@ -233,6 +236,23 @@ def measure(env, args, dtype, steps, warmup, roofline):
                            "tflops": by["flops"] / max(by["launches"], 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                            "timed_in": "eager pass after the timed region (HIP events on the launch stream)",
                            "per_step_ms": {k: timers[k][0] / nprof for k in timers}}
+        # every conv kernel class of the step, same pricing (the headline object above is the dominant one)
+        classes = {}
+        for kind in ("gather_conv", "gather_dw", "conv_backward"):
+            k_ms, k_n = timers[kind]
+            kb = per_kind.get(kind)
+            if not k_n or not kb:
+                continue
+            k_us = k_ms / k_n * 1e3
+            k_bytes = kb["bytes"] / max(kb["launches"], 1)
+            classes[kind] = {"launches_per_step": kb["launches"], "avg_launch_us": k_us,
+                             "algorithmic_bytes_per_launch": k_bytes, "achieved": k_bytes / k_us / 1e3,
+                             "frac": k_bytes / k_us / 1e3 / HBM_PEAK_GBS}
+            kr_us, _src = rocprof_launch_us(kind, dtype)
+            if kr_us:
+                classes[kind]["rocprof_avg_launch_us"] = kr_us
+                classes[kind]["rocprof_frac"] = k_bytes / kr_us / 1e3 / HBM_PEAK_GBS
+        out["roofline"]["classes"] = classes
         rp_us, rp_src = rocprof_launch_us(dom, dtype)
         if rp_us:
             out["roofline"]["rocprof"] = {"avg_launch_us": rp_us, "source": rp_src,
@@ -264,7 +284,7 @@ def pmc_traffic(kind, dtype):
     in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for 16-B-per-lane reads on gfx950),
     launch-weighted over the kernels of that class.  None when no PMC summary for this dtype is committed."""
     path = None
-    for rnd in ("r03", "r02", "r01"):               # the newest committed summary
+    for rnd in ("r04", "r03", "r02", "r01"):        # the newest committed summary
         cand = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%s.json" % (rnd, dtype))
         if os.path.exists(cand):
             path = cand
@@ -273,7 +293,8 @@ def pmc_traffic(kind, dtype):
         return None, None
     with open(path) as f:
         pmc = json.load(f)
-    prefixes = {"gather_conv": ("k_gconv", "k_gather_conv"), "gather_dw": ("k_gdw", "k_gather_dw", "k_slab_reduce")}[kind]
+    prefixes = {"gather_conv": ("k_gconv", "k_gather_conv"), "gather_dw": ("k_gdw", "k_gather_dw", "k_slab_reduce"),
+                "conv_backward": ("k_bwd32",)}[kind]
     tot, launches = 0.0, 0
     for name, rec in pmc.items():
         if name.startswith(prefixes):
@@ -288,7 +309,8 @@ def pmc_traffic(kind, dtype):
     return tot / launches * 1024.0, "profiles/%s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, FETCH x2)" % os.path.basename(path)
 
 
-_KIND_PREFIXES = {"gather_conv": ("k_gconv", "k_gather_conv"), "gather_dw": ("k_gdw", "k_gather_dw")}
+_KIND_PREFIXES = {"gather_conv": ("k_gconv", "k_gather_conv"), "gather_dw": ("k_gdw", "k_gather_dw"),
+                  "conv_backward": ("k_bwd32",)}
 
 
 def rocprof_launch_us(kind, dtype):
@@ -297,7 +319,7 @@ def rocprof_launch_us(kind, dtype):
     ``avg_launch_us`` (HIP events, eager pass).  (None, None) when no summary for this dtype is committed."""
     import csv
     import re
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_hipgraph_%s_kernel_stats.csv" % (rnd, dtype))
         if not os.path.exists(path):
             continue
@@ -311,6 +333,55 @@ def rocprof_launch_us(kind, dtype):
         if calls:
             return tot / calls / 1e3, "profiles/%s (rocprofv3 --kernel-trace --stats of the graph replay)" % os.path.basename(path)
     return None, None
+
+
+def large_batch_roofline(env, dtype, events=2048, samples=256):
+    """The dominant kernel class at 2048 events per rank (673 k voxels): the SubM 32 -> 32 forward launch alone, inside a
+    replayed graph, priced with the same algorithmic bytes.  What the gather / table organisation itself
+    allows once a launch's fixed latency chain is amortised over 8x the rows."""
+    from waveformml_amd.psd import synthetic
+    from waveformml_amd.spconv import functional as Fsp
+    from waveformml_amd.spconv import ops
+    dev = env.dev
+    fdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
+    c, _f, _y = synthetic.generate(events, samples, 3, seed=1234)
+    idx = torch.from_numpy(np.ascontiguousarray(c[:, [3, 0, 1, 2]])).to(dev)
+    rb = ops.build_rulebook(idx, events, [14, 11, samples], [3] * 3, [1] * 3, [0] * 3, [1] * 3, True)
+    N = rb.N
+    X = torch.randn(N, 32, device=dev).to(fdtype)
+    W = torch.randn(27, 32, 32, device=dev) * 0.1
+    table, kmap = rb.table_by_out()
+    pairs = int((rb.nbr_out >= 0).sum().item())
+    es = X.element_size()
+    nbytes = 2 * N * 32 * es + pairs * 8 + 27 * 32 * 32 * 4
+
+    def fn():
+        return Fsp.gather_conv(table, kmap, 27, rb.centre_k, N, X, W, False, None)
+
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    reps, iters = 10, 10
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / (iters * reps) * 1e3
+    g.reset()
+    achieved = nbytes / us / 1e3
+    return {"bound": "hbm", "kernel": "gather_conv (SubM 32->32 forward, one launch)", "events_per_rank": events,
+            "active_voxels": N, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
+            "timed_in": "%d launches inside a replayed HIP graph, %d replays (torch events on the launch stream)" % (reps, iters),
+            "note": "knock-outs at this size: profiles/r04_gconv32_large_batch_knockouts.txt"}
 
 
 def cpu_reference(env, extras, n_steps):
@@ -510,6 +581,8 @@ def main():
         result["timing"] = main_out["timing"]
         if "roofline" in main_out:
             result["roofline"] = main_out["roofline"]
+            if single:
+                result["roofline_large_batch"] = large_batch_roofline(env, args.dtype)
         if single and args.cpu_steps > 0:
             ref_extras = f32_extras if f32 is not None else extras
             cpu_logits, cpu_loss, base = cpu_reference(env, ref_extras, args.cpu_steps)

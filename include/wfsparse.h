@@ -552,7 +552,8 @@ int wfs_load_batch(const int32_t *coords, int64_t n, int32_t cols, const int32_t
 #define WFS_TIMER_GATHER_CONV 0
 #define WFS_TIMER_GATHER_DW 1
 #define WFS_TIMER_RULEBOOK 2
-#define WFS_TIMER_COUNT 3
+#define WFS_TIMER_CONV_BACKWARD 3   /* wfs_conv_backward's one-launch form (dW + dX) */
+#define WFS_TIMER_COUNT 4
 int wfs_timing_enable(int32_t on);                        /* also clears the table            */
 int wfs_timing_read(int32_t timer, double *total_ms, int64_t *launches);  /* synchronises     */
 

@@ -270,8 +270,11 @@ def _trainer_run(rank, world, dev):
     mod = _small_c2()
     batches = []
     uneven = os.environ.get("WFS_TEST_UNEVEN_FIRST") == "1"
+    odd_labels = os.environ.get("WFS_TEST_ODD_FIRST_LABELS") == "1"
     for s in range(5):
-        n = 32 if (s == 2 and rank == 1 and not uneven) else 16
+        n = 32 if (s == 2 and rank == 1 and not uneven and not odd_labels) else 16
+        if odd_labels and s == 0 and rank == 0:
+            n = 12                               # rank 0's FIRST batch holds fewer events than everybody's batches
         c, f, y = synthetic.generate(n, 64, 3, seed=400 + s, rank=rank)
         if uneven and s == 0 and rank == 0:
             # rank 0's FIRST batch (the one its step is captured on) keeps about half of its rows, every event's first
@@ -576,3 +579,16 @@ def test_two_rank_trainer_with_unequal_first_batches_keeps_the_ranks_together(tm
     assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"])
     if agree_block > 0:
         assert r0["n_cap"] == r1["n_cap"] and r0["eager_fallbacks"] == 0
+
+
+def test_two_rank_trainer_with_an_odd_first_label_count_captures_on_the_first_agreed_batch(tmp_path):
+    """rank 0's first batch holds 12 events, every other batch 16.  Captured on its own first batch, rank 0's
+    step would misfit on every later batch (its label buffer has 12 entries) and run eagerly forever, alone.  With the
+    counts agreed ahead of time nobody captures while the ranks' label counts differ: both step eagerly for that batch,
+    both capture on the next one, and no further fallback happens."""
+    r0, r1 = _launch_two_ranks(tmp_path, "trainer_misfit",
+                               extra_env={"WFS_TEST_AGREE_BLOCK": "4", "WFS_TEST_ODD_FIRST_LABELS": "1"})
+    assert r0["eager_fallbacks"] == 1 and r1["eager_fallbacks"] == 1
+    assert r0["n_cap"] == r1["n_cap"] and r0["n_cap"] > 0
+    assert torch.equal(r0["params"], r1["params"])
+    assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"])

@@ -13,7 +13,7 @@ WFS_OK, WFS_EINVAL, WFS_EOVERFLOW, WFS_EHIP, WFS_EWORKSPACE = 0, 1, 2, 3, 4
 WFS_F32, WFS_BF16, WFS_F16 = 0, 1, 2
 WFS_MAX_DIM = 4
 WFS_ABI_VERSION = 6         # include/wfsparse.h: this binding's struct layouts and signatures
-TIMER_GATHER_CONV, TIMER_GATHER_DW, TIMER_RULEBOOK = 0, 1, 2
+TIMER_GATHER_CONV, TIMER_GATHER_DW, TIMER_RULEBOOK, TIMER_CONV_BACKWARD = 0, 1, 2, 3
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)

@@ -675,7 +675,7 @@ extern "C" int wfs_conv_backward(const int32_t *table, int32_t K, int32_t identi
     const size_t need = wfs_gather_dw_workspace_bytes(K, R, Cin, Cout);
     WFS_REQUIRE(workspace_bytes >= need, WFS_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     if (defer) *defer = wfs_dw_job{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
-    WfsTimerScope timer(WFS_TIMER_GATHER_CONV, stream);
+    WfsTimerScope timer(WFS_TIMER_CONV_BACKWARD, stream);
     return wfs_launch_bwd32_h16(table, packed_kl, K, identity_k, R, (const long long *)r_dev, X, dY, W, dX, 0, dW,
                                 (float *)workspace, dtype, defer, stream);
 }

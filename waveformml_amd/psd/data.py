@@ -122,6 +122,9 @@ class RingBatch(list):
 class _SlotToken(object):
     def __init__(self, ring, slot, batches):
         self.ring, self.slot, self.left = ring, slot, batches
+        # events of copies that read FROM the slot (DevicePrefetcher records one per staged batch): the slot must not
+        # go back to the workers before they have completed
+        self.guards = []
 
     def done(self):
         self.left -= 1
@@ -130,7 +133,13 @@ class _SlotToken(object):
             self.slot = None
 
     def force(self):
+        """Reclaim by age (PackedLoader.HOLD).  A consumer that copies asynchronously out of the slot registered its
+        copy events in ``guards``: they are WAITED for first -- an issued copy whose completion nobody has waited on
+        may still be reading the slot a worker is about to overwrite."""
         if self.slot is not None:
+            for ev in self.guards:
+                ev.synchronize()
+            self.guards = []
             self.ring.free.put(self.slot)
             self.slot = None
 
@@ -206,6 +215,7 @@ class PackedLoader(object):
     each (tools/soak_from_files.py -> profiles/r03_soak_from_files.json)."""
 
     HOLD = 3            # messages a consumer that never calls RingBatch.release() may keep alive
+    HOLD_MAX = 8        # slots are provisioned for a HOLD up to this (a deeper consumer falls back on the copy guards)
 
     def __init__(self, dataset, collate_fn, group=None, ring_slot_mb=None, **loader_kwargs):
         import os
@@ -220,7 +230,9 @@ class PackedLoader(object):
         self.ring = None
         if nw > 0 and os.environ.get("WFS_LOADER_RING", "1") != "0" and loader_kwargs.get("multiprocessing_context") is None:
             mb = float(ring_slot_mb if ring_slot_mb is not None else os.environ.get("WFS_LOADER_SLOT_MB", "4"))
-            slots = nw * int(loader_kwargs.get("prefetch_factor", 2) or 2) + self.HOLD + 3
+            # + HOLD_MAX: a consumer may raise HOLD up to that (DevicePrefetcher: its staging depth + 1) without the
+            # workers running out of slots
+            slots = nw * int(loader_kwargs.get("prefetch_factor", 2) or 2) + self.HOLD_MAX + 3
             try:
                 self.ring = _SharedRing(slots, int(mb * (1 << 20)) * max(self.group, 1))
                 loader_kwargs["pin_memory"] = False       # the ring is page-locked once instead
@@ -282,6 +294,10 @@ class DevicePrefetcher(object):
     def __init__(self, loader, device, feature_dtype=None, depth=2, on_stage=None, on_exhausted=None):
         self.loader, self.device, self.feature_dtype, self.depth = loader, torch.device(device), feature_dtype, depth
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        # this consumer releases ring slots itself (after each copy): the loader's reclaim-by-age must sit behind the
+        # staging depth, so that it only ever fires for batches this queue has already let go
+        if hasattr(loader, "HOLD"):
+            loader.HOLD = max(int(loader.HOLD), int(depth) + 1)
         # on_stage(rows, labels) for every batch as it is staged (``depth`` batches before it is yielded), on_exhausted()
         # when the loader has no more: the multi-rank Trainer agrees on batch shapes ahead of time through these
         self.on_stage, self.on_exhausted = on_stage, on_exhausted
@@ -301,6 +317,8 @@ class DevicePrefetcher(object):
                 dev[1] = dev[1].to(self.feature_dtype)
             done = torch.cuda.Event()
             done.record(self.copy_stream)
+        if ring and batch.token is not None:
+            batch.token.guards.append(done)            # reclaim-by-age waits for this copy (see _SlotToken.force)
         return (batch if ring else host), dev, done    # kept alive until the copy has been waited on
 
     def __iter__(self):

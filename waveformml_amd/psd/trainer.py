@@ -158,6 +158,7 @@ class Trainer(object):
         self.recaptures = 0
         self.last_capacity = 0
         self._size_misfits = 0
+        self._label_misfits = 0
         self.eager_fallbacks = 0
         self.global_step = 0
         self.last_checkpoint = None
@@ -202,7 +203,14 @@ class Trainer(object):
         if agreed is not None:
             from .graph import GraphedTrainStep
             floor = GraphedTrainStep.capacity_for(agreed[0], agreed[1])     # largest rows, smallest label count (= largest headroom)
+        per_row = bool(getattr(module, "per_row_targets", False))
         if self._graph is None:
+            if agreed is not None and not per_row and agreed[1] != agreed[2]:
+                # the ranks' batches hold different numbers of events (a partial last file): a step captured on this
+                # rank's odd count would misfit on every later batch -- and only on this rank.  Everybody
+                # steps eagerly (same agreed counts -> same decision); the first batch with an agreed count is captured
+                self.eager_fallbacks += 1
+                return self.training_step(module, reducer, optimizer, batch, batch_idx)
             self._graph = self._capture(module, reducer, optimizer, batch, min_rows=floor)
         # more voxels than the capacity, or another number of events -> an ordinary step.  With several ranks the
         # decision is taken together: a rank replaying while another steps eagerly must never depend on the two paths
@@ -226,9 +234,17 @@ class Trainer(object):
             code = _agree_max((1 if misfit else 0) | (2 if (misfit and too_big) else 0), reducer.group)
             # MAX of the codes: 1 < 2 < 3, and a rank reporting 2 cannot exist (too_big implies misfit)
             misfit, too_big = code > 0, code >= 2
+        # a batch that fits the rows but holds another number of labels than the capture (and every rank agrees on that
+        # number): counted like the size misfits -- `recapture_after` of them in a row re-capture on the new shape
+        fresh_now = hasattr(optimizer, "has_fresh") and optimizer.has_fresh()
+        labels_agree = agreed is None or per_row or agreed[1] == agreed[2]
+        label_misfit = (misfit and not too_big and not fresh_now and labels_agree
+                        and (agreed is not None or not (reducer.world > 1 and reducer.exchange)))
+        self._label_misfits = self._label_misfits + 1 if label_misfit else 0
+        recapture_labels = label_misfit and self.recapture_after > 0 and self._label_misfits >= self.recapture_after
         if misfit:
             self._size_misfits += 1 if too_big else 0
-            if too_big and self.recapture_after > 0 and self._size_misfits >= self.recapture_after:
+            if recapture_labels or (too_big and self.recapture_after > 0 and self._size_misfits >= self.recapture_after):
                 # the capacity is too small for this data: capture again, sized on this batch (never smaller than before)
                 old = self._graph
                 self._graph = None
@@ -237,6 +253,7 @@ class Trainer(object):
                 del old
                 self._graph = self._capture(module, reducer, optimizer, batch, min_rows=max(n_old, floor))
                 self._size_misfits = 0
+                self._label_misfits = 0
                 self.recaptures += 1
                 return self._graph(batch)
             self.eager_fallbacks += 1

@@ -378,9 +378,18 @@ def conv_backward(table, K, identity_k, R, X, dY, W, r_dev=None, like=None, pack
     if defer and job.nslabs > 0:
         _DEFERRED_DW.append((job, ws))
     if ACCOUNT is not None:
+        # SURVEY.md 8d "backward": X, dY and dX once each, the rulebook twice (8 B per pair), the filters twice
         dense = (table >> 3).clamp_(min=-1) if packed_kl else table
-        _account("gather_dw", dense, R, R, Cin, dY.shape[0], Cout, K, Cin, Cout, X.element_size())
-        _account("gather_conv", dense, R, dY.shape[0], Cout, R, Cin, K, Cin, Cout, X.element_size())
+        pairs = int((dense >= 0).sum().item())
+        es = X.element_size()
+        fused = Cin == 32 and Cout == 32 and X.dtype in (torch.bfloat16, torch.float16) and K <= 27      # one launch
+        if fused:
+            ACCOUNT.append(dict(kind="conv_backward", pairs=pairs,
+                                bytes=2 * R * Cin * es + dY.shape[0] * Cout * es + 2 * pairs * 8 + 2 * K * Cin * Cout * 4,
+                                flops=4 * pairs * Cin * Cout))
+        else:
+            _account("gather_dw", dense, R, R, Cin, dY.shape[0], Cout, K, Cin, Cout, es)
+            _account("gather_conv", dense, R, dY.shape[0], Cout, R, Cin, K, Cin, Cout, es)
     return dX, dW
 
 
