@@ -354,3 +354,45 @@ def test_member_reads_through_the_c_abi():
             t.read_member("PID", 0, rows + 1)
     with h5data.H5Table(os.path.join(R3, "ioni", "run_1_Label.h5"), "EventLabels", "", "") as t:
         assert t.n_events == 9 and np.array_equal(t.read_member(None, 0, 9).numpy(), EXP3["ioni/run_1/label"])
+
+
+# ---- round 4: the reference's label rules per path (src/datasets/HDF5Dataset.py:319-341, :582-585) ---------
+R4 = os.path.join(H5, "r4", "labels")
+EXP4 = np.load(os.path.join(os.path.dirname(H5), "expected_r4.npz"))
+
+
+def _r4(**kw):
+    return h5data.HDF5Dataset([R4], "*WaveformPairSim.h5", "WaveformPairs", "coord", "waveform", 6, **kw)
+
+
+def _chained(values, mapping):
+    """The reference's convert_label: ``for key, val in label_map.items(): y[y == key] = val`` -- in place, in order."""
+    y = np.array(values, copy=True)
+    for k, v in mapping.items():
+        y[y == (float(k) if y.dtype.kind == "f" else int(k))] = v
+    return y
+
+
+def test_per_row_labels_follow_the_stored_type_and_the_map_is_chained():
+    """One label per row: int64 class indices only for a member STORED as int32, float32 for every other stored type
+    (int8 / int16 / int64 included) -- reference :331-341; the label map is applied key by key in place, so 1 -> 4 -> 6
+    chains (reference :582-585)."""
+    m = {"1": 4, "4": 6}                                   # a 1 becomes a 4, which the next key turns into a 6
+    want = _chained(EXP4["pid"], m)
+    assert set(np.unique(want)) <= {6, 7}
+    (c, f), y = _r4(label_name="PID", label_map=m)[0]
+    assert y.dtype == torch.int64 and np.array_equal(y.numpy(), want) and np.array_equal(c.numpy(), EXP4["coord"])
+    for name in ("PID16", "PID8", "PID64"):
+        (c, f), y = _r4(label_name=name, label_map=m)[0]
+        assert y.dtype == torch.float32, name
+        assert np.array_equal(y.numpy(), want.astype(np.float32)), name
+
+
+def test_event_level_labels_are_always_int64_also_from_a_float_label_file():
+    """Label files (one label per event): the reference maps in place on the stored (float) values and then casts to
+    int64 whatever the stored type (:319-327): 2.5 -> 2."""
+    ds = _r4(label_name="EventLabels", label_file_pattern="*FLabel.h5", label_map={"3": 1, "1": 0})
+    (c, f), y = ds[0]
+    want = _chained(EXP4["flabel"], {"3": 1, "1": 0}).astype(np.int64)      # 3.0 -> 1.0 -> 0.0 (chained), 2.5 -> 2
+    assert y.dtype == torch.int64 and np.array_equal(y.numpy(), want)
+    assert 2 in want or 2.5 not in EXP4["flabel"]

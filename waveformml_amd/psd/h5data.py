@@ -268,15 +268,23 @@ class HDF5Dataset(Dataset):
             raise RuntimeError("No corresponding label file found for file {0}, tried {1}".format(file_path, path))
         return path
 
-    def _convert_label(self, y):
-        """label_map applied in place on integer labels, then the reference's tensor type: int32 labels become int64
-        class indices, everything else float32 regression targets (reference :331-341, :582-585)."""
-        if self.info["label_map"] and not y.is_floating_point():
-            m = {int(k): int(v) for k, v in self.info["label_map"].items()}
-            src = y.clone()
-            for k, v in m.items():
-                y[src == k] = v
-        return y.to(torch.int64) if not y.is_floating_point() else y.to(torch.float32)
+    def _convert_label(self, y, per_row, stored_int32=None):
+        """The reference's label handling, per path (src/datasets/HDF5Dataset.py:582-585, :319-341):
+        * ``label_map`` is applied IN PLACE, key by key in the map's order, to labels of any stored type -- so a value
+          produced by an earlier key is remapped again by a later key equal to it (chained), exactly as the reference's
+          ``for key, val in label_map.items(): y[y == key] = val``;
+        * one label per ROW (the compound-table layout, :331-341): int64 class indices only when the member is stored as
+          int32, float32 for EVERY other stored type (int8 / int16 / int64 columns included);
+        * one label per EVENT (group layout, label files; :319-327): always int64."""
+        if self.info["label_map"]:
+            for k, v in self.info["label_map"].items():
+                key = int(k) if not y.is_floating_point() else float(k)
+                y[y == key] = v
+        if per_row:
+            # read_member hands every integer member of <= 4 bytes over as int32: the STORED width decides
+            is_i32 = (y.dtype == torch.int32) if stored_int32 is None else bool(stored_int32)
+            return y.to(torch.int64) if is_i32 else y.to(torch.float32)
+        return y.to(torch.int64)
 
     def _add_data_infos(self, file_path, dir_index):
         n_file_events = self._get_event_num(file_path)
@@ -309,13 +317,15 @@ class HDF5Dataset(Dataset):
                 y = None                                               # from the label file, below
             elif t.layout == WFH5_GROUP:
                 y = self._convert_label(t.read_labels(e0, e1 + 1) if label_name == "labels"
-                                        else t.read_member(label_name, e0, e1 + 1))      # one label per EVENT (:319-327)
+                                        else t.read_member(label_name, e0, e1 + 1), False)   # one label per EVENT (:319-327)
             else:
-                y = self._convert_label(t.read_member(label_name, r0, r1))               # one label per ROW (:331-341)
+                _r, _c, is_float, esize = t.member_info(label_name)
+                y = self._convert_label(t.read_member(label_name, r0, r1), True,
+                                        stored_int32=(not is_float and esize == 4))       # one label per ROW (:331-341)
         if y is None:
             # a separate label file: the FIRST member of its `label_name` table, one entry per event (:483, :319-327)
             with H5Table(self._label_file(di["file_path"]), label_name, "", "") as lt:
-                y = self._convert_label(lt.read_member(None, e0, e1 + 1))
+                y = self._convert_label(lt.read_member(None, e0, e1 + 1), False)
         if self.half_precision:
             feats = feats.half()
         if self.info["additional_fields"] is not None:
