@@ -280,39 +280,6 @@ int wfs_event_rulebook_conv(const wfs_geometry *g, const int32_t *indices, int64
                             int32_t *events_out, int32_t *nbr_out, int32_t packed_kl, int32_t *nbr_in,
                             int32_t *cell_row, int32_t *overflow_dev, int32_t *flags, void *state, void *stream);
 
-/* The same product when an nn.BatchNorm1d in TRAINING mode directly follows the convolution inside
- * spconv.SparseSequential (reference src/models/SPConvBlocks.py:505-508, SURVEY.md 8a rows a9 + a12): the conv
- * kernel's epilogue also takes the per-channel batch statistics of the rows it stores, so BatchNorm needs no
- * reduction pass of its own (wfs_bn_apply_fwd then normalises with save_mean / save_invstd).
- * On return (stream order): save_mean, save_invstd [Cy] hold the batch mean and 1/sqrt(biased var + eps);
- * running_mean / running_var (optional) are updated with momentum and the unbiased variance, num_batches_tracked
- * (optional) is incremented -- exactly what torch.nn.functional.batch_norm(training=True) does.
- * workspace: wfs_conv_stats_workspace_bytes(R, Cy) bytes (per-block partial statistics, folded by one small launch).
- * Shapes without a fused epilogue run the convolution followed by the reduction kernels of wfs_bn_relu_fwd: same
- * results, same interface.
- * pending_blocks (host int, may be NULL): when given, the call may SKIP the folding launch and leave the per-block
- * partials in `workspace`; it then returns their number (> 0) and save_mean / save_invstd / the running statistics
- * are NOT written yet -- the caller finishes with wfs_bn_apply_fwd_fold(..., stats, pending_blocks, ...), whose
- * blocks fold the partials in their prologue (one launch less per layer).  0 = everything is final, as without it. */
-typedef struct wfs_bn_stats {
-    float *save_mean;
-    float *save_invstd;
-    float *running_mean;          /* may be NULL (track_running_stats=False) */
-    float *running_var;
-    int64_t *num_batches_tracked; /* may be NULL */
-    float momentum;
-    float eps;
-    void *workspace;
-    size_t workspace_bytes;
-} wfs_bn_stats;
-
-size_t wfs_conv_stats_workspace_bytes(int64_t R, int32_t C);
-
-int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
-                            int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
-                            int32_t Cw_in, int32_t Cw_out, const float *bias, void *Y, int32_t dtype,
-                            const int64_t *r_dev, const wfs_bn_stats *stats, int32_t *pending_blocks, void *stream);
-
 /* Replaces the dW half of torch.ops.spconv.indice_conv_backward:
  *     dW[k, a, b] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 0)
  *     dW[k, b, a] = sum_r  S[r, a] * G[table[k, r], b]          (swap == 1)
@@ -395,20 +362,6 @@ int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t C, const f
                     int32_t training, int32_t relu, void *dX, float *dgamma, float *dbeta,
                     void *workspace, size_t workspace_bytes, int32_t dtype, const int64_t *n_dev,
                     void *stream);
-
-/* The elementwise half of wfs_bn_relu_fwd alone, for statistics that are already known (taken by
- * wfs_gather_conv_bnstats):  Y = [relu] (gamma * (X - mean) * invstd + beta). */
-int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
-                     const float *save_mean, const float *save_invstd, int32_t relu, void *Y, int32_t dtype,
-                     const int64_t *n_dev, void *stream);
-
-/* The same with statistics still in the form of `pending_blocks` per-block partials left in stats->workspace by
- * wfs_gather_conv_bnstats: every block first merges the partials (Chan's update, fixed order), block 0 publishes
- * save_mean / save_invstd, updates the running statistics and bumps num_batches_tracked, then all normalise.
- * C == 32 (the convolutions with a statistics epilogue produce 32-channel rows). */
-int wfs_bn_apply_fwd_fold(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
-                          const wfs_bn_stats *stats, int32_t pending_blocks, int32_t relu, void *Y, int32_t dtype,
-                          const int64_t *n_dev, void *stream);
 
 /* After wfs_rulebook_emit of a regular conv whose site table was a direct grid: pointers into `workspace` to the
  * cell -> output row map of the build (ticket[cell] != 0xFFFFFFFF <=> the output cell b * out_volume + pos is active,

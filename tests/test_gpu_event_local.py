@@ -394,7 +394,7 @@ def test_packed_table_products_equal_the_dense_table_products(dtype):
     W = torch.randn((27, 32, 32), device=DEV, generator=g)
     t_p, pk = rb.table_by_in(32, 32, X, 1)
     assert pk == 3 and t_p is rb.nbr_out_packed
-    dx_p = Fsp.gather_conv(t_p, None, 27, -1, N, dY, W, True, None, nv, None, None, pk)
+    dx_p = Fsp.gather_conv(t_p, None, 27, -1, N, dY, W, True, None, nv, None, pk)
     dx_d = Fsp.gather_conv(rb.nbr_out, None, 27, -1, N, dY, W, True, None, nv)
     t_p, pk = rb.table_by_in(32, 32, X, 3)
     assert pk == 3
@@ -432,7 +432,7 @@ def test_one_launch_conv_backward_equals_the_two_products(dtype, device_counts):
         cases.append(("conv packed", con.nbr_out_packed, con.packed_kl, -1, con.M))
     for name, table, pk, ident, rows_out in cases:
         dY = torch.randn((rows_out, 32), device=DEV, generator=g).to(dtype)
-        dx1 = Fsp.gather_conv(table, None, 27, ident, N, dY, W, True, None, nv, None, None, pk)
+        dx1 = Fsp.gather_conv(table, None, 27, ident, N, dY, W, True, None, nv, None, pk)
         dw1 = Fsp.gather_dw(table, 27, ident, N, X, dY, False, None, nv, False, None, pk)
         dx2, dw2 = Fsp.conv_backward(table, 27, ident, N, X, dY, W, nv, None, pk)
         torch.cuda.synchronize()

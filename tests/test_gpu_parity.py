@@ -668,94 +668,6 @@ def test_training_from_hdf5_files_matches_the_cpu_path():
         _assert_close(a.detach().cpu().numpy(), b.detach().numpy(), 1e-5, name)
 
 
-@pytest.mark.parametrize("cin,cout,dtype,kind", [
-    (32, 32, torch.float32, "subm"), (32, 32, torch.bfloat16, "subm"), (2, 32, torch.bfloat16, "subm"),
-    (32, 32, torch.bfloat16, "conv"), (32, 32, torch.float32, "conv"),
-    (2, 32, torch.float32, "subm"), (16, 24, torch.float32, "subm"),
-    (32, 32, torch.float16, "subm"), (2, 32, torch.float16, "subm")],
-    ids=["f32_subm32", "bf16_subm32", "bf16_subm2", "bf16_conv32", "f32_conv32", "f32_subm2_unfused", "f32_generic_unfused",
-         "f16_subm32", "f16_subm2"])
-def test_conv_epilogue_takes_the_batchnorm_statistics(cin, cout, dtype, kind, monkeypatch):
-    """conv -> BatchNorm1d(training) -> ReLU inside SparseSequential: the conv kernel's epilogue takes the batch
-    statistics (wfs_gather_conv_bnstats; shapes without a fused epilogue run conv + reduction behind the same entry
-    point).  Against the CPU restatement + torch's BatchNorm1d: output, running statistics, num_batches_tracked, and
-    all gradients; two steps (running statistics accumulate); row count not a multiple of 32."""
-    from oracle import spconv as osp
-    sp = _sp()
-    monkeypatch.setattr(sp.ops, "FUSE_CONV_BN_STATS", True)
-    rng = np.random.default_rng(4242)
-    B, T = 6, 40
-    idx = _waveform_like(rng, B, T)
-    assert len(idx) % 32 != 0
-
-    def build(m):
-        conv = (m.SubMConv3d(cin, cout, 3, 1, 0, 1, 1, False, "k") if kind == "subm"
-                else m.SparseConv3d(cin, cout, 3, (1, 1, 2), 0, 1, 1, False))
-        return m.SparseSequential(conv, torch.nn.BatchNorm1d(cout), torch.nn.ReLU())
-
-    torch.manual_seed(11)
-    ref_net = build(osp)
-    with torch.no_grad():
-        ref_net[1].weight.uniform_(0.5, 1.5)
-        ref_net[1].bias.uniform_(-0.3, 0.3)
-        if dtype != torch.float32:                      # both sides multiply the same representable filters
-            ref_net[0].weight.copy_(ref_net[0].weight.to(dtype).float())
-    net = build(sp).to(DEV)
-    net.load_state_dict(ref_net.state_dict())
-    tol = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
-    for step in range(2):
-        feat = (rng.standard_normal((len(idx), cin)) + 0.5).astype(np.float32)
-        fin = torch.from_numpy(feat).to(dtype).float()
-        fr = fin.clone().requires_grad_(True)
-        fg = fin.to(DEV).to(dtype).requires_grad_(True)
-        yr = ref_net(osp.SparseConvTensor(fr, torch.from_numpy(idx), [14, 11, T], B))
-        yg = net(sp.SparseConvTensor(fg, torch.from_numpy(idx).to(DEV), [14, 11, T], B))
-        _assert_close(yg.features.detach().float().cpu().numpy(), yr.features.detach().numpy(), tol, "y step %d" % step)
-        _assert_close(net[1].running_mean.cpu().numpy(), ref_net[1].running_mean.numpy(), tol, "running_mean")
-        _assert_close(net[1].running_var.cpu().numpy(), ref_net[1].running_var.numpy(), tol, "running_var")
-        assert int(net[1].num_batches_tracked) == step + 1
-        g = rng.standard_normal(tuple(yr.features.shape)).astype(np.float32)
-        for n_ in (net, ref_net):
-            n_.zero_grad()
-        yr.features.backward(torch.from_numpy(g))
-        yg.features.backward(torch.from_numpy(g).to(DEV).to(dtype))
-        if dtype == torch.float32:
-            _assert_close(net[0].weight.grad.cpu().numpy(), ref_net[0].weight.grad.numpy(), 1e-4, "dW")
-            _assert_close(net[1].weight.grad.cpu().numpy(), ref_net[1].weight.grad.numpy(), 1e-4, "dgamma")
-            _assert_close(net[1].bias.grad.cpu().numpy(), ref_net[1].bias.grad.numpy(), 1e-4, "dbeta")
-            if cin > 2:
-                bad = np.abs(fg.grad.cpu().numpy() - fr.grad.numpy()) > 1e-4 * np.abs(fr.grad.numpy()).max()
-                assert bad.mean() < 1e-3, bad.mean()
-
-
-def test_conv_epilogue_statistics_survive_extreme_offsets(monkeypatch):
-    """Channel means up to ~1.7e4 standard deviations from zero (|mean| 300, sigma 0.018): E[x^2] - mean^2 in fp32
-    would be off by more than the variance itself (9e4 * 6e-8 >> 3e-4);
-    the tile-wise (count, mean, M2) merge must not.  32 -> 32 fp32, bias-shifted outputs, against fp64."""
-    sp = _sp()
-    monkeypatch.setattr(sp.ops, "FUSE_CONV_BN_STATS", True)
-    rng = np.random.default_rng(77)
-    B, T = 4, 48
-    idx = _waveform_like(rng, B, T)
-    conv = sp.SubMConv3d(32, 32, 3, 1, 0, 1, 1, True, "k").to(DEV)
-    with torch.no_grad():
-        conv.weight.mul_(0.3)
-        conv.bias.copy_(torch.linspace(-300.0, 300.0, 32))
-    bn = torch.nn.BatchNorm1d(32, momentum=1.0).to(DEV)      # running statistics = this batch's
-    net = sp.SparseSequential(conv, bn)
-    feat = torch.from_numpy(rng.standard_normal((len(idx), 32)).astype(np.float32)).to(DEV)
-    x = sp.SparseConvTensor(feat, torch.from_numpy(idx).to(DEV), [14, 11, T], B)
-    y = net(x).features
-    raw = conv(sp.SparseConvTensor(feat, torch.from_numpy(idx).to(DEV), [14, 11, T], B)).features.detach().double().cpu()
-    want = (raw - raw.mean(0)) / torch.sqrt(raw.var(0, unbiased=False) + bn.eps)
-    # the variance itself is the cancellation-sensitive quantity: 1e-4 against fp64
-    _assert_close(bn.running_var.double().cpu().numpy(), raw.var(0, unbiased=True).numpy(), 1e-3, "variance")
-    _assert_close(bn.running_mean.double().cpu().numpy(), raw.mean(0).numpy(), 1e-6, "mean")
-    # the normalised rows carry the fp32 rounding of (x - mean) at |x| ~ 300: a property of fp32 BatchNorm, not of
-    # the statistics
-    _assert_close(y.detach().double().cpu().numpy(), want.numpy(), 5e-3, "normalised output")
-
-
 @pytest.mark.parametrize("B,C", [(256, 3), (7, 2), (3000, 5)])
 def test_fused_cross_entropy_matches_torch(B, C):
     """wfs_xent_mean_fwd_bwd against torch.nn.CrossEntropyLoss(reduction='mean') on the CPU in fp32: loss and the

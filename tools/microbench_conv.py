@@ -57,9 +57,6 @@ by = N * 32 * ES * 2 + P * 8 + 27 * 4096
 timeit("subm fwd 32->32", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None), by)
 timeit("subm dX 32->32", lambda: Fsp.gather_conv(rb.nbr_out, None, 27, rb.centre_k, N, dY, W, True, None), by)
 timeit("subm dW 32x32", lambda: Fsp.gather_dw(rb.nbr_out, 27, rb.centre_k, N, X, dY, False), by)
-bns = torch.nn.BatchNorm1d(32).to(dev)
-timeit("subm fwd 32->32 + BN stats", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X, W, False, None, None, Fsp.BatchNormRequest(bns)), by)
-timeit("subm fwd 2->32 + BN stats", lambda: Fsp.gather_conv(t, km, 27, rb.centre_k, N, X2, W2, False, None, None, Fsp.BatchNormRequest(bns)), N * 136 + P * 8)
 by1 = N * 32 * ES + M1 * 32 * ES + P1 * 8 + 27 * 4096
 timeit("conv s4 fwd 32->32", lambda: Fsp.gather_conv(rb1.nbr_in, None, 27, -1, M1, X, W, False, None), by1)
 timeit("conv s4 dX", lambda: Fsp.gather_conv(rb1.nbr_out, None, 27, -1, N, dY1, W, True, None), by1)

@@ -87,6 +87,6 @@ dense = rb.nbr_out
 tp, pk = rb.table_by_in(32, 32, X, 1)
 timeit("conv s4 fwd 32->32 (dense nbr_in)", lambda: Fsp.gather_conv(rb.nbr_in, None, 27, -1, rb.M, X, W, False, None, rb.m_dev), by1)
 timeit("conv s4 dX, dense [27, N] table", lambda: Fsp.gather_conv(dense, None, 27, -1, N, dY1, W, True, None, nv), by1)
-timeit("conv s4 dX, packed [9, N] table", lambda: Fsp.gather_conv(tp, None, 27, -1, N, dY1, W, True, None, nv, None, None, pk), by1)
+timeit("conv s4 dX, packed [9, N] table", lambda: Fsp.gather_conv(tp, None, 27, -1, N, dY1, W, True, None, nv, None, pk), by1)
 timeit("conv s4 dW, dense [27, N] table", lambda: Fsp.gather_dw(dense, 27, -1, N, X, dY1, False, None, nv), by1)
 timeit("conv s4 dW, packed [9, N] table", lambda: Fsp.gather_dw(tp, 27, -1, N, X, dY1, False, None, nv, False, None, pk), by1)

@@ -29,13 +29,6 @@ class Geometry(ctypes.Structure):
                 ("transposed", _i32), ("output_padding", _i32 * WFS_MAX_DIM)]
 
 
-class BnStats(ctypes.Structure):
-    """struct wfs_bn_stats"""
-    _fields_ = [("save_mean", _vp), ("save_invstd", _vp), ("running_mean", _vp), ("running_var", _vp),
-                ("num_batches_tracked", _vp), ("momentum", ctypes.c_float), ("eps", ctypes.c_float),
-                ("workspace", _vp), ("workspace_bytes", _sz)]
-
-
 class DwJob(ctypes.Structure):
     """struct wfs_dw_job"""
     _fields_ = [("part", _vp), ("nslabs", _i64), ("per", _i64), ("K", _i32), ("A", _i32), ("B", _i32),
@@ -78,12 +71,6 @@ SIGNATURES = {
     "wfs_event_rulebook_ok": (ctypes.c_int, [ctypes.POINTER(Geometry)]),
     "wfs_event_rulebook_flag_ints": (_sz, [_i32]),
     "wfs_event_rulebook_subm": (ctypes.c_int, [ctypes.POINTER(Geometry), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "wfs_conv_stats_workspace_bytes": (_sz, [_i64, _i32]),
-    "wfs_gather_conv_bnstats": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp,
-                                               _i32, _vp, ctypes.POINTER(BnStats), c_i32p, _vp]),
-    "wfs_bn_apply_fwd": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
-    "wfs_bn_apply_fwd_fold": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, ctypes.POINTER(BnStats), _i32, _i32, _vp, _i32,
-                                             _vp, _vp]),
     "wfs_gather_dw_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "wfs_gather_dw": (ctypes.c_int, [_vp, c_i32p, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
                                      _sz, _vp, ctypes.POINTER(DwJob), _i32, _vp]),

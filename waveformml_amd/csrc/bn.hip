@@ -13,7 +13,6 @@
 //             dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)              (training)
 //             dx = gamma*invstd*g                                           (eval: running statistics)
 #include "wfs_common.h"
-#include "conv_stats.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -135,74 +134,6 @@ __global__ void __launch_bounds__(TB) k_bn_reduce(const T *__restrict__ X, const
             p[C + c0 + i] = sb[i];
         }
     }
-}
-
-// Fold of the partials: block = 32 slices x 32 channels (1024 threads); slice s sums partials s, s+32, ... on four
-// interleaved chains (loads overlap, order fixed), slices are added in slice order.
-//   MODE 0: (sum d, sum d^2) -> mean, invstd (+ running statistics, num_batches_tracked)
-//   MODE 1: (sum g, sum g*xhat) -> sums[2][C] (= dbeta, dgamma)
-constexpr int FOLD_SL = 32;
-template <typename T, int MODE>
-__global__ void __launch_bounds__(FOLD_SL * 32) k_bn_fold(const float *__restrict__ partial, int nblk, int C,
-                                                const T *__restrict__ X, long long Ncap,
-                                                const long long *__restrict__ n_dev, float *__restrict__ running_mean,
-                                                float *__restrict__ running_var, long long *__restrict__ batches_tracked,
-                                                float momentum, float eps, float *__restrict__ out_a,
-                                                float *__restrict__ out_b) {
-    __shared__ float tA[FOLD_SL][32], tB[FOLD_SL][32];
-    const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + lane;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (c < C) {
-        int p = sl;
-        const long long st = 2ll * C;
-        for (; p + 3 * FOLD_SL < nblk; p += 4 * FOLD_SL) {
-            const float *q = partial + (long long)p * st + c;
-            a0 += q[0];
-            b0 += q[C];
-            a1 += q[FOLD_SL * st];
-            b1 += q[FOLD_SL * st + C];
-            a2 += q[2 * FOLD_SL * st];
-            b2 += q[2 * FOLD_SL * st + C];
-            a3 += q[3 * FOLD_SL * st];
-            b3 += q[3 * FOLD_SL * st + C];
-        }
-        for (; p < nblk; p += FOLD_SL) {
-            a0 += partial[(long long)p * st + c];
-            b0 += partial[(long long)p * st + C + c];
-        }
-    }
-    tA[sl][lane] = (a0 + a1) + (a2 + a3);
-    tB[sl][lane] = (b0 + b1) + (b2 + b3);
-    __syncthreads();
-    if (sl == 0 && c < C) {
-        float a = 0.f, bb = 0.f;
-#pragma unroll
-        for (int q = 0; q < FOLD_SL; ++q) {
-            a += tA[q][lane];
-            bb += tB[q][lane];
-        }
-        if (MODE == 0) {
-            const long long N = valid_rows(Ncap, n_dev);
-            const float n = N > 0 ? (float)N : 1.f;
-            float shift = wfs_ld(X + c);
-            float md = a / n;                           // mean of (x - shift)
-            float var = bb / n - md * md;               // biased, what torch normalises with
-            var = var > 0.f ? var : 0.f;
-            float mean = shift + md;
-            out_a[c] = mean;
-            out_b[c] = rsqrtf(var + eps);
-            if (running_mean) {
-                float unbiased = N > 1 ? var * (n / (n - 1.f)) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-            }
-        } else {
-            out_a[c] = a;
-            out_b[c] = bb;
-        }
-    }
-    if (MODE == 0 && batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;
 }
 
 // Sums of the per-block partials [nblk][2][C] in a fixed order, computed by EVERY block of the elementwise kernels in
@@ -544,9 +475,7 @@ __global__ void __launch_bounds__(TB) k_bn_reduce_rr(const T *__restrict__ X, co
     }
 }
 
-// CHAN: `partial` holds the conv epilogue's per-block (mean, M2) [nblk][2][32] and `partn` the block row counts
-// (conv_stats.h) instead of shifted sums; they are merged with Chan's update, C == 32.
-template <typename T, int PER, bool CHAN>
+template <typename T, int PER>
 __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, long long Ncap,
                                                     const long long *__restrict__ n_dev, int C,
                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -554,7 +483,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
                                                     long long *__restrict__ batches_tracked, float momentum, float eps,
                                                     int relu, T *__restrict__ Y, float *__restrict__ save_mean,
                                                     float *__restrict__ save_invstd, const float *__restrict__ partial,
-                                                    int nblk, const float *__restrict__ partn) {
+                                                    int nblk) {
     constexpr int VEC = 4;
     __shared__ float sSlice[2 * TB];
     __shared__ float sA[MAXC], sB[MAXC];
@@ -576,47 +505,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
         ga[i] = (gamma && active) ? gamma[c0 + i] : 1.f;
         be[i] = (beta && active) ? beta[c0 + i] : 0.f;
     }
-    if constexpr (CHAN) {
-        // Block partials (n_b, mean_b, M2_b) become shifted sums about ONE common shift, block 0's mean m0 (within a
-        // few sigma / sqrt(rows of a block) of the batch mean, so nothing cancels):
-        //     sum_b d = n_b (mean_b - m0),      sum_b d^2 = M2_b + n_b (mean_b - m0)^2
-        // -- independent per partial (no chain of Chan merges, no divisions), then plain sums in a fixed order: thread
-        // (column c, slice sl of 8) takes partials sl, sl + 8, ..., 16 at a time; slices are added in slice order.
-        const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
-        const float m0 = partial[c];
-        float a = 0.f, bb = 0.f;
-        for (int b0 = sl; b0 < nblk; b0 += 16 * 8) {
-            float n16[16], m16[16], q16[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int b = b0 + u * 8, bc = b < nblk ? b : nblk - 1;
-                const float nn = partn[bc];
-                m16[u] = partial[((long long)bc * 2) * 32 + c];
-                q16[u] = partial[((long long)bc * 2 + 1) * 32 + c];
-                n16[u] = b < nblk ? nn : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const float dl = m16[u] - m0, nd = n16[u] * dl;
-                a += nd;
-                bb += n16[u] > 0.f ? fmaf(nd, dl, q16[u]) : 0.f;
-            }
-        }
-        sSlice[threadIdx.x] = a;
-        sSlice[TB + threadIdx.x] = bb;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            float ta = 0.f, tb = 0.f;
-#pragma unroll
-            for (int q = 0; q < TB / 32; ++q) {
-                ta += sSlice[q * 32 + c];
-                tb += sSlice[TB + q * 32 + c];
-            }
-            sA[c] = ta;                     // sum of (x - m0)
-            sB[c] = tb;                     // sum of (x - m0)^2
-        }
-        __syncthreads();
-    } else if (WFS_BN_KNOCK & 1) {
+    if (WFS_BN_KNOCK & 1) {
         for (int c = threadIdx.x; c < C; c += TB) sA[c] = sB[c] = 1.f;
         __syncthreads();
     } else {
@@ -625,7 +514,7 @@ __global__ void __launch_bounds__(TB) k_bn_apply_rr(const T *__restrict__ X, lon
     const float n = N > 0 ? (float)N : 1.f;
     for (int c = threadIdx.x; c < C; c += TB) {
         float mean, var;
-        const float shift = CHAN ? partial[c] : wfs_ld(X + c);      // CHAN: block 0's mean, see above
+        const float shift = wfs_ld(X + c);
         const float md = sA[c] / n;
         var = sB[c] / n - md * md;
         mean = shift + md;
@@ -1031,9 +920,9 @@ static int bn_fwd_slice(const void *X, int64_t N, int32_t C, long long ld, const
     do {                                                                                                               \
         k_bn_reduce_rr<T, PER, 0><<<g2, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, nullptr, nullptr,      \
                                                              nullptr, nullptr, 0, partial);                            \
-        k_bn_apply_rr<T, PER, false><<<g2, block, 0, stream>>>(                                                        \
+        k_bn_apply_rr<T, PER><<<g2, block, 0, stream>>>(                                                               \
             (const T *)X, N, n_dev, C, gamma, beta, running_mean, running_var, (long long *)num_batches_tracked,       \
-            momentum, eps, relu, (T *)Y, save_mean, save_invstd, partial, (int)rb, nullptr);                           \
+            momentum, eps, relu, (T *)Y, save_mean, save_invstd, partial, (int)rb);                                    \
     } while (0)
 #define WFS_BN_FWD_RR_T(T)                                                                                             \
     if (per == 2) WFS_BN_FWD_RR(T, 2); else if (per == 4) WFS_BN_FWD_RR(T, 4); else if (per == 8) WFS_BN_FWD_RR(T, 8);   \
@@ -1107,60 +996,6 @@ extern "C" int wfs_bn_relu_fwd(const void *X, int64_t N, int32_t C, const float 
                               workspace_bytes, dtype, n_dev, stream);
         if (rc != WFS_OK) return rc;
     }
-    return WFS_OK;
-}
-
-int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long long *n_dev, const wfs_bn_stats *st,
-                        hipStream_t stream) {
-    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
-    const long long nblk = bn_reduce_blocks(N, C);
-    const long long rpb = wfs_cdiv(N, nblk);
-    float *partial = (float *)st->workspace;
-    dim3 grid((unsigned)nblk), grid_f((unsigned)wfs_cdiv(C, 32)), block(TB);
-#define WFS_BN_STATS(T, VEC)                                                                                        \
-    do {                                                                                                            \
-        k_bn_reduce<T, VEC, 0><<<grid, block, 0, stream>>>((const T *)X, nullptr, N, n_dev, C, C, rpb, nullptr,     \
-                                                            nullptr, nullptr, nullptr, 0, partial);                 \
-        k_bn_fold<T, 0><<<grid_f, dim3(FOLD_SL * 32), 0, stream>>>(                                                 \
-            partial, (int)nblk, C, (const T *)X, N, n_dev, st->running_mean, st->running_var,                       \
-            (long long *)st->num_batches_tracked, st->momentum, st->eps, st->save_mean, st->save_invstd);           \
-    } while (0)
-    if (dtype == WFS_F32) {
-        if (C % 4 == 0) WFS_BN_STATS(float, 4); else WFS_BN_STATS(float, 1);
-    } else if (dtype == WFS_BF16) {
-        if (C % 4 == 0) WFS_BN_STATS(wfs_bf16, 4); else WFS_BN_STATS(wfs_bf16, 1);
-    } else {
-        if (C % 4 == 0) WFS_BN_STATS(wfs_f16, 4); else WFS_BN_STATS(wfs_f16, 1);
-    }
-#undef WFS_BN_STATS
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
-}
-
-extern "C" int wfs_bn_apply_fwd(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
-                                const float *save_mean, const float *save_invstd, int32_t relu, void *Y, int32_t dtype,
-                                const int64_t *n_dev_, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long *n_dev = (const long long *)n_dev_;
-    WFS_REQUIRE(C >= 1 && C <= MAXC && (C % 4 == 0 ? C / 4 : C) <= TB, WFS_EINVAL, "unsupported channel count %d", C);
-    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
-    if (N == 0) return WFS_OK;
-    WFS_REQUIRE(X && Y && save_mean && save_invstd, WFS_EINVAL, "NULL device pointer");
-    const long long nblk_a = bn_apply_blocks(N), rpb_a = wfs_cdiv(N, nblk_a);
-    dim3 grid_a((unsigned)nblk_a), block(TB);
-    float *sm = const_cast<float *>(save_mean), *si = const_cast<float *>(save_invstd);     // only read when training = 1
-#define WFS_BN_APPLY(T, VEC)                                                                                         \
-    k_bn_apply<T, VEC><<<grid_a, block, 0, stream>>>((const T *)X, N, n_dev, C, C, rpb_a, gamma, beta, nullptr, nullptr, \
-                                                      nullptr, 0.f, 0.f, 1, relu, (T *)Y, sm, si, nullptr, 0)
-    if (dtype == WFS_F32) {
-        if (C % 4 == 0) WFS_BN_APPLY(float, 4); else WFS_BN_APPLY(float, 1);
-    } else if (dtype == WFS_BF16) {
-        if (C % 4 == 0) WFS_BN_APPLY(wfs_bf16, 4); else WFS_BN_APPLY(wfs_bf16, 1);
-    } else {
-        if (C % 4 == 0) WFS_BN_APPLY(wfs_f16, 4); else WFS_BN_APPLY(wfs_f16, 1);
-    }
-#undef WFS_BN_APPLY
-    WFS_LAUNCH_CHECK();
     return WFS_OK;
 }
 
@@ -1262,36 +1097,3 @@ extern "C" int wfs_bn_relu_bwd(const void *X, const void *dY, int64_t N, int32_t
     return WFS_OK;
 }
 
-bool wfs_bn_fold_ok(long long N, int C) {
-    long long rb = 0;
-    return C == 32 && N > 0 && rr_plan(N, C, 16, &rb) != 0;
-}
-
-extern "C" int wfs_bn_apply_fwd_fold(const void *X, int64_t N, int32_t C, const float *gamma, const float *beta,
-                                     const wfs_bn_stats *st, int32_t pending_blocks, int32_t relu, void *Y,
-                                     int32_t dtype, const int64_t *n_dev_, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    const long long *n_dev = (const long long *)n_dev_;
-    WFS_REQUIRE(wfs_dtype_ok(dtype), WFS_EINVAL, "bad dtype %d", dtype);
-    WFS_REQUIRE(st && st->save_mean && st->save_invstd && st->workspace, WFS_EINVAL, "incomplete wfs_bn_stats");
-    WFS_REQUIRE(pending_blocks >= 1 && pending_blocks <= 256, WFS_EINVAL, "%d pending partials (1 .. 256)", pending_blocks);
-    WFS_REQUIRE(X && Y, WFS_EINVAL, "NULL device pointer");
-    long long rb = 0;
-    const int per = C == 32 && N > 0 ? rr_plan(N, C, 16, &rb) : 0;
-    WFS_REQUIRE(per != 0, WFS_EINVAL, "folding apply covers C == 32 and batches that fit the register files (N = %lld)",
-                (long long)N);
-    const float *part = (const float *)st->workspace, *partn = part + (size_t)pending_blocks * 64;   // stats_args()
-    const dim3 g2((unsigned)rb), block(TB);
-#define WFS_BN_FOLD(T, PER)                                                                                            \
-    k_bn_apply_rr<T, PER, true><<<g2, block, 0, stream>>>(                                                             \
-        (const T *)X, N, n_dev, C, gamma, beta, st->running_mean, st->running_var, (long long *)st->num_batches_tracked, \
-        st->momentum, st->eps, relu, (T *)Y, st->save_mean, st->save_invstd, part, pending_blocks, partn)
-#define WFS_BN_FOLD_T(T)                                                                                               \
-    if (per == 2) WFS_BN_FOLD(T, 2); else if (per == 4) WFS_BN_FOLD(T, 4); else if (per == 8) WFS_BN_FOLD(T, 8);         \
-    else WFS_BN_FOLD(T, 16)
-    if (dtype == WFS_F32) { WFS_BN_FOLD_T(float); } else if (dtype == WFS_BF16) { WFS_BN_FOLD_T(wfs_bf16); } else { WFS_BN_FOLD_T(wfs_f16); }
-#undef WFS_BN_FOLD_T
-#undef WFS_BN_FOLD
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
-}

@@ -15,7 +15,6 @@
 #include <stdlib.h>
 
 #include "wfs_common.h"
-#include "conv_stats.h"
 
 namespace {
 
@@ -45,182 +44,6 @@ __device__ __forceinline__ void table_row_of(int pk, int k, int *trow, int *osel
     *osel = pk ? k - kq * pk : -1;
 }
 __device__ __forceinline__ int table_value(int e, int osel) { return osel < 0 ? e : packed_entry(e, osel); }
-
-// ------------------------------------------------------------------------------------------ 32 -> 32
-// LDS image of the filters: sW[k][h][q][j][e] = B[c = h*16 + q*4 + e][j], with B[c][j] = W[k][c][j]
-// (forward) or W[k][j][c] (dX).  One ds_read_b128 per (q) gives a lane its 4 consecutive k-steps.
-template <bool TRANSPOSE_W, bool STATS>
-__global__ void __launch_bounds__(1024) k_gconv32_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
-                                                      long long R, const long long *__restrict__ r_dev,
-                                                      const float *__restrict__ X,
-                                                      const float *__restrict__ W, const float *__restrict__ bias,
-                                                      float *__restrict__ Y, long long ntiles, long long tiles_per_xcd,
-                                                      WfsStatsArgs sa) {
-    extern __shared__ __attribute__((aligned(16))) float sW[];
-    __shared__ float sStat[STATS ? 16 * 65 : 1];
-    WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
-    const int nthreads = blockDim.x;
-    if (!TRANSPOSE_W) {
-        for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
-            int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;
-            const float *src = W + ((long long)k * 32 + c4 * 4) * 32 + j4 * 4;
-            f32x4 r0 = *(const f32x4 *)(src), r1 = *(const f32x4 *)(src + 32);
-            f32x4 r2 = *(const f32x4 *)(src + 64), r3 = *(const f32x4 *)(src + 96);
-            int h = c4 >> 2, q = c4 & 3;
-            float *dst = sW + ((((k * 2 + h) * 4 + q) * 32) + j4 * 4) * 4;
-            *(f32x4 *)(dst + 0) = f32x4{r0.x, r1.x, r2.x, r3.x};
-            *(f32x4 *)(dst + 4) = f32x4{r0.y, r1.y, r2.y, r3.y};
-            *(f32x4 *)(dst + 8) = f32x4{r0.z, r1.z, r2.z, r3.z};
-            *(f32x4 *)(dst + 12) = f32x4{r0.w, r1.w, r2.w, r3.w};
-        }
-    } else {
-        for (int e = threadIdx.x; e < K * 256; e += nthreads) {
-            int k = e >> 8, j = (e >> 3) & 31, c4 = e & 7;
-            f32x4 v = *(const f32x4 *)(W + ((long long)k * 32 + j) * 32 + c4 * 4);
-            int h = c4 >> 2, q = c4 & 3;
-            *(f32x4 *)(sW + ((((k * 2 + h) * 4 + q) * 32) + j) * 4) = v;
-        }
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    // XCD-aware tile map: blocks with equal blockIdx % 8 share an L2 -> give them one contiguous row range
-    // The ranges are cut from the VALID tiles, not from the capacity: with the capacity's ranges the padding tiles all
-    // fall to the last XCD's blocks, which idle while the others do capacity / valid times their share (a launch's time
-    // grew in proportion to the headroom: 87 -> 123 us per step for the four dX launches at 1.19 -> 1.60).
-    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const long long Rv = valid_rows(R, r_dev);
-    const long long nt_v = (Rv + 31) >> 5, tpx_v = (nt_v + 7) >> 3;
-    (void)ntiles;
-    (void)tiles_per_xcd;
-    const long long t_begin = (long long)xcd * tpx_v;
-    const long long t_end = t_begin + tpx_v < nt_v ? t_begin + tpx_v : nt_v;
-    const float bj = bias ? bias[r] : 0.f;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (long long tile = t_begin + (long long)wid * bpx + bi; tile < t_end; tile += (long long)bpx * nw) {
-        if (tile * 32 >= Rv) break;
-        const long long row = tile * 32 + r;
-        const bool live = row < Rv;
-        const long long rowc = live ? row : 0;
-        // ---- phase 1: which kernel offsets does this tile use?  All K table reads are issued together
-        // (unconditional, clamped addresses: a per-element "load or zero" would make hipcc branch around and
-        // wait for every single load), then one ballot each.
-        int v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            int kk = k < K ? k : K - 1;
-            v[k] = table[(long long)(mirror ? K - 1 - kk : kk) * R + rowc];
-        }
-        unsigned mask = 0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            bool ok = live && k < K && (k == identity_k || v[k] >= 0);
-            if (__ballot(ok) != 0ull) mask |= 1u << k;
-        }
-        mask = __builtin_amdgcn_readfirstlane(mask);
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = bj;
-        if (mask != 0) {
-            // ---- phase 2: the active offsets are taken F32_GROUP at a time, in ascending order (the fp32 sum of a
-            // row keeps the order of the oracle's loop): ALL the group's row gathers (4 x 16 B per lane and offset) are
-            // issued back to back, then the next group's table entries (L1 / L2 hits: phase 1 touched the lines), then
-            // the group's 16 MFMAs per offset run as their rows arrive.  One offset in flight at a time (round 2) left
-            // a wave waiting out a full gather round trip per offset: 9.7 dependent round trips per tile.
-            // the group's table entries: F32_GROUP loads on clamped addresses issued back to back, selects afterwards
-            // (a load per "slot in use?" branch made hipcc wait for each one -- and for the gathers in front of it)
-            auto entry_loads = [&](const int (&kk)[F32_GROUP], int (&t)[F32_GROUP]) {
-#pragma unroll
-                for (int g = 0; g < F32_GROUP; ++g) {
-                    const int k = kk[g] >= 0 ? kk[g] : 0;
-                    t[g] = table[(long long)(mirror ? K - 1 - k : k) * R + rowc];
-                }
-            };
-            auto entry_values = [&](const int (&kk)[F32_GROUP], const int (&t)[F32_GROUP], int (&nb)[F32_GROUP]) {
-#pragma unroll
-                for (int g = 0; g < F32_GROUP; ++g) {
-                    const int v1 = (kk[g] == identity_k) ? (int)rowc : t[g];
-                    nb[g] = (live && kk[g] >= 0) ? v1 : -1;
-                }
-            };
-            int kq[F32_GROUP], nbq[F32_GROUP];
-#pragma unroll
-            for (int g = 0; g < F32_GROUP; ++g) {
-                kq[g] = mask ? __builtin_ctz(mask) : -1;
-                mask = mask ? (mask & (mask - 1)) : 0u;
-            }
-            {
-                int t0[F32_GROUP];
-                entry_loads(kq, t0);
-                entry_values(kq, t0, nbq);
-            }
-            while (true) {
-                f32x4 a[F32_GROUP][4];
-#pragma unroll
-                for (int g = 0; g < F32_GROUP; ++g) {
-                    // unconditional (an empty slot of the last group reads row 0): with the loads behind "slot in use?"
-                    // branches the first MFMA waited for the whole group's rows instead of its own
-                    const f32x4 *xp = (const f32x4 *)(X + (long long)(nbq[g] >= 0 ? nbq[g] : 0) * 32 + h * 16);
-                    a[g][0] = xp[0];
-                    a[g][1] = xp[1];
-                    a[g][2] = xp[2];
-                    a[g][3] = xp[3];
-                }
-                int kn[F32_GROUP], tn[F32_GROUP], nbn[F32_GROUP];
-#pragma unroll
-                for (int g = 0; g < F32_GROUP; ++g) {
-                    kn[g] = mask ? __builtin_ctz(mask) : -1;
-                    mask = mask ? (mask & (mask - 1)) : 0u;
-                }
-                entry_loads(kn, tn);
-                // keep hipcc from (a) issuing the first offset's rows last and (b) consuming the next group's entries --
-                // i.e. waiting for every load above -- in front of the MFMAs
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < F32_GROUP; ++g)
-                    if (kq[g] >= 0) {
-                        f32x4 a0 = a[g][0], a1 = a[g][1], a2 = a[g][2], a3 = a[g][3];
-                        if (nbq[g] < 0) a0 = a1 = a2 = a3 = zero4;
-                        const f32x4 *bp = (const f32x4 *)(sW + (((kq[g] * 2 + h) * 4) * 32 + r) * 4);
-                        f32x4 b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
-#define WFS_MFMA4(a, b)                                                          \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);          \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);          \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);          \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-                        WFS_MFMA4(a0, b0)
-                        WFS_MFMA4(a1, b1)
-                        WFS_MFMA4(a2, b2)
-                        WFS_MFMA4(a3, b3)
-#undef WFS_MFMA4
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-                if (kn[0] < 0) break;
-                entry_values(kn, tn, nbn);
-#pragma unroll
-                for (int g = 0; g < F32_GROUP; ++g) {
-                    kq[g] = kn[g];
-                    nbq[g] = nbn[g];
-                }
-            }
-        }
-        // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            long long orow = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (orow < Rv) Y[orow * 32 + r] = acc[i];
-        }
-        if constexpr (STATS) {
-            float vals[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vals[i] = acc[i];
-            const long long left = Rv - tile * 32;
-            wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
-        }
-    }
-    if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
-}
 
 // ------------------------------------------------------------------------------------------ 32 -> 32, fp32, 16-row tiles
 // k_gconv32_f32 gives every wave ONE 32-row tile, and a launch then lasts as long as its heaviest tile: 16 dependent
@@ -459,15 +282,13 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 #endif
 // (the body is a device function so that the backward pass can run it beside the dW kernel's body in ONE launch:
 // k_bwd32_bf16 below; vbid / vgrid = this product's block index and block count, nthreads = its threads)
-template <typename H, bool TRANSPOSE_W, bool STATS, int PK = 0>
+template <typename H, bool TRANSPOSE_W, int PK = 0>
 __device__ __forceinline__ void gconv32_bf16_body(unsigned char *smem, int vbid, int vgrid, int nthreads,
                                                   const int *__restrict__ table, int mirror, int K, int identity_k,
                                                   long long R, const long long *__restrict__ r_dev,
                                                   const H *__restrict__ X, const float *__restrict__ W,
                                                   const float *__restrict__ bias, H *__restrict__ Y, long long ntiles,
-                                                  long long tiles_per_xcd, WfsStatsArgs sa) {
-    __shared__ float sStat[STATS ? 16 * 65 : 1];
-    WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
+                                                  long long tiles_per_xcd) {
     uint4 *sWb = reinterpret_cast<uint4 *>(smem);                           // K * 128 fragments of 16 B
     int *sNb = reinterpret_cast<int *>(smem + (size_t)K * 2048);            // [waves][K][32]
     // filter staging, WSB fragments per thread at a time: all their loads are issued (unconditionally, clamped)
@@ -614,28 +435,20 @@ __device__ __forceinline__ void gconv32_bf16_body(unsigned char *smem, int vbid,
             if (!(WFS_KNOCK & 8) || packed == 0x12345678u)
                 if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
         }
-        if constexpr (STATS) {
-            float vals[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vals[i] = wfs_round_to<H>(acc[i]);      // statistics of the values as stored
-            const long long left = Rv - tile * 32;
-            wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
-        }
     }
-    if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
 }
 
-template <typename H, bool TRANSPOSE_W, bool STATS, int PK = 0>
+template <typename H, bool TRANSPOSE_W, int PK = 0>
 __global__ void __launch_bounds__(1024) k_gconv32_bf16(const int *__restrict__ table, int mirror, int K,
                                                        int identity_k,
                                                        long long R, const long long *__restrict__ r_dev,
                                                        const H *__restrict__ X,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                        H *__restrict__ Y, long long ntiles,
-                                                       long long tiles_per_xcd, WfsStatsArgs sa) {
+                                                       long long tiles_per_xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gconv32_bf16_body<H, TRANSPOSE_W, STATS, PK>(smem, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, table, mirror, K,
-                                                 identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
+    gconv32_bf16_body<H, TRANSPOSE_W, PK>(smem, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, table, mirror, K,
+                                          identity_k, R, r_dev, X, W, bias, Y, ntiles, tiles_per_xcd);
 }
 
 // ------------------------------------------------------------------------------------------ 2 -> 32
@@ -849,16 +662,13 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32_f32(const int *__restrict__
 // (2 bf16 channels each) of offsets 8s + 4h + {0,1,2,3} of row r -- read straight from global memory, no LDS, no
 // transpose; all 16 table entries of a lane are loaded together, then all 16 gathers.  The filter image
 // sWc[s][h][co][j] = W[k = 8s + 4h + j/2][c = j & 1][co] (zero for k >= K) is 4 KiB.
-template <typename H, bool STATS>
-__global__ void __launch_bounds__(STATS ? 1024 : 256) k_gconv_c2c32_bf16(const int *__restrict__ table, int mirror, int K,
+template <typename H>
+__global__ void __launch_bounds__(256) k_gconv_c2c32_bf16(const int *__restrict__ table, int mirror, int K,
                                                          int identity_k, long long R,
                                                          const long long *__restrict__ r_dev,
                                                          const H *__restrict__ X, const float *__restrict__ W,
-                                                         const float *__restrict__ bias, H *__restrict__ Y,
-                                                         WfsStatsArgs sa) {
+                                                         const float *__restrict__ bias, H *__restrict__ Y) {
     __shared__ __attribute__((aligned(16))) uint4 sWc[4 * 2 * 32];
-    __shared__ float sStat[STATS ? 16 * 65 : 1];
-    WfsLaneStats cst = {0.f, 0.f, 0.f, 0.f};
     if (threadIdx.x < 256) {
         const int u = threadIdx.x;                 // 256 threads = 4 steps x 2 halves x 32 output channels
         const int st = u >> 6, hh = (u >> 5) & 1, co = u & 31;
@@ -923,15 +733,7 @@ __global__ void __launch_bounds__(STATS ? 1024 : 256) k_gconv_c2c32_bf16(const i
             long long orow = tile * 32 + (ri & 3) + 8 * (ri >> 2) + 4 * h;
             if (orow < Rv) Yw[orow * 16 + (r >> 1)] = packed;
         }
-        if constexpr (STATS) {
-            float vals[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vals[i] = wfs_round_to<H>(acc[i]);
-            const long long left = Rv - tile * 32;
-            wfs_lane_stats_tile(cst, vals, left < 32 ? (int)left : 32, h);
-        }
     }
-    if constexpr (STATS) wfs_stats_finish(wfs_lane_stats_close(cst), sStat, sa);
 }
 
 // ------------------------------------------------------------------------------------------ dW 32 x 32, bf16
@@ -1107,9 +909,8 @@ __global__ void __launch_bounds__(1024) k_bwd32_bf16(const int *__restrict__ tab
                            ngroups);
     } else {
         if ((int)threadIdx.x >= dx_threads) return;          // the dX body was tuned for fewer waves per block
-        const WfsStatsArgs none = {};
-        gconv32_bf16_body<H, true, false, PK>(smem, bid - n_dw_pad, n_dx, dx_threads, table, 0, K, identity_k, Rcap, r_dev, G,
-                                              W, nullptr, dX, 0, 0, none);
+        gconv32_bf16_body<H, true, PK>(smem, bid - n_dw_pad, n_dx, dx_threads, table, 0, K, identity_k, Rcap, r_dev, G, W,
+                                       nullptr, dX, 0, 0);
     }
 }
 
@@ -1405,7 +1206,7 @@ template <typename KernelT, typename... Args>
 static int launch_big_lds(KernelT kernel, bool *attr_done, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
                           Args... args) {
     if (!*attr_done) {
-        // 160 KiB per CU minus the kernels' static LDS (statistics scratch of the STATS variants)
+        // 160 KiB per CU minus the kernels' static LDS
         WFS_HIP_CHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         *attr_done = true;
     }
@@ -1433,129 +1234,72 @@ static void gconv32_grid(long long R, bool padded, long long *ntiles, int *wpb, 
     *tiles_per_xcd = (*ntiles + 7) / 8;
 }
 
-// block partials of the fused BatchNorm statistics: (mean, M2)[32] + count per block
-size_t wfs_conv_stats_fast_workspace(long long R) {
-    long long blocks = ((R + 31) / 32 + 3) / 4;       // the 2 -> 32 kernel launches the most blocks
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 256) blocks = 256;
-    return (size_t)blocks * 65 * sizeof(float);
-}
-
-// pending == NULL: fold the block partials now (one small launch).  Otherwise the partials stay in the workspace and
-// *pending = their number: the BatchNorm apply kernel folds them in its prologue (wfs_bn_apply_fwd_fold), which saves
-// the launch.
-static int stats_fold(const WfsStatsArgs &sa, long long nblk, int *pending, hipStream_t stream) {
-    if (pending) {
-        *pending = (int)nblk;
-        return WFS_OK;
-    }
-    k_stats_fold<<<dim3(1), dim3(1024), 0, stream>>>(sa, (int)nblk);
-    WFS_LAUNCH_CHECK();
-    return WFS_OK;
-}
-
-static WfsStatsArgs stats_args(const wfs_bn_stats *st, long long nblk) {
-    WfsStatsArgs sa = {};
-    if (st) {
-        sa.part = (float *)st->workspace;
-        sa.partn = sa.part + (size_t)nblk * 64;
-        sa.save_mean = st->save_mean;
-        sa.save_invstd = st->save_invstd;
-        sa.running_mean = st->running_mean;
-        sa.running_var = st->running_var;
-        sa.batches_tracked = (long long *)st->num_batches_tracked;
-        sa.momentum = st->momentum;
-        sa.eps = st->eps;
-    }
-    return sa;
-}
-
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl) {
+                           hipStream_t stream, int packed_kl) {
     const size_t lds = (size_t)K * 4096;
-    WFS_REQUIRE(packed_kl == 0 || (packed_kl == 3 && transpose_w && !stats && !mirror && identity_k < 0), WFS_EINVAL,
+    WFS_REQUIRE(packed_kl == 0 || (packed_kl == 3 && transpose_w && !mirror && identity_k < 0), WFS_EINVAL,
                 "packed tables: kl = 3, dX products only");
-    if (!stats) {
-        // 16-row tiles taken off a per-block counter (k_gconv16_f32): up to 16 waves per block, <= 256 blocks
-        static bool attr16[2] = {false, false};
-        const long long nt16 = (R + 15) >> 4;
-        const long long expect = r_dev ? (nt16 * 7 + 7) / 8 : nt16;
-        int w = (int)((expect + 255) / 256);
-        w = w < 4 ? 4 : (w > 16 ? 16 : (w + 3) / 4 * 4);
-        long long nb = (expect + w - 1) / w;
-        nb = nb > 256 ? 256 : (nb + 7) / 8 * 8;
-        if (nb < 8) nb = 8;
-        const dim3 g16((unsigned)nb), b16(w * 64);
-        if (packed_kl) {
-            static bool attr16p = false;
-            return launch_big_lds(k_gconv16_f32<true, 3>, &attr16p, g16, b16, lds, stream, table, mirror, K, identity_k, R,
-                                  r_dev, X, W, bias, Y);
-        }
-        if (transpose_w)
-            return launch_big_lds(k_gconv16_f32<true>, &attr16[0], g16, b16, lds, stream, table, mirror, K, identity_k, R,
-                                  r_dev, X, W, bias, Y);
-        return launch_big_lds(k_gconv16_f32<false>, &attr16[1], g16, b16, lds, stream, table, mirror, K, identity_k, R,
+    // 16-row tiles taken off a per-block counter (k_gconv16_f32): up to 16 waves per block, <= 256 blocks
+    static bool attr16[2] = {false, false};
+    const long long nt16 = (R + 15) >> 4;
+    const long long expect = r_dev ? (nt16 * 7 + 7) / 8 : nt16;
+    int w = (int)((expect + 255) / 256);
+    w = w < 4 ? 4 : (w > 16 ? 16 : (w + 3) / 4 * 4);
+    long long nb = (expect + w - 1) / w;
+    nb = nb > 256 ? 256 : (nb + 7) / 8 * 8;
+    if (nb < 8) nb = 8;
+    const dim3 g16((unsigned)nb), b16(w * 64);
+    if (packed_kl) {
+        static bool attr16p = false;
+        return launch_big_lds(k_gconv16_f32<true, 3>, &attr16p, g16, b16, lds, stream, table, mirror, K, identity_k, R,
                               r_dev, X, W, bias, Y);
     }
-    // forward with the BatchNorm statistics in the epilogue (spconv.ops.FUSE_CONV_BN_STATS): the 32-row kernel, whose
-    // per-block statistics do not depend on which wave took which tile
-    WFS_REQUIRE(!transpose_w, WFS_EINVAL, "batch statistics are taken by forward products only");
-    long long ntiles, nblk, tiles_per_xcd;
-    int wpb;
-    gconv32_grid(R, r_dev != nullptr, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
-    static bool attr = false;
-    const WfsStatsArgs sa = stats_args(stats, nblk);
-    const dim3 grid((unsigned)nblk), block(wpb * 64);
-    const int rc = launch_big_lds(k_gconv32_f32<false, true>, &attr, grid, block, lds, stream, table, mirror, K, identity_k, R,
-                                  r_dev, X, W, bias, Y, ntiles, tiles_per_xcd, sa);
-    return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
+    if (transpose_w)
+        return launch_big_lds(k_gconv16_f32<true>, &attr16[0], g16, b16, lds, stream, table, mirror, K, identity_k, R,
+                              r_dev, X, W, bias, Y);
+    return launch_big_lds(k_gconv16_f32<false>, &attr16[1], g16, b16, lds, stream, table, mirror, K, identity_k, R,
+                          r_dev, X, W, bias, Y);
 }
 
 template <typename H>
 static int launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                               const H *Xb, const float *W, int transpose_w, const float *bias, H *Yb,
-                              const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl) {
+                              hipStream_t stream, int packed_kl) {
     long long ntiles, nblk, tiles_per_xcd;
     int wpb;
     gconv32_grid(R, r_dev != nullptr, &ntiles, &wpb, &nblk, &tiles_per_xcd, 16);
     const size_t lds = (size_t)K * 2048 + (size_t)wpb * K * 32 * sizeof(int);
-    static bool attr[3] = {false, false, false};          // per instantiation of this template, i.e. per H
-    const WfsStatsArgs sa = stats_args(stats, nblk);
+    static bool attr[2] = {false, false};          // per instantiation of this template, i.e. per H
     const dim3 grid((unsigned)nblk), block(wpb * 64);
-    WFS_REQUIRE(packed_kl == 0 || (packed_kl == 3 && transpose_w && !stats && !mirror && identity_k < 0), WFS_EINVAL,
+    WFS_REQUIRE(packed_kl == 0 || (packed_kl == 3 && transpose_w && !mirror && identity_k < 0), WFS_EINVAL,
                 "packed tables: kl = 3, dX products only");
     if (packed_kl) {
         static bool attr_p = false;
-        return launch_big_lds(k_gconv32_bf16<H, true, false, 3>, &attr_p, grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+        return launch_big_lds(k_gconv32_bf16<H, true, 3>, &attr_p, grid, block, lds, stream, table, mirror, K, identity_k, R,
+                              r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd);
     }
     if (transpose_w)
-        return launch_big_lds(k_gconv32_bf16<H, true, false>, &attr[0], grid, block, lds, stream, table, mirror, K,
-                              identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
-    if (stats) {
-        const int rc = launch_big_lds(k_gconv32_bf16<H, false, true>, &attr[1], grid, block, lds, stream, table, mirror, K,
-                                      identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
-        return rc != WFS_OK ? rc : stats_fold(sa, nblk, pending, stream);
-    }
-    return launch_big_lds(k_gconv32_bf16<H, false, false>, &attr[2], grid, block, lds, stream, table, mirror, K,
-                          identity_k, R, r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd, sa);
+        return launch_big_lds(k_gconv32_bf16<H, true>, &attr[0], grid, block, lds, stream, table, mirror, K, identity_k, R,
+                              r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd);
+    return launch_big_lds(k_gconv32_bf16<H, false>, &attr[1], grid, block, lds, stream, table, mirror, K, identity_k, R,
+                          r_dev, Xb, W, bias, Yb, ntiles, tiles_per_xcd);
 }
 
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl) {
+                           hipStream_t stream, int packed_kl) {
     if (dtype == WFS_F16)
         return launch_gconv32_h16<wfs_f16>(table, mirror, K, identity_k, R, r_dev, (const wfs_f16 *)X, W, transpose_w,
-                                           bias, (wfs_f16 *)Y, stats, pending, stream, packed_kl);
+                                           bias, (wfs_f16 *)Y, stream, packed_kl);
     return launch_gconv32_h16<wfs_bf16>(table, mirror, K, identity_k, R, r_dev, (const wfs_bf16 *)X, W, transpose_w, bias,
-                                        (wfs_bf16 *)Y, stats, pending, stream, packed_kl);
+                                        (wfs_bf16 *)Y, stream, packed_kl);
 }
 
-// 2 -> 32.  *stats_done tells the caller whether the kernel that ran took the BatchNorm statistics itself.
+// 2 -> 32
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream) {
+                           hipStream_t stream) {
     KMap km;
     bool is_ident = true, is_mirror = true;
     for (int k = 0; k < K; ++k) {
@@ -1563,28 +1307,17 @@ int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identit
         is_ident = is_ident && km.v[k] == k;
         is_mirror = is_mirror && km.v[k] == K - 1 - k;
     }
-    if (stats_done) *stats_done = false;
     if (dtype != WFS_F32 && K <= 32 && (is_ident || is_mirror)) {
-        long long nb = ((R + 31) / 32 + 3) / 4;
+        long long nb = ((R + 31) / 32 + 3) / 4;              // one 32-row tile per wave, 4 waves per block
         if (nb > 4096) nb = 4096;
-        if (stats && nb > 1024) nb = 1024;          // one partial per block for k_stats_fold
-        if (stats && pending && nb > 256) nb = 256; // ... every block of the BatchNorm apply kernel folds them all
-        const WfsStatsArgs sa = stats_args(stats, nb);
-        // with the partials left to the BatchNorm kernel (<= 256 of them) the blocks get 12 waves instead of 4, so
-        // that the launch still holds about one 32-row tile per wave
-        const dim3 grid((unsigned)nb), block((stats && pending) ? 768 : 256);
+        const dim3 grid((unsigned)nb), block(256);
         const int mir = is_ident ? 0 : 1;
-#define WFS_C2(H, ST)                                                                                                \
-    k_gconv_c2c32_bf16<H, ST><<<grid, block, 0, stream>>>(table, mir, K, identity_k, R, r_dev, (const H *)X, W, bias,  \
-                                                          (H *)Y, sa)
-        if (stats) {
-            if (dtype == WFS_F16) WFS_C2(wfs_f16, true); else WFS_C2(wfs_bf16, true);
-            WFS_LAUNCH_CHECK();
-            if (stats_done) *stats_done = true;
-            return stats_fold(sa, nb, pending, stream);
-        }
-        if (dtype == WFS_F16) WFS_C2(wfs_f16, false); else WFS_C2(wfs_bf16, false);
-#undef WFS_C2
+        if (dtype == WFS_F16)
+            k_gconv_c2c32_bf16<wfs_f16><<<grid, block, 0, stream>>>(table, mir, K, identity_k, R, r_dev, (const wfs_f16 *)X, W,
+                                                                    bias, (wfs_f16 *)Y);
+        else
+            k_gconv_c2c32_bf16<wfs_bf16><<<grid, block, 0, stream>>>(table, mir, K, identity_k, R, r_dev, (const wfs_bf16 *)X,
+                                                                     W, bias, (wfs_bf16 *)Y);
         WFS_LAUNCH_CHECK();
         return WFS_OK;
     }

@@ -406,10 +406,8 @@ long long dw_chunks_mfma(long long R, int K, int Cs, int Cg) {
 static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                             int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
                             int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
-                            const int64_t *r_dev_, const wfs_bn_stats *stats, bool *stats_done, int *pending,
-                            void *stream_, int packed_kl = 0) {
+                            const int64_t *r_dev_, void *stream_, int packed_kl = 0) {
     hipStream_t stream = (hipStream_t)stream_;
-    *stats_done = false;
     WFS_REQUIRE(packed_kl == 0 || wfs_gather_packed_ok(packed_kl, K, Cx, transpose_w ? Cw_in : Cw_out, dtype, transpose_w ? 1 : 2),
                 WFS_EINVAL, "a packed table (kl %d) is not taken by this product (wfs_gather_packed_ok): expand it with "
                 "wfs_unpack_table", packed_kl);
@@ -437,19 +435,16 @@ static int gather_conv_impl(const int32_t *table, const int32_t *kmap_host, int3
     // (the fp32 kernel addresses the gathered rows through 32-bit byte offsets: fewer than 2^24 rows of 128 B)
     if (dtype == WFS_F32 && Cx == 32 && Cy == 32 && wfs_mfma_gconv32_ok(K) && table && (is_ident || is_mirror) &&
         X_rows < (1ll << 24)) {
-        *stats_done = stats != nullptr;
         return wfs_launch_gconv32_f32(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, (const float *)X, W, transpose_w,
-                                      bias, (float *)Y, stats, pending, stream, packed_kl);
+                                      bias, (float *)Y, stream, packed_kl);
     }
     if (dtype != WFS_F32 && Cx == 32 && Cy == 32 && K <= 27 && table && (is_ident || is_mirror) && X_rows < (1ll << 25)) {
-        *stats_done = stats != nullptr;
         return wfs_launch_gconv32_h16(table, is_ident ? 0 : 1, K, identity_k, R, r_dev, X, W, transpose_w, bias, Y,
-                                      dtype, stats, pending, stream, packed_kl);
+                                      dtype, stream, packed_kl);
     }
     WFS_REQUIRE(packed_kl == 0, WFS_EINVAL, "a packed table reached a kernel that reads dense ones");
     if (Cx == 2 && Cy == 32 && !transpose_w && table)
-        return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stats, stats_done,
-                                      pending, stream);
+        return wfs_launch_gconv_c2c32(table, kmap_host, K, identity_k, R, r_dev, X, W, bias, Y, dtype, stream);
     if (gm_shape(Cx, Cy) && table) {
         const dim3 g((unsigned)wfs_cdiv(R, 32), (unsigned)wfs_cdiv(Cy, 32)), b(64 * GM_WAVES);
 #define WFS_GM(T, TR)                                                                                            \
@@ -486,10 +481,9 @@ extern "C" int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, i
                                int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W, int32_t Cw_in,
                                int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y, int32_t dtype,
                                const int64_t *r_dev, int32_t packed_kl, void *stream) {
-    bool unused;
     WFS_REQUIRE(packed_kl == 0 || !kmap_host, WFS_EINVAL, "a packed table takes no column map");
     return gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, transpose_w, bias, Y,
-                            dtype, r_dev, nullptr, &unused, nullptr, stream, packed_kl);
+                            dtype, r_dev, stream, packed_kl);
 }
 
 // which = 1: wfs_gather_conv with transpose_w (dX), 2: wfs_gather_conv forward, 3: wfs_gather_dw
@@ -498,36 +492,6 @@ extern "C" int wfs_gather_packed_ok(int32_t packed_kl, int32_t K, int32_t Ca, in
         return 0;
     if (which == 3) return 1;
     return which == 1 && packed_kl == 3 && K <= 27;
-}
-
-extern "C" size_t wfs_conv_stats_workspace_bytes(int64_t R, int32_t C) {
-    size_t fused = wfs_conv_stats_fast_workspace(R), plain = wfs_bn_workspace_bytes(R, C);
-    return fused > plain ? fused : plain;
-}
-
-extern "C" int wfs_gather_conv_bnstats(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
-                                       int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
-                                       int32_t Cw_in, int32_t Cw_out, const float *bias, void *Y, int32_t dtype,
-                                       const int64_t *r_dev, const wfs_bn_stats *stats, int32_t *pending_blocks,
-                                       void *stream) {
-    WFS_REQUIRE(stats && stats->save_mean && stats->save_invstd && stats->workspace, WFS_EINVAL,
-                "incomplete wfs_bn_stats");
-    WFS_REQUIRE((stats->running_mean == nullptr) == (stats->running_var == nullptr), WFS_EINVAL,
-                "running_mean and running_var come together");
-    WFS_REQUIRE(stats->workspace_bytes >= wfs_conv_stats_workspace_bytes(R, Cw_out), WFS_EWORKSPACE,
-                "statistics workspace %zu < %zu", stats->workspace_bytes, wfs_conv_stats_workspace_bytes(R, Cw_out));
-    WFS_REQUIRE(R > 0, WFS_EINVAL, "batch statistics of zero rows");
-    bool done = false;
-    int pending = 0;
-    // the partials may stay unfolded when the caller can take them (pending_blocks) and the BatchNorm apply kernel
-    // that folds them covers this batch (32 channels, rows fit its register-resident form)
-    const bool defer = pending_blocks && Cw_out == 32 && wfs_bn_fold_ok(R, Cw_out);
-    if (pending_blocks) *pending_blocks = 0;
-    int rc = gather_conv_impl(table, kmap_host, K, identity_k, R, X, X_rows, Cx, W, Cw_in, Cw_out, 0, bias, Y, dtype, r_dev,
-                              stats, &done, defer ? &pending : nullptr, stream);
-    if (rc == WFS_OK && done && pending_blocks) *pending_blocks = pending;
-    if (rc != WFS_OK || done) return rc;
-    return wfs_launch_bn_stats(Y, R, Cw_out, dtype, (const long long *)r_dev, stats, (hipStream_t)stream);
 }
 
 extern "C" int wfs_scatter_conv(const int32_t *table, int32_t K, int32_t identity_k, int64_t R, const void *X,
@@ -667,9 +631,8 @@ extern "C" int wfs_conv_backward(const int32_t *table, int32_t K, int32_t identi
         int rc = gather_dw_impl(table, nullptr, K, identity_k, R, X, Cin, dY, dY_rows, Cout, 0, dW, dtype, workspace,
                                 workspace_bytes, r_dev, defer, stream_, packed_kl);
         if (rc != WFS_OK) return rc;
-        bool unused;
         return gather_conv_impl(table, nullptr, K, identity_k, R, dY, dY_rows, Cout, W, Cin, Cout, 1, nullptr, dX, dtype, r_dev,
-                                nullptr, &unused, nullptr, stream_, packed_kl);
+                                stream_, packed_kl);
     }
     WFS_REQUIRE(X && dY && W && workspace, WFS_EINVAL, "NULL device pointer");
     const size_t need = wfs_gather_dw_workspace_bytes(K, R, Cin, Cout);

@@ -104,29 +104,22 @@ struct WfsTimerScope {
 
 // shape-specialised launchers (conv_mfma.hip); r_dev: optional device-side count of valid rows (<= R)
 bool wfs_mfma_gconv32_ok(int K);
-// stats (optional): BatchNorm statistics taken in the epilogue (conv_stats.h); forward products only.
-// pending (optional): leave the per-block partials unfolded and return their number (see stats_fold, conv_mfma.hip)
-bool wfs_bn_fold_ok(long long N, int C);          // bn.hip: can the apply kernel fold conv partials for this batch?
 int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const float *X, const float *W, int transpose_w, const float *bias, float *Y,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl = 0);
+                           hipStream_t stream, int packed_kl = 0);
 // 16-bit rows (dtype WFS_BF16 or WFS_F16)
 int wfs_launch_gconv32_h16(const int *table, int mirror, int K, int identity_k, long long R, const long long *r_dev,
                            const void *X, const float *W, int transpose_w, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, int *pending, hipStream_t stream, int packed_kl = 0);
+                           hipStream_t stream, int packed_kl = 0);
 int wfs_launch_gconv_c2c32(const int *table, const int *kmap, int K, int identity_k, long long R,
                            const long long *r_dev, const void *X, const float *W, const float *bias, void *Y, int dtype,
-                           const wfs_bn_stats *stats, bool *stats_done, int *pending, hipStream_t stream);
-size_t wfs_conv_stats_fast_workspace(long long R);
+                           hipStream_t stream);
 // wide layers (wide.hip): dW as dense matrix-core products
 bool wfs_wide_dw_ok(int K, long long R, int Cs, int Cg, int dtype);
 size_t wfs_wide_dw_workspace(int K, long long R, int Cs, int Cg, int dtype);
 int wfs_launch_wide_dw(const int *table, const int *kmap_host, int K, int identity_k, long long R, const long long *r_dev,
                        const void *S, int Cs, const void *G, long long G_rows, int Cg, int swap, float *dW, int dtype,
                        void *workspace, size_t workspace_bytes, hipStream_t stream);
-// bn.hip: the stand-alone statistics pass (reduce + fold) over X [N, C]
-int wfs_launch_bn_stats(const void *X, long long N, int C, int dtype, const long long *n_dev, const wfs_bn_stats *stats,
-                        hipStream_t stream);
 size_t wfs_dw_fast_workspace(int K, long long R, int Cs, int Cg);
 int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const long long *r_dev, const void *S,
                      const void *G, int swap, float *dW, float *part, int dtype, wfs_dw_job *defer, hipStream_t stream,

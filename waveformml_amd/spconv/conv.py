@@ -87,15 +87,13 @@ class SparseConvolution(SparseModule):
             out_tensor.prefetched = getattr(input, "prefetched", None)
             return out_tensor
         datas = input.find_indice_pair(self.indice_key)
-        bn_request = getattr(input, "bn_request", None)      # set by SparseSequential when a BatchNorm1d follows
-        input.bn_request = None
         if self.inverse:
             assert datas is not None and self.indice_key is not None
             rb = datas.rulebook
             out_spatial_shape = datas.spatial_shape
             assert rb.K == np.prod(self.kernel_size), "inverse conv must have same kernel size as its couple conv"
             out_indices = rb.indices
-            out_features = Fsp.indice_inverse_conv(features, self.weight, self.bias, rb, bn_request)
+            out_features = Fsp.indice_inverse_conv(features, self.weight, self.bias, rb)
             out_unique = None if rb.has_dup else True
             out_n_valid = rb.n_dev
         else:
@@ -124,10 +122,10 @@ class SparseConvolution(SparseModule):
                 input.indice_dict[self.indice_key] = IndiceData(rb, spatial_shape)
             out_indices = rb.out_indices
             if self.subm:
-                out_features = Fsp.indice_subm_conv(features, self.weight, self.bias, rb, bn_request)
+                out_features = Fsp.indice_subm_conv(features, self.weight, self.bias, rb)
                 out_unique = input.unique
             else:
-                out_features = Fsp.indice_conv(features, self.weight, self.bias, rb, bn_request)
+                out_features = Fsp.indice_conv(features, self.weight, self.bias, rb)
                 out_unique = True      # a regular conv numbers DISTINCT output sites
             out_n_valid = rb.m_dev
         out_tensor = SparseConvTensor(out_features, out_indices, out_spatial_shape, batch_size)
@@ -140,7 +138,6 @@ class SparseConvolution(SparseModule):
             out_tensor.events = getattr(input, "events", None)          # same row set, same event offsets
         elif not self.inverse and getattr(rb, "events_out", None) is not None:
             out_tensor.events = rb.events_out                           # the event-local build numbered them by event
-        out_tensor.bn_stats = bn_request if (bn_request is not None and bn_request.stats is not None) else None
         if not self.subm and not self.inverse:
             out_tensor.cell_map = getattr(rb, "cell_map", None)      # dense() of THIS row set can use the build's map
         return out_tensor

@@ -59,28 +59,6 @@ def _masked_column_sum(t, r_dev):
     return out
 
 
-class BatchNormRequest(object):
-    """Hand-over between a convolution and the training-mode nn.BatchNorm1d that follows it in a SparseSequential:
-    the conv kernel's epilogue takes the batch statistics (include/wfsparse.h, wfs_gather_conv_bnstats), the
-    BatchNorm step then only normalises.  ``stats`` is filled by the convolution that honoured the request."""
-
-    def __init__(self, bn, allow_pending=True):
-        self.bn = bn
-        self.stats = None          # (save_mean, save_invstd, pending partials or None)
-        # allow_pending: the per-block partials may stay unfolded for the BatchNorm apply kernel to fold
-        self.allow_pending = allow_pending
-
-
-def can_take_batch_norm_stats(bn, features):
-    """A conv can take the statistics for ``bn`` when the fused BatchNorm kernels would run it anyway
-    (can_fuse_batch_norm) and it normalises with batch statistics."""
-    return (type(bn) is torch.nn.BatchNorm1d and bn.momentum is not None and features.is_cuda
-            and features.dtype in (torch.float32, torch.bfloat16, torch.float16) and features.shape[0] > 0
-            and (bn.num_features <= 256 or (bn.num_features % 4 == 0 and bn.num_features <= 1024))
-            and (bn.weight is None or bn.weight.dtype == torch.float32)
-            and (bn.training or bn.running_mean is None))
-
-
 # Every layer runs in libwfsparse: the 32- and 2-channel MFMA kernels of conv_mfma.hip, the shape-generic 32 x 32-tile MFMA
 # kernels of gather_conv.hip (k_gconv_mfma / k_gdw_mfma: 16 / 24 / 64-channel layers) and, from 128 channels on a side,
 # the dense 128 x 128-tile matrix-core products of wide.hip (the reference's GEP.json 300 -> 252 -> 158 -> 64 stack,
@@ -113,8 +91,7 @@ def takes_wide_path(K, R, X, Cy):
 
 def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev, w16=None):
     """>= 128 channels on a side: one dense matrix-core product over the shorter side of the layer
-    (csrc/wide.hip; include/wfsparse.h wfs_wide_gather_conv).  The BatchNorm statistics, when a BatchNorm1d follows,
-    are taken by its own kernel (bn_request stays unanswered)."""
+    (csrc/wide.hip; include/wfsparse.h wfs_wide_gather_conv)."""
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
     Cx, Cy = int(X.shape[1]), (Cw_in if transpose_w else Cw_out)
     assert W.dtype == torch.float32 and W.is_contiguous() and X.is_contiguous()
@@ -131,10 +108,8 @@ def _wide_gather_conv(lib, table, kmap, K, identity_k, R, X, W, transpose_w, bia
     return Y
 
 
-def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, bn_request=None, w16=None,
-                packed_kl=0):
+def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=None, w16=None, packed_kl=0):
     """Y[r] = bias + sum_k X[table[kmap[k], r]] . W[k]   (W fp32 [K, Cin, Cout]; ^T if transpose_w).
-    With ``bn_request`` the launch also produces the BatchNorm statistics of Y (forward products only).
     ``packed_kl`` > 0: ``table`` is the packed by-input table [K / packed_kl, R] (Rulebook.table_by_in)."""
     lib = _lib.load()
     Cw_in, Cw_out = int(W.shape[-2]), int(W.shape[-1])
@@ -162,29 +137,9 @@ def gather_conv(table, kmap, K, identity_k, R, X, W, transpose_w, bias, r_dev=No
     assert X.dim() == 2 and X.shape[1] == (Cw_out if transpose_w else Cw_in), (X.shape, W.shape, transpose_w)
     assert table is None or (table.dtype == torch.int32 and table.shape == (K, R)), (None if table is None else table.shape, K, R)
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cy)
-    if bn_request is not None and not transpose_w and R > 0 and bn_request.bn.num_features == Cy:
-        bn = bn_request.bn
-        track = bn.track_running_stats and bn.running_mean is not None
-        save_mean = torch.empty((Cy,), dtype=torch.float32, device=X.device)
-        save_invstd = torch.empty((Cy,), dtype=torch.float32, device=X.device)
-        ws = torch.empty((int(lib.wfs_conv_stats_workspace_bytes(R, Cy)),), dtype=torch.uint8, device=X.device)
-        st = _lib.BnStats(_lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(bn.running_mean) if track else None,
-                          _lib.ptr(bn.running_var) if track else None,
-                          _lib.ptr(bn.num_batches_tracked) if (track and bn.training) else None,
-                          float(bn.momentum), float(bn.eps), _lib.ptr(ws), ws.numel())
-        pending = ctypes.c_int32(0)
-        _lib.check(lib.wfs_gather_conv_bnstats(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0],
-                                               X.shape[1], _lib.ptr(W), Cw_in, Cw_out, _lib.ptr(bias), _lib.ptr(Y),
-                                               _lib.dtype_code(X), _lib.ptr(r_dev), ctypes.byref(st),
-                                               ctypes.byref(pending) if bn_request.allow_pending else None,
-                                               _lib.stream_ptr()))
-        # pending > 0: the per-block partial statistics are still in `ws`; the BatchNorm step's own kernel folds them
-        # (one launch less than folding here)
-        bn_request.stats = (save_mean, save_invstd, (int(pending.value), ws) if pending.value > 0 else None)
-    else:
-        _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
-                                       _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias),
-                                       _lib.ptr(Y), _lib.dtype_code(X), _lib.ptr(r_dev), 0, _lib.stream_ptr()))
+    _lib.check(lib.wfs_gather_conv(_lib.ptr(table), kmap, K, identity_k, R, _lib.ptr(X), X.shape[0], X.shape[1],
+                                   _lib.ptr(W), Cw_in, Cw_out, 1 if transpose_w else 0, _lib.ptr(bias),
+                                   _lib.ptr(Y), _lib.dtype_code(X), _lib.ptr(r_dev), 0, _lib.stream_ptr()))
     _account("gather_conv", table, R, X.shape[0], X.shape[1], R, Cy, K, Cw_in, Cw_out, X.element_size())
     return Y
 
@@ -401,7 +356,7 @@ class SparseConvFunction(Function):
     """features [n_in, Cin], filters [*k, Cin, Cout] fp32, bias [Cout] or None -> [n_out, Cout]."""
 
     @staticmethod
-    def forward(ctx, features, filters, bias, rulebook, mode, bn_request=None):
+    def forward(ctx, features, filters, bias, rulebook, mode):
         rb = rulebook
         features = _features_ok(features)
         K = rb.K
@@ -412,14 +367,14 @@ class SparseConvFunction(Function):
         if mode == INVERSE:
             assert features.shape[0] == rb.M, "inverse conv input must be the coupled conv's output set"
             w16 = filters16(W, features) if takes_wide_path(K, rb.N, features, W.shape[2]) else None
-            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b, rb.n_dev, bn_request, w16)
+            out = gather_conv(rb.nbr_out, None, K, ident, rb.N, features, W, False, b, rb.n_dev, w16)
         elif rb.has_dup:
             out = scatter_conv(rb.nbr_out, K, ident, rb.N, features, W, False, rb.M, b)
         else:
             assert features.shape[0] == rb.N
             table, kmap = rb.table_by_out()
             w16 = filters16(W, features) if takes_wide_path(K, rb.M, features, W.shape[2]) else None
-            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev, bn_request, w16)
+            out = gather_conv(table, kmap, K, ident, rb.M, features, W, False, b, rb.m_dev, w16)
         ctx.save_for_backward(features, filters, bias)
         ctx.rb, ctx.mode = rb, mode
         ctx.w16 = w16 if ctx.needs_input_grad[0] else None       # the 16-bit filters of a wide layer: dX reads them again
@@ -443,7 +398,7 @@ class SparseConvFunction(Function):
                 if rb.has_dup:
                     dX = scatter_conv(rb.nbr_out, K, ident, rb.N, dY, W, True, rb.M, None)
                 else:
-                    dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev, None, ctx.w16)
+                    dX = gather_conv(rb.nbr_in, None, K, ident, rb.M, dY, W, True, None, rb.m_dev, ctx.w16)
             if ctx.needs_input_grad[1]:
                 dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev, ov, filters)
         elif (FUSED_CONV_BACKWARD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ov and not rb.has_dup
@@ -465,13 +420,13 @@ class SparseConvFunction(Function):
                     dW = gather_dw(table, K, ident, rb.N, features, dY, False, None, rb.n_dev, ov, filters, pk)
             if ctx.needs_input_grad[0]:
                 table, pk = rb.table_by_in(dY.shape[1], W.shape[1], dY, 1)
-                dX = gather_conv(table, None, K, ident, rb.N, dY, W, True, None, rb.n_dev, None, ctx.w16, pk)
+                dX = gather_conv(table, None, K, ident, rb.N, dY, W, True, None, rb.n_dev, ctx.w16, pk)
         if dW is not None:
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if bias is not None and ctx.needs_input_grad[2]:
             # dY has one row per OUTPUT of this product: rb.N rows for an inverse conv, rb.M otherwise
             db = _masked_column_sum(dY, rb.n_dev if mode == INVERSE else rb.m_dev).to(bias.dtype)
-        return dX, dW, db, None, None, None
+        return dX, dW, db, None, None
 
 
 class PointwiseConvFunction(Function):
@@ -486,7 +441,7 @@ class PointwiseConvFunction(Function):
         W = filters.detach().reshape(1, filters.shape[-2], filters.shape[-1]).float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
         w16 = filters16(W, features) if takes_wide_path(1, R, features, W.shape[2]) else None
-        out = gather_conv(None, None, 1, 0, R, features, W, False, b, n_dev, None, w16)
+        out = gather_conv(None, None, 1, 0, R, features, W, False, b, n_dev, w16)
         ctx.save_for_backward(features, filters, bias)
         ctx.n_dev = n_dev
         ctx.w16 = w16 if ctx.needs_input_grad[0] else None
@@ -506,7 +461,7 @@ class PointwiseConvFunction(Function):
             dW = gather_dw(None, 1, 0, R, features, dY, False, None, n_dev, False, filters)
             dW = dW.reshape(filters.shape).to(filters.dtype)
         if ctx.needs_input_grad[0]:
-            dX = gather_conv(None, None, 1, 0, R, dY, W, True, None, n_dev, None, ctx.w16)
+            dX = gather_conv(None, None, 1, 0, R, dY, W, True, None, n_dev, ctx.w16)
         if bias is not None and ctx.needs_input_grad[2]:
             db = _masked_column_sum(dY, n_dev).to(bias.dtype)
         return dX, dW, db, None
@@ -593,33 +548,13 @@ class BatchNormReLUFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, n_dev=None,
-                batches_tracked=None, stats=None):
+                batches_tracked=None):
         lib = _lib.load()
         x = _features_ok(x)
         N, C = x.shape
         y = _rows(tuple(x.shape), x, n_dev)
         for t in (weight, bias, running_mean, running_var):
             assert t is None or (t.dtype == torch.float32 and t.numel() == C and t.is_contiguous())
-        if stats is not None:
-            # the producing convolution took the statistics (and updated the running ones): normalise only
-            assert training
-            save_mean, save_invstd, pending = stats
-            if pending is not None:
-                nblk, ws = pending
-                st = _lib.BnStats(_lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(running_mean),
-                                  _lib.ptr(running_var), _lib.ptr(batches_tracked), float(momentum), float(eps),
-                                  _lib.ptr(ws), ws.numel())
-                _lib.check(lib.wfs_bn_apply_fwd_fold(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias), ctypes.byref(st),
-                                                     nblk, 1 if relu else 0, _lib.ptr(y), _lib.dtype_code(x),
-                                                     _lib.ptr(n_dev), _lib.stream_ptr()))
-            else:
-                _lib.check(lib.wfs_bn_apply_fwd(_lib.ptr(x), N, C, _lib.ptr(weight), _lib.ptr(bias),
-                                                _lib.ptr(save_mean), _lib.ptr(save_invstd), 1 if relu else 0, _lib.ptr(y),
-                                                _lib.dtype_code(x), _lib.ptr(n_dev), _lib.stream_ptr()))
-            ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
-            ctx.flags = (True, bool(relu))
-            ctx.n_dev = n_dev
-            return y
         save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
         save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         ws = torch.empty((max(int(lib.wfs_bn_workspace_bytes(N, C)), 1),), dtype=torch.uint8, device=x.device)
@@ -639,7 +574,7 @@ class BatchNormReLUFunction(Function):
         x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         training, relu = ctx.flags
         dx, dgamma, dbeta = bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, ctx.n_dev)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, training, relu, n_dev):
@@ -661,15 +596,14 @@ def bn_relu_backward(x, grad_output, weight, bias, save_mean, save_invstd, train
     return dx, dgamma, dbeta
 
 
-def batch_norm_relu(features, bn, relu, n_dev=None, stats=None):
+def batch_norm_relu(features, bn, relu, n_dev=None):
     """Apply an nn.BatchNorm1d module (and optionally the nn.ReLU that follows it) to [N, C] features
-    (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts";
-    ``stats``: (save_mean, save_invstd) already taken by the producing convolution)."""
+    (``n_dev``: device-side count of valid rows, see include/wfsparse.h "device-side row counts")."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # bumped by the kernel
     return BatchNormReLUFunction.apply(
         features, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked, stats)
+        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, training, relu, n_dev, tracked)
 
 
 def can_fuse_batch_norm(bn, features):
@@ -937,16 +871,16 @@ def cross_entropy_mean(logits, target, ignore_index=-100):
 
 # 16-bit storage: bf16, and fp16 for the reference's ``half_precision`` / ``use_half`` (float16 features,
 # src/datasets/HDF5Dataset.py:227-228).  Both have native kernels (fp32 accumulate, fp32 master filters).
-def indice_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV, bn_request)
+def indice_conv(features, filters, bias, rulebook):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, CONV)
 
 
-def indice_subm_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM, bn_request)
+def indice_subm_conv(features, filters, bias, rulebook):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, SUBM)
 
 
-def indice_inverse_conv(features, filters, bias, rulebook, bn_request=None):
-    return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE, bn_request)
+def indice_inverse_conv(features, filters, bias, rulebook):
+    return SparseConvFunction.apply(features, filters, bias, rulebook, INVERSE)
 
 
 def to_dense(features, indices, spatial_shape, batch_size, unique, m_dev=None, cell_map=None):

@@ -143,12 +143,6 @@ class SparseSequential(SparseModule):
             if stop_before_dense and i == len(mods) - 1 and isinstance(module, ToDense) and _is_sparse_tensor(input):
                 break
             if isinstance(module, SparseModule):
-                if (ops.FUSE_CONV_BN_STATS and _is_sparse_tensor(input) and i + 1 < len(mods)
-                        and isinstance(mods[i + 1], nn.BatchNorm1d)
-                        and getattr(module, "weight", None) is not None
-                        and Fsp.can_take_batch_norm_stats(mods[i + 1], input.features)):
-                    # conv -> BatchNorm1d (training): the conv's epilogue takes the batch statistics
-                    input.bn_request = Fsp.BatchNormRequest(mods[i + 1])
                 if _is_sparse_tensor(input):
                     input.dense_follows = self._dense_follows(mods, i)
                 input = module(input)
@@ -162,10 +156,7 @@ class SparseSequential(SparseModule):
                     if isinstance(module, nn.BatchNorm1d) and Fsp.can_fuse_batch_norm(module, input.features):
                         # BatchNorm1d [+ ReLU] over the active rows: one fused pair of HIP launches
                         relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                        req = getattr(input, "bn_stats", None)
-                        stats = req.stats if (req is not None and req.bn is module) else None
-                        input.bn_stats = None
-                        input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid, stats)
+                        input.features = Fsp.batch_norm_relu(input.features, module, relu, input.n_valid)
                         if relu:
                             i += 1
                     else:

@@ -33,13 +33,6 @@ ASSUME_VALID_UNIQUE_INDICES = False
 PREFETCH_RULEBOOKS = False
 OVERLAP_DW = False
 
-# conv -> nn.BatchNorm1d (training) inside SparseSequential: the conv kernel's epilogue can take the batch statistics
-# (functional.BatchNormRequest; include/wfsparse.h wfs_gather_conv_bnstats + wfs_bn_apply_fwd_fold), which saves
-# BatchNorm's reduction launch and its read of the conv output.  Same results either way.  OFF by default: at the PSD
-# batch sizes (256 events, ~10^5 voxels) it measured slower in a same-box A/B (0.647 vs 0.638 ms/step, DESIGN.md 4
-# "measured dead ends"); it should pay when the rows no longer fit the L2s.
-FUSE_CONV_BN_STATS = os.environ.get("WFS_FUSE_CONV_BN_STATS", "0") != "0"
-
 # Event-local SubM rulebook build (round 3; csrc/evrulebook.hip): in device-count mode -- captured steps, where the index
 # rows come from the reference's collate_fn, i.e. grouped by event -- a SubM rulebook is built by a pair of workgroups
 # per event with the event's site table in LDS: no site grid over the batch in HBM (18.5 MB cleared per build at the PSD
