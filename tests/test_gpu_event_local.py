@@ -406,7 +406,7 @@ def test_packed_table_products_equal_the_dense_table_products(dtype):
     assert float(dx_d[:nvv].float().abs().max()) > 0 and float(dw_d.abs().max()) > 0
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("device_counts", [False, True])
 def test_one_launch_conv_backward_equals_the_two_products(dtype, device_counts):
     """wfs_conv_backward (dW and dX of a 32 -> 32 layer in ONE launch, conv_mfma.hip k_bwd32_bf16) against wfs_gather_dw +

@@ -61,14 +61,15 @@ __device__ __forceinline__ int table_value(int e, int osel) { return osel < 0 ? 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int F16_GROUP = 3;      // offsets whose gathers a wave has in flight together (2 x 16 B per lane each)
 
+// (body as a device function, like gconv32_bf16_body: sW = the filter image [K * 1024 floats] in LDS, sNextp = the
+// block's tile counter, vbid / vgrid / nthreads = this product's grid)
 template <bool TRANSPOSE_W, int PK = 0>
-__global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
-                                                      long long R, const long long *__restrict__ r_dev,
-                                                      const float *__restrict__ X, const float *__restrict__ W,
-                                                      const float *__restrict__ bias, float *__restrict__ Y) {
-    extern __shared__ __attribute__((aligned(16))) float sW[];
-    __shared__ int sNext;
-    const int nthreads = blockDim.x;
+__device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbid, int vgrid, int nthreads,
+                                                 const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                 long long R, const long long *__restrict__ r_dev,
+                                                 const float *__restrict__ X, const float *__restrict__ W,
+                                                 const float *__restrict__ bias, float *__restrict__ Y) {
+    int &sNext = *sNextp;
     if (threadIdx.x == 0) sNext = 0;
     if (!TRANSPOSE_W) {
         for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ ta
     const int r = lane & 15, q = lane >> 4;
     // XCD-aware: blocks with equal blockIdx % 8 share an L2 and take one contiguous range of the VALID tiles; inside it
     // block bi owns tiles bi, bi + bpx, ... (consecutive tiles -- one event's, alike in cost -- go to different CUs)
-    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int xcd = vbid & 7, bi = vbid >> 3, bpx = vgrid >> 3;
     const long long Rv = valid_rows(R, r_dev);
     const long long nt_v = (Rv + 15) >> 4, tpx_v = (nt_v + 7) >> 3;
     const long long t_begin = (long long)xcd * tpx_v;
@@ -233,6 +234,17 @@ __global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ ta
             }
         }
     }
+}
+
+template <bool TRANSPOSE_W, int PK = 0>
+__global__ void __launch_bounds__(1024) k_gconv16_f32(const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                      long long R, const long long *__restrict__ r_dev,
+                                                      const float *__restrict__ X, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, float *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) float sW_dyn[];
+    __shared__ int sNext;
+    gconv16_f32_body<TRANSPOSE_W, PK>(sW_dyn, &sNext, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, table, mirror, K,
+                                      identity_k, R, r_dev, X, W, bias, Y);
 }
 
 // ------------------------------------------------------------------------------------------ 32 -> 32, bf16
@@ -503,18 +515,18 @@ __global__ void __launch_bounds__(256) k_gconv_c2c32(const int *__restrict__ tab
 constexpr int DW_KG = 4;        // offsets per wave (4 x 16 accumulator registers)
 constexpr int DW_WAVES = 8;
 
+constexpr int DW_LDS = DW_WAVES * 1024 * 4;                        // block reduction staging, 32 KiB
+// (body as a device function; bx / by / nbx = the block's coordinates in this product's grid)
 template <typename T>
-__global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table, int pk, int K, int identity_k, long long Rcap,
-                                                  const long long *__restrict__ r_dev, const T *__restrict__ S,
-                                                  const T *__restrict__ G,
-                                                  float *__restrict__ part, int ngroups, long long tiles_per_block) {
-    __shared__ float sRed[DW_WAVES * 1024];                           // block reduction staging, 32 KiB
+__device__ __forceinline__ void gdw32_body(float *sRed, int bx, int by, int nbx, const int *__restrict__ table, int pk, int K,
+                                           int identity_k, long long Rcap, const long long *__restrict__ r_dev,
+                                           const T *__restrict__ S, const T *__restrict__ G, float *__restrict__ part,
+                                           int ngroups) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int g = blockIdx.y;
+    const int g = by;
     const long long R = valid_rows(Rcap, r_dev);            // rows to process; Rcap stays the table stride
     const long long ntiles = (R + 31) >> 5;
-    (void)tiles_per_block;                                   // cut from the capacity: the valid tiles are shared out instead
     static_assert(sizeof(T) == 4, "fp32 rows");
     // raw buffers (stride 0, byte offsets): S holds R valid rows of 128 B; G is addressed below 2 GiB, anything at or
     // above reads as 0 (the launcher checks both sizes)
@@ -533,7 +545,7 @@ __global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table,
         const int k = g + q * ngroups;
         table_row_of(pk, k < K ? k : K - 1, &trw[q], &osel[q]);
     }
-    for (long long tile = blockIdx.x + (long long)wid * gridDim.x; tile < ntiles; tile += (long long)DW_WAVES * gridDim.x) {
+    for (long long tile = bx + (long long)wid * nbx; tile < ntiles; tile += (long long)DW_WAVES * nbx) {
         const long long row0 = tile * 32;
         // lane j holds the table entries of row (row0 + j) for this wave's offsets.  Loads are unconditional
         // on clamped addresses (see k_gconv32_f32), validity is applied afterwards.
@@ -600,9 +612,20 @@ __global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table,
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < DW_WAVES; ++w) v += sRed[w * 1024 + e];
-            if (k < K) part[((long long)blockIdx.x * K + k) * 1024 + e] = v;
+            if (k < K) part[((long long)bx * K + k) * 1024 + e] = v;
         }
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512, 4) k_gdw32(const int *__restrict__ table, int pk, int K, int identity_k, long long Rcap,
+                                                  const long long *__restrict__ r_dev, const T *__restrict__ S,
+                                                  const T *__restrict__ G,
+                                                  float *__restrict__ part, int ngroups, long long tiles_per_block) {
+    __shared__ float sRed[DW_WAVES * 1024];
+    (void)tiles_per_block;                                   // cut from the capacity: the valid tiles are shared out instead
+    gdw32_body<T>(sRed, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, table, pk, K, identity_k, Rcap, r_dev, S, G, part,
+                  ngroups);
 }
 
 // ------------------------------------------------------------------------------------------ 2 -> 32, fp32 MFMA
@@ -1426,6 +1449,9 @@ static int launch_bwd32_h16(const int *table, int packed_kl, int K, int identity
                           part, ngroups, (int)nbx_dw, (int)n_dw_pad, (int)n_dx, wpb * 64);
 }
 
+// 16-bit rows only: the fp32 kernels were measured too (same construction: 0.828 vs 0.808 ms per captured step) -- the
+// fp32 dW body is tuned for two 512-thread blocks per CU with 32 KB of LDS each, which it loses inside a 1024-thread,
+// 110-KB launch
 bool wfs_bwd32_fused_ok(int K, int packed_kl, int dtype) {
     return (dtype == WFS_BF16 || dtype == WFS_F16) && K >= 1 && K <= 27 && (packed_kl == 0 || (packed_kl == 3 && K % 3 == 0));
 }

@@ -625,8 +625,9 @@ extern "C" int wfs_conv_backward(const int32_t *table, int32_t K, int32_t identi
                                  wfs_dw_job *defer, int32_t packed_kl, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WFS_REQUIRE(dX && dW, WFS_EINVAL, "wfs_conv_backward computes both gradients (use wfs_gather_conv / wfs_gather_dw for one)");
+    const long long row_lim = dtype == WFS_F32 ? (1ll << 24) : (1ll << 25);       // 32-bit byte offsets of the gathers
     const bool fused = Cin == 32 && Cout == 32 && table && wfs_bwd32_fused_ok(K, packed_kl, dtype) && R > 0 &&
-                       R < (1ll << 25) && dY_rows < (1ll << 25) && (packed_kl == 0 || identity_k < 0);
+                       R < row_lim && dY_rows < row_lim && (packed_kl == 0 || identity_k < 0);
     if (!fused) {
         int rc = gather_dw_impl(table, nullptr, K, identity_k, R, X, Cin, dY, dY_rows, Cout, 0, dW, dtype, workspace,
                                 workspace_bytes, r_dev, defer, stream_, packed_kl);
