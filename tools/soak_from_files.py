@@ -55,6 +55,8 @@ print(rows)
 
 def main():
     import torch
+    if os.environ.get("WFS_SWITCH_INTERVAL"):           # experiment: GIL hand-over between the trainer and stager threads
+        sys.setswitchinterval(float(os.environ["WFS_SWITCH_INTERVAL"]))
     from waveformml_amd.psd.config import DictionaryUtility
     from waveformml_amd.psd.lit import LitPSD
     from waveformml_amd.psd.PSDDataModule import PSDDataModule
@@ -132,7 +134,8 @@ def main():
         torch.manual_seed(0)
         conf, loader = module_and_loader(workers)
         mod = LitPSD(conf)
-        tr = Trainer(max_epochs=epochs, device="cuda:0", feature_dtype=torch.bfloat16, capture=True, check_every=25)
+        tr = Trainer(max_epochs=epochs, device="cuda:0", feature_dtype=torch.bfloat16, capture=True,
+                     check_every=int(os.environ.get("WFS_SOAK_CHECK_EVERY", "100")))
         t0 = time.perf_counter()
         hist = tr.fit(mod, loader)
         torch.cuda.synchronize()

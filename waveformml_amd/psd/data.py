@@ -4,6 +4,9 @@ of ``HDF5Dataset.__getitem__`` (src/datasets/HDF5Dataset.py:186-217: ONE item = 
 range, ``[[coords, feats], labels]`` with event ids starting at 0).
 """
 import numpy as np
+import queue as _queue
+import time as _time
+
 import torch
 from torch.utils.data import DataLoader, Dataset
 
@@ -291,8 +294,11 @@ class DevicePrefetcher(object):
     host.  Replaces the reference's synchronous ``.to(self.device)`` inside ``_concat_range``
     (src/datasets/HDF5Dataset.py:250-300), which a forked DataLoader worker cannot do on a HIP device anyway."""
 
-    def __init__(self, loader, device, feature_dtype=None, depth=2, on_stage=None, on_exhausted=None):
+    def __init__(self, loader, device, feature_dtype=None, depth=2, on_stage=None, on_exhausted=None, threaded=None):
         self.loader, self.device, self.feature_dtype, self.depth = loader, torch.device(device), feature_dtype, depth
+        import os
+        self.threaded = (os.environ.get("WFS_PREFETCH_THREAD", "0") != "0") if threaded is None else bool(threaded)
+        self.wait_seconds = 0.0
         self.copy_stream = torch.cuda.Stream(device=self.device)
         # this consumer releases ring slots itself (after each copy): the loader's reclaim-by-age must sit behind the
         # staging depth, so that it only ever fires for batches this queue has already let go
@@ -305,9 +311,9 @@ class DevicePrefetcher(object):
     def __len__(self):
         return len(self.loader)
 
-    def _stage(self, batch):
+    def _stage(self, batch, notify=True):
         (c, f), y = batch
-        if self.on_stage is not None:
+        if notify and self.on_stage is not None:
             self.on_stage(int(c.shape[0]), int(y.shape[0]))
         ring = isinstance(batch, RingBatch)            # views of a page-locked ring slot: copy straight from it
         host = [t if (ring or t.is_pinned()) else t.pin_memory() for t in (c, f, y)]
@@ -319,16 +325,73 @@ class DevicePrefetcher(object):
             done.record(self.copy_stream)
         if ring and batch.token is not None:
             batch.token.guards.append(done)            # reclaim-by-age waits for this copy (see _SlotToken.force)
-        return (batch if ring else host), dev, done    # kept alive until the copy has been waited on
+        # (host buffers kept alive until the copy has been waited on, device tensors, copy event, rows, labels)
+        return (batch if ring else host), dev, done, int(c.shape[0]), int(y.shape[0])
+
+    def _producer(self, out, stop):
+        """Background thread: pulls batches off the loader and stages them (worker-message unpacking, the host -> device
+        copies and the dtype cast all happen here); hands (staged | exception | None at the end) to the consumer."""
+        try:
+            if self.device.type == "cuda":
+                torch.cuda.set_device(self.device)
+            for batch in self.loader:
+                if stop.is_set():
+                    break
+                item = self._stage(batch, notify=False)
+                while not stop.is_set():
+                    try:
+                        out.put(item, timeout=0.05)
+                        break
+                    except _queue.Full:
+                        continue
+            out.put(None)
+        except BaseException as e:          # noqa: BLE001  -- delivered to the consumer, which re-raises it
+            out.put(e)
+
+    def _staged_batches(self):
+        """Staged batches in loader order; with ``threaded`` (WFS_PREFETCH_THREAD=1; off by default) they are produced by a
+        background thread, so that the training thread's step is the hand-over launch + the graph replay and nothing
+        else.  Measured from files at the bench's density (tools/soak_from_files.py 600 85 8 16, round 4): 466-469 k
+        events/s per epoch with the thread, 462-468 k without -- the training thread then WAITS 45 us per step for the
+        next staged batch instead of staging it itself: neutral, so the simpler single-threaded form stays the default."""
+        if not self.threaded:
+            for batch in self.loader:
+                yield self._stage(batch, notify=False)
+            return
+        import threading
+        out, stop = _queue.Queue(maxsize=max(2, self.depth)), threading.Event()
+        th = threading.Thread(target=self._producer, args=(out, stop), name="wfs-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = out.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            while th.is_alive():             # unblock a producer waiting on a full queue, then let it finish
+                try:
+                    out.get_nowait()
+                except _queue.Empty:
+                    pass
+                th.join(timeout=0.05)
 
     def __iter__(self):
         queue = []
-        it = iter(self.loader)
+        it = self._staged_batches()
         more = True
         while True:
             while more and len(queue) < self.depth:
                 try:
-                    queue.append(self._stage(next(it)))
+                    t_wait = _time.perf_counter()
+                    item = next(it)
+                    self.wait_seconds += _time.perf_counter() - t_wait      # time the consumer spent waiting for a batch
+                    if self.on_stage is not None:       # in consumption order, `depth` batches ahead, on THIS thread
+                        self.on_stage(item[3], item[4])
+                    queue.append(item[:3])
                 except StopIteration:
                     more = False
                     if self.on_exhausted is not None:
@@ -344,7 +407,11 @@ class DevicePrefetcher(object):
                     queue[j] = (None, d, e)
             host, dev, done = queue.pop(0)
             cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(done)
+            if not done.query():
+                # the copy was issued `depth` batches ago and has normally completed: only then does the consumer's stream
+                # need to wait for it at all (a cross-stream wait is a barrier packet in front of the step: ~10 us of
+                # launch latency per step in the from-files soak)
+                cur.wait_event(done)
             if isinstance(host, RingBatch):
                 done.synchronize()        # issued a batch ago: long finished; the slot may now be overwritten
                 host.release()

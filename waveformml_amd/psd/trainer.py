@@ -159,11 +159,34 @@ class Trainer(object):
         self.last_capacity = 0
         self._size_misfits = 0
         self._label_misfits = 0
+        self._rows_stats = [0, 0.0, 0.0, 0]          # batches seen, sum of rows, sum of squares, largest
         self.eager_fallbacks = 0
         self.global_step = 0
         self.last_checkpoint = None
 
-    def _capture(self, module, reducer, optimizer, batch, min_rows=0):
+    def _observe_rows(self, rows):
+        """Row counts of the batches seen so far (with several ranks: the agreed maximum over the ranks), for sizing a
+        RE-capture: by then the loop knows the data's spread, which the first capture had to guess."""
+        st = self._rows_stats
+        st[0] += 1
+        st[1] += float(rows)
+        st[2] += float(rows) * float(rows)
+        st[3] = max(st[3], int(rows))
+
+    def _recapture_rows(self, batch_rows):
+        """Row capacity of a re-capture: room for the largest batch seen and for mean + 4 sigma of the row counts seen,
+        plus 2 % -- instead of the first capture's 1 + 3 / sqrt(events) on top of an already large batch (from files
+        that compounded to 1.40 x the mean: 121 k rows of capacity for batches of 85 k, +20 us per step).  None until
+        enough batches have been seen.  An absolute row count: with several ranks it is computed from the AGREED maxima,
+        so every rank arrives at the same capacity."""
+        n, s1, s2, mx = self._rows_stats
+        if n < 8:
+            return None
+        mean = s1 / n
+        sigma = max(0.0, s2 / n - mean * mean) ** 0.5
+        return int(max(float(mx), mean + 4.0 * sigma, float(batch_rows)) * 1.02) + 1
+
+    def _capture(self, module, reducer, optimizer, batch, min_rows=0, headroom=None):
         """Capture the step on ``batch`` without letting the capture's calibration / warm-up steps train the model."""
         from .graph import GraphedTrainStep
         params = reducer.flat_param.detach().clone() if reducer.flat_param is not None else \
@@ -174,7 +197,7 @@ class Trainer(object):
         # is zeroed (zero momentum == no history).
         kept = {id(p): {k: v.detach().clone() for k, v in optimizer.state[p].items() if torch.is_tensor(v)}
                 for g in optimizer.param_groups for p in g["params"] if p in optimizer.state and len(optimizer.state[p]) > 0}
-        graph = GraphedTrainStep(module, optimizer, reducer, batch, min_rows=min_rows)
+        graph = GraphedTrainStep(module, optimizer, reducer, batch, min_rows=min_rows, headroom=headroom)
         with torch.no_grad():
             if reducer.flat_param is not None:
                 reducer.flat_param.copy_(params)
@@ -204,6 +227,7 @@ class Trainer(object):
             from .graph import GraphedTrainStep
             floor = GraphedTrainStep.capacity_for(agreed[0], agreed[1])     # largest rows, smallest label count (= largest headroom)
         per_row = bool(getattr(module, "per_row_targets", False))
+        self._observe_rows(agreed[0] if agreed is not None else batch[0][0].shape[0])
         if self._graph is None:
             if agreed is not None and not per_row and agreed[1] != agreed[2]:
                 # the ranks' batches hold different numbers of events (a partial last file): a step captured on this
@@ -251,7 +275,14 @@ class Trainer(object):
                 n_old = old.n_cap
                 old.close(remove_hooks=False)          # the old graph goes (device idle) before the new one is captured
                 del old
-                self._graph = self._capture(module, reducer, optimizer, batch, min_rows=max(n_old, floor))
+                rows_now = agreed[0] if agreed is not None else batch[0][0].shape[0]
+                target = self._recapture_rows(rows_now)
+                if recapture_labels and not too_big:
+                    target = n_old                   # only the label shape changed: the row capacity stays
+                if target is not None:
+                    self._graph = self._capture(module, reducer, optimizer, batch, min_rows=target, headroom=1.0)
+                else:
+                    self._graph = self._capture(module, reducer, optimizer, batch, min_rows=max(n_old, floor))
                 self._size_misfits = 0
                 self._label_misfits = 0
                 self.recaptures += 1
@@ -311,7 +342,8 @@ class Trainer(object):
             if scheduler is not None:
                 scheduler.step()
             rec = {"epoch": epoch, "train_loss": float(loss.item()),           # .item(): the epoch's work is done
-                   "train_seconds": time.perf_counter() - t_epoch, "steps": i + 1}
+                   "train_seconds": time.perf_counter() - t_epoch, "steps": i + 1,
+                   "loader_wait_seconds": round(prefetch.wait_seconds, 4)}   # of which: waiting for the next batch
             if val_loader is not None:
                 rec.update(self.validate(module, val_loader))        # all-reduced: every rank sees the same numbers
                 if self.root and rec["val_loss"] < best:
