@@ -16,6 +16,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -- python3 $R/bench.py --dtype f32 --cpu-steps 0 --no-roofline --steps 100 > $O/stats_f32.log 2>&1 || exit 1
 cd $R
 cp $(ls $O/stats/*/*kernel_stats.csv | tail -n 1) $O/kernel_stats.csv
+python tools/trace_step.py $O/stats -v > $O/step_timeline_bf16.txt
+python tools/trace_step.py $O/stats_f32 -v > $O/step_timeline_f32.txt
 cp $(ls $O/stats_f32/*/*kernel_stats.csv | tail -n 1) $O/kernel_stats_f32.csv
 python tools/pmc_summary.py $(ls $O/pmc_fetch/*/*counter_collection.csv | tail -n 1) $(ls $O/pmc_write/*/*counter_collection.csv | tail -n 1) $O/pmc_hbm_traffic_bf16.json
 rm -rf $O/stats $O/stats_f32 $O/pmc_fetch $O/pmc_write

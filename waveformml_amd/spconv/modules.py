@@ -80,10 +80,12 @@ class SparseSequential(SparseModule):
         return False
 
     @staticmethod
-    def _prefetch_rulebooks(mods, x):
+    def _prefetch_rulebooks(mods, x, owner=None):
         """Build every layer's rulebook on a side stream now (device-count mode: nothing synchronises with the
         host).  Rulebooks depend on indices only, so the strided layers' builds run while the first layers
-        compute; each conv waits for its own rulebook's event."""
+        compute; each conv waits for its own rulebook's event.  ``owner``: a submanifold layer about to run on the
+        calling stream -- it and the layers sharing its indice_key keep building / finding their rulebook there, the
+        branch forks BEFORE it (its output has the input's rows, so nothing on the branch depends on it)."""
         from . import ops
         from .conv import SparseConvolution
         main = torch.cuda.current_stream()
@@ -101,6 +103,9 @@ class SparseSequential(SparseModule):
                         continue
                     if m.inverse or m.transposed:
                         break                       # geometry comes from a coupled layer: leave the rest to the layers
+                    if owner is not None and (m is owner or (m.subm and m.indice_key is not None
+                                                             and m.indice_key == owner.indice_key)):
+                        continue
                     if m.indice_key is not None and m.indice_key in keyed:
                         rb = keyed[m.indice_key]
                     else:
@@ -145,6 +150,13 @@ class SparseSequential(SparseModule):
             if isinstance(module, SparseModule):
                 if _is_sparse_tensor(input):
                     input.dense_follows = self._dense_follows(mods, i)
+                if (want_prefetch and ops.PREFETCH_BEFORE_FIRST and getattr(input, "events", None) is not None
+                        and getattr(module, "subm", False) and not getattr(module, "conv1x1", False)
+                        and input.find_indice_pair(module.indice_key) is None):
+                    # the event offsets came with the batch: the strided layers' builds need nothing the first layer
+                    # makes, so the branch forks before its build and its conv rather than after them
+                    want_prefetch = False
+                    self._prefetch_rulebooks(mods[i:], input, owner=module)
                 input = module(input)
                 if want_prefetch and _is_sparse_tensor(input):
                     # the first layer has built its own rulebook and launched its conv on this stream; the

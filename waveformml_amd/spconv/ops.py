@@ -32,6 +32,12 @@ ASSUME_VALID_UNIQUE_INDICES = False
 #                       when the backward pass ends).
 PREFETCH_RULEBOOKS = False
 OVERLAP_DW = False
+# WFS_PREFETCH_BEFORE_FIRST=1: the branch of the prefetched builds forks BEFORE the first layer when the batch came with its
+# event offsets (a captured step's hand-over launch writes them) instead of behind the first layer's conv.  Off: same-box
+# A/B 0.4813 / 0.4806 ms against 0.4716 / 0.4704 -- the builds then end 23 us earlier, but the main chain's first kernel
+# (the SubM build) starts 18 us after the hand-over launch on the replay's second queue and shares the chip with the
+# first strided build (27 us instead of 18)
+PREFETCH_BEFORE_FIRST = os.environ.get("WFS_PREFETCH_BEFORE_FIRST", "0") == "1"
 
 # Event-local SubM rulebook build (round 3; csrc/evrulebook.hip): in device-count mode -- captured steps, where the index
 # rows come from the reference's collate_fn, i.e. grouped by event -- a SubM rulebook is built by a pair of workgroups
