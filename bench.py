@@ -589,7 +589,8 @@ def main():
             result["cpu_baseline"] = base
             if f32 is not None:
                 result["parity"] = parity(cpu_logits, cpu_loss, f32_extras["logits0"], f32_extras["loss0"])
-                result["parity"]["path"] = "f32 storage, exact fp32 MFMA: the 1e-5 bar"
+                result["parity"]["path"] = ("f32 storage; 32 -> 32 products as exact three-piece bf16 splits on the bf16 matrix cores, "
+                                            "fp32 accumulation (WFS_SPLIT_BF16=0: fp32 matrix instructions): the 1e-5 bar")
                 result["parity_%s" % args.dtype] = parity(cpu_logits, cpu_loss, extras["logits0"], extras["loss0"])
                 result["f32_path"] = {k: f32[k] for k in ("value", "ms_per_step", "execution", "timing") if k in f32}
                 if "roofline" in f32:

@@ -45,6 +45,37 @@ __device__ __forceinline__ void table_row_of(int pk, int k, int *trow, int *osel
 }
 __device__ __forceinline__ int table_value(int e, int osel) { return osel < 0 ? e : packed_entry(e, osel); }
 
+typedef __bf16 bf16x8e __attribute__((ext_vector_type(8)));
+
+// ---- fp32 numbers as three bf16 pieces (round 4; the whole story is at k_gdw32_split below)
+// x[0..3] -> the three pieces, each as 4 packed bf16 (element i in bits 16 (i & 1) of word i >> 1)
+__device__ __forceinline__ void split3_bf16(f32x4 x, bool keep, uint2 &p1, uint2 &p2, uint2 &p3) {
+    unsigned u[4], v[4], w[4];
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xi = x[i];       // (a bit_cast straight from the vector element reads element 0 with this compiler)
+        u[i] = keep ? __builtin_bit_cast(unsigned, xi) : 0u;
+        r[i] = __builtin_bit_cast(float, u[i]) - __builtin_bit_cast(float, u[i] & 0xFFFF0000u);
+        v[i] = __builtin_bit_cast(unsigned, r[i]);
+        w[i] = __builtin_bit_cast(unsigned, r[i] - __builtin_bit_cast(float, v[i] & 0xFFFF0000u));
+    }
+    // v_perm_b32: bytes 3, 2 of the second operand below bytes 3, 2 of the first
+    p1 = uint2{__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u)};
+    p2 = uint2{__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u)};
+    p3 = uint2{__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u)};
+}
+
+// 8 floats (two f32x4: elements 0..3, 4..7) -> the three pieces as MFMA operands of 8 bf16
+__device__ __forceinline__ void split3_bf16x8(f32x4 lo, f32x4 hi, uint4 &p1, uint4 &p2, uint4 &p3) {
+    uint2 a1, a2, a3, b1, b2, b3;
+    split3_bf16(lo, true, a1, a2, a3);
+    split3_bf16(hi, true, b1, b2, b3);
+    p1 = uint4{a1.x, a1.y, b1.x, b1.y};
+    p2 = uint4{a2.x, a2.y, b2.x, b2.y};
+    p3 = uint4{a3.x, a3.y, b3.x, b3.y};
+}
+
 // ------------------------------------------------------------------------------------------ 32 -> 32, fp32, 16-row tiles
 // k_gconv32_f32 gives every wave ONE 32-row tile, and a launch then lasts as long as its heaviest tile: 16 dependent
 // v_mfma_f32_32x32x2_f32 (1024 cycles) per active offset, up to K = 27 of them, on a SIMD shared with two other waves --
@@ -63,7 +94,13 @@ constexpr int F16_GROUP = 3;      // offsets whose gathers a wave has in flight 
 
 // (body as a device function, like gconv32_bf16_body: sW = the filter image [K * 1024 floats] in LDS, sNextp = the
 // block's tile counter, vbid / vgrid / nthreads = this product's grid)
-template <bool TRANSPOSE_W, int PK = 0>
+//
+// SPLIT (round 4): the same tiles on v_mfma_f32_16x16x32_bf16 with every fp32 number cut into three bf16 pieces (exact:
+// split3_bf16) and the six leading piece products summed in fp32 -- 12 matrix instructions of 16 cycles per active offset
+// instead of 16 of 32.  The A operand of that instruction is lane (r, q) <-> row r, channels 8q .. 8q+7: exactly the
+// gathered registers, cut in place.  The filter pieces are B fragments sB[slot][cb][piece][lane] (16 B each, 6 KiB per
+// offset): K - 1 offsets fill the LDS (26 x 6 KiB = 156 KiB at K = 27), the last offset's fragments stay in registers.
+template <bool TRANSPOSE_W, int PK = 0, bool SPLIT = false>
 __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbid, int vgrid, int nthreads,
                                                  const int *__restrict__ table, int mirror, int K, int identity_k,
                                                  long long R, const long long *__restrict__ r_dev,
@@ -71,7 +108,40 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
                                                  const float *__restrict__ bias, float *__restrict__ Y) {
     int &sNext = *sNextp;
     if (threadIdx.x == 0) sNext = 0;
-    if (!TRANSPOSE_W) {
+    uint4 *sB = reinterpret_cast<uint4 *>(sW);
+    uint4 wc00, wc01, wc02, wc10, wc11, wc12;         // SPLIT: the pieces of offset K - 1, this lane's B fragments
+    auto filter_frag = [&](int k, int cb, int l, uint4 &p1, uint4 &p2, uint4 &p3) {     // fragment of lane l = (n, q)
+        const int n = l & 15, qq = l >> 4;
+        f32x4 lo, hi;
+        if (!TRANSPOSE_W) {
+            const float *src = W + ((long long)k * 32 + 8 * qq) * 32 + 16 * cb + n;
+            lo = f32x4{src[0], src[32], src[64], src[96]};
+            hi = f32x4{src[128], src[160], src[192], src[224]};
+        } else {
+            const float *src = W + ((long long)k * 32 + 16 * cb + n) * 32 + 8 * qq;
+            lo = *(const f32x4 *)src;
+            hi = *(const f32x4 *)(src + 4);
+        }
+        split3_bf16x8(lo, hi, p1, p2, p3);
+    };
+    if constexpr (SPLIT) {
+        for (int f = threadIdx.x; f < (K - 1) * 128; f += nthreads) {
+            const int k = f >> 7, cb = (f >> 6) & 1, l = f & 63;
+            uint4 p1, p2, p3;
+            filter_frag(k, cb, l, p1, p2, p3);
+            uint4 *dst = sB + ((k * 2 + cb) * 3) * 64 + l;
+            dst[0] = p1;
+            dst[64] = p2;
+            dst[128] = p3;
+        }
+        {
+            uint4 p1, p2, p3;
+            filter_frag(K - 1, 0, threadIdx.x & 63, p1, p2, p3);
+            wc00 = p1, wc01 = p2, wc02 = p3;
+            filter_frag(K - 1, 1, threadIdx.x & 63, p1, p2, p3);
+            wc10 = p1, wc11 = p2, wc12 = p3;
+        }
+    } else if (!TRANSPOSE_W) {
         for (int blk = threadIdx.x; blk < K * 64; blk += nthreads) {
             const int k = blk >> 6, c4 = (blk >> 3) & 7, j4 = blk & 7;          // channels 4 c4 .., columns 4 j4 ..
             const float *src = W + ((long long)k * 32 + c4 * 4) * 32 + j4 * 4;
@@ -190,6 +260,35 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
                 for (int g = 0; g < F16_GROUP; ++g)
                     if (gr.k[g] >= 0) {
                         const f32x4 a0 = gr.a[g][0], a1 = gr.a[g][1];
+                        if constexpr (SPLIT) {
+                            uint4 x1, x2, x3;
+                            split3_bf16x8(a0, a1, x1, x2, x3);
+                            // smallest products first; the two column blocks' chains alternate.  (Written as a function
+                            // of the six fragments and called once per source: a select between register and LDS
+                            // fragments would go through scratch.)
+                            auto six = [&](const uint4 &b00, const uint4 &b01, const uint4 &b02, const uint4 &b10,
+                                           const uint4 &b11, const uint4 &b12) {
+#define WFS_SPLIT2(xa, pb0, pb1)                                                                                       \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8e, xa), __builtin_bit_cast(bf16x8e, pb0),   \
+                                                   acc0, 0, 0, 0);                                                     \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8e, xa), __builtin_bit_cast(bf16x8e, pb1),   \
+                                                   acc1, 0, 0, 0);
+                                WFS_SPLIT2(x3, b00, b10)
+                                WFS_SPLIT2(x1, b02, b12)
+                                WFS_SPLIT2(x2, b01, b11)
+                                WFS_SPLIT2(x2, b00, b10)
+                                WFS_SPLIT2(x1, b01, b11)
+                                WFS_SPLIT2(x1, b00, b10)
+                            };
+                            if (gr.k[g] == K - 1) {
+                                six(wc00, wc01, wc02, wc10, wc11, wc12);
+                            } else {
+                                const uint4 *bp = sB + gr.k[g] * 384 + lane;
+                                six(bp[0], bp[64], bp[128], bp[192], bp[256], bp[320]);
+                            }
+#undef WFS_SPLIT2
+                            continue;
+                        }
                         const f32x4 *bp = (const f32x4 *)(sW + ((gr.k[g] * 16 + q) * 16 + r) * 4);   // (k, cb 0, jq 0, q, n)
                         const f32x4 b00 = bp[0], b01 = bp[64], b10 = bp[128], b11 = bp[192];   // [cb][jq]: +64 f32x4 per jq, +128 per cb
                         // the two column blocks' chains alternate: a dependent MFMA never follows its producer directly
@@ -234,6 +333,17 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
             }
         }
     }
+}
+
+template <bool TRANSPOSE_W, int PK = 0>
+__global__ void __launch_bounds__(768) k_gconv16_split(const int *__restrict__ table, int mirror, int K, int identity_k,
+                                                       long long R, const long long *__restrict__ r_dev,
+                                                       const float *__restrict__ X, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, float *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) float sW_dyn[];
+    __shared__ int sNext;
+    gconv16_f32_body<TRANSPOSE_W, PK, true>(sW_dyn, &sNext, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, table, mirror,
+                                            K, identity_k, R, r_dev, X, W, bias, Y);
 }
 
 template <bool TRANSPOSE_W, int PK = 0>
@@ -913,6 +1023,172 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
                        part, ngroups);
 }
 
+// ------------------------------------------------------------------------------------------ dW 32 x 32, fp32 rows in three pieces
+// fp32 rows on the bf16 matrix cores without giving up a bit (round 4).  A float's 24-bit significand cut 8 / 8 / 8 by
+// truncation is three bf16 numbers whose sum is the float EXACTLY (p1 = the high half of the word, p2 = the high half of
+// x - p1, p3 = x - p1 - p2: every subtraction is exact); products of two pieces are exact in fp32.  Of the nine piece
+// products the six with orders (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) are summed -- the three left out are below 2^-24 of
+// the leading one, the size of one fp32 rounding -- by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 12 matrix
+// instructions of 32 cycles per (tile, offset) instead of k_gdw32<float>'s 16 v_mfma_f32_32x32x2_f32 of 64 cycles.
+// The pieces are made where the tile is staged (fp32 rows in registers -> three [32][32] bf16 planes in the wave's LDS
+// region), operands then read column-wise as in k_gdw32_bf16.  Work units, block reduction and slabs as k_gdw32<float>.
+constexpr int DWS_WAVES = 8;
+constexpr int DWS_KG = 4;
+constexpr int DWS_LDS = DWS_WAVES * 6 * 2048;          // per wave: 3 planes of the S tile, 3 of the gathered tile (96 KiB)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ table, int pk, int K, int identity_k,
+                                                     long long Rcap, const long long *__restrict__ r_dev,
+                                                     const float *__restrict__ S, const float *__restrict__ G,
+                                                     float *__restrict__ part, int ngroups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short(*sTiles)[6][32 * 32] = reinterpret_cast<unsigned short(*)[6][32 * 32]>(smem);   // [DWS_WAVES][6][1024]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;          // fragment coordinates
+    const int srow = lane >> 3, chunk = lane & 7;    // staging coordinates: rows srow + 8 p, 16-B chunk (4 floats)
+    const int bx = (int)blockIdx.x, nbx = (int)gridDim.x, g = (int)blockIdx.y;
+    const long long R = valid_rows(Rcap, r_dev);
+    const long long ntiles = (R + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc((void *)S, 0, (int)(R * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcG = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, 0x7FFFFFFF, 0x00020000);
+    f32x16 acc[DWS_KG];
+#pragma unroll
+    for (int q = 0; q < DWS_KG; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    int trw[DWS_KG], osel[DWS_KG];
+#pragma unroll
+    for (int q = 0; q < DWS_KG; ++q) {
+        const int k = g + q * ngroups;
+        table_row_of(pk, k < K ? k : K - 1, &trw[q], &osel[q]);
+    }
+    unsigned short *sS = sTiles[wid][0], *sG = sTiles[wid][3];
+    const int soff = srow * 32 + chunk * 4;          // this lane's place in a plane (bf16 elements), + 256 per pass
+    // consecutive tiles go to different blocks: an event's tiles (similar numbers of active offsets) spread over the chip.
+    // The table entries and the S rows of a wave's NEXT tile are asked for while the current one is worked on (one
+    // memory round trip per tile instead of two).
+    int nbv_n[DWS_KG];
+    f32x4 sv_n[4];
+    auto ask = [&](long long tile) {
+        const long long row0 = tile * 32;
+        const long long trow = row0 + c < R ? row0 + c : R - 1;
+#pragma unroll
+        for (int q = 0; q < DWS_KG; ++q) nbv_n[q] = table_value(table[(long long)trw[q] * Rcap + (trow > 0 ? trow : 0)], osel[q]);
+        // the S tile through a raw buffer sized by the VALID rows (rows past the end read as 0)
+        int voff = (int)((unsigned)(row0 + srow) * 128u + (unsigned)chunk * 16u);
+        asm volatile("" : "+v"(voff));
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            sv_n[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, voff + p * 1024, 0, 0));
+    };
+    const long long tstep = (long long)DWS_WAVES * nbx;
+    long long tile = bx + (long long)wid * nbx;
+    if (tile < ntiles) ask(tile);
+    for (; tile < ntiles; tile += tstep) {
+        const long long row0 = tile * 32;
+        const long long trow = row0 + c < R ? row0 + c : R - 1;
+        int nbv[DWS_KG];
+        f32x4 sv[4];
+#pragma unroll
+        for (int q = 0; q < DWS_KG; ++q) nbv[q] = nbv_n[q];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sv[p] = sv_n[p];
+        unsigned long long act[DWS_KG];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < DWS_KG; ++q) {
+            const int k = g + q * ngroups;
+            int nb = (k == identity_k) ? (int)trow : nbv[q];
+            nb = (k < K && row0 + c < R) ? nb : -1;
+            nbv[q] = nb;
+            act[q] = __ballot(nb >= 0);
+            any = any || act[q] != 0ull;
+        }
+        if (!any) {
+            if (tile + tstep < ntiles) ask(tile + tstep);
+            continue;
+        }
+        // gathers of all the block's offsets, issued together: a missing row gets an offset past the end and reads as 0
+        f32x4 gv[DWS_KG][4];
+#pragma unroll
+        for (int q = 0; q < DWS_KG; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int nb = __shfl(nbv[q], srow + 8 * p, 64);
+                const unsigned off = nb >= 0 ? (unsigned)nb * 128u + (unsigned)chunk * 16u : 0x80000000u;
+                gv[q][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcG, (int)off, 0, 0));
+            }
+        __builtin_amdgcn_wave_barrier();               // the previous tile's fragment reads are done (LDS is in order)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint2 p1, p2, p3;
+            split3_bf16(sv[p], true, p1, p2, p3);
+            *(uint2 *)(sS + soff + p * 256) = p1;
+            *(uint2 *)(sS + 1024 + soff + p * 256) = p2;
+            *(uint2 *)(sS + 2048 + soff + p * 256) = p3;
+        }
+        if (tile + tstep < ntiles) ask(tile + tstep);
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 a[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            a[pl][0] = lds_column_frag_tr(sS + pl * 1024, lane, 0);
+            a[pl][1] = lds_column_frag_tr(sS + pl * 1024, lane, 1);
+        }
+#pragma unroll
+        for (int q = 0; q < DWS_KG; ++q) {
+            if (act[q] == 0ull) continue;
+            __builtin_amdgcn_wave_barrier();           // the previous offset's fragment reads are done
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint2 p1, p2, p3;
+                split3_bf16(gv[q][p], true, p1, p2, p3);
+                *(uint2 *)(sG + soff + p * 256) = p1;
+                *(uint2 *)(sG + 1024 + soff + p * 256) = p2;
+                *(uint2 *)(sG + 2048 + soff + p * 256) = p3;
+            }
+            __builtin_amdgcn_wave_barrier();
+            bf16x8 b[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                b[pl][0] = lds_column_frag_tr(sG + pl * 1024, lane, 0);
+                b[pl][1] = lds_column_frag_tr(sG + pl * 1024, lane, 1);
+            }
+            // smallest products first: they meet in the accumulator before the leading one swamps them
+#define WFS_SPLIT_MFMA(i, j)                                                                    \
+    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[q], 0, 0, 0);         \
+    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[q], 0, 0, 0);
+            WFS_SPLIT_MFMA(2, 0)
+            WFS_SPLIT_MFMA(0, 2)
+            WFS_SPLIT_MFMA(1, 1)
+            WFS_SPLIT_MFMA(1, 0)
+            WFS_SPLIT_MFMA(0, 1)
+            WFS_SPLIT_MFMA(0, 0)
+#undef WFS_SPLIT_MFMA
+        }
+    }
+    // deterministic block reduction, one offset at a time (as k_gdw32): the waves park that offset's accumulator in LDS
+    // (the tile planes are free now), every thread adds two output elements over the waves in wave order
+    float *sRed = reinterpret_cast<float *>(smem);                      // [DWS_WAVES][1024]
+#pragma unroll
+    for (int q = 0; q < DWS_KG; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int arow = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sRed[wid * 1024 + arow * 32 + c] = acc[q][i];
+        }
+        __syncthreads();
+        const int k = g + q * ngroups;
+        for (int e = threadIdx.x; e < 1024; e += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < DWS_WAVES; ++w) v += sRed[w * 1024 + e];
+            if (k < K) part[((long long)bx * K + k) * 1024 + e] = v;
+        }
+    }
+}
+
 // dW and dX of a 32 -> 32 layer in ONE launch (round 4): both gather dY through the same by-input table and neither
 // reads what the other writes, but as two launches the second waits for the first one's last block and pays a kernel
 // boundary of its own (~4.6 us inside a captured step, as much as its bytes).  Blocks [0, n_dw) run the dW body --
@@ -1222,6 +1498,16 @@ int wfs_launch_dw_jobs(const wfs_dw_job *jobs, int n, hipStream_t stream) {
     return WFS_OK;
 }
 
+// fp32 rows of the 32 -> 32 layers as three bf16 pieces on the bf16 matrix cores (k_gdw32_split, k_gconv16_split);
+// WFS_SPLIT_BF16=0 keeps the fp32 matrix instructions (read once)
+static bool wfs_split_bf16() {
+    static const int on = [] {
+        const char *e = getenv("WFS_SPLIT_BF16");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on != 0;
+}
+
 // ---- launchers used by gather_conv.hip's C entry points -------------------------------------------------
 bool wfs_mfma_gconv32_ok(int K) { return K >= 1 && K <= 32; }       // K * 4 KiB of LDS <= 128 KiB
 
@@ -1230,7 +1516,7 @@ static int launch_big_lds(KernelT kernel, bool *attr_done, dim3 grid, dim3 block
                           Args... args) {
     if (!*attr_done) {
         // 160 KiB per CU minus the kernels' static LDS
-        WFS_HIP_CHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        WFS_HIP_CHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         *attr_done = true;
     }
     kernel<<<grid, block, lds, stream>>>(args...);
@@ -1272,6 +1558,24 @@ int wfs_launch_gconv32_f32(const int *table, int mirror, int K, int identity_k, 
     long long nb = (expect + w - 1) / w;
     nb = nb > 256 ? 256 : (nb + 7) / 8 * 8;
     if (nb < 8) nb = 8;
+    if (wfs_split_bf16() && K <= 27) {
+        // 12 waves at most (the pieces cost registers), K - 1 offsets of 6 KiB in LDS
+        int ws = w > 12 ? 12 : w;
+        long long nbs = (expect + ws - 1) / ws;
+        nbs = nbs > 256 ? 256 : (nbs + 7) / 8 * 8;
+        if (nbs < 8) nbs = 8;
+        const dim3 gs((unsigned)nbs), bs(ws * 64);
+        const size_t lds_s = (size_t)(K - 1) * 6144;
+        static bool attrs[3] = {false, false, false};
+        if (packed_kl)
+            return launch_big_lds(k_gconv16_split<true, 3>, &attrs[2], gs, bs, lds_s, stream, table, mirror, K, identity_k, R,
+                                  r_dev, X, W, bias, Y);
+        if (transpose_w)
+            return launch_big_lds(k_gconv16_split<true>, &attrs[0], gs, bs, lds_s, stream, table, mirror, K, identity_k, R,
+                                  r_dev, X, W, bias, Y);
+        return launch_big_lds(k_gconv16_split<false>, &attrs[1], gs, bs, lds_s, stream, table, mirror, K, identity_k, R, r_dev,
+                              X, W, bias, Y);
+    }
     const dim3 g16((unsigned)nb), b16(w * 64);
     if (packed_kl) {
         static bool attr16p = false;
@@ -1394,12 +1698,17 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
                      int packed_kl) {
     WFS_REQUIRE(packed_kl == 0 || (packed_kl >= 1 && packed_kl <= 8 && K % packed_kl == 0 && identity_k < 0), WFS_EINVAL,
                 "packed tables: K must be a multiple of kl <= 8, no identity offset");
-    const long long nblk = dw32_blocks(R, dtype == WFS_F32);
+    const long long nblk = dw32_blocks(R, dtype == WFS_F32 && !wfs_split_bf16());
     const long long ntiles = (R + 31) >> 5;
     const long long tiles_per_block = (ntiles + nblk - 1) / nblk;
     const int ngroups = (K + DW_KG - 1) / DW_KG;
     const dim3 grid((unsigned)nblk, (unsigned)ngroups);
-    if (dtype == WFS_F32) {
+    if (dtype == WFS_F32 && wfs_split_bf16()) {
+        static bool attr = false;
+        const int rc = launch_big_lds(k_gdw32_split, &attr, grid, dim3(512), DWS_LDS, stream, table, packed_kl, K, identity_k, R,
+                                      r_dev, (const float *)S, (const float *)G, part, ngroups);
+        if (rc != WFS_OK) return rc;
+    } else if (dtype == WFS_F32) {
         k_gdw32<float><<<grid, dim3(512), 0, stream>>>(table, packed_kl, K, identity_k, R, r_dev, (const float *)S,
                                                        (const float *)G, part, ngroups, tiles_per_block);
         WFS_LAUNCH_CHECK();
