@@ -47,7 +47,11 @@ cp("microbench_conv_bf16_batch2048.txt", R + "microbench_conv_bf16_batch2048.txt
    "# python tools/microbench_conv.py 30 bf16 2048")
 cp("c5_bf16_kernel_table.txt", R + "c5_bf16_kernel_table.txt")
 cp("c5_f32_kernel_table.txt", R + "c5_f32_kernel_table.txt")
-cp("soak_from_files.json", R + "soak_from_files.json")
+if os.path.exists(os.path.join(F, "soak_from_files.json")):      # the tool prints progress lines before its JSON object
+    rec = [l for l in open(os.path.join(F, "soak_from_files.json")) if l.startswith("{")]
+    with open(os.path.join(P, R + "soak_from_files.json"), "w") as f:
+        json.dump(json.loads(rec[-1]), f, indent=1)
+    print("profiles/" + R + "soak_from_files.json")
 cp("pytest_gpu.log", R + "pytest_gpu.log")
 # the other configs: six lines of tools/exp/bench_2d_nets.sh (f32 then bf16: GEP, Ioni, C5), the eval loops, C4
 lines = [json.loads(l) for l in open(os.path.join(F, "bench_2d_nets.txt")) if l.startswith("{")]
