@@ -90,6 +90,7 @@ __device__ __forceinline__ void split3_bf16x8(f32x4 lo, f32x4 hi, uint4 &p1, uin
 //   B: sW[k][cb][jq][q][n][e] = B[c = 8q + 4jq + e][col = 16cb + n]: one ds_read_b128 gives a lane four steps of a column block.
 //   D: lane holds rows 4q .. 4q+3 of column n (+ 16 per column block).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int SPLIT_GROUP = 2;    // the same for the three-piece form (its pieces and fragments want the registers)
 constexpr int F16_GROUP = 3;      // offsets whose gathers a wave has in flight together (2 x 16 B per lane each)
 
 // (body as a device function, like gconv32_bf16_body: sW = the filter image [K * 1024 floats] in LDS, sNextp = the
@@ -106,6 +107,7 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
                                                  long long R, const long long *__restrict__ r_dev,
                                                  const float *__restrict__ X, const float *__restrict__ W,
                                                  const float *__restrict__ bias, float *__restrict__ Y) {
+    constexpr int GROUP = SPLIT ? SPLIT_GROUP : F16_GROUP;      // offsets in flight together
     int &sNext = *sNextp;
     if (threadIdx.x == 0) sNext = 0;
     uint4 *sB = reinterpret_cast<uint4 *>(sW);
@@ -124,21 +126,24 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
         }
         split3_bf16x8(lo, hi, p1, p2, p3);
     };
+    // SPLIT: offset kc keeps its fragments in registers -- the centre offset of a SubM layer (every tile uses it), the
+    // middle one otherwise; the others sit in LDS slot k - (k > kc)
+    const int kc = identity_k >= 0 ? identity_k : K / 2;
     if constexpr (SPLIT) {
         for (int f = threadIdx.x; f < (K - 1) * 128; f += nthreads) {
-            const int k = f >> 7, cb = (f >> 6) & 1, l = f & 63;
+            const int slot = f >> 7, cb = (f >> 6) & 1, l = f & 63;
             uint4 p1, p2, p3;
-            filter_frag(k, cb, l, p1, p2, p3);
-            uint4 *dst = sB + ((k * 2 + cb) * 3) * 64 + l;
+            filter_frag(slot + (slot >= kc ? 1 : 0), cb, l, p1, p2, p3);
+            uint4 *dst = sB + ((slot * 2 + cb) * 3) * 64 + l;
             dst[0] = p1;
             dst[64] = p2;
             dst[128] = p3;
         }
         {
             uint4 p1, p2, p3;
-            filter_frag(K - 1, 0, threadIdx.x & 63, p1, p2, p3);
+            filter_frag(kc, 0, threadIdx.x & 63, p1, p2, p3);
             wc00 = p1, wc01 = p2, wc02 = p3;
-            filter_frag(K - 1, 1, threadIdx.x & 63, p1, p2, p3);
+            filter_frag(kc, 1, threadIdx.x & 63, p1, p2, p3);
             wc10 = p1, wc11 = p2, wc12 = p3;
         }
     } else if (!TRANSPOSE_W) {
@@ -215,7 +220,7 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
             acc1[i] = bj1;
         }
         if (mask != 0) {
-            // ---- phase 2: groups of F16_GROUP active offsets in ascending order: all the group's gathers are in flight
+            // ---- phase 2: groups of GROUP active offsets in ascending order: all the group's gathers are in flight
             // before its MFMAs.  The table entry of (row r, offset k) sits in register k >> 2 of lane (r, k & 3) since
             // phase 1: one select chain + one lane exchange per offset instead of a second read of the table.
             auto entry_of = [&](int k) -> int {
@@ -230,22 +235,22 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
             // Software pipeline over the groups: while a group's MFMAs run, the NEXT group's gathers are in flight (two
             // register sets, the loop body written out twice so that they swap without moves).
             struct Group {
-                int k[F16_GROUP], nb[F16_GROUP];
-                f32x4 a[F16_GROUP][2];
+                int k[GROUP], nb[GROUP];
+                f32x4 a[GROUP][2];
             };
-            auto fetch = [&](Group &gr) {                     // takes the next F16_GROUP offsets off the mask
+            auto fetch = [&](Group &gr) {                     // takes the next GROUP offsets off the mask
 #pragma unroll
-                for (int g = 0; g < F16_GROUP; ++g) {
+                for (int g = 0; g < GROUP; ++g) {
                     gr.k[g] = mask ? __builtin_ctz(mask) : -1;
                     mask = mask ? (mask & (mask - 1)) : 0u;
                 }
 #pragma unroll
-                for (int g = 0; g < F16_GROUP; ++g) {
+                for (int g = 0; g < GROUP; ++g) {
                     const int e = entry_of(gr.k[g] >= 0 ? gr.k[g] : 0);
                     gr.nb[g] = gr.k[g] >= 0 ? e : -1;
                 }
 #pragma unroll
-                for (int g = 0; g < F16_GROUP; ++g) {
+                for (int g = 0; g < GROUP; ++g) {
                     // unconditional (loads behind branches make hipcc wait for all of them), through a raw buffer: a
                     // missing neighbour / empty slot points at or past the end of the buffer and reads as 0 -- no select
                     // on the 8 registers afterwards, a 32-bit offset instead of a 64-bit address
@@ -255,38 +260,46 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
                     gr.a[g][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff + 16, 0, 0));
                 }
             };
-            auto multiply = [&](const Group &gr) {
-#pragma unroll
-                for (int g = 0; g < F16_GROUP; ++g)
-                    if (gr.k[g] >= 0) {
-                        const f32x4 a0 = gr.a[g][0], a1 = gr.a[g][1];
-                        if constexpr (SPLIT) {
-                            uint4 x1, x2, x3;
-                            split3_bf16x8(a0, a1, x1, x2, x3);
-                            // smallest products first; the two column blocks' chains alternate.  (Written as a function
-                            // of the six fragments and called once per source: a select between register and LDS
-                            // fragments would go through scratch.)
-                            auto six = [&](const uint4 &b00, const uint4 &b01, const uint4 &b02, const uint4 &b10,
-                                           const uint4 &b11, const uint4 &b12) {
+            // SPLIT: one offset = cut the gathered registers, six fragments, twelve matrix instructions (smallest
+            // products first; the two column blocks' chains alternate).  Written as a function of the six fragments and
+            // called once per source: a select between register and LDS fragments would go through scratch.
 #define WFS_SPLIT2(xa, pb0, pb1)                                                                                       \
     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8e, xa), __builtin_bit_cast(bf16x8e, pb0),   \
                                                    acc0, 0, 0, 0);                                                     \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8e, xa), __builtin_bit_cast(bf16x8e, pb1),   \
                                                    acc1, 0, 0, 0);
-                                WFS_SPLIT2(x3, b00, b10)
-                                WFS_SPLIT2(x1, b02, b12)
-                                WFS_SPLIT2(x2, b01, b11)
-                                WFS_SPLIT2(x2, b00, b10)
-                                WFS_SPLIT2(x1, b01, b11)
-                                WFS_SPLIT2(x1, b00, b10)
-                            };
-                            if (gr.k[g] == K - 1) {
-                                six(wc00, wc01, wc02, wc10, wc11, wc12);
-                            } else {
-                                const uint4 *bp = sB + gr.k[g] * 384 + lane;
-                                six(bp[0], bp[64], bp[128], bp[192], bp[256], bp[320]);
-                            }
+            auto six = [&](const uint4 &x1, const uint4 &x2, const uint4 &x3, const uint4 &b00, const uint4 &b01,
+                           const uint4 &b02, const uint4 &b10, const uint4 &b11, const uint4 &b12) {
+                WFS_SPLIT2(x3, b00, b10)
+                WFS_SPLIT2(x1, b02, b12)
+                WFS_SPLIT2(x2, b01, b11)
+                WFS_SPLIT2(x2, b00, b10)
+                WFS_SPLIT2(x1, b01, b11)
+                WFS_SPLIT2(x1, b00, b10)
+            };
 #undef WFS_SPLIT2
+            auto split_one = [&](const f32x4 &a0, const f32x4 &a1, int k) {          // k != kc: fragments from LDS
+                uint4 x1, x2, x3;
+                split3_bf16x8(a0, a1, x1, x2, x3);
+                const uint4 *bp = sB + (k - (k > kc ? 1 : 0)) * 384 + lane;
+                six(x1, x2, x3, bp[0], bp[64], bp[128], bp[192], bp[256], bp[320]);
+            };
+            auto multiply = [&](const Group &gr) {
+                if constexpr (SPLIT) {
+                    if (gr.k[GROUP - 1] >= 0) {
+                        // a full group (every group but a tile's last): one basic block, so that the cutting and the
+                        // fragment reads of an offset can be scheduled under the matrix instructions of its neighbour
+#pragma unroll
+                        for (int g = 0; g < GROUP; ++g) split_one(gr.a[g][0], gr.a[g][1], gr.k[g]);
+                        return;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g)
+                    if (gr.k[g] >= 0) {
+                        const f32x4 a0 = gr.a[g][0], a1 = gr.a[g][1];
+                        if constexpr (SPLIT) {
+                            split_one(a0, a1, gr.k[g]);
                             continue;
                         }
                         const f32x4 *bp = (const f32x4 *)(sW + ((gr.k[g] * 16 + q) * 16 + r) * 4);   // (k, cb 0, jq 0, q, n)
@@ -307,8 +320,30 @@ __device__ __forceinline__ void gconv16_f32_body(float *sW, int *sNextp, int vbi
                     }
             };
             Group ga, gb;
-            fetch(ga);
-            while (true) {
+#pragma unroll
+            for (int g = 0; g < GROUP; ++g) ga.k[g] = -1;
+            if constexpr (SPLIT) {
+                // the register-resident offset first: its rows are asked for together with the first group's and
+                // multiplied while those are in flight
+                const bool use_c = (mask >> kc) & 1u;
+                mask &= ~(1u << kc);
+                if (use_c) {
+                    const int nbc = entry_of(kc);
+                    int voff = nbc >= 0 ? (int)((unsigned)nbc * 128u + (unsigned)q * 32u) : (int)0x80000000;
+                    asm volatile("" : "+v"(voff));
+                    const f32x4 c0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff, 0, 0));
+                    const f32x4 c1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voff + 16, 0, 0));
+                    if (mask != 0) fetch(ga);
+                    uint4 x1, x2, x3;
+                    split3_bf16x8(c0, c1, x1, x2, x3);
+                    six(x1, x2, x3, wc00, wc01, wc02, wc10, wc11, wc12);
+                } else {
+                    fetch(ga);
+                }
+            } else {
+                fetch(ga);
+            }
+            while (SPLIT ? ga.k[0] >= 0 : true) {
                 const bool more_b = mask != 0;
                 if (more_b) fetch(gb);
                 __builtin_amdgcn_sched_barrier(0);
