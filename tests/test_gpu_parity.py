@@ -1439,3 +1439,52 @@ def test_transposed_rulebook_bitexact_and_layer_parity(case):
     assert m == len(want[0]) and int(rb.overflow) == 0
     assert np.array_equal(rb.out_indices[:m].cpu().numpy(), want[0])
     assert np.array_equal(rb.indice_pair_num.cpu().numpy(), want[2])
+
+
+def test_three_piece_bf16_products_of_fp32_rows_over_a_wide_dynamic_range():
+    """The fp32 32 -> 32 products run on the bf16 matrix cores with every number cut into three bf16 pieces
+    (csrc/conv_mfma.hip k_gconv16_split / k_gdw32_split).  The cut is exact for every exponent, so the result must be
+    as good as an fp32 dot product whatever the scale of a row: rows scaled by 2^-40 .. 2^40 (and filters by 2^-12 ..
+    2^12), compared element by element with float64 against the fp32 bar of 1e-5 x sum |x| |w| -- a bar on each
+    element's OWN scale, not the tensor's, which a lost low piece (2^-16 of the element) would miss by a factor 1.5."""
+    from waveformml_amd.spconv import functional as Fsp
+    rng = np.random.default_rng(4242)
+    N, M, K = 1500, 1300, 27
+    table = rng.integers(-1, N, size=(K, M)).astype(np.int32)
+    table[rng.random((K, M)) < 0.6] = -1
+    x = rng.standard_normal((N, 32)) * np.exp2(rng.integers(-40, 41, size=(N, 1)))
+    w = rng.standard_normal((K, 32, 32)) * np.exp2(rng.integers(-12, 13, size=(K, 1, 1)))
+    x32, w32 = x.astype(np.float32), w.astype(np.float32)
+    X, W, T = torch.from_numpy(x32).to(DEV), torch.from_numpy(w32).to(DEV), torch.from_numpy(table).to(DEV)
+    xd, wd = x32.astype(np.float64), w32.astype(np.float64)
+
+    def bar(got, want, scale, what):
+        err = np.abs(np.asarray(got, np.float64) - want)
+        worst = float((err / np.maximum(scale, 1e-300)).max())
+        assert worst <= 1e-5, "%s: %.3g of the element's own scale" % (what, worst)
+        return worst
+
+    for transpose in (False, True):
+        wk = wd.transpose(0, 2, 1) if transpose else wd
+        want = np.zeros((M, 32))
+        scale = np.zeros((M, 32))
+        for k in range(K):
+            rows = np.nonzero(table[k] >= 0)[0]
+            want[rows] += xd[table[k, rows]] @ wk[k]
+            scale[rows] += np.abs(xd[table[k, rows]]) @ np.abs(wk[k])
+        got = Fsp.gather_conv(T, None, K, -1, M, X, W, transpose, None)
+        bar(got.cpu().numpy(), want, scale, "conv (transposed filters)" if transpose else "conv")
+    # dW[k, a, b] = sum_r S[r, a] G[table[k, r], b] with rows of moderate scale on the stationary side (the sum runs over
+    # rows: one row 2^80 above another would own the element in any arithmetic)
+    s = rng.standard_normal((M, 32)) * np.exp2(rng.integers(-6, 7, size=(M, 1)))
+    g = rng.standard_normal((N, 32)) * np.exp2(rng.integers(-6, 7, size=(N, 1)))
+    s32, g32 = s.astype(np.float32), g.astype(np.float32)
+    sd, gd = s32.astype(np.float64), g32.astype(np.float64)
+    want = np.zeros((K, 32, 32))
+    scale = np.zeros((K, 32, 32))
+    for k in range(K):
+        rows = np.nonzero(table[k] >= 0)[0]
+        want[k] = sd[rows].T @ gd[table[k, rows]]
+        scale[k] = np.abs(sd[rows]).T @ np.abs(gd[table[k, rows]])
+    got = Fsp.gather_dw(T, K, -1, M, torch.from_numpy(s32).to(DEV), torch.from_numpy(g32).to(DEV), False)
+    bar(got.cpu().numpy(), want, scale, "dW")
