@@ -46,19 +46,28 @@ __device__ __forceinline__ void table_row_of(int pk, int k, int *trow, int *osel
 __device__ __forceinline__ int table_value(int e, int osel) { return osel < 0 ? e : packed_entry(e, osel); }
 
 typedef __bf16 bf16x8e __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- fp32 numbers as three bf16 pieces (round 4; the whole story is at k_gdw32_split below)
 // x[0..3] -> the three pieces, each as 4 packed bf16 (element i in bits 16 (i & 1) of word i >> 1)
 __device__ __forceinline__ void split3_bf16(f32x4 x, bool keep, uint2 &p1, uint2 &p2, uint2 &p3) {
     unsigned u[4], v[4], w[4];
-    float r[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float xi = x[i];       // (a bit_cast straight from the vector element reads element 0 with this compiler)
-        u[i] = keep ? __builtin_bit_cast(unsigned, xi) : 0u;
-        r[i] = __builtin_bit_cast(float, u[i]) - __builtin_bit_cast(float, u[i] & 0xFFFF0000u);
-        v[i] = __builtin_bit_cast(unsigned, r[i]);
-        w[i] = __builtin_bit_cast(unsigned, r[i] - __builtin_bit_cast(float, v[i] & 0xFFFF0000u));
+    for (int i = 0; i < 4; i += 2) {        // two at a time: the subtractions are v_pk_add_f32
+        const float xa = x[i], xb = x[i + 1];      // (a bit_cast straight from a vector element reads element 0 with this compiler)
+        u[i] = keep ? __builtin_bit_cast(unsigned, xa) : 0u;
+        u[i + 1] = keep ? __builtin_bit_cast(unsigned, xb) : 0u;
+        const f32x2 full = {__builtin_bit_cast(float, u[i]), __builtin_bit_cast(float, u[i + 1])};
+        const f32x2 top = {__builtin_bit_cast(float, u[i] & 0xFFFF0000u), __builtin_bit_cast(float, u[i + 1] & 0xFFFF0000u)};
+        const f32x2 r = full - top;
+        const float ra = r[0], rb = r[1];
+        v[i] = __builtin_bit_cast(unsigned, ra);
+        v[i + 1] = __builtin_bit_cast(unsigned, rb);
+        const f32x2 top2 = {__builtin_bit_cast(float, v[i] & 0xFFFF0000u), __builtin_bit_cast(float, v[i + 1] & 0xFFFF0000u)};
+        const f32x2 r2 = r - top2;
+        const float sa = r2[0], sb = r2[1];
+        w[i] = __builtin_bit_cast(unsigned, sa);
+        w[i + 1] = __builtin_bit_cast(unsigned, sb);
     }
     // v_perm_b32: bytes 3, 2 of the second operand below bytes 3, 2 of the first
     p1 = uint2{__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u)};
@@ -1067,12 +1076,11 @@ __global__ void __launch_bounds__(1024) k_gdw32_bf16(const int *__restrict__ tab
 // instructions of 32 cycles per (tile, offset) instead of k_gdw32<float>'s 16 v_mfma_f32_32x32x2_f32 of 64 cycles.
 // The pieces are made where the tile is staged (fp32 rows in registers -> three [32][32] bf16 planes in the wave's LDS
 // region), operands then read column-wise as in k_gdw32_bf16.  Work units, block reduction and slabs as k_gdw32<float>.
-constexpr int DWS_WAVES = 8;
+constexpr int DWS_WAVES = 12;
 constexpr int DWS_KG = 4;
-constexpr int DWS_LDS = DWS_WAVES * 6 * 2048;          // per wave: 3 planes of the S tile, 3 of the gathered tile (96 KiB)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int DWS_LDS = DWS_WAVES * 6 * 2048;          // per wave: 3 planes of the S tile, 3 of the gathered tile (144 KiB)
 
-__global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ table, int pk, int K, int identity_k,
+__global__ void __launch_bounds__(DWS_WAVES * 64) k_gdw32_split(const int *__restrict__ table, int pk, int K, int identity_k,
                                                      long long Rcap, const long long *__restrict__ r_dev,
                                                      const float *__restrict__ S, const float *__restrict__ G,
                                                      float *__restrict__ part, int ngroups) {
@@ -1100,34 +1108,24 @@ __global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ tab
     unsigned short *sS = sTiles[wid][0], *sG = sTiles[wid][3];
     const int soff = srow * 32 + chunk * 4;          // this lane's place in a plane (bf16 elements), + 256 per pass
     // consecutive tiles go to different blocks: an event's tiles (similar numbers of active offsets) spread over the chip.
-    // The table entries and the S rows of a wave's NEXT tile are asked for while the current one is worked on (one
-    // memory round trip per tile instead of two).
-    int nbv_n[DWS_KG];
-    f32x4 sv_n[4];
-    auto ask = [&](long long tile) {
-        const long long row0 = tile * 32;
-        const long long trow = row0 + c < R ? row0 + c : R - 1;
-#pragma unroll
-        for (int q = 0; q < DWS_KG; ++q) nbv_n[q] = table_value(table[(long long)trw[q] * Rcap + (trow > 0 ? trow : 0)], osel[q]);
-        // the S tile through a raw buffer sized by the VALID rows (rows past the end read as 0)
-        int voff = (int)((unsigned)(row0 + srow) * 128u + (unsigned)chunk * 16u);
-        asm volatile("" : "+v"(voff));
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            sv_n[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, voff + p * 1024, 0, 0));
-    };
+    // (Asking for the NEXT tile's table entries and S rows under the current tile measured nothing here -- 35.6 vs 34.4
+    // us -- and cost 20 register copies per tile.)
     const long long tstep = (long long)DWS_WAVES * nbx;
-    long long tile = bx + (long long)wid * nbx;
-    if (tile < ntiles) ask(tile);
-    for (; tile < ntiles; tile += tstep) {
+    for (long long tile = bx + (long long)wid * nbx; tile < ntiles; tile += tstep) {
         const long long row0 = tile * 32;
         const long long trow = row0 + c < R ? row0 + c : R - 1;
         int nbv[DWS_KG];
+#pragma unroll
+        for (int q = 0; q < DWS_KG; ++q) nbv[q] = table_value(table[(long long)trw[q] * Rcap + (trow > 0 ? trow : 0)], osel[q]);
+        // the S tile through a raw buffer sized by the VALID rows (rows past the end read as 0)
         f32x4 sv[4];
+        {
+            int voff = (int)((unsigned)(row0 + srow) * 128u + (unsigned)chunk * 16u);
+            asm volatile("" : "+v"(voff));
 #pragma unroll
-        for (int q = 0; q < DWS_KG; ++q) nbv[q] = nbv_n[q];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) sv[p] = sv_n[p];
+            for (int p = 0; p < 4; ++p)
+                sv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, voff + p * 1024, 0, 0));
+        }
         unsigned long long act[DWS_KG];
         bool any = false;
 #pragma unroll
@@ -1139,20 +1137,20 @@ __global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ tab
             act[q] = __ballot(nb >= 0);
             any = any || act[q] != 0ull;
         }
-        if (!any) {
-            if (tile + tstep < ntiles) ask(tile + tstep);
-            continue;
-        }
-        // gathers of all the block's offsets, issued together: a missing row gets an offset past the end and reads as 0
+        if (any) {
+        // gathers: two offsets in flight at a time (a missing row gets an offset past the end and reads as 0); the next
+        // offset's rows are asked for as soon as an offset's registers are cut
         f32x4 gv[DWS_KG][4];
-#pragma unroll
-        for (int q = 0; q < DWS_KG; ++q)
+        auto issue = [&](int q) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int nb = __shfl(nbv[q], srow + 8 * p, 64);
                 const unsigned off = nb >= 0 ? (unsigned)nb * 128u + (unsigned)chunk * 16u : 0x80000000u;
                 gv[q][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcG, (int)off, 0, 0));
             }
+        };
+        issue(0);
+        issue(1);
         __builtin_amdgcn_wave_barrier();               // the previous tile's fragment reads are done (LDS is in order)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1162,7 +1160,6 @@ __global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ tab
             *(uint2 *)(sS + 1024 + soff + p * 256) = p2;
             *(uint2 *)(sS + 2048 + soff + p * 256) = p3;
         }
-        if (tile + tstep < ntiles) ask(tile + tstep);
         __builtin_amdgcn_wave_barrier();
         bf16x8 a[3][2];
 #pragma unroll
@@ -1172,7 +1169,7 @@ __global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ tab
         }
 #pragma unroll
         for (int q = 0; q < DWS_KG; ++q) {
-            if (act[q] == 0ull) continue;
+            if (act[q] != 0ull) {
             __builtin_amdgcn_wave_barrier();           // the previous offset's fragment reads are done
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -1200,6 +1197,9 @@ __global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ tab
             WFS_SPLIT_MFMA(0, 1)
             WFS_SPLIT_MFMA(0, 0)
 #undef WFS_SPLIT_MFMA
+            }
+            if (q + 2 < DWS_KG) issue(q + 2);
+        }
         }
     }
     // deterministic block reduction, one offset at a time (as k_gdw32): the waves park that offset's accumulator in LDS
@@ -1215,7 +1215,7 @@ __global__ void __launch_bounds__(512) k_gdw32_split(const int *__restrict__ tab
         }
         __syncthreads();
         const int k = g + q * ngroups;
-        for (int e = threadIdx.x; e < 1024; e += 512) {
+        for (int e = threadIdx.x; e < 1024; e += DWS_WAVES * 64) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < DWS_WAVES; ++w) v += sRed[w * 1024 + e];
@@ -1740,7 +1740,7 @@ int wfs_launch_gdw32(const int *table, int K, int identity_k, long long R, const
     const dim3 grid((unsigned)nblk, (unsigned)ngroups);
     if (dtype == WFS_F32 && wfs_split_bf16()) {
         static bool attr = false;
-        const int rc = launch_big_lds(k_gdw32_split, &attr, grid, dim3(512), DWS_LDS, stream, table, packed_kl, K, identity_k, R,
+        const int rc = launch_big_lds(k_gdw32_split, &attr, grid, dim3(DWS_WAVES * 64), DWS_LDS, stream, table, packed_kl, K, identity_k, R,
                                       r_dev, (const float *)S, (const float *)G, part, ngroups);
         if (rc != WFS_OK) return rc;
     } else if (dtype == WFS_F32) {
