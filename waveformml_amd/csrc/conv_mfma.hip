@@ -1080,16 +1080,15 @@ constexpr int DWS_WAVES = 12;
 constexpr int DWS_KG = 4;
 constexpr int DWS_LDS = DWS_WAVES * 6 * 2048;          // per wave: 3 planes of the S tile, 3 of the gathered tile (144 KiB)
 
-__global__ void __launch_bounds__(DWS_WAVES * 64) k_gdw32_split(const int *__restrict__ table, int pk, int K, int identity_k,
-                                                     long long Rcap, const long long *__restrict__ r_dev,
-                                                     const float *__restrict__ S, const float *__restrict__ G,
-                                                     float *__restrict__ part, int ngroups) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// (body as a device function: bx / g / nbx = the block's coordinates in this product's grid)
+__device__ __forceinline__ void gdw32_split_body(unsigned char *smem, int bx, int g, int nbx, const int *__restrict__ table,
+                                                 int pk, int K, int identity_k, long long Rcap,
+                                                 const long long *__restrict__ r_dev, const float *__restrict__ S,
+                                                 const float *__restrict__ G, float *__restrict__ part, int ngroups) {
     unsigned short(*sTiles)[6][32 * 32] = reinterpret_cast<unsigned short(*)[6][32 * 32]>(smem);   // [DWS_WAVES][6][1024]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;          // fragment coordinates
     const int srow = lane >> 3, chunk = lane & 7;    // staging coordinates: rows srow + 8 p, 16-B chunk (4 floats)
-    const int bx = (int)blockIdx.x, nbx = (int)gridDim.x, g = (int)blockIdx.y;
     const long long R = valid_rows(Rcap, r_dev);
     const long long ntiles = (R + 31) >> 5;
     const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc((void *)S, 0, (int)(R * 128), 0x00020000);
@@ -1221,6 +1220,37 @@ __global__ void __launch_bounds__(DWS_WAVES * 64) k_gdw32_split(const int *__res
             for (int w = 0; w < DWS_WAVES; ++w) v += sRed[w * 1024 + e];
             if (k < K) part[((long long)bx * K + k) * 1024 + e] = v;
         }
+    }
+}
+
+__global__ void __launch_bounds__(DWS_WAVES * 64) k_gdw32_split(const int *__restrict__ table, int pk, int K, int identity_k,
+                                                               long long Rcap, const long long *__restrict__ r_dev,
+                                                               const float *__restrict__ S, const float *__restrict__ G,
+                                                               float *__restrict__ part, int ngroups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gdw32_split_body(smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, table, pk, K, identity_k, Rcap, r_dev, S, G, part,
+                     ngroups);
+}
+
+// dW and dX of an fp32 32 -> 32 layer in one launch, as k_bwd32_bf16 below: the three-piece bodies have the same block
+// size (12 waves) and nearly the same LDS (144 / 156 KiB), which the fp32-instruction bodies did not
+template <int PK>
+__global__ void __launch_bounds__(DWS_WAVES * 64) k_bwd32_split(const int *__restrict__ table, int K, int identity_k,
+                                                               long long Rcap, const long long *__restrict__ r_dev,
+                                                               const float *__restrict__ S, const float *__restrict__ G,
+                                                               const float *__restrict__ W, float *__restrict__ dX,
+                                                               float *__restrict__ part, int ngroups, int nbx_dw,
+                                                               int n_dw_pad, int n_dx, int dx_threads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int sNext;
+    const int bid = (int)blockIdx.x;
+    if (bid < n_dw_pad) {
+        if (bid >= nbx_dw * ngroups) return;
+        gdw32_split_body(smem, bid % nbx_dw, bid / nbx_dw, nbx_dw, table, PK, K, identity_k, Rcap, r_dev, S, G, part, ngroups);
+    } else {
+        if ((int)threadIdx.x >= dx_threads) return;
+        gconv16_f32_body<true, PK, true>(reinterpret_cast<float *>(smem), &sNext, bid - n_dw_pad, n_dx, dx_threads, table, 0,
+                                         K, identity_k, Rcap, r_dev, G, W, nullptr, dX);
     }
 }
 
@@ -1793,18 +1823,56 @@ static int launch_bwd32_h16(const int *table, int packed_kl, int K, int identity
                           part, ngroups, (int)nbx_dw, (int)n_dw_pad, (int)n_dx, wpb * 64);
 }
 
-// 16-bit rows only: the fp32 kernels were measured too (same construction: 0.828 vs 0.808 ms per captured step) -- the
-// fp32 dW body is tuned for two 512-thread blocks per CU with 32 KB of LDS each, which it loses inside a 1024-thread,
-// 110-KB launch
+// 16-bit rows and three-piece fp32 rows.  The fp32-INSTRUCTION kernels were measured too (same construction: 0.828 vs
+// 0.808 ms per captured step) -- that dW body is tuned for two 512-thread blocks per CU with 32 KB of LDS each, which it
+// loses inside a 1024-thread, 110-KB launch
 bool wfs_bwd32_fused_ok(int K, int packed_kl, int dtype) {
-    return (dtype == WFS_BF16 || dtype == WFS_F16) && K >= 1 && K <= 27 && (packed_kl == 0 || (packed_kl == 3 && K % 3 == 0));
+    const bool row_type = dtype == WFS_BF16 || dtype == WFS_F16 || (dtype == WFS_F32 && wfs_split_bf16());
+    return row_type && K >= 1 && K <= 27 && (packed_kl == 0 || (packed_kl == 3 && K % 3 == 0));
+}
+
+// grid of the three-piece conv: <= 12 waves per block, <= 256 blocks (multiple of 8)
+static void gconv16_split_grid(long long R, bool padded, int *waves, long long *nblk) {
+    const long long nt16 = (R + 15) >> 4;
+    const long long expect = padded ? (nt16 * 7 + 7) / 8 : nt16;
+    int w = (int)((expect + 255) / 256);
+    w = w < 4 ? 4 : (w > 12 ? 12 : (w + 3) / 4 * 4);
+    long long nb = (expect + w - 1) / w;
+    nb = nb > 256 ? 256 : (nb + 7) / 8 * 8;
+    if (nb < 8) nb = 8;
+    *waves = w;
+    *nblk = nb;
+}
+
+static int launch_bwd32_split(const int *table, int packed_kl, int K, int identity_k, long long R, const long long *r_dev,
+                              const float *S, const float *G, const float *W, float *dX, float *part, hipStream_t stream) {
+    const long long nbx_dw = dw32_blocks(R, false);
+    const int ngroups = (K + DWS_KG - 1) / DWS_KG;
+    const long long n_dw = nbx_dw * ngroups, n_dw_pad = (n_dw + 7) / 8 * 8;
+    int ws;
+    long long n_dx;
+    gconv16_split_grid(R, r_dev != nullptr, &ws, &n_dx);
+    size_t lds = (size_t)(K - 1) * 6144;
+    if (lds < (size_t)DWS_LDS) lds = DWS_LDS;
+    const dim3 grid((unsigned)(n_dw_pad + n_dx)), block(DWS_WAVES * 64);
+    if (packed_kl) {
+        static bool attr = false;
+        return launch_big_lds(k_bwd32_split<3>, &attr, grid, block, lds, stream, table, K, identity_k, R, r_dev, S, G, W, dX,
+                              part, ngroups, (int)nbx_dw, (int)n_dw_pad, (int)n_dx, ws * 64);
+    }
+    static bool attr0 = false;
+    return launch_big_lds(k_bwd32_split<0>, &attr0, grid, block, lds, stream, table, K, identity_k, R, r_dev, S, G, W, dX,
+                          part, ngroups, (int)nbx_dw, (int)n_dw_pad, (int)n_dx, ws * 64);
 }
 
 int wfs_launch_bwd32_h16(const int *table, int packed_kl, int K, int identity_k, long long R, const long long *r_dev,
                          const void *S, const void *G, const float *W, void *dX, int swap, float *dW, float *part, int dtype,
                          wfs_dw_job *defer, hipStream_t stream) {
     int rc;
-    if (dtype == WFS_F16)
+    if (dtype == WFS_F32)
+        rc = launch_bwd32_split(table, packed_kl, K, identity_k, R, r_dev, (const float *)S, (const float *)G, W, (float *)dX,
+                                part, stream);
+    else if (dtype == WFS_F16)
         rc = launch_bwd32_h16<wfs_f16>(table, packed_kl, K, identity_k, R, r_dev, (const wfs_f16 *)S, (const wfs_f16 *)G, W,
                                        (wfs_f16 *)dX, part, stream);
     else

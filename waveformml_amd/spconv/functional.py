@@ -337,7 +337,7 @@ def conv_backward(table, K, identity_k, R, X, dY, W, r_dev=None, like=None, pack
         dense = (table >> 3).clamp_(min=-1) if packed_kl else table
         pairs = int((dense >= 0).sum().item())
         es = X.element_size()
-        fused = Cin == 32 and Cout == 32 and X.dtype in (torch.bfloat16, torch.float16) and K <= 27      # one launch
+        fused = Cin == 32 and Cout == 32 and _one_launch_rows(X.dtype) and K <= 27      # one launch
         if fused:
             ACCOUNT.append(dict(kind="conv_backward", pairs=pairs,
                                 bytes=2 * R * Cin * es + dY.shape[0] * Cout * es + 2 * pairs * 8 + 2 * K * Cin * Cout * 4,
@@ -348,8 +348,15 @@ def conv_backward(table, K, identity_k, R, X, dY, W, r_dev=None, like=None, pack
     return dX, dW
 
 
-# dW and dX of a 32 -> 32 layer with 16-bit rows in one launch (WFS_FUSED_CONV_BACKWARD=0: two launches)
+# dW and dX of a 32 -> 32 layer in one launch (WFS_FUSED_CONV_BACKWARD=0: two launches): 16-bit rows, and fp32 rows on the
+# three-piece kernels (the library's WFS_SPLIT_BF16, default on; WFS_FUSED_CONV_BACKWARD_F32=0 keeps fp32 on two launches)
 FUSED_CONV_BACKWARD = __import__("os").environ.get("WFS_FUSED_CONV_BACKWARD", "1") != "0"
+FUSED_CONV_BACKWARD_F32 = (__import__("os").environ.get("WFS_SPLIT_BF16", "1") != "0"
+                           and __import__("os").environ.get("WFS_FUSED_CONV_BACKWARD_F32", "1") != "0")
+
+
+def _one_launch_rows(dtype):
+    return dtype in (torch.bfloat16, torch.float16) or (dtype == torch.float32 and FUSED_CONV_BACKWARD_F32)
 
 
 class SparseConvFunction(Function):
@@ -402,7 +409,7 @@ class SparseConvFunction(Function):
             if ctx.needs_input_grad[1]:
                 dW = gather_dw(rb.nbr_out, K, ident, rb.N, dY, features, True, None, rb.n_dev, ov, filters)
         elif (FUSED_CONV_BACKWARD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ov and not rb.has_dup
-              and features.shape[1] == 32 and dY.shape[1] == 32 and features.dtype in (torch.bfloat16, torch.float16)
+              and features.shape[1] == 32 and dY.shape[1] == 32 and _one_launch_rows(features.dtype)
               and features.is_cuda):
             table, pk = rb.table_by_in(32, 32, features, 3)
             if pk and rb.table_by_in(32, 32, dY, 1)[1] != pk:
