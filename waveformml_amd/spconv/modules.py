@@ -115,6 +115,8 @@ class SparseSequential(SparseModule):
                                                 flags=m._sticky_flags(),
                                                 want_cell_map=SparseSequential._dense_follows(mods, at))
                         built.append(rb)
+                        if ops.JOIN_PER_BUILD:
+                            rb.ready = _SideJoin(side)      # its own edge: the layer waits for THIS build only
                         if m.indice_key is not None:
                             keyed[m.indice_key] = rb
                     plan[id(m)] = rb
@@ -123,9 +125,9 @@ class SparseSequential(SparseModule):
                         events = getattr(rb, "events_out", None)
                 elif isinstance(m, SparseModule):
                     break                           # ToDense or an unknown sparse module ends the sparse stack
-            if built:
+            if built and not ops.JOIN_PER_BUILD:
                 # ONE join for the whole branch: the first layer that needs any of these rulebooks waits for all of them
-                # (they are done long before; every further cross-stream edge costs a captured step 5 - 10 us)
+                # (every further cross-stream edge costs a captured step 5 - 10 us)
                 join = _SideJoin(side)
                 for rb in built:
                     rb.ready = join

@@ -38,6 +38,10 @@ OVERLAP_DW = False
 # (the SubM build) starts 18 us after the hand-over launch on the replay's second queue and shares the chip with the
 # first strided build (27 us instead of 18)
 PREFETCH_BEFORE_FIRST = os.environ.get("WFS_PREFETCH_BEFORE_FIRST", "0") == "1"
+# every prefetched rulebook has its own edge back to the main chain: the first strided layer does not wait for the second
+# one's build.  WFS_JOIN_PER_BUILD=0: one join for the whole branch (each cross-stream edge of a replayed graph costs
+# 6 - 10 us; with the 512-thread builds the per-build edges win: 0.4642 / 0.4659 vs 0.4695 / 0.4699 ms per step)
+JOIN_PER_BUILD = os.environ.get("WFS_JOIN_PER_BUILD", "1") != "0"
 
 # Event-local SubM rulebook build (round 3; csrc/evrulebook.hip): in device-count mode -- captured steps, where the index
 # rows come from the reference's collate_fn, i.e. grouped by event -- a SubM rulebook is built by a pair of workgroups
