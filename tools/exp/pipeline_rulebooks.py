@@ -74,7 +74,7 @@ orig = modules.SparseSequential._prefetch_rulebooks
 LOW = None
 
 
-def patched(mods, x):
+def patched(mods, x, owner=None):
     if STATE["plan"] is None:
         already = {id(v.rulebook) for v in x.indice_dict.values() if hasattr(v, "rulebook")}
         torch.cuda.synchronize()
@@ -82,6 +82,9 @@ def patched(mods, x):
         side = ops.side_stream
         ops.side_stream = lambda d: torch.cuda.current_stream()
         try:
+            orig(mods, x)                      # once eagerly: the layers' sticky flags and state buffers must exist
+            x.prefetched = None
+            torch.cuda.synchronize()
             with torch.cuda.graph(S, stream=LOW):
                 orig(mods, x)
         finally:
