@@ -166,7 +166,13 @@ int wfs_indices_check(const wfs_geometry *g_subm, const int32_t *indices, int64_
  * k = q * kl + (e & 7)", -1 = none (9 instead of 27 table rows at that geometry, 54 % instead of 18 % of them used).
  * packed_kl = kl hands such a table to wfs_gather_conv (transpose_w products, i.e. dX) and wfs_gather_dw; 0 = the
  * dense form.  wfs_gather_packed_ok(kl, K, Ca, Cb, dtype, which) tells whether a product takes it (which = 1: dX,
- * 2: forward, 3: dW); wfs_unpack_table expands a packed table to the dense one for every other consumer. */
+ * 2: forward, 3: dW); wfs_unpack_table expands a packed table to the dense one for every other consumer.
+ * Arithmetic of fp32 rows (WFS_F32), 32 -> 32 channels (round 4): every fp32 number -- rows and filters -- is cut into
+ * three bf16 pieces whose sum is the number exactly, and the six leading piece products are summed in fp32 on
+ * v_mfma_f32_16x16x32_bf16 / _32x32x16_bf16 (csrc/conv_mfma.hip k_gconv16_split, k_gdw32_split); what is left out is
+ * below 2^-24 of the leading product, the size of one fp32 rounding -- the same 1e-5 bar as the fp32 instructions
+ * (v_mfma_f32_16x16x4_f32, taken with the environment's WFS_SPLIT_BF16=0) at 0.6x their time.  Non-finite inputs give
+ * NaN (Inf - Inf inside the cut) where an fp32 product would give +-Inf. */
 int wfs_gather_conv(const int32_t *table, const int32_t *kmap_host, int32_t K, int32_t identity_k,
                     int64_t R, const void *X, int64_t X_rows, int32_t Cx, const float *W,
                     int32_t Cw_in, int32_t Cw_out, int32_t transpose_w, const float *bias, void *Y,

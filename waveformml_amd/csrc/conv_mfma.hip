@@ -49,7 +49,8 @@ typedef __bf16 bf16x8e __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- fp32 numbers as three bf16 pieces (round 4; the whole story is at k_gdw32_split below)
-// x[0..3] -> the three pieces, each as 4 packed bf16 (element i in bits 16 (i & 1) of word i >> 1)
+// x[0..3] -> the three pieces, each as 4 packed bf16 (element i in bits 16 (i & 1) of word i >> 1).  Finite inputs only:
+// for +-Inf the first residual is Inf - Inf = NaN (an fp32 product would stay +-Inf); fp32 denormals give denormal pieces
 __device__ __forceinline__ void split3_bf16(f32x4 x, bool keep, uint2 &p1, uint2 &p2, uint2 &p3) {
     unsigned u[4], v[4], w[4];
 #pragma unroll
