@@ -90,11 +90,25 @@ __global__ void __launch_bounds__(256) k_load_batch(const int *__restrict__ coor
         bad = __syncthreads_or(bad);
         if (threadIdx.x == 0) ev_off[ev_B + 1 + blockIdx.x] = bad;
     }
-    for (long long i = tid; i < n * cols; i += nth) {
-        const long long row = i / cols;
-        const int col = (int)(i - row * cols);
-        if (coords_dst) coords_dst[i] = coords[i];
-        if (indices_dst) indices_dst[i] = coords[row * cols + perm.v[col]];
+    if (cols == 4 && ((reinterpret_cast<uintptr_t>(coords) | reinterpret_cast<uintptr_t>(coords_dst) |
+                       reinterpret_cast<uintptr_t>(indices_dst)) & 15) == 0) {
+        // the PSD nets' rows (x, y, t, event): one 16-byte row per thread, no division
+        const int4 *src = reinterpret_cast<const int4 *>(coords);
+        int4 *dst = reinterpret_cast<int4 *>(coords_dst), *idx = reinterpret_cast<int4 *>(indices_dst);
+        const int p0 = perm.v[0], p1 = perm.v[1], p2 = perm.v[2], p3 = perm.v[3];
+        auto pick = [](const int4 &r, int p) { return p == 0 ? r.x : (p == 1 ? r.y : (p == 2 ? r.z : r.w)); };
+        for (long long row = tid; row < n; row += nth) {
+            const int4 r = src[row];
+            if (dst) dst[row] = r;
+            if (idx) idx[row] = int4{pick(r, p0), pick(r, p1), pick(r, p2), pick(r, p3)};
+        }
+    } else {
+        for (long long i = tid; i < n * cols; i += nth) {
+            const long long row = i / cols;
+            const int col = (int)(i - row * cols);
+            if (coords_dst) coords_dst[i] = coords[i];
+            if (indices_dst) indices_dst[i] = coords[row * cols + perm.v[col]];
+        }
     }
     for (long long i = tid; i < feat_words; i += nth) feats_dst[i] = feats[i];
     for (long long i = tid; i < tail_bytes; i += nth) feats_tail_dst[i] = feats_tail[i];
