@@ -442,7 +442,8 @@ __device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {      // component-w
 
 // Timing knock-outs (tools/exp/knock.sh, profiles/r01_gconv32_bf16_knockouts.txt): -DWFS_KNOCK=bits builds a library
 // whose k_gconv32_bf16 skips a phase -- 1 filter staging, 2 table reads, 4 gathers + MFMA, 8 stores, 16 gathers read the
-// tile's own rows, 32 only one of a plane's three time offsets is gathered -- to measure what
+// tile's own rows, 32 only one of a plane's three time offsets is gathered, 64 the dW body's gathers read the tile's
+// own rows -- to measure what
 // each phase costs inside a replayed graph.  Results are wrong by construction; 0 (the default) compiles to nothing.
 #ifndef WFS_KNOCK
 #define WFS_KNOCK 0
@@ -1019,8 +1020,9 @@ __device__ __forceinline__ void gdw32_bf16_body(unsigned char *smem, int bx, int
         uint4 g0[DWB_KG], g1[DWB_KG];
 #pragma unroll
         for (int q = 0; q < DWB_KG; ++q) {
-            g0[q] = *(const uint4 *)(G + (long long)(ta[q] >= 0 ? ta[q] : 0) * 32 + gchunk * 8);
-            g1[q] = *(const uint4 *)(G + (long long)(tb[q] >= 0 ? tb[q] : 0) * 32 + gchunk * 8);
+            // WFS_KNOCK & 64: the gathers read the tile's OWN rows (what the fetch of a perfectly local table would be)
+            g0[q] = *(const uint4 *)(G + (long long)(ta[q] >= 0 ? ((WFS_KNOCK & 64) ? rac : ta[q]) : 0) * 32 + gchunk * 8);
+            g1[q] = *(const uint4 *)(G + (long long)(tb[q] >= 0 ? ((WFS_KNOCK & 64) ? rbc : tb[q]) : 0) * 32 + gchunk * 8);
         }
         a0 = lds_column_frag_tr(sS, lane, 0), a1 = lds_column_frag_tr(sS, lane, 1);
 #pragma unroll
